@@ -1,0 +1,492 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes bindings of the CPU oracles.
+
+* ``RefKarto``   -> oracle/_ref/libkarto_ref.so : the reference's own open_karto, compiled from
+  /root/reference by oracle/Makefile (exists only where that build ran; travels to the GPU box).
+* ``PortKarto``  -> oracle/libkarto_oracle.so   : plain-C restatement (oracle/karto_oracle.c).
+* ``PortHector`` -> oracle/libhector_oracle.so  : plain-C restatement (oracle/hector_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pathlib
+import subprocess
+
+import numpy as np
+
+HERE = pathlib.Path(__file__).resolve().parent
+
+
+class KrefCfg(C.Structure):
+    _fields_ = [
+        ("search_size", C.c_double),
+        ("resolution", C.c_double),
+        ("smear_deviation", C.c_double),
+        ("coarse_angle_offset", C.c_double),
+        ("coarse_angle_resolution", C.c_double),
+        ("fine_angle_offset", C.c_double),
+        ("distance_variance_penalty", C.c_double),
+        ("angle_variance_penalty", C.c_double),
+        ("minimum_distance_penalty", C.c_double),
+        ("minimum_angle_penalty", C.c_double),
+        ("use_response_expansion", C.c_int),
+        ("scan_buffer_size", C.c_int),
+        ("scan_buffer_max_scan_distance", C.c_double),
+        ("minimum_travel_distance", C.c_double),
+        ("minimum_travel_heading", C.c_double),
+    ]
+
+
+class KrefLaser(C.Structure):
+    _fields_ = [
+        ("min_angle", C.c_double),
+        ("max_angle", C.c_double),
+        ("angular_resolution", C.c_double),
+        ("min_range", C.c_double),
+        ("max_range", C.c_double),
+        ("range_threshold", C.c_double),
+        ("offset_x", C.c_double),
+        ("offset_y", C.c_double),
+        ("offset_heading", C.c_double),
+    ]
+
+
+def default_cfg(**kw) -> KrefCfg:
+    """BASELINE cfg 3/4 parameters (SURVEY.md §8 sizes table, column 1)."""
+    d = dict(
+        search_size=1.0,
+        resolution=0.05,
+        smear_deviation=0.03,
+        coarse_angle_offset=0.349,
+        coarse_angle_resolution=0.0349,
+        fine_angle_offset=0.00349,
+        distance_variance_penalty=0.3 * 0.3,  # library default Mapper.cpp:1608 (variance)
+        angle_variance_penalty=np.deg2rad(20.0) ** 2,  # Mapper.cpp:1614
+        minimum_distance_penalty=0.5,
+        minimum_angle_penalty=0.9,
+        use_response_expansion=0,
+        scan_buffer_size=70,
+        scan_buffer_max_scan_distance=20.0,
+        minimum_travel_distance=0.2,
+        minimum_travel_heading=np.deg2rad(10.0),
+    )
+    d.update(kw)
+    return KrefCfg(**d)
+
+
+def laser_struct(laser, range_threshold=49.5, offset=(0.0, 0.0, 0.0)) -> KrefLaser:
+    return KrefLaser(
+        laser.angle_min,
+        laser.angle_max,
+        laser.angle_increment,
+        laser.range_min,
+        laser.range_max,
+        range_threshold,
+        *offset,
+    )
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def build(target: str = "all") -> None:
+    """make -C oracle <target>; quiet no-op when everything is fresh."""
+    subprocess.run(["make", "-s", "-C", str(HERE), target], check=True)
+
+
+def have_ref() -> bool:
+    return (HERE / "_ref" / "libkarto_ref.so").exists()
+
+
+class RefKarto:
+    """The reference's own karto::ScanMatcher / karto::Mapper behind oracle/ref_driver.cpp."""
+
+    def __init__(self, cfg: KrefCfg, laser: KrefLaser):
+        path = HERE / "_ref" / "libkarto_ref.so"
+        if not path.exists():
+            raise FileNotFoundError(f"{path} (build it here with `make -C oracle ref`)")
+        L = C.CDLL(str(path))
+        L.kref_create.restype = C.c_void_p
+        L.kref_create.argtypes = [C.POINTER(KrefCfg), C.POINTER(KrefLaser)]
+        L.kref_destroy.argtypes = [C.c_void_p]
+        L.kref_num_beams.argtypes = [C.c_void_p]
+        L.kref_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                 C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kref_match_timed.restype = C.c_double
+        L.kref_match_timed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.kref_grid_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kref_grid_copy.argtypes = [C.c_void_p, C.c_void_p]
+        L.kref_kernel_copy.argtypes = [C.c_void_p, C.c_void_p]
+        L.kref_table_dims.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kref_table_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kref_probs_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kref_get_response.restype = C.c_double
+        L.kref_get_response.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.kref_point_readings.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.kref_find_valid_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kref_process.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kref_running_scans.argtypes = [C.c_void_p]
+        L.kref_occupancy_grid.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kref_last_error.restype = C.c_char_p
+        L.kref_last_error.argtypes = [C.c_void_p]
+        L.kref_round.restype = C.c_double
+        L.kref_round.argtypes = [C.c_double]
+        self.L = L
+        self.h = L.kref_create(C.byref(cfg), C.byref(laser))
+        if not self.h:
+            raise RuntimeError("kref_create failed (ScanMatcher::Create returned NULL or threw)")
+
+    def close(self):
+        if self.h:
+            self.L.kref_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_beams(self) -> int:
+        return self.L.kref_num_beams(self.h)
+
+    def match(self, base_ranges, base_poses, q_ranges, q_pose, do_penalize=True, do_refine=True):
+        br = np.ascontiguousarray(base_ranges, dtype=np.float64)
+        bp = np.ascontiguousarray(base_poses, dtype=np.float64)
+        qr = np.ascontiguousarray(q_ranges, dtype=np.float64)
+        qp = np.ascontiguousarray(q_pose, dtype=np.float64)
+        pose = np.zeros(3)
+        cov = np.zeros(9)
+        resp = C.c_double()
+        rc = self.L.kref_match(self.h, br.shape[0], br.ctypes.data, bp.ctypes.data, qr.shape[-1],
+                               qr.ctypes.data, qp.ctypes.data, int(do_penalize), int(do_refine),
+                               pose.ctypes.data, cov.ctypes.data, C.byref(resp))
+        if rc != 0:
+            raise RuntimeError(self.L.kref_last_error(self.h).decode())
+        return pose, cov.reshape(3, 3), resp.value
+
+    def match_timed(self, base_ranges, base_poses, q_ranges, q_poses):
+        br = np.ascontiguousarray(base_ranges, dtype=np.float64)
+        bp = np.ascontiguousarray(base_poses, dtype=np.float64)
+        qr = np.ascontiguousarray(q_ranges, dtype=np.float64)
+        qp = np.ascontiguousarray(q_poses, dtype=np.float64)
+        n = qr.shape[0]
+        poses = np.zeros((n, 3))
+        resp = np.zeros(n)
+        sec = self.L.kref_match_timed(self.h, br.shape[0], br.ctypes.data, bp.ctypes.data,
+                                      qr.shape[1], qr.ctypes.data, qp.ctypes.data, n,
+                                      poses.ctypes.data, resp.ctypes.data)
+        return sec, poses, resp
+
+    def grid_info(self):
+        i = np.zeros(8, dtype=np.int32)
+        off = np.zeros(2)
+        self.L.kref_grid_info(self.h, i.ctypes.data, off.ctypes.data)
+        keys = ("width", "height", "stride", "roi_x", "roi_y", "roi_w", "roi_h", "kernel_size")
+        d = {k: int(v) for k, v in zip(keys, i)}
+        d["offset"] = off
+        return d
+
+    def grid(self) -> np.ndarray:
+        gi = self.grid_info()
+        out = np.zeros((gi["height"], gi["stride"]), dtype=np.uint8)
+        self.L.kref_grid_copy(self.h, out.ctypes.data)
+        return out
+
+    def kernel(self) -> np.ndarray:
+        k = self.grid_info()["kernel_size"]
+        out = np.zeros((k, k), dtype=np.uint8)
+        self.L.kref_kernel_copy(self.h, out.ctypes.data)
+        return out
+
+    def tables(self):
+        na, npnt = C.c_int(), C.c_int()
+        self.L.kref_table_dims(self.h, C.byref(na), C.byref(npnt))
+        out = np.zeros((na.value, npnt.value), dtype=np.int32)
+        ang = np.zeros(na.value)
+        self.L.kref_table_copy(self.h, out.ctypes.data, ang.ctypes.data)
+        return out, ang
+
+    def probs(self) -> np.ndarray:
+        d = np.zeros(3, dtype=np.int32)
+        self.L.kref_probs_copy(self.h, d.ctypes.data, None)
+        out = np.zeros((d[1], d[2]))
+        self.L.kref_probs_copy(self.h, d.ctypes.data, out.ctypes.data)
+        return out[:, : d[0]]
+
+    def get_response(self, angle_index: int, grid_index: int) -> float:
+        return self.L.kref_get_response(self.h, angle_index, grid_index)
+
+    def point_readings(self, ranges, pose, filtered=False) -> np.ndarray:
+        r = np.ascontiguousarray(ranges, dtype=np.float64)
+        p = np.ascontiguousarray(pose, dtype=np.float64)
+        out = np.zeros((r.shape[0], 2))
+        n = self.L.kref_point_readings(self.h, r.shape[0], r.ctypes.data, p.ctypes.data,
+                                       int(filtered), out.ctypes.data)
+        return out[:n]
+
+    def find_valid_points(self, ranges, pose, viewpoint) -> np.ndarray:
+        r = np.ascontiguousarray(ranges, dtype=np.float64)
+        p = np.ascontiguousarray(pose, dtype=np.float64)
+        v = np.ascontiguousarray(viewpoint, dtype=np.float64)
+        out = np.zeros((r.shape[0], 2))
+        n = self.L.kref_find_valid_points(self.h, r.shape[0], r.ctypes.data, p.ctypes.data,
+                                          v.ctypes.data, out.ctypes.data)
+        return out[:n]
+
+    def process(self, ranges, odom_pose):
+        r = np.ascontiguousarray(ranges, dtype=np.float64)
+        p = np.ascontiguousarray(odom_pose, dtype=np.float64)
+        out = np.zeros(3)
+        rc = self.L.kref_process(self.h, r.shape[0], r.ctypes.data, p.ctypes.data, out.ctypes.data, None)
+        if rc < 0:
+            raise RuntimeError(self.L.kref_last_error(self.h).decode())
+        return bool(rc), out
+
+    def running_scans(self) -> int:
+        return self.L.kref_running_scans(self.h)
+
+    def occupancy_grid(self, resolution: float):
+        d = np.zeros(2, dtype=np.int32)
+        off = np.zeros(2)
+        if self.L.kref_occupancy_grid(self.h, resolution, d.ctypes.data, off.ctypes.data, None) != 0:
+            return None, None
+        out = np.zeros((d[1], d[0]), dtype=np.uint8)
+        self.L.kref_occupancy_grid(self.h, resolution, d.ctypes.data, off.ctypes.data, out.ctypes.data)
+        return out, off
+
+    def round(self, v: float) -> float:
+        return self.L.kref_round(v)
+
+
+class KorConfig(C.Structure):
+    _fields_ = [
+        ("search_size", C.c_double),
+        ("resolution", C.c_double),
+        ("smear_deviation", C.c_double),
+        ("range_threshold", C.c_double),
+        ("coarse_search_angle_offset", C.c_double),
+        ("coarse_angle_resolution", C.c_double),
+        ("fine_search_angle_offset", C.c_double),
+        ("distance_variance_penalty", C.c_double),
+        ("angle_variance_penalty", C.c_double),
+        ("minimum_distance_penalty", C.c_double),
+        ("minimum_angle_penalty", C.c_double),
+        ("use_response_expansion", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+def kor_config_from(cfg: KrefCfg, range_threshold: float) -> KorConfig:
+    return KorConfig(cfg.search_size, cfg.resolution, cfg.smear_deviation, range_threshold,
+                     cfg.coarse_angle_offset, cfg.coarse_angle_resolution, cfg.fine_angle_offset,
+                     cfg.distance_variance_penalty, cfg.angle_variance_penalty,
+                     cfg.minimum_distance_penalty, cfg.minimum_angle_penalty,
+                     cfg.use_response_expansion, 0)
+
+
+class PortKarto:
+    """oracle/karto_oracle.c (plain-C restatement) -- sensor poses in, sensor poses out."""
+
+    def __init__(self, cfg: KrefCfg, laser: KrefLaser):
+        path = HERE / "libkarto_oracle.so"
+        if not path.exists():
+            build("libkarto_oracle.so")
+        L = C.CDLL(str(path))
+        vp = C.c_void_p
+        L.kor_create.restype = vp
+        L.kor_create.argtypes = [C.POINTER(KorConfig), C.POINTER(KrefLaser)]
+        L.kor_destroy.argtypes = [vp]
+        L.kor_num_beams.argtypes = [vp]
+        L.kor_grid_info.argtypes = [vp, vp, vp]
+        L.kor_grid_data.restype = vp
+        L.kor_grid_data.argtypes = [vp]
+        L.kor_kernel_data.restype = vp
+        L.kor_kernel_data.argtypes = [vp]
+        L.kor_sensor_pose_from_robot.argtypes = [vp, vp, vp]
+        L.kor_robot_pose_from_sensor.argtypes = [vp, vp, vp]
+        L.kor_point_readings.argtypes = [vp, vp, vp, vp]
+        L.kor_find_valid_points.argtypes = [vp, C.c_int, vp, vp]
+        L.kor_set_base_scans.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
+        L.kor_set_grid.argtypes = [vp, vp, vp]
+        L.kor_compute_offsets.argtypes = [vp, vp, vp, C.c_double, C.c_double, C.c_double, vp]
+        L.kor_response_sum.restype = C.c_int64
+        L.kor_response_sum.argtypes = [vp, vp, C.c_int32]
+        L.kor_correlate_scan.restype = C.c_double
+        L.kor_correlate_scan.argtypes = [vp, vp, vp, vp] + [C.c_double] * 6 + [C.c_int, C.c_int, vp, vp, vp, vp]
+        L.kor_match.restype = C.c_double
+        L.kor_match.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+        L.kor_match_scan.restype = C.c_double
+        L.kor_match_scan.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+        L.kor_probs.argtypes = [vp, vp]
+        L.kor_frontend_create.restype = vp
+        L.kor_frontend_create.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double]
+        L.kor_frontend_destroy.argtypes = [vp]
+        L.kor_frontend_process.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.kor_frontend_running_scans.argtypes = [vp]
+        self.L = L
+        self.cfg = cfg
+        kc = kor_config_from(cfg, laser.range_threshold)
+        self.h = L.kor_create(C.byref(kc), C.byref(laser))
+        if not self.h:
+            raise ValueError("kor_create: invalid parameters (ScanMatcher::Create -> NULL)")
+        self.fe = None
+
+    def close(self):
+        if getattr(self, "fe", None):
+            self.L.kor_frontend_destroy(self.fe)
+            self.fe = None
+        if getattr(self, "h", None):
+            self.L.kor_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_beams(self) -> int:
+        return self.L.kor_num_beams(self.h)
+
+    def grid_info(self):
+        i = np.zeros(8, dtype=np.int32)
+        off = np.zeros(2)
+        self.L.kor_grid_info(self.h, i.ctypes.data, off.ctypes.data)
+        keys = ("width", "height", "stride", "roi_x", "roi_y", "roi_w", "roi_h", "kernel_size")
+        d = {k: int(v) for k, v in zip(keys, i)}
+        d["offset"] = off
+        return d
+
+    def grid(self) -> np.ndarray:
+        gi = self.grid_info()
+        n = gi["height"] * gi["stride"]
+        buf = (C.c_uint8 * n).from_address(self.L.kor_grid_data(self.h))
+        return np.frombuffer(buf, dtype=np.uint8).reshape(gi["height"], gi["stride"]).copy()
+
+    def kernel(self) -> np.ndarray:
+        k = self.grid_info()["kernel_size"]
+        buf = (C.c_uint8 * (k * k)).from_address(self.L.kor_kernel_data(self.h))
+        return np.frombuffer(buf, dtype=np.uint8).reshape(k, k).copy()
+
+    def sensor_pose_from_robot(self, robot):
+        r = np.ascontiguousarray(robot, dtype=np.float64)
+        out = np.zeros(3)
+        self.L.kor_sensor_pose_from_robot(self.h, r.ctypes.data, out.ctypes.data)
+        return out
+
+    def robot_pose_from_sensor(self, sensor):
+        s = np.ascontiguousarray(sensor, dtype=np.float64)
+        out = np.zeros(3)
+        self.L.kor_robot_pose_from_sensor(self.h, s.ctypes.data, out.ctypes.data)
+        return out
+
+    def point_readings(self, ranges, sensor_pose) -> np.ndarray:
+        r = np.ascontiguousarray(ranges, dtype=np.float64)
+        p = np.ascontiguousarray(sensor_pose, dtype=np.float64)
+        out = np.zeros((self.num_beams, 2))
+        self.L.kor_point_readings(self.h, r.ctypes.data, p.ctypes.data, out.ctypes.data)
+        return out
+
+    def find_valid_points(self, pts, viewpoint) -> np.ndarray:
+        p = np.ascontiguousarray(pts, dtype=np.float64)
+        v = np.ascontiguousarray(viewpoint, dtype=np.float64)
+        out = np.zeros_like(p)
+        n = self.L.kor_find_valid_points(p.ctypes.data, p.shape[0], v.ctypes.data, out.ctypes.data)
+        return out[:n]
+
+    def set_base_scans(self, ranges, sensor_poses, center_pose):
+        r = np.ascontiguousarray(ranges, dtype=np.float64)
+        p = np.ascontiguousarray(sensor_poses, dtype=np.float64)
+        c = np.ascontiguousarray(center_pose, dtype=np.float64)
+        self.L.kor_set_base_scans(self.h, r.shape[0], r.ctypes.data, r.shape[1], p.ctypes.data, c.ctypes.data)
+
+    def set_grid(self, grid, offset):
+        g = np.ascontiguousarray(grid, dtype=np.uint8)
+        o = np.ascontiguousarray(offset, dtype=np.float64)
+        self.L.kor_set_grid(self.h, g.ctypes.data, o.ctypes.data)
+
+    def compute_offsets(self, ranges, sensor_pose, angle_center, angle_offset, angle_resolution):
+        r = np.ascontiguousarray(ranges, dtype=np.float64)
+        p = np.ascontiguousarray(sensor_pose, dtype=np.float64)
+        na = self.L.kor_compute_offsets(self.h, r.ctypes.data, p.ctypes.data, angle_center,
+                                        angle_offset, angle_resolution, None)
+        out = np.zeros((na, self.num_beams), dtype=np.int32)
+        self.L.kor_compute_offsets(self.h, r.ctypes.data, p.ctypes.data, angle_center, angle_offset,
+                                   angle_resolution, out.ctypes.data)
+        return out
+
+    def response_sum(self, table_row, pos) -> int:
+        t = np.ascontiguousarray(table_row, dtype=np.int32)
+        return self.L.kor_response_sum(self.h, t.ctypes.data, int(pos))
+
+    def correlate_scan(self, ranges, sensor_pose, center, off, res, ang_off, ang_res, do_penalize,
+                       doing_fine, want_sums=False):
+        r = np.ascontiguousarray(ranges, dtype=np.float64)
+        p = np.ascontiguousarray(sensor_pose, dtype=np.float64)
+        c = np.ascontiguousarray(center, dtype=np.float64)
+        mean, cov, st = np.zeros(3), np.zeros(9), C.c_int()
+        sums = None
+        if want_sums:
+            nx = int(np.floor(off * 2.0 / res + 0.5) + 1)
+            na = int(np.floor(ang_off * 2.0 / ang_res + 0.5) + 1)
+            sums = np.zeros((nx, nx, na), dtype=np.int32)
+        resp = self.L.kor_correlate_scan(self.h, r.ctypes.data, p.ctypes.data, c.ctypes.data, off, off,
+                                         res, res, ang_off, ang_res, int(do_penalize), int(doing_fine),
+                                         mean.ctypes.data, cov.ctypes.data,
+                                         sums.ctypes.data if sums is not None else None, C.byref(st))
+        return resp, mean, cov.reshape(3, 3), st.value, sums
+
+    def match(self, ranges, sensor_pose, do_penalize=True, do_refine=True):
+        r = np.ascontiguousarray(ranges, dtype=np.float64)
+        p = np.ascontiguousarray(sensor_pose, dtype=np.float64)
+        mean, cov, st = np.zeros(3), np.zeros(9), C.c_int()
+        resp = self.L.kor_match(self.h, r.ctypes.data, p.ctypes.data, int(do_penalize), int(do_refine),
+                                mean.ctypes.data, cov.ctypes.data, C.byref(st))
+        if st.value:
+            raise RuntimeError(f"kor_match status {st.value}")
+        return mean, cov.reshape(3, 3), resp
+
+    def match_scan(self, base_ranges, base_poses, q_ranges, q_pose, do_penalize=True, do_refine=True):
+        br = np.ascontiguousarray(base_ranges, dtype=np.float64)
+        bp = np.ascontiguousarray(base_poses, dtype=np.float64)
+        qr = np.ascontiguousarray(q_ranges, dtype=np.float64)
+        qp = np.ascontiguousarray(q_pose, dtype=np.float64)
+        mean, cov, st = np.zeros(3), np.zeros(9), C.c_int()
+        resp = self.L.kor_match_scan(self.h, br.shape[0], br.ctypes.data, br.shape[1] if br.ndim == 2 else 0,
+                                     bp.ctypes.data, qr.ctypes.data, qp.ctypes.data, int(do_penalize),
+                                     int(do_refine), mean.ctypes.data, cov.ctypes.data, C.byref(st))
+        if st.value:
+            raise RuntimeError(f"kor_match_scan status {st.value}")
+        return mean, cov.reshape(3, 3), resp
+
+    def probs(self) -> np.ndarray:
+        side = int(np.floor(self.cfg.search_size / self.cfg.resolution + 0.5) + 1)
+        out = np.zeros((side, side))
+        self.L.kor_probs(self.h, out.ctypes.data)
+        return out
+
+    # streaming front-end
+    def frontend(self):
+        c = self.cfg
+        self.fe = self.L.kor_frontend_create(self.h, c.scan_buffer_size, c.scan_buffer_max_scan_distance,
+                                             c.minimum_travel_distance, c.minimum_travel_heading)
+
+    def process(self, ranges, odom_pose):
+        r = np.ascontiguousarray(ranges, dtype=np.float64)
+        p = np.ascontiguousarray(odom_pose, dtype=np.float64)
+        out, cov, resp = np.zeros(3), np.zeros(9), C.c_double()
+        rc = self.L.kor_frontend_process(self.fe, r.ctypes.data, p.ctypes.data, out.ctypes.data,
+                                         cov.ctypes.data, C.byref(resp))
+        if rc < 0:
+            raise RuntimeError(f"kor_frontend_process status {rc}")
+        return bool(rc), out, cov.reshape(3, 3), resp.value
+
+    def running_scans(self) -> int:
+        return self.L.kor_frontend_running_scans(self.fe)
