@@ -1,0 +1,486 @@
+"""ctypes host binding of liblslam_gpu.so (include/lslam_gpu.h).
+
+Python is only the harness language of this repo (tests, bench); the classes mirror the
+reference's operator interface for the hot path so the parity tests read like calls into the
+reference:
+
+* ``ScanMatcher``  <-> karto::ScanMatcher      (Mapper.h:1127-1279): Create / MatchScan /
+  CorrelateScan-level batched search / GetCorrelationGrid
+* ``OccGridMap``   <-> hectorslam::OccGridMapBase + MapRepMultiMap (H/map/OccGridMapBase.h,
+  H/slam_main/MapRepMultiMap.h): updateByScan / updateByScanJustOnce / getGridMap
+
+There is NO CPU fallback here: if the shared library or a GPU is missing, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import math
+
+import numpy as np
+
+from . import build as _build
+
+LSLAM_OK = 0
+ERRORS = {
+    -1: "LSLAM_ERR_INVALID_ARGUMENT",
+    -2: "LSLAM_ERR_NO_DEVICE",
+    -3: "LSLAM_ERR_INDEX_OUT_OF_RANGE",
+    -4: "LSLAM_ERR_PROBABILITY_SEARCH",
+    -5: "LSLAM_ERR_NO_BEST_POSE",
+    -6: "LSLAM_ERR_HIP",
+    -7: "LSLAM_ERR_SMEAR_DEVIATION",
+    -8: "LSLAM_ERR_UNSUPPORTED",
+}
+
+
+class LslamError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class MatcherConfig(C.Structure):
+    """lslam_matcher_config (ScanMatcher::Create args + the Mapper parameters the matcher reads)."""
+
+    _fields_ = [
+        ("search_size", C.c_double),
+        ("resolution", C.c_double),
+        ("smear_deviation", C.c_double),
+        ("range_threshold", C.c_double),
+        ("coarse_search_angle_offset", C.c_double),
+        ("coarse_angle_resolution", C.c_double),
+        ("fine_search_angle_offset", C.c_double),
+        ("distance_variance_penalty", C.c_double),
+        ("angle_variance_penalty", C.c_double),
+        ("minimum_distance_penalty", C.c_double),
+        ("minimum_angle_penalty", C.c_double),
+        ("use_response_expansion", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class LaserParams(C.Structure):
+    """lslam_laser (karto::LaserRangeFinder parameters)."""
+
+    _fields_ = [
+        ("minimum_angle", C.c_double),
+        ("maximum_angle", C.c_double),
+        ("angular_resolution", C.c_double),
+        ("minimum_range", C.c_double),
+        ("maximum_range", C.c_double),
+        ("range_threshold", C.c_double),
+        ("offset_x", C.c_double),
+        ("offset_y", C.c_double),
+        ("offset_heading", C.c_double),
+    ]
+
+
+class MatchResult(C.Structure):
+    _fields_ = [
+        ("pose", C.c_double * 3),
+        ("response", C.c_double),
+        ("covariance", C.c_double * 9),
+        ("status", C.c_int32),
+        ("flags", C.c_int32),
+    ]
+
+
+RESULT_DTYPE = np.dtype(
+    [("pose", "f8", 3), ("response", "f8"), ("covariance", "f8", (3, 3)), ("status", "i4"), ("flags", "i4")]
+)
+assert RESULT_DTYPE.itemsize == 112 == C.sizeof(MatchResult)
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("total_ms", C.c_double)]
+
+
+def baseline_config(**kw) -> MatcherConfig:
+    """BASELINE.json cfg 3/4: 0.05 m cells, +-0.5 m / +-20 deg window, 2005x2005 grid."""
+    d = dict(
+        search_size=1.0,
+        resolution=0.05,
+        smear_deviation=0.03,
+        range_threshold=49.5,
+        coarse_search_angle_offset=0.349,
+        coarse_angle_resolution=0.0349,
+        fine_search_angle_offset=0.00349,
+        distance_variance_penalty=0.3 * 0.3,
+        angle_variance_penalty=math.radians(20.0) ** 2,
+        minimum_distance_penalty=0.5,
+        minimum_angle_penalty=0.9,
+        use_response_expansion=0,
+        reserved=0,
+    )
+    d.update(kw)
+    return MatcherConfig(**d)
+
+
+def laser_params(laser, range_threshold: float = 49.5, offset=(0.0, 0.0, 0.0)) -> LaserParams:
+    """From a synth.Laser (LaserScan header fields, karto_slam.cc:384-395)."""
+    return LaserParams(laser.angle_min, laser.angle_max, laser.angle_increment, laser.range_min,
+                       laser.range_max, range_threshold, *offset)
+
+
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    """Load (building if needed) liblslam_gpu.so and declare the prototypes."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.build_library()
+    L = C.CDLL(str(path))
+    vp, i32, dbl = C.c_void_p, C.c_int, C.c_double
+    L.lslam_abi_version.restype = i32
+    L.lslam_create.argtypes = [i32, C.POINTER(vp)]
+    L.lslam_destroy.argtypes = [vp]
+    L.lslam_last_error.restype = C.c_char_p
+    L.lslam_last_error.argtypes = [vp]
+    L.lslam_synchronize.argtypes = [vp]
+    L.lslam_stream.restype = vp
+    L.lslam_stream.argtypes = [vp]
+    L.lslam_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.lslam_dev_free.argtypes = [vp, vp]
+    L.lslam_dev_upload.argtypes = [vp, vp, vp, C.c_size_t]
+    L.lslam_dev_download.argtypes = [vp, vp, vp, C.c_size_t]
+    L.lslam_profile_enable.argtypes = [vp, i32]
+    L.lslam_profile_reset.argtypes = [vp]
+    L.lslam_profile_read.argtypes = [vp, vp, i32]
+    L.lslam_matcher_config_defaults.argtypes = [C.POINTER(MatcherConfig)]
+    L.lslam_matcher_config_defaults.restype = None
+    L.lslam_matcher_create.argtypes = [vp, C.POINTER(MatcherConfig), C.POINTER(LaserParams), C.POINTER(vp)]
+    L.lslam_matcher_destroy.argtypes = [vp]
+    L.lslam_matcher_destroy.restype = None
+    L.lslam_matcher_num_beams.argtypes = [vp]
+    L.lslam_matcher_grid_info.argtypes = [vp, vp, vp]
+    L.lslam_matcher_get_grid_u8.argtypes = [vp, vp]
+    L.lslam_matcher_get_kernel_u8.argtypes = [vp, vp]
+    L.lslam_matcher_set_grid_u8.argtypes = [vp, vp, vp]
+    L.lslam_matcher_set_grid_u8_dev.argtypes = [vp, vp, vp]
+    L.lslam_matcher_grid_dev_ptr.restype = vp
+    L.lslam_matcher_grid_dev_ptr.argtypes = [vp]
+    L.lslam_sensor_pose_from_robot.argtypes = [C.POINTER(LaserParams), vp, vp]
+    L.lslam_sensor_pose_from_robot.restype = None
+    L.lslam_robot_pose_from_sensor.argtypes = [C.POINTER(LaserParams), vp, vp]
+    L.lslam_robot_pose_from_sensor.restype = None
+    L.lslam_matcher_set_base_scans.argtypes = [vp, i32, vp, i32, vp, vp]
+    L.lslam_matcher_match_scan.argtypes = [vp, i32, vp, i32, vp, vp, vp, i32, i32, vp]
+    L.lslam_matcher_match_batch.argtypes = [vp, i32, vp, i32, vp, i32, i32, vp]
+    L.lslam_matcher_match_batch_dev_f32.argtypes = [vp, i32, vp, i32, vp, i32, i32, vp]
+    L.lslam_matcher_match_batch_dev_f64.argtypes = [vp, i32, vp, i32, vp, i32, i32, vp]
+    L.lslam_matcher_debug_lookup_table.argtypes = [vp, vp, vp, dbl, dbl, dbl, vp, C.POINTER(i32)]
+    L.lslam_matcher_debug_coarse_sums.argtypes = [vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32),
+                                                  C.POINTER(i32), i32]
+    L.lslam_matcher_debug_valid_mask.argtypes = [vp, vp, vp, vp, vp]
+    L.lslam_map_create.argtypes = [vp, i32, i32, C.c_float, C.c_float, C.c_float, i32, C.POINTER(vp)]
+    L.lslam_map_destroy.argtypes = [vp]
+    L.lslam_map_destroy.restype = None
+    L.lslam_map_reset.argtypes = [vp]
+    L.lslam_map_set_update_factor_free.argtypes = [vp, C.c_float]
+    L.lslam_map_set_update_factor_occupied.argtypes = [vp, C.c_float]
+    L.lslam_map_levels.argtypes = [vp]
+    L.lslam_map_size.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.lslam_map_scale_to_map.restype = C.c_float
+    L.lslam_map_scale_to_map.argtypes = [vp, i32]
+    L.lslam_map_update_by_scan.argtypes = [vp, vp, i32, vp, vp]
+    L.lslam_map_update_by_scan_dev.argtypes = [vp, vp, i32, vp, vp]
+    L.lslam_map_update_just_once.argtypes = [vp, vp, i32, vp, C.c_float, C.c_float, dbl]
+    L.lslam_map_read_logodds.argtypes = [vp, i32, vp]
+    L.lslam_map_read_occupancy_i8.argtypes = [vp, i32, vp]
+    L.lslam_map_cells_dev_ptr.restype = vp
+    L.lslam_map_cells_dev_ptr.argtypes = [vp, i32]
+    _LIB = L
+    return L
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Context:
+    """lslam_context: one GPU, one HIP stream."""
+
+    def __init__(self, device: int = 0):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.lslam_create(device, C.byref(h))
+        if rc != LSLAM_OK:
+            raise LslamError(rc, self.L.lslam_last_error(None).decode())
+        self.h = h
+        self.device = device
+
+    def check(self, rc: int):
+        if rc != LSLAM_OK:
+            raise LslamError(rc, self.L.lslam_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lslam_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self.check(self.L.lslam_synchronize(self.h))
+
+    @property
+    def stream(self) -> int:
+        return self.L.lslam_stream(self.h)
+
+    # raw HBM helpers (bench/tests); torch tensors' data_ptr() work just as well
+    def alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self.check(self.L.lslam_dev_alloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, ptr: int):
+        self.check(self.L.lslam_dev_free(self.h, ptr))
+
+    def upload(self, ptr: int, arr: np.ndarray):
+        a = np.ascontiguousarray(arr)
+        self.check(self.L.lslam_dev_upload(self.h, ptr, a.ctypes.data, a.nbytes))
+
+    def download(self, ptr: int, arr: np.ndarray):
+        assert arr.flags["C_CONTIGUOUS"]
+        self.check(self.L.lslam_dev_download(self.h, arr.ctypes.data, ptr, arr.nbytes))
+
+    def profile(self, on: bool):
+        self.check(self.L.lslam_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self.check(self.L.lslam_profile_reset(self.h))
+
+    def profile_read(self) -> dict:
+        buf = (KernelTime * 64)()
+        n = self.L.lslam_profile_read(self.h, buf, 64)
+        return {buf[i].name.decode(): (int(buf[i].launches), float(buf[i].total_ms)) for i in range(n)}
+
+
+class ScanMatcher:
+    """karto::ScanMatcher on the GPU.  Poses are SENSOR poses (x, y, heading)."""
+
+    def __init__(self, ctx: Context, cfg: MatcherConfig, laser: LaserParams):
+        self.ctx, self.L, self.cfg, self.laser = ctx, ctx.L, cfg, laser
+        h = C.c_void_p()
+        ctx.check(self.L.lslam_matcher_create(ctx.h, C.byref(cfg), C.byref(laser), C.byref(h)))
+        self.h = h
+
+    # reference spelling
+    @classmethod
+    def Create(cls, ctx, cfg, laser):
+        """ScanMatcher::Create: returns None where the reference returns NULL."""
+        try:
+            return cls(ctx, cfg, laser)
+        except LslamError as e:
+            if e.code == -1:
+                return None
+            raise
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lslam_matcher_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_beams(self) -> int:
+        return self.L.lslam_matcher_num_beams(self.h)
+
+    def grid_info(self) -> dict:
+        i = np.zeros(8, dtype=np.int32)
+        off = np.zeros(2)
+        self.ctx.check(self.L.lslam_matcher_grid_info(self.h, i.ctypes.data, off.ctypes.data))
+        keys = ("width", "height", "stride", "roi_x", "roi_y", "roi_w", "roi_h", "kernel_size")
+        d = {k: int(v) for k, v in zip(keys, i)}
+        d["offset"] = off
+        return d
+
+    def GetCorrelationGrid(self) -> np.ndarray:
+        gi = self.grid_info()
+        out = np.zeros((gi["height"], gi["stride"]), dtype=np.uint8)
+        self.ctx.check(self.L.lslam_matcher_get_grid_u8(self.h, out.ctypes.data))
+        return out
+
+    def kernel(self) -> np.ndarray:
+        k = self.grid_info()["kernel_size"]
+        out = np.zeros((k, k), dtype=np.uint8)
+        self.ctx.check(self.L.lslam_matcher_get_kernel_u8(self.h, out.ctypes.data))
+        return out
+
+    def set_grid(self, grid: np.ndarray, offset):
+        g = np.ascontiguousarray(grid, dtype=np.uint8)
+        gi = self.grid_info()
+        assert g.size == gi["height"] * gi["stride"]
+        o = _f64(offset)
+        self.ctx.check(self.L.lslam_matcher_set_grid_u8(self.h, g.ctypes.data, o.ctypes.data))
+
+    def set_grid_dev(self, ptr: int, offset):
+        o = _f64(offset)
+        self.ctx.check(self.L.lslam_matcher_set_grid_u8_dev(self.h, ptr, o.ctypes.data))
+
+    @property
+    def grid_dev_ptr(self) -> int:
+        return self.L.lslam_matcher_grid_dev_ptr(self.h)
+
+    def sensor_pose_from_robot(self, robot):
+        r, out = _f64(robot), np.zeros(3)
+        self.L.lslam_sensor_pose_from_robot(C.byref(self.laser), r.ctypes.data, out.ctypes.data)
+        return out
+
+    def robot_pose_from_sensor(self, sensor):
+        s, out = _f64(sensor), np.zeros(3)
+        self.L.lslam_robot_pose_from_sensor(C.byref(self.laser), s.ctypes.data, out.ctypes.data)
+        return out
+
+    def AddScans(self, base_ranges, base_sensor_poses, center_pose):
+        """MatchScan steps 1-4 + AddScans: rebuild the grid around center_pose."""
+        r, p, c = _f64(base_ranges), _f64(base_sensor_poses), _f64(center_pose)
+        r = r.reshape(-1, r.shape[-1]) if r.size else r.reshape(0, max(self.num_beams, 1))
+        self.ctx.check(self.L.lslam_matcher_set_base_scans(self.h, r.shape[0], r.ctypes.data, r.shape[1],
+                                                           p.ctypes.data, c.ctypes.data))
+
+    def MatchScan(self, query_ranges, query_sensor_pose, base_ranges, base_sensor_poses,
+                  doPenalize: bool = True, doRefineMatch: bool = True):
+        """ScanMatcher::MatchScan -> (response, mean pose, covariance 3x3)."""
+        q, qp = _f64(query_ranges), _f64(query_sensor_pose)
+        r, p = _f64(base_ranges), _f64(base_sensor_poses)
+        r = r.reshape(-1, r.shape[-1]) if r.size else r.reshape(0, max(self.num_beams, 1))
+        res = np.zeros(1, dtype=RESULT_DTYPE)
+        self.ctx.check(self.L.lslam_matcher_match_scan(self.h, r.shape[0], r.ctypes.data, r.shape[1], p.ctypes.data,
+                                                       q.ctypes.data, qp.ctypes.data, int(doPenalize),
+                                                       int(doRefineMatch), res.ctypes.data))
+        if res["status"][0] != 0:
+            raise LslamError(int(res["status"][0]), "the reference would have thrown here")
+        return float(res["response"][0]), res["pose"][0].copy(), res["covariance"][0].copy()
+
+    def match_batch(self, ranges, sensor_poses, doPenalize: bool = True, doRefineMatch: bool = True) -> np.ndarray:
+        """Coarse+fine search of S independent scans against the CURRENT grid (host arrays)."""
+        r, p = _f64(ranges), _f64(sensor_poses)
+        r = r.reshape(-1, r.shape[-1])
+        res = np.zeros(r.shape[0], dtype=RESULT_DTYPE)
+        self.ctx.check(self.L.lslam_matcher_match_batch(self.h, r.shape[0], r.ctypes.data, r.shape[1], p.ctypes.data,
+                                                        int(doPenalize), int(doRefineMatch), res.ctypes.data))
+        return res
+
+    def match_batch_dev(self, n_scans: int, ranges_ptr: int, stride: int, poses_ptr: int, out_ptr: int,
+                        dtype="f32", doPenalize: bool = True, doRefineMatch: bool = True):
+        """Same with float32/float64 ranges, poses and results resident in HBM; asynchronous."""
+        fn = self.L.lslam_matcher_match_batch_dev_f32 if dtype == "f32" else self.L.lslam_matcher_match_batch_dev_f64
+        self.ctx.check(fn(self.h, n_scans, ranges_ptr, stride, poses_ptr, int(doPenalize), int(doRefineMatch), out_ptr))
+
+    # inspection hooks (parity tests)
+    def lookup_table(self, ranges, sensor_pose, angle_center, angle_offset, angle_resolution) -> np.ndarray:
+        r, p = _f64(ranges), _f64(sensor_pose)
+        na = C.c_int()
+        self.ctx.check(self.L.lslam_matcher_debug_lookup_table(self.h, r.ctypes.data, p.ctypes.data, angle_center,
+                                                               angle_offset, angle_resolution, None, C.byref(na)))
+        out = np.zeros((na.value, self.num_beams), dtype=np.int32)
+        self.ctx.check(self.L.lslam_matcher_debug_lookup_table(self.h, r.ctypes.data, p.ctypes.data, angle_center,
+                                                               angle_offset, angle_resolution, out.ctypes.data,
+                                                               C.byref(na)))
+        return out
+
+    def coarse_sums(self, ranges, sensor_pose, force_generic: bool = False) -> np.ndarray:
+        r, p = _f64(ranges), _f64(sensor_pose)
+        nx, ny, na = C.c_int(), C.c_int(), C.c_int()
+        self.ctx.check(self.L.lslam_matcher_debug_coarse_sums(self.h, r.ctypes.data, p.ctypes.data, None,
+                                                              C.byref(nx), C.byref(ny), C.byref(na), 0))
+        out = np.zeros((ny.value, nx.value, na.value), dtype=np.int32)
+        self.ctx.check(self.L.lslam_matcher_debug_coarse_sums(self.h, r.ctypes.data, p.ctypes.data, out.ctypes.data,
+                                                              C.byref(nx), C.byref(ny), C.byref(na),
+                                                              int(force_generic)))
+        return out
+
+    def valid_mask(self, ranges, sensor_pose, viewpoint) -> np.ndarray:
+        r, p, v = _f64(ranges), _f64(sensor_pose), _f64(viewpoint)
+        out = np.zeros(self.num_beams, dtype=np.uint8)
+        self.ctx.check(self.L.lslam_matcher_debug_valid_mask(self.h, r.ctypes.data, p.ctypes.data, v.ctypes.data,
+                                                             out.ctypes.data))
+        return out
+
+
+class OccGridMap:
+    """hectorslam log-odds occupancy grid pyramid on the GPU (OccGridMapBase / MapRepMultiMap)."""
+
+    def __init__(self, ctx: Context, size_x: int, size_y: int, cell_length: float, offset=(0.0, 0.0),
+                 levels: int = 1):
+        self.ctx, self.L = ctx, ctx.L
+        h = C.c_void_p()
+        ctx.check(self.L.lslam_map_create(ctx.h, size_x, size_y, cell_length, offset[0], offset[1], levels, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lslam_map_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.ctx.check(self.L.lslam_map_reset(self.h))
+
+    def setUpdateFreeFactor(self, p: float):
+        self.ctx.check(self.L.lslam_map_set_update_factor_free(self.h, p))
+
+    def setUpdateOccupiedFactor(self, p: float):
+        self.ctx.check(self.L.lslam_map_set_update_factor_occupied(self.h, p))
+
+    @property
+    def levels(self) -> int:
+        return self.L.lslam_map_levels(self.h)
+
+    def size(self, level: int = 0):
+        sx, sy = C.c_int(), C.c_int()
+        self.ctx.check(self.L.lslam_map_size(self.h, level, C.byref(sx), C.byref(sy)))
+        return sx.value, sy.value
+
+    def getScaleToMap(self, level: int = 0) -> float:
+        return self.L.lslam_map_scale_to_map(self.h, level)
+
+    def updateByScan(self, points_xy, origo_xy, robot_pose_world):
+        p = np.ascontiguousarray(points_xy, dtype=np.float32).reshape(-1, 2)
+        o = np.ascontiguousarray(origo_xy, dtype=np.float32)
+        w = np.ascontiguousarray(robot_pose_world, dtype=np.float32)
+        self.ctx.check(self.L.lslam_map_update_by_scan(self.h, p.ctypes.data, p.shape[0], o.ctypes.data, w.ctypes.data))
+
+    def updateByScan_dev(self, points_ptr: int, n: int, origo_xy, robot_pose_world):
+        o = np.ascontiguousarray(origo_xy, dtype=np.float32)
+        w = np.ascontiguousarray(robot_pose_world, dtype=np.float32)
+        self.ctx.check(self.L.lslam_map_update_by_scan_dev(self.h, points_ptr, n, o.ctypes.data, w.ctypes.data))
+
+    def updateByScanJustOnce(self, points_xy_m, origo_xy=(0.0, 0.0), begin=(800.0, 800.0), metres_per_cell=0.05):
+        p = np.ascontiguousarray(points_xy_m, dtype=np.float32).reshape(-1, 2)
+        o = np.ascontiguousarray(origo_xy, dtype=np.float32)
+        self.ctx.check(self.L.lslam_map_update_just_once(self.h, p.ctypes.data, p.shape[0], o.ctypes.data,
+                                                         begin[0], begin[1], metres_per_cell))
+
+    def logodds(self, level: int = 0) -> np.ndarray:
+        sx, sy = self.size(level)
+        out = np.zeros((sy, sx), dtype=np.float32)
+        self.ctx.check(self.L.lslam_map_read_logodds(self.h, level, out.ctypes.data))
+        return out
+
+    def occupancy_i8(self, level: int = 0) -> np.ndarray:
+        sx, sy = self.size(level)
+        out = np.zeros((sy, sx), dtype=np.int8)
+        self.ctx.check(self.L.lslam_map_read_occupancy_i8(self.h, level, out.ctypes.data))
+        return out
+
+    def cells_dev_ptr(self, level: int = 0) -> int:
+        return self.L.lslam_map_cells_dev_ptr(self.h, level)

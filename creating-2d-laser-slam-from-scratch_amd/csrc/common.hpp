@@ -1,0 +1,132 @@
+// Shared host-side plumbing of liblslam_gpu.so: context, error reporting, device buffers,
+// HIP-event kernel timing.  gfx950 only, no compatibility layers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/lslam_gpu.h"
+
+namespace lslam {
+
+extern thread_local std::string g_last_error;
+
+struct KernelTimer {
+  struct Rec {
+    const char* name;
+    hipEvent_t e0, e1;
+  };
+  bool enabled = false;
+  std::vector<Rec> pending;
+  std::vector<hipEvent_t> pool;
+  std::map<std::string, std::pair<int64_t, double>> totals;  // name -> (launches, ms)
+
+  hipEvent_t get() {
+    if (!pool.empty()) {
+      hipEvent_t e = pool.back();
+      pool.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  // fold finished records into totals (synchronises on the last event)
+  void drain() {
+    for (auto& r : pending) {
+      (void)hipEventSynchronize(r.e1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+      auto& t = totals[r.name];
+      t.first += 1;
+      t.second += ms;
+      pool.push_back(r.e0);
+      pool.push_back(r.e1);
+    }
+    pending.clear();
+  }
+  ~KernelTimer() {
+    for (auto& r : pending) {
+      (void)hipEventDestroy(r.e0);
+      (void)hipEventDestroy(r.e1);
+    }
+    for (auto e : pool) (void)hipEventDestroy(e);
+  }
+};
+
+}  // namespace lslam
+
+struct lslam_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+  lslam::KernelTimer timer;
+  hipDeviceProp_t prop;
+
+  int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error = buf;
+    lslam::g_last_error = buf;
+    return code;
+  }
+};
+
+namespace lslam {
+
+#define LSLAM_HIP(ctx, expr)                                                                   \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return (ctx)->fail(LSLAM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                         __FILE__, __LINE__);                                                  \
+  } while (0)
+
+// Growable device buffer (never shrinks; sized for 288 GB of HBM, so we keep everything resident).
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;  // elements
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// Launch with optional HIP-event timing on the context stream.
+template <typename K, typename... Args>
+inline void launch(lslam_context* ctx, const char* name, K kernel, dim3 grid, dim3 block,
+                   size_t shmem, Args... args) {
+  if (ctx->timer.enabled) {
+    hipEvent_t e0 = ctx->timer.get(), e1 = ctx->timer.get();
+    (void)hipEventRecord(e0, ctx->stream);
+    hipLaunchKernelGGL(kernel, grid, block, shmem, ctx->stream, args...);
+    (void)hipEventRecord(e1, ctx->stream);
+    ctx->timer.pending.push_back({name, e0, e1});
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, shmem, ctx->stream, args...);
+  }
+}
+
+}  // namespace lslam

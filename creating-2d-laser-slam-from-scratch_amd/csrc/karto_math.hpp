@@ -1,0 +1,134 @@
+// Scalar fp64 building blocks of the correlative scan matcher, usable from host and device.
+// Everything here is bit-relevant: lattice cells and lookup-table indices are *rounded* values,
+// so the operation order follows the reference expression by expression and the translation
+// unit is built with -ffp-contract=off (no FMA contraction, like the reference's x86-64 build).
+// Citations: Math.h / Karto.h = lesson6/lib/open_karto/include/open_karto/...
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdint>
+
+namespace lslam {
+
+#define LSLAM_HD __host__ __device__ __forceinline__
+
+constexpr double kPi = 3.14159265358979323846;    // KT_PI    (Math.h:30)
+constexpr double k2Pi = 6.28318530717958647692;   // KT_2PI   (Math.h:31)
+constexpr double kPi180 = 0.01745329251994329577; // KT_PI_180 (Math.h:35)
+constexpr double kTol = 1e-06;                    // KT_TOLERANCE (Math.h:41)
+constexpr int32_t kInvalidScan = INT_MAX;         // INVALID_SCAN (Math.h:47)
+constexpr double kMaxVariance = 500.0;            // MAX_VARIANCE (Mapper.cpp:36)
+constexpr double kDistPenaltyGain = 0.2;          // Mapper.cpp:37
+constexpr double kAnglePenaltyGain = 0.2;         // Mapper.cpp:38
+constexpr int kOccupied = 100;                    // GridStates_Occupied (Karto.h:4196)
+
+// math::Round -- half away from zero (Math.h:87-90)
+LSLAM_HD double kround(double v) { return v >= 0.0 ? floor(v + 0.5) : ceil(v - 0.5); }
+LSLAM_HD double ksq(double v) { return v * v; }
+// math::DoubleEqual (Math.h:135-139)
+LSLAM_HD bool double_equal(double a, double b) {
+  double d = a - b;
+  return d < 0.0 ? d >= -kTol : d <= kTol;
+}
+// math::NormalizeAngle (Math.h:182-211)
+LSLAM_HD double normalize_angle(double angle) {
+  while (angle < -kPi) {
+    if (angle < -k2Pi)
+      angle += (uint32_t)(angle / -k2Pi) * k2Pi;
+    else
+      angle += k2Pi;
+  }
+  while (angle > kPi) {
+    if (angle > k2Pi)
+      angle -= (uint32_t)(angle / k2Pi) * k2Pi;
+    else
+      angle -= k2Pi;
+  }
+  return angle;
+}
+// math::NormalizeAngleDifference (Math.h:221-234)
+LSLAM_HD double normalize_angle_difference(double minuend, double subtrahend) {
+  while (minuend - subtrahend < -kPi) minuend += k2Pi;
+  while (minuend - subtrahend > kPi) minuend -= k2Pi;
+  return minuend;
+}
+// CoordinateConverter::WorldToGrid, one axis (Karto.h:4237-4252)
+LSLAM_HD int world_to_grid(double w, double offset, double scale) {
+  return (int)kround((w - offset) * scale);
+}
+// number of angles / lattice points: (kt_int32u)(Round(off*2/res)+1) (Mapper.cpp:339-361, Karto.h:6417)
+LSLAM_HD int lattice_count(double offset, double resolution) {
+  return (int)(uint32_t)(kround(offset * 2.0 / resolution) + 1);
+}
+
+// Rows 0,1 of Matrix3::FromAxisAngle(0,0,1,radians) (Karto.h:2392-2417), spelled out so the
+// zero terms are rounded exactly as the reference rounds them.
+struct Rot2 {
+  double m00, m01, m02, m10, m11, m12;
+};
+LSLAM_HD Rot2 rot_z(double radians) {
+  const double x = 0.0, y = 0.0, z = 1.0;
+  double c = cos(radians), s = sin(radians), omc = 1.0 - c;
+  double xyM = x * y * omc, xzM = x * z * omc, yzM = y * z * omc;
+  double xS = x * s, yS = y * s, zS = z * s;
+  Rot2 r;
+  r.m00 = x * x * omc + c;
+  r.m01 = xyM - zS;
+  r.m02 = xzM + yS;
+  r.m10 = xyM + zS;
+  r.m11 = y * y * omc + c;
+  r.m12 = yzM - xS;
+  return r;
+}
+LSLAM_HD Rot2 rot_identity() { return Rot2{1.0, 0.0, 0.0, 0.0, 1.0, 0.0}; }
+// Matrix3 * Pose2, rows x and y (Karto.h:2574-2583)
+LSLAM_HD void rot_apply(const Rot2& r, double x, double y, double h, double& ox, double& oy) {
+  ox = r.m00 * x + r.m01 * y + r.m02 * h;
+  oy = r.m10 * x + r.m11 * y + r.m12 * h;
+}
+
+// karto::Transform(Pose2) = SetTransform(origin, pose) (Karto.h:2860-2863,2909-2935)
+struct SensorXform {
+  Rot2 rot, inv;
+  double tx, ty, th;
+};
+LSLAM_HD SensorXform sensor_xform(double px, double py, double ph) {
+  SensorXform t;
+  if (px == 0.0 && py == 0.0 && ph == 0.0) {  // rPose1 == rPose2 (Karto.h:2911-2917)
+    t.rot = rot_identity();
+    t.inv = rot_identity();
+    t.tx = t.ty = t.th = 0.0;
+    return t;
+  }
+  t.rot = rot_z(ph - 0.0);
+  t.inv = rot_z(0.0 - ph);
+  t.tx = px;  // rPose1 is the origin -> newPosition = rPose2 (Karto.h:2929-2932)
+  t.ty = py;
+  t.th = ph - 0.0;
+  return t;
+}
+
+// One beam of LocalizedRangeScan::Update (Karto.h:5384-5388 == :5394-5398)
+LSLAM_HD void beam_world_point(double sx, double sy, double sh, double min_angle, double ang_res,
+                               uint32_t beam, double r, double& px, double& py) {
+  double angle = sh + min_angle + beam * ang_res;
+  px = sx + (r * cos(angle));
+  py = sy + (r * sin(angle));
+}
+
+// One lookup-table entry of GridIndexLookup::ComputeOffsets (Karto.h:6486-6496): local point
+// rotated by the candidate angle, WorldToGrid(offset + rGridOffset), base-class GridIndex
+// (no ROI, no bounds check).
+LSLAM_HD int32_t lookup_offset(double lx, double ly, double cosine, double sine, double off_x,
+                               double off_y, double scale, int stride) {
+  double ox = cosine * lx - sine * ly;
+  double oy = sine * lx + cosine * ly;
+  int gx = world_to_grid(ox + off_x, off_x, scale);
+  int gy = world_to_grid(oy + off_y, off_y, scale);
+  return gx + gy * stride;
+}
+
+}  // namespace lslam

@@ -1,0 +1,1257 @@
+// Karto-style correlative scan matcher on MI355X (gfx950): HIP kernels + C ABI.
+//
+// Reference behaviour being reproduced (never copied): karto::ScanMatcher
+// (lesson6/lib/open_karto/src/Mapper.cpp:126-856), karto::CorrelationGrid (Mapper.h:900-1118),
+// karto::GridIndexLookup (Karto.h:6359-6555).  See DESIGN.md for the data layout and the
+// roofline of each kernel.
+//
+// Device pipeline of one batch of S independent scans against the resident correlation grid:
+//   k_scan_prep      S*N threads   ranges -> scan-frame points (Karto.h:5384-5388, 6423-6434)
+//   k_pass_setup     S threads     lattice cell coordinates of the pass (Mapper.cpp:339-386)
+//   k_resp_lattice2  S*nA waves    ** hot kernel ** all nX*nY response sums of one (scan, angle)
+//                                  for a uniform 2-cell lattice (Mapper.cpp:373-424, 819-856)
+//   k_resp_generic   work list     same sums for arbitrary lattices (fine pass, fall-back)
+//   k_reduce_coarse  S blocks      penalties, max, tie average, positional covariance
+//   k_reduce_fine    S blocks      same + angular covariance (Mapper.cpp:431-506, 535-692)
+// Response numerators stay integers end to end (sum of uint8 <= 255*N); the fp64 part follows
+// the reference's expression order (built with -ffp-contract=off).
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+#include "karto_math.hpp"
+
+using namespace lslam;
+
+namespace {
+
+constexpr int kMaxLattice = 32;   // nX, nY per pass handled by the reduce kernels
+constexpr int kMaxAngles = 128;   // nA per pass
+constexpr int kMaxProbsSide = 63; // search-space probability grid side
+constexpr int kGuard = 256;       // zero bytes before/after the grid: unaligned row loads may overhang
+
+struct Geom {
+  int width, height, stride, border, roi_w, roi_h, data_size, kernel_size;
+  int n_beams, probs_side;
+  double scale;         // 1/resolution (Mapper.h:1020)
+  double off_x, off_y;  // CoordinateConverter offset of the correlation grid
+  double min_angle, ang_res;
+};
+
+struct PassCfg {
+  double off_x, off_y;  // rSearchSpaceOffset
+  double res_x, res_y;  // rSearchSpaceResolution
+  double ang_off, ang_res;
+  int nx, ny, na;
+  int mode;  // 0 coarse, 1 coarse expansion, 2 fine
+};
+
+struct SearchCfg {
+  double dvp, avp, min_dp, min_ap;
+  int do_penalize;
+};
+
+struct Lattice {  // per scan, per pass
+  double center[3];
+  int gx[kMaxLattice], gy[kMaxLattice];  // full-grid cell coordinates (ROI offset included)
+  int step_x, step_y;                    // uniform cell step, 0 if not uniform
+  int status, active;
+};
+
+struct CoarseOut {
+  double mean[3];
+  double cov[9];
+  double best;
+  int status;
+  int expand;  // response expansion requested for the next pass (Mapper.cpp:242-244)
+  int flags;
+  int pad;
+};
+
+// ------------------------------------------------------------------------------------------
+// k_scan_prep: ranges -> world point (LocalizedRangeScan::Update, Karto.h:5384-5388) -> point in
+// the scan frame (Transform::InverseTransformPose, Karto.h:6426-6434).  lx = NaN marks INVALID_SCAN
+// (reading NaN/Inf, Karto.h:6478-6483).  One thread per (scan, beam); coalesced.
+// ------------------------------------------------------------------------------------------
+template <typename RT>
+__global__ void __launch_bounds__(256)
+k_scan_prep(const RT* __restrict__ ranges, int stride, const double* __restrict__ poses, Geom g,
+            double2* __restrict__ local, double2* __restrict__ world) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  int s = blockIdx.y;
+  if (b >= g.n_beams) return;
+  double sx = poses[3 * s], sy = poses[3 * s + 1], sh = poses[3 * s + 2];
+  double r = (double)ranges[(size_t)s * stride + b];
+  double px, py;
+  beam_world_point(sx, sy, sh, g.min_angle, g.ang_res, (uint32_t)b, r, px, py);
+  size_t o = (size_t)s * g.n_beams + b;
+  if (world) world[o] = make_double2(px, py);
+  if (local) {
+    double lx, ly;
+    if (isnan(r) || isinf(r)) {
+      lx = ly = __builtin_nan("");
+    } else {
+      SensorXform t = sensor_xform(sx, sy, sh);
+      // rSourcePose - m_Transform (Pose2 operator-, Karto.h:2138-2141), heading = normalize(0 - th)
+      double h = normalize_angle(0.0 - t.th);
+      rot_apply(t.inv, px - t.tx, py - t.ty, h, lx, ly);
+    }
+    local[o] = make_double2(lx, ly);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pass_setup: candidate-lattice cell coordinates of one CorrelateScan pass
+// (Mapper.cpp:339-386): each lattice coordinate is rounded on its own, exactly like the reference
+// (the fine pass is centred on a possibly off-lattice tie average).
+// ------------------------------------------------------------------------------------------
+__global__ void k_pass_setup(int S, Geom g, PassCfg pc, const double* __restrict__ poses,
+                             const CoarseOut* __restrict__ coarse, Lattice* __restrict__ lat,
+                             int* __restrict__ slow_list, int* __restrict__ slow_count,
+                             int want_step) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  Lattice L;
+  L.status = 0;
+  L.active = 1;
+  if (pc.mode == 0) {
+    L.center[0] = poses[3 * s]; L.center[1] = poses[3 * s + 1]; L.center[2] = poses[3 * s + 2];
+  } else if (pc.mode == 1) {
+    L.center[0] = poses[3 * s]; L.center[1] = poses[3 * s + 1]; L.center[2] = poses[3 * s + 2];
+    L.active = coarse[s].expand && coarse[s].status == 0;
+  } else {
+    L.center[0] = coarse[s].mean[0]; L.center[1] = coarse[s].mean[1]; L.center[2] = coarse[s].mean[2];
+    L.active = coarse[s].status == 0;
+  }
+  double start_x = -pc.off_x, start_y = -pc.off_y;
+  for (int i = 0; i < kMaxLattice; i++) L.gx[i] = L.gy[i] = 0;
+  for (int i = 0; i < pc.nx; i++) {
+    double x = start_x + (uint32_t)i * pc.res_x;
+    double npx = L.center[0] + x;
+    int c = world_to_grid(npx, g.off_x, g.scale) + g.border;  // CorrelationGrid::GridIndex adds the ROI
+    if (c < 0 || c >= g.width) L.status = LSLAM_ERR_INDEX_OUT_OF_RANGE;
+    L.gx[i] = c;
+  }
+  for (int j = 0; j < pc.ny; j++) {
+    double y = start_y + (uint32_t)j * pc.res_y;
+    double npy = L.center[1] + y;
+    int c = world_to_grid(npy, g.off_y, g.scale) + g.border;
+    if (c < 0 || c >= g.height) L.status = LSLAM_ERR_INDEX_OUT_OF_RANGE;
+    L.gy[j] = c;
+  }
+  int stx = pc.nx > 1 ? L.gx[1] - L.gx[0] : want_step;
+  int sty = pc.ny > 1 ? L.gy[1] - L.gy[0] : want_step;
+  for (int i = 1; i < pc.nx; i++)
+    if (L.gx[i] - L.gx[i - 1] != stx) stx = 0;
+  for (int j = 1; j < pc.ny; j++)
+    if (L.gy[j] - L.gy[j - 1] != sty) sty = 0;
+  L.step_x = stx;
+  L.step_y = sty;
+  lat[s] = L;
+  // scans the fast lattice kernel cannot take go to the generic kernel's work list
+  if (slow_list && L.active && L.status == 0 && !(stx == want_step && sty == want_step)) {
+    int k = atomicAdd(slow_count, 1);
+    slow_list[k] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_resp_lattice2 -- THE HOT KERNEL.
+// One wave = one (scan, angle[, beam slice]).  Each lane owns beams lane, lane+64, ...; for a
+// beam it computes the lookup-table offset on the fly (no table round trip through HBM), then
+// reads the beam's whole candidate neighbourhood -- NY rows of 4*NXD bytes, the 2-cell lattice
+// lives on the even byte offsets of each row -- with unaligned dwordx4/x2 loads and accumulates
+// TWO candidates per VALU op in packed 16-bit fields (dword & 0x00FF00FF).  The per-lane packed
+// partials are transposed through LDS and reduced to the exact int32 response numerators.
+// No MFMA: this is a gather/compare path (byte gathers out of an L2-resident 4 MB grid).
+// Grid bounds: the reference skips a byte iff its FLAT index is outside [0,dataSize)
+// (Mapper.cpp:841-845); zero guard bands around the grid make partially overhanging rows exact.
+// ------------------------------------------------------------------------------------------
+template <int NXD, int NYC>
+__global__ void __launch_bounds__(64)
+k_resp_lattice2(const uint8_t* __restrict__ grid, Geom g, PassCfg pc,
+                const Lattice* __restrict__ lat, const double2* __restrict__ local,
+                int32_t* __restrict__ resp, size_t resp_stride, int beam_slices) {
+  __shared__ uint32_t red[NXD * NYC][65];
+  const int lane = threadIdx.x;
+  int w = blockIdx.x;
+  const int slice = w % beam_slices;
+  w /= beam_slices;
+  const int a = w % pc.na;
+  const int s = w / pc.na;
+  const Lattice& L = lat[s];
+  if (!L.active || L.status != 0 || L.step_x != 2 || L.step_y != 2) return;
+
+  const double angle = (L.center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;  // Mapper.cpp:390-393
+  const double cosine = cos(angle), sine = sin(angle);                         // Karto.h:6465-6466
+  const int pos00 = L.gx[0] + L.gy[0] * g.stride;
+  const double2* lp = local + (size_t)s * g.n_beams;
+  const int row_step = 2 * g.stride;
+
+  for (int j0 = 0; j0 < pc.ny; j0 += NYC) {
+    uint32_t acc[NYC][NXD];
+#pragma unroll
+    for (int j = 0; j < NYC; j++)
+#pragma unroll
+      for (int k = 0; k < NXD; k++) acc[j][k] = 0u;
+
+    for (int b = lane + 64 * slice; b < g.n_beams; b += 64 * beam_slices) {
+      double2 p = lp[b];
+      const bool beam_ok = !isnan(p.x);  // NaN = INVALID_SCAN
+      int t = lookup_offset(p.x, p.y, cosine, sine, g.off_x, g.off_y, g.scale, g.stride);
+      long long base = (long long)pos00 + t + (long long)j0 * row_step;
+      // Branch-free: rows that lie wholly outside [0,dataSize) (or belong to an invalid beam)
+      // read the zero guard band instead, so all 2*NYC loads of a beam are in flight together.
+      uint32_t d[NYC][NXD];
+#pragma unroll
+      for (int j = 0; j < NYC; j++) {
+        long long rs = base + (long long)j * row_step;
+        bool ok = beam_ok && (j0 + j < pc.ny) && rs >= -(long long)(4 * NXD) && rs < (long long)g.data_size;
+        const uint8_t* src = grid + (ok ? rs : -(long long)kGuard);
+        __builtin_memcpy(d[j], src, 4 * NXD);
+      }
+#pragma unroll
+      for (int j = 0; j < NYC; j++)
+#pragma unroll
+        for (int k = 0; k < NXD; k++) acc[j][k] += d[j][k] & 0x00FF00FFu;
+    }
+    // transpose through LDS, then lane i reduces packed word i over the 64 lanes
+#pragma unroll
+    for (int j = 0; j < NYC; j++)
+#pragma unroll
+      for (int k = 0; k < NXD; k++) red[j * NXD + k][lane] = acc[j][k];
+    __syncthreads();
+    for (int idx = lane; idx < NXD * NYC; idx += 64) {
+      uint32_t lo = 0, hi = 0;
+#pragma unroll 8
+      for (int k = 0; k < 64; k++) {
+        uint32_t v = red[idx][k];
+        lo += v & 0xFFFFu;
+        hi += v >> 16;
+      }
+      int j = j0 + idx / NXD, i = 2 * (idx % NXD);
+      if (j < pc.ny) {
+        int32_t* o = resp + (size_t)s * resp_stride + ((size_t)j * pc.nx + i) * pc.na + a;
+        if (beam_slices == 1) {
+          if (i < pc.nx) o[0] = (int32_t)lo;
+          if (i + 1 < pc.nx) o[pc.na] = (int32_t)hi;
+        } else {
+          if (i < pc.nx) atomicAdd(o, (int32_t)lo);
+          if (i + 1 < pc.nx) atomicAdd(o + pc.na, (int32_t)hi);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_resp_generic: exact response numerators for arbitrary candidate positions (fine pass 3x3,
+// non-uniform lattices, anything the packed kernel does not cover).  Work item = (scan, angle,
+// chunk of 16 positions); lanes stride over beams; per-byte bounds check exactly as
+// Mapper.cpp:841-845.  `list` (optional) restricts the scans to a device-built work list.
+// ------------------------------------------------------------------------------------------
+constexpr int kPosChunk = 16;
+__global__ void __launch_bounds__(64)
+k_resp_generic(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, const Lattice* __restrict__ lat,
+               const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride,
+               int S, const int* __restrict__ list, const int* __restrict__ list_count) {
+  const int lane = threadIdx.x;
+  const int np = pc.nx * pc.ny;
+  const int chunks = (np + kPosChunk - 1) / kPosChunk;
+  const int per_scan = pc.na * chunks;
+  const long long n_scans = list ? *list_count : S;
+  const long long total = n_scans * per_scan;
+  for (long long w = blockIdx.x; w < total; w += gridDim.x) {
+    int s = (int)(w / per_scan);
+    if (list) s = list[s];
+    int rem = (int)(w % per_scan);
+    const int a = rem / chunks, c = rem % chunks;
+    const Lattice& L = lat[s];
+    if (!L.active || L.status != 0) continue;
+    const double angle = (L.center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;
+    const double cosine = cos(angle), sine = sin(angle);
+    int pos[kPosChunk];
+#pragma unroll
+    for (int q = 0; q < kPosChunk; q++) {
+      int f = c * kPosChunk + q;
+      pos[q] = f < np ? L.gx[f % pc.nx] + L.gy[f / pc.nx] * g.stride : -1;
+    }
+    int32_t acc[kPosChunk];
+#pragma unroll
+    for (int q = 0; q < kPosChunk; q++) acc[q] = 0;
+    const double2* lp = local + (size_t)s * g.n_beams;
+    for (int b = lane; b < g.n_beams; b += 64) {
+      double2 p = lp[b];
+      if (isnan(p.x)) continue;
+      int t = lookup_offset(p.x, p.y, cosine, sine, g.off_x, g.off_y, g.scale, g.stride);
+#pragma unroll
+      for (int q = 0; q < kPosChunk; q++) {
+        long long idx = (long long)pos[q] + t;
+        if (pos[q] >= 0 && idx >= 0 && idx < g.data_size) acc[q] += grid[idx];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kPosChunk; q++) {
+      int v = acc[q];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      int f = c * kPosChunk + q;
+      if (lane == 0 && f < np) resp[(size_t)s * resp_stride + (size_t)f * pc.na + a] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// shared pieces of the two reduce kernels
+// ------------------------------------------------------------------------------------------
+struct Cand {
+  double x, y, angle;  // lattice offsets and absolute angle of candidate k
+};
+
+__device__ __forceinline__ Cand cand_of(int k, const PassCfg& pc, const double* center) {
+  int a = k % pc.na, c = k / pc.na;
+  int xi = c % pc.nx, yi = c / pc.nx;
+  Cand cd;
+  cd.x = -pc.off_x + (uint32_t)xi * pc.res_x;  // Mapper.cpp:342-345
+  cd.y = -pc.off_y + (uint32_t)yi * pc.res_y;  // :353-356
+  cd.angle = (center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;  // :390-393
+  return cd;
+}
+
+// GetResponse normalisation + odometry penalty (Mapper.cpp:852, 399-414)
+__device__ __forceinline__ double penalized(int32_t sum, const Cand& cd, const double* center, int n_beams,
+                                            const SearchCfg& sc) {
+  double r = (double)sum / (double)((uint32_t)n_beams * (uint32_t)kOccupied);
+  if (sc.do_penalize && !double_equal(r, 0.0)) {
+    double sd = ksq(cd.x) + ksq(cd.y);
+    double dp = 1.0 - (kDistPenaltyGain * sd / sc.dvp);
+    dp = dp > sc.min_dp ? dp : sc.min_dp;
+    double sad = ksq(cd.angle - center[2]);
+    double ap = 1.0 - (kAnglePenaltyGain * sad / sc.avp);
+    ap = ap > sc.min_ap ? ap : sc.min_ap;
+    r *= (dp * ap);
+  }
+  return r;
+}
+
+__device__ __forceinline__ double block_max(double v, double* sh, int tid, int nthreads) {
+  sh[tid] = v;
+  __syncthreads();
+  for (int o = nthreads / 2; o > 0; o >>= 1) {
+    if (tid < o) sh[tid] = sh[tid] > sh[tid + o] ? sh[tid] : sh[tid + o];
+    __syncthreads();
+  }
+  double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+// Average of all poses whose response equals the best within KT_TOLERANCE, accumulated in
+// lattice order by ONE thread so the fp64 sums round exactly like the reference's sequential loop
+// (Mapper.cpp:456-483).  `mask` holds the tie bits.
+__device__ int tie_average(const uint32_t* mask, int total, const PassCfg& pc, const double* center,
+                           double* avg) {
+  double ax = 0, ay = 0, tx = 0, ty = 0;
+  int cnt = 0;
+  int words = (total + 31) / 32;
+  for (int wd = 0; wd < words; wd++) {
+    uint32_t m = mask[wd];
+    while (m) {
+      int bit = __ffs(m) - 1;
+      m &= m - 1;
+      int k = wd * 32 + bit;
+      Cand cd = cand_of(k, pc, center);
+      double h = normalize_angle(cd.angle);  // stored heading (:417-418)
+      ax += center[0] + cd.x;
+      ay += center[1] + cd.y;
+      tx += cos(h);
+      ty += sin(h);
+      cnt++;
+    }
+  }
+  if (cnt == 0) return 0;
+  ax /= cnt; ay /= cnt; tx /= cnt; ty /= cnt;
+  avg[0] = ax; avg[1] = ay; avg[2] = atan2(ty, tx);
+  return cnt;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_reduce_coarse: one block per scan (Mapper.cpp:431-501, 535-630)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_reduce_coarse(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ lat,
+                const int32_t* __restrict__ resp, size_t resp_stride, CoarseOut* __restrict__ out,
+                int use_expansion, int pass_index) {
+  __shared__ double sh[256];
+  __shared__ double latmax[kMaxLattice * kMaxLattice];
+  __shared__ double probs[kMaxProbsSide * kMaxProbsSide];
+  __shared__ uint32_t mask[(kMaxLattice * kMaxLattice * kMaxAngles + 31) / 32];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const Lattice& L = lat[s];
+  if (!L.active) return;
+  if (L.status != 0) {
+    if (tid == 0) { out[s].status = L.status; out[s].expand = 0; out[s].best = 0.0; }
+    return;
+  }
+  const int total = pc.nx * pc.ny * pc.na;
+  const int32_t* r = resp + (size_t)s * resp_stride;
+  const double center[3] = {L.center[0], L.center[1], L.center[2]};
+
+  double lm = -1.0;  // bestResponse starts at -1 (Mapper.cpp:431)
+  for (int k = tid; k < total; k += 256) {
+    double v = penalized(r[k], cand_of(k, pc, center), center, g.n_beams, sc);
+    lm = lm > v ? lm : v;
+  }
+  const double best = block_max(lm, sh, tid, 256);
+
+  // best response per lattice cell over all angles (what the reference max-merges into
+  // m_pSearchSpaceProbs, Mapper.cpp:437-450)
+  for (int c = tid; c < pc.nx * pc.ny; c += 256) {
+    double m = -1.0;
+    for (int a = 0; a < pc.na; a++) {
+      int k = c * pc.na + a;
+      double v = penalized(r[k], cand_of(k, pc, center), center, g.n_beams, sc);
+      m = m > v ? m : v;
+    }
+    latmax[c] = m;
+  }
+  const int words = (total + 31) / 32;
+  for (int wd = tid; wd < words; wd += 256) mask[wd] = 0u;
+  for (int c = tid; c < g.probs_side * g.probs_side; c += 256) probs[c] = 0.0;  // Clear (:329)
+  __syncthreads();
+  for (int k = tid; k < total; k += 256) {
+    double v = penalized(r[k], cand_of(k, pc, center), center, g.n_beams, sc);
+    if (double_equal(v, best)) atomicOr(&mask[k >> 5], 1u << (k & 31));
+  }
+  __syncthreads();
+  if (tid != 0) return;
+
+  CoarseOut o;
+  o.status = 0;
+  o.flags = pass_index > 0 ? 1 : 0;
+  o.pad = 0;
+  // search-space probability grid: offset = searchCenter - searchSpaceOffset (:332-333)
+  const double p_off_x = center[0] - pc.off_x, p_off_y = center[1] - pc.off_y;
+  for (int c = 0; c < pc.nx * pc.ny && o.status == 0; c++) {
+    int xi = c % pc.nx, yi = c / pc.nx;
+    double wx = center[0] + (-pc.off_x + (uint32_t)xi * pc.res_x);
+    double wy = center[1] + (-pc.off_y + (uint32_t)yi * pc.res_y);
+    int gx = world_to_grid(wx, p_off_x, g.scale), gy = world_to_grid(wy, p_off_y, g.scale);
+    if (gx < 0 || gx >= g.probs_side || gy < 0 || gy >= g.probs_side) {
+      o.status = LSLAM_ERR_PROBABILITY_SEARCH;
+      break;
+    }
+    double* p = &probs[gy * g.probs_side + gx];
+    *p = latmax[c] > *p ? latmax[c] : *p;
+  }
+  double avg[3] = {0, 0, 0};
+  if (o.status == 0 && tie_average(mask, total, pc, center, avg) == 0) o.status = LSLAM_ERR_NO_BEST_POSE;
+
+  // ComputePositionalCovariance (Mapper.cpp:535-630)
+  double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (o.status == 0) {
+    if (best < kTol) {
+      cov[0] = kMaxVariance; cov[4] = kMaxVariance; cov[8] = 4 * ksq(pc.ang_res);
+    } else {
+      double axx = 0, axy = 0, ayy = 0, norm = 0;
+      double dx = avg[0] - center[0], dy = avg[1] - center[1];
+      for (int yi = 0; yi < pc.ny && o.status == 0; yi++) {
+        double y = -pc.off_y + (uint32_t)yi * pc.res_y;
+        for (int xi = 0; xi < pc.nx; xi++) {
+          double x = -pc.off_x + (uint32_t)xi * pc.res_x;
+          int gx = world_to_grid(center[0] + x, p_off_x, g.scale);
+          int gy = world_to_grid(center[1] + y, p_off_y, g.scale);
+          if (gx < 0 || gx >= g.probs_side || gy < 0 || gy >= g.probs_side) {
+            o.status = LSLAM_ERR_INDEX_OUT_OF_RANGE;
+            break;
+          }
+          double rr = probs[gy * g.probs_side + gx];
+          if (rr >= (best - 0.1)) {
+            norm += rr;
+            axx += (ksq(x - dx) * rr);
+            axy += ((x - dx) * (y - dy) * rr);
+            ayy += (ksq(y - dy) * rr);
+          }
+        }
+      }
+      if (norm > kTol) {
+        double vxx = axx / norm, vxy = axy / norm, vyy = ayy / norm;
+        double vthth = 4 * ksq(pc.ang_res);
+        double min_xx = 0.1 * ksq(pc.res_x), min_yy = 0.1 * ksq(pc.res_y);
+        vxx = vxx > min_xx ? vxx : min_xx;
+        vyy = vyy > min_yy ? vyy : min_yy;
+        double mult = 1.0 / best;
+        cov[0] = vxx * mult; cov[1] = vxy * mult; cov[3] = vxy * mult; cov[4] = vyy * mult;
+        cov[8] = vthth;
+      }
+      if (double_equal(cov[0], 0.0)) cov[0] = kMaxVariance;
+      if (double_equal(cov[4], 0.0)) cov[4] = kMaxVariance;
+    }
+  }
+  o.mean[0] = avg[0]; o.mean[1] = avg[1]; o.mean[2] = avg[2];
+  for (int i = 0; i < 9; i++) o.cov[i] = cov[i];
+  o.best = best > 1.0 ? 1.0 : best;  // :514-517
+  // Mapper.cpp:242-244,259: expand (again) while the best response is still zero
+  o.expand = (use_expansion && o.status == 0 && pass_index < 3 && double_equal(o.best, 0.0)) ? 1 : 0;
+  out[s] = o;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_reduce_fine: one block per scan: max + tie average of the fine lattice, then
+// ComputeAngularCovariance (Mapper.cpp:641-692): nA more response sums at the best cell,
+// gathered by the whole block; final result record.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc,
+              const Lattice* __restrict__ lat, const int32_t* __restrict__ resp, size_t resp_stride,
+              const double2* __restrict__ local, const CoarseOut* __restrict__ coarse,
+              lslam_match_result* __restrict__ out, int do_refine) {
+  __shared__ double sh[256];
+  __shared__ uint32_t mask[(kMaxLattice * kMaxLattice * kMaxAngles + 31) / 32];
+  __shared__ int32_t asum[kMaxAngles];
+  __shared__ double s_avg[3];
+  __shared__ double s_best;
+  __shared__ int s_status, s_pos;
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const CoarseOut& co = coarse[s];
+  if (!do_refine || co.status != 0) {
+    if (tid == 0) {
+      lslam_match_result res;
+      for (int i = 0; i < 3; i++) res.pose[i] = co.status ? 0.0 : co.mean[i];
+      for (int i = 0; i < 9; i++) res.covariance[i] = co.status ? 0.0 : co.cov[i];
+      res.response = co.status ? 0.0 : co.best;
+      res.status = co.status;
+      res.flags = co.flags;
+      out[s] = res;
+    }
+    return;
+  }
+  const Lattice& L = lat[s];
+  if (L.status != 0) {
+    if (tid == 0) {
+      lslam_match_result res;
+      memset(&res, 0, sizeof res);
+      res.status = L.status;
+      res.flags = co.flags;
+      out[s] = res;
+    }
+    return;
+  }
+  const int total = pc.nx * pc.ny * pc.na;
+  const int32_t* r = resp + (size_t)s * resp_stride;
+  const double center[3] = {L.center[0], L.center[1], L.center[2]};
+  double lm = -1.0;
+  for (int k = tid; k < total; k += 256) {
+    double v = penalized(r[k], cand_of(k, pc, center), center, g.n_beams, sc);
+    lm = lm > v ? lm : v;
+  }
+  const double best = block_max(lm, sh, tid, 256);
+  const int words = (total + 31) / 32;
+  for (int wd = tid; wd < words; wd += 256) mask[wd] = 0u;
+  if (tid < kMaxAngles) asum[tid] = 0;
+  __syncthreads();
+  for (int k = tid; k < total; k += 256) {
+    double v = penalized(r[k], cand_of(k, pc, center), center, g.n_beams, sc);
+    if (double_equal(v, best)) atomicOr(&mask[k >> 5], 1u << (k & 31));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double avg[3] = {0, 0, 0};
+    int st = 0;
+    if (tie_average(mask, total, pc, center, avg) == 0) st = LSLAM_ERR_NO_BEST_POSE;
+    int pos = 0;
+    if (st == 0) {  // Mapper.cpp:653-654
+      int gx = world_to_grid(avg[0], g.off_x, g.scale) + g.border;
+      int gy = world_to_grid(avg[1], g.off_y, g.scale) + g.border;
+      if (gx < 0 || gx >= g.width || gy < 0 || gy >= g.height) st = LSLAM_ERR_INDEX_OUT_OF_RANGE;
+      pos = gx + gy * g.stride;
+    }
+    s_avg[0] = avg[0]; s_avg[1] = avg[1]; s_avg[2] = avg[2];
+    s_best = best;
+    s_status = st;
+    s_pos = pos;
+  }
+  __syncthreads();
+  if (s_status == 0) {
+    // GetResponse(angleIndex, gridIndex) for every fine angle at the best cell (:663-666)
+    const double2* lp = local + (size_t)s * g.n_beams;
+    const int pos = s_pos;
+    for (int a = 0; a < pc.na; a++) {
+      double angle = (center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;
+      double cosine = cos(angle), sine = sin(angle);
+      int32_t part = 0;
+      for (int b = tid; b < g.n_beams; b += 256) {
+        double2 p = lp[b];
+        if (isnan(p.x)) continue;
+        int t = lookup_offset(p.x, p.y, cosine, sine, g.off_x, g.off_y, g.scale, g.stride);
+        long long idx = (long long)pos + t;
+        if (idx >= 0 && idx < g.data_size) part += grid[idx];
+      }
+      for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+      if ((tid & 63) == 0) atomicAdd(&asum[a], part);
+    }
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  lslam_match_result res;
+  memset(&res, 0, sizeof res);
+  res.flags = co.flags;
+  res.status = s_status;
+  if (s_status == 0) {
+    double bestAngle = normalize_angle_difference(s_avg[2], center[2]);  // :651
+    double norm = 0.0, acc = 0.0;
+    double start = center[2] - pc.ang_off;
+    for (int a = 0; a < pc.na; a++) {
+      double angle = start + (uint32_t)a * pc.ang_res;
+      double rr = (double)asum[a] / (double)((uint32_t)g.n_beams * (uint32_t)kOccupied);
+      if (rr >= (s_best - 0.1)) {
+        norm += rr;
+        acc += (ksq(angle - bestAngle) * rr);
+      }
+    }
+    if (norm > kTol) {
+      if (acc < kTol) acc = ksq(pc.ang_res);
+      acc /= norm;
+    } else {
+      acc = 1000 * ksq(pc.ang_res);
+    }
+    for (int i = 0; i < 9; i++) res.covariance[i] = co.cov[i];  // NOTE: covariance is not reset (:648)
+    res.covariance[8] = acc;
+    res.pose[0] = s_avg[0]; res.pose[1] = s_avg[1]; res.pose[2] = s_avg[2];
+    res.response = s_best > 1.0 ? 1.0 : s_best;
+  }
+  out[s] = res;
+}
+
+// result for a laser with zero beams (Mapper.cpp:199-209)
+__global__ void k_result_no_readings(int S, const double* poses, double coarse_ang_res,
+                                     lslam_match_result* out) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  lslam_match_result r;
+  memset(&r, 0, sizeof r);
+  r.pose[0] = poses[3 * s]; r.pose[1] = poses[3 * s + 1]; r.pose[2] = poses[3 * s + 2];
+  r.covariance[0] = kMaxVariance; r.covariance[4] = kMaxVariance;
+  r.covariance[8] = 4 * ksq(coarse_ang_res);
+  out[s] = r;
+}
+
+// ------------------------------------------------------------------------------------------
+// correlation-grid construction (AddScans, Mapper.cpp:699-748)
+// ------------------------------------------------------------------------------------------
+// FindValidPoints (Mapper.cpp:756-811) is a sequential scan with a lagging iterator: one thread
+// per base scan walks its points; valid[] marks the points the reference would push_back.
+__global__ void k_find_valid(int B, int n, const double2* __restrict__ world, double vx, double vy,
+                             uint8_t* __restrict__ valid) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= B) return;
+  const double2* p = world + (size_t)s * n;
+  uint8_t* v = valid + (size_t)s * n;
+  for (int i = 0; i < n; i++) v[i] = 0;
+  const double min_sq = ksq(0.1);
+  int trailing = 0;
+  bool first_time = true;
+  double fx = 0.0, fy = 0.0;
+  for (int i = 0; i < n; i++) {
+    double cx = p[i].x, cy = p[i].y;
+    if (first_time && !isnan(cx) && !isnan(cy)) {
+      fx = cx; fy = cy; first_time = false;
+    }
+    double dx = fx - cx, dy = fy - cy;
+    if (ksq(dx) + ksq(dy) > min_sq) {
+      double a = vy - fy;
+      double b = fx - vx;
+      double c = fy * vx - fx * vy;
+      double ss = cx * a + cy * b + c;
+      fx = cx; fy = cy;
+      if (ss < 0.0) {
+        trailing = i;
+      } else {
+        for (; trailing != i; ++trailing) v[trailing] = 1;
+      }
+    }
+  }
+}
+
+// Pass 1: occupied cells (AddScan, Mapper.cpp:723-740).  Racing byte stores all write 100.
+__global__ void __launch_bounds__(256)
+k_mark_occupied(int total, const double2* __restrict__ world, const uint8_t* __restrict__ valid, Geom g,
+                uint8_t* __restrict__ grid) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total || !valid[i]) return;
+  int gx = world_to_grid(world[i].x, g.off_x, g.scale);
+  int gy = world_to_grid(world[i].y, g.off_y, g.scale);
+  if (gx < 0 || gx >= g.roi_w || gy < 0 || gy >= g.roi_h) return;  // IsUpTo on the ROI (:724-729)
+  grid[(size_t)(gx + g.border) + (size_t)(gy + g.border) * g.stride] = (uint8_t)kOccupied;
+}
+
+__device__ __forceinline__ void atomic_max_u8(uint8_t* base, size_t idx, uint32_t v) {
+  uint32_t* w = (uint32_t*)(base + (idx & ~(size_t)3));
+  const int sh = (int)(idx & 3) * 8;
+  uint32_t old = *w;
+  while (((old >> sh) & 0xFFu) < v) {
+    uint32_t want = (old & ~(0xFFu << sh)) | (v << sh);
+    uint32_t prev = atomicCAS(w, old, want);
+    if (prev == old) break;
+    old = prev;
+  }
+}
+
+// Pass 2: SmearPoint (Mapper.h:971-1005) as a max-merge scatter.  Order-independent because the
+// kernel's only 100 is its centre (checked at create time; otherwise k_add_scans_serial runs).
+__global__ void __launch_bounds__(256)
+k_smear(int total, const double2* __restrict__ world, const uint8_t* __restrict__ valid, Geom g,
+        const uint8_t* __restrict__ kernel, uint8_t* __restrict__ grid) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total || !valid[i]) return;
+  int gx = world_to_grid(world[i].x, g.off_x, g.scale);
+  int gy = world_to_grid(world[i].y, g.off_y, g.scale);
+  if (gx < 0 || gx >= g.roi_w || gy < 0 || gy >= g.roi_h) return;
+  const int hk = g.kernel_size / 2;
+  for (int j = -hk; j <= hk; j++) {
+    size_t row = (size_t)(gx + g.border) + (size_t)(gy + j + g.border) * g.stride;
+    for (int k = -hk; k <= hk; k++) {
+      uint32_t kv = kernel[(k + hk) + g.kernel_size * (j + hk)];
+      if (kv) atomic_max_u8(grid, row + k, kv);
+    }
+  }
+}
+
+// Exact sequential AddScans for smear kernels that contain 100 off-centre (then "already
+// occupied -> skip" makes the result order dependent, Mapper.cpp:734-738).  One thread.
+__global__ void k_add_scans_serial(int total, const double2* __restrict__ world,
+                                   const uint8_t* __restrict__ valid, Geom g,
+                                   const uint8_t* __restrict__ kernel, uint8_t* __restrict__ grid) {
+  if (blockIdx.x || threadIdx.x) return;
+  const int hk = g.kernel_size / 2;
+  for (int i = 0; i < total; i++) {
+    if (!valid[i]) continue;
+    int gx = world_to_grid(world[i].x, g.off_x, g.scale);
+    int gy = world_to_grid(world[i].y, g.off_y, g.scale);
+    if (gx < 0 || gx >= g.roi_w || gy < 0 || gy >= g.roi_h) continue;
+    size_t idx = (size_t)(gx + g.border) + (size_t)(gy + g.border) * g.stride;
+    if (grid[idx] == kOccupied) continue;
+    grid[idx] = kOccupied;
+    for (int j = -hk; j <= hk; j++) {
+      uint8_t* row = grid + (size_t)(gx + g.border) + (size_t)(gy + j + g.border) * g.stride;
+      for (int k = -hk; k <= hk; k++) {
+        uint8_t kv = kernel[(k + hk) + g.kernel_size * (j + hk)];
+        if (kv > row[k]) row[k] = kv;
+      }
+    }
+  }
+}
+
+// lookup tables of one scan for the inspection hook
+__global__ void k_debug_table(Geom g, const double2* __restrict__ local, double angle_center,
+                              double angle_offset, double angle_res, int na, int32_t* __restrict__ out) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  int a = blockIdx.y;
+  if (b >= g.n_beams || a >= na) return;
+  double angle = (angle_center - angle_offset) + (uint32_t)a * angle_res;  // Karto.h:6439-6442
+  double2 p = local[b];
+  int32_t v = kInvalidScan;
+  if (!isnan(p.x)) v = lookup_offset(p.x, p.y, cos(angle), sin(angle), g.off_x, g.off_y, g.scale, g.stride);
+  out[(size_t)a * g.n_beams + b] = v;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// host side
+// ==========================================================================================
+struct lslam_matcher {
+  lslam_context* ctx = nullptr;
+  lslam_matcher_config cfg;
+  lslam_laser laser;
+  Geom g;
+  std::vector<uint8_t> h_kernel;
+  bool kernel_center_only = true;
+  // device state
+  uint8_t* d_grid_alloc = nullptr;  // kGuard + data_size + kGuard
+  uint8_t* d_grid = nullptr;        // d_grid_alloc + kGuard
+  uint8_t* d_kernel = nullptr;
+  // workspaces
+  DevBuf<double> d_ranges64;
+  DevBuf<double> d_poses;
+  DevBuf<double2> d_local, d_world;
+  DevBuf<uint8_t> d_valid;
+  DevBuf<Lattice> d_lat;
+  DevBuf<CoarseOut> d_coarse;
+  DevBuf<int32_t> d_resp;
+  DevBuf<int> d_slow;  // [0] = count, [1..] = list
+  DevBuf<lslam_match_result> d_results;
+  DevBuf<int32_t> d_dbg;
+};
+
+namespace {
+
+int n_angles_of(double off, double res) { return lattice_count(off, res); }
+
+template <typename RT>
+int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, const double* d_poses,
+                     int do_penalize, int do_refine, lslam_match_result* d_out,
+                     int32_t* dbg_coarse_sums /*device, optional*/, int force_generic) {
+  lslam_context* ctx = m->ctx;
+  Geom g = m->g;
+  if (S <= 0) return LSLAM_OK;
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  if (g.n_beams == 0) {
+    launch(ctx, "result_no_readings", k_result_no_readings, dim3((S + 255) / 256), dim3(256), 0, S,
+           d_poses, m->cfg.coarse_angle_resolution, d_out);
+    return LSLAM_OK;
+  }
+  const double res = 1.0 / g.scale;  // GetResolution() (Karto.h:4335-4338)
+  // coarse pass geometry (Mapper.cpp:228-240)
+  PassCfg pc;
+  pc.off_x = pc.off_y = 0.5 * ((double)g.probs_side - 1) * res;
+  pc.res_x = pc.res_y = 2 * res;
+  pc.ang_off = m->cfg.coarse_search_angle_offset;
+  pc.ang_res = m->cfg.coarse_angle_resolution;
+  pc.nx = lattice_count(pc.off_x, pc.res_x);
+  pc.ny = lattice_count(pc.off_y, pc.res_y);
+  pc.na = n_angles_of(pc.ang_off, pc.ang_res);
+  pc.mode = 0;
+  // fine pass geometry (:276-281)
+  PassCfg pf;
+  pf.off_x = pf.off_y = pc.res_x * 0.5;
+  pf.res_x = pf.res_y = res;
+  pf.ang_off = 0.5 * m->cfg.coarse_angle_resolution;
+  pf.ang_res = m->cfg.fine_search_angle_offset;
+  pf.nx = lattice_count(pf.off_x, pf.res_x);
+  pf.ny = lattice_count(pf.off_y, pf.res_y);
+  pf.na = n_angles_of(pf.ang_off, pf.ang_res);
+  pf.mode = 2;
+  int na_max = pc.na;
+  const int n_exp = m->cfg.use_response_expansion ? 3 : 0;
+  PassCfg pe[3];
+  for (int e = 0; e < n_exp; e++) {
+    pe[e] = pc;
+    pe[e].mode = 1;
+    double o = m->cfg.coarse_search_angle_offset;
+    for (int i = 0; i <= e; i++) o += 20.0 * kPi180;  // math::DegreesToRadians(20) (Mapper.cpp:253)
+    pe[e].ang_off = o;
+    pe[e].na = n_angles_of(o, pc.ang_res);
+    na_max = std::max(na_max, pe[e].na);
+  }
+  na_max = std::max(na_max, pf.na);
+  if (pc.nx > kMaxLattice || pc.ny > kMaxLattice || pf.nx > kMaxLattice || pf.ny > kMaxLattice ||
+      na_max > kMaxAngles || pc.nx < 1 || pf.nx < 1 || pc.na < 1 || pf.na < 1)
+    return ctx->fail(LSLAM_ERR_UNSUPPORTED, "search lattice %dx%dx%d exceeds the built limits (%d,%d,%d)",
+                     pc.nx, pc.ny, na_max, kMaxLattice, kMaxLattice, kMaxAngles);
+  const size_t resp_stride = (size_t)std::max(pc.nx * pc.ny, pf.nx * pf.ny) * na_max;
+
+  LSLAM_HIP(ctx, m->d_local.reserve((size_t)S * g.n_beams));
+  LSLAM_HIP(ctx, m->d_lat.reserve(S));
+  LSLAM_HIP(ctx, m->d_coarse.reserve(S));
+  LSLAM_HIP(ctx, m->d_resp.reserve((size_t)S * resp_stride));
+  LSLAM_HIP(ctx, m->d_slow.reserve((size_t)S + 1));
+
+  SearchCfg sc{m->cfg.distance_variance_penalty, m->cfg.angle_variance_penalty,
+               m->cfg.minimum_distance_penalty, m->cfg.minimum_angle_penalty, do_penalize};
+
+  launch(ctx, "scan_prep", k_scan_prep<RT>, dim3((g.n_beams + 255) / 256, S), dim3(256), 0, d_ranges,
+         stride, d_poses, g, m->d_local.p, (double2*)nullptr);
+
+  // fast-kernel selection: 2-cell lattice that fits the packed accumulators
+  auto run_coarse = [&](const PassCfg& p, int pass_index) -> int {
+    const bool fast6 = !force_generic && p.nx <= 12;
+    const bool fast8 = !force_generic && !fast6 && p.nx <= 16;
+    LSLAM_HIP(ctx, hipMemsetAsync(m->d_slow.p, 0, sizeof(int), ctx->stream));
+    int* slow_cnt = m->d_slow.p;
+    int* slow_list = m->d_slow.p + 1;
+    launch(ctx, "pass_setup", k_pass_setup, dim3((S + 127) / 128), dim3(128), 0, S, g, p, d_poses,
+           (const CoarseOut*)m->d_coarse.p, m->d_lat.p, (fast6 || fast8) ? slow_list : (int*)nullptr,
+           slow_cnt, 2);
+    if (fast6 || fast8) {
+      // small batches: split the beams of one (scan, angle) over several waves to fill the chip
+      int slices = 1;
+      long long waves = (long long)S * p.na;
+      while (slices < 8 && waves * slices < 2048) slices *= 2;
+      if (slices > 1)
+        LSLAM_HIP(ctx, hipMemsetAsync(m->d_resp.p, 0, (size_t)S * resp_stride * sizeof(int32_t), ctx->stream));
+      dim3 grid((unsigned)(waves * slices));
+      if (fast6)
+        launch(ctx, "resp_lattice2", k_resp_lattice2<6, 11>, grid, dim3(64), 0, (const uint8_t*)m->d_grid, g, p,
+               (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices);
+      else
+        launch(ctx, "resp_lattice2", k_resp_lattice2<8, 8>, grid, dim3(64), 0, (const uint8_t*)m->d_grid, g, p,
+               (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices);
+      // scans with a non-uniform lattice (rounding on a cell boundary) take the generic kernel
+      launch(ctx, "resp_generic_fallback", k_resp_generic, dim3(256), dim3(64), 0, (const uint8_t*)m->d_grid, g,
+             p, (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S,
+             (const int*)slow_list, (const int*)slow_cnt);
+    } else {
+      int chunks = (p.nx * p.ny + kPosChunk - 1) / kPosChunk;
+      long long items = (long long)S * p.na * chunks;
+      launch(ctx, "resp_generic", k_resp_generic, dim3((unsigned)std::min<long long>(items, 1 << 20)), dim3(64), 0,
+             (const uint8_t*)m->d_grid, g, p, (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p,
+             m->d_resp.p, resp_stride, S, (const int*)nullptr, (const int*)nullptr);
+    }
+    if (dbg_coarse_sums && pass_index == 0)
+      LSLAM_HIP(ctx, hipMemcpyAsync(dbg_coarse_sums, m->d_resp.p, (size_t)p.nx * p.ny * p.na * sizeof(int32_t),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+    launch(ctx, "reduce_coarse", k_reduce_coarse, dim3(S), dim3(256), 0, g, p, sc, (const Lattice*)m->d_lat.p,
+           (const int32_t*)m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion,
+           pass_index);
+    return LSLAM_OK;
+  };
+
+  int rc = run_coarse(pc, 0);
+  if (rc) return rc;
+  for (int e = 0; e < n_exp; e++) {
+    rc = run_coarse(pe[e], e + 1);
+    if (rc) return rc;
+  }
+  if (do_refine) {
+    launch(ctx, "pass_setup", k_pass_setup, dim3((S + 127) / 128), dim3(128), 0, S, g, pf, d_poses,
+           (const CoarseOut*)m->d_coarse.p, m->d_lat.p, (int*)nullptr, (int*)nullptr, 1);
+    int chunks = (pf.nx * pf.ny + kPosChunk - 1) / kPosChunk;
+    long long items = (long long)S * pf.na * chunks;
+    launch(ctx, "resp_fine", k_resp_generic, dim3((unsigned)std::min<long long>(items, 1 << 20)), dim3(64), 0,
+           (const uint8_t*)m->d_grid, g, pf, (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p,
+           resp_stride, S, (const int*)nullptr, (const int*)nullptr);
+  }
+  launch(ctx, "reduce_fine", k_reduce_fine, dim3(S), dim3(256), 0, (const uint8_t*)m->d_grid, g, pf, sc,
+         (const Lattice*)m->d_lat.p, (const int32_t*)m->d_resp.p, resp_stride, (const double2*)m->d_local.p,
+         (const CoarseOut*)m->d_coarse.p, d_out, do_refine);
+  LSLAM_HIP(ctx, hipGetLastError());
+  return LSLAM_OK;
+}
+
+int upload_scans(lslam_matcher* m, int S, const double* ranges, int stride, const double* poses) {
+  lslam_context* ctx = m->ctx;
+  const int n = m->g.n_beams;
+  if (stride < n) return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "ranges_stride %d < num_beams %d", stride, n);
+  LSLAM_HIP(ctx, m->d_ranges64.reserve((size_t)S * std::max(n, 1)));
+  LSLAM_HIP(ctx, m->d_poses.reserve((size_t)S * 3));
+  if (n > 0)
+    LSLAM_HIP(ctx, hipMemcpy2DAsync(m->d_ranges64.p, (size_t)n * sizeof(double), ranges, (size_t)stride * sizeof(double),
+                                    (size_t)n * sizeof(double), S, hipMemcpyHostToDevice, ctx->stream));
+  LSLAM_HIP(ctx, hipMemcpyAsync(m->d_poses.p, poses, (size_t)S * 3 * sizeof(double), hipMemcpyHostToDevice,
+                                ctx->stream));
+  return LSLAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void lslam_matcher_config_defaults(lslam_matcher_config* c) {
+  // Mapper.cpp:1572-1647
+  c->search_size = 0.3;
+  c->resolution = 0.01;
+  c->smear_deviation = 0.03;
+  c->range_threshold = 12.0;  // LaserRangeFinder default RangeThreshold (Karto.h:4137)
+  c->coarse_search_angle_offset = 20.0 * kPi180;
+  c->coarse_angle_resolution = 2.0 * kPi180;
+  c->fine_search_angle_offset = 0.2 * kPi180;
+  c->distance_variance_penalty = 0.3 * 0.3;
+  c->angle_variance_penalty = (20.0 * kPi180) * (20.0 * kPi180);
+  c->minimum_distance_penalty = 0.5;
+  c->minimum_angle_penalty = 0.9;
+  c->use_response_expansion = 0;
+  c->reserved = 0;
+}
+
+void lslam_sensor_pose_from_robot(const lslam_laser* l, const double robot[3], double sensor[3]) {
+  // GetSensorAt: Transform(rPose).TransformPose(offsetPose) (Karto.h:5310-5313, 2881-2887)
+  SensorXform t = sensor_xform(robot[0], robot[1], robot[2]);
+  double rx, ry;
+  rot_apply(t.rot, l->offset_x, l->offset_y, l->offset_heading, rx, ry);
+  sensor[0] = t.tx + rx;
+  sensor[1] = t.ty + ry;
+  sensor[2] = normalize_angle(l->offset_heading + t.th);
+}
+
+void lslam_robot_pose_from_sensor(const lslam_laser* l, const double sensor[3], double robot[3]) {
+  // SetSensorPose (Karto.h:5289-5303)
+  double len = sqrt(ksq(l->offset_x) + ksq(l->offset_y));
+  double angleoffset = atan2(l->offset_y, l->offset_x);
+  double ch = normalize_angle(sensor[2]);
+  double wx = len * cos(ch + angleoffset - l->offset_heading);
+  double wy = len * sin(ch + angleoffset - l->offset_heading);
+  robot[0] = sensor[0] - wx;
+  robot[1] = sensor[1] - wy;
+  robot[2] = normalize_angle(sensor[2] - l->offset_heading);
+}
+
+int lslam_matcher_create(lslam_context* ctx, const lslam_matcher_config* cfg, const lslam_laser* laser,
+                         lslam_matcher** out) {
+  if (!ctx || !cfg || !laser || !out) return LSLAM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  // ScanMatcher::Create returns NULL for these (Mapper.cpp:130-145)
+  if (!(cfg->resolution > 0) || !(cfg->search_size > 0) || cfg->smear_deviation < 0 || !(cfg->range_threshold > 0))
+    return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "invalid matcher parameters (ScanMatcher::Create -> NULL)");
+  // CalculateKernel throws for these (Mapper.h:1041-1053)
+  if (!(cfg->smear_deviation >= 0.5 * cfg->resolution && cfg->smear_deviation <= 10 * cfg->resolution))
+    return ctx->fail(LSLAM_ERR_SMEAR_DEVIATION, "smear deviation must be within [%g, %g]", 0.5 * cfg->resolution,
+                     10 * cfg->resolution);
+  if (!(laser->angular_resolution != 0.0))
+    return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "laser angular_resolution must be non-zero");
+  lslam_matcher* m = new lslam_matcher();
+  m->ctx = ctx;
+  m->cfg = *cfg;
+  m->laser = *laser;
+  Geom& g = m->g;
+  g.n_beams = (int)(uint32_t)kround((laser->maximum_angle - laser->minimum_angle) / laser->angular_resolution);
+  uint32_t side = (uint32_t)(kround(cfg->search_size / cfg->resolution) + 1);  // Mapper.cpp:150
+  uint32_t margin = (uint32_t)ceil(cfg->range_threshold / cfg->resolution);    // :154
+  int grid_size = (int)(side + 2 * margin);                                     // :156
+  int half = (int)kround(2.0 * cfg->smear_deviation / cfg->resolution);         // Mapper.h:1096-1101
+  g.border = half + 1;                                                          // Mapper.h:928
+  g.roi_w = g.roi_h = grid_size;
+  g.width = g.height = grid_size + 2 * g.border;  // Mapper.h:1018
+  g.stride = (g.width + 7) & ~7;                   // Karto.h:4442
+  g.data_size = g.stride * g.height;
+  g.scale = 1.0 / cfg->resolution;  // Mapper.h:1020
+  g.off_x = g.off_y = 0.0;
+  g.min_angle = laser->minimum_angle;
+  g.ang_res = laser->angular_resolution;
+  g.probs_side = (int)side;
+  if (g.probs_side > kMaxProbsSide) {
+    delete m;
+    return ctx->fail(LSLAM_ERR_UNSUPPORTED, "search space of %d cells per side exceeds the built limit %d",
+                     g.probs_side, kMaxProbsSide);
+  }
+  // CalculateKernel (Mapper.h:1058-1086), host fp64
+  const double resolution = 1.0 / g.scale;
+  g.kernel_size = 2 * (int)kround(2.0 * cfg->smear_deviation / resolution) + 1;
+  const int hk = g.kernel_size / 2;
+  m->h_kernel.resize((size_t)g.kernel_size * g.kernel_size);
+  for (int i = -hk; i <= hk; i++)
+    for (int j = -hk; j <= hk; j++) {
+      double d = hypot(i * resolution, j * resolution);
+      double z = exp(-0.5 * pow(d / cfg->smear_deviation, 2));
+      uint32_t v = (uint32_t)kround(z * kOccupied);
+      m->h_kernel[(i + hk) + g.kernel_size * (j + hk)] = (uint8_t)v;
+      if (v >= (uint32_t)kOccupied && (i != 0 || j != 0)) m->kernel_center_only = false;
+    }
+  if (hipSetDevice(ctx->device) != hipSuccess ||
+      hipMalloc((void**)&m->d_grid_alloc, (size_t)g.data_size + 2 * kGuard) != hipSuccess ||
+      hipMalloc((void**)&m->d_kernel, m->h_kernel.size()) != hipSuccess) {
+    if (m->d_grid_alloc) (void)hipFree(m->d_grid_alloc);
+    delete m;
+    return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the correlation grid in HBM");
+  }
+  m->d_grid = m->d_grid_alloc + kGuard;
+  (void)hipMemsetAsync(m->d_grid_alloc, 0, (size_t)g.data_size + 2 * kGuard, ctx->stream);
+  (void)hipMemcpyAsync(m->d_kernel, m->h_kernel.data(), m->h_kernel.size(), hipMemcpyHostToDevice, ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);
+  *out = m;
+  return LSLAM_OK;
+}
+
+void lslam_matcher_destroy(lslam_matcher* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->ctx->device);
+  (void)hipStreamSynchronize(m->ctx->stream);
+  (void)hipFree(m->d_grid_alloc);
+  (void)hipFree(m->d_kernel);
+  m->d_ranges64.release(); m->d_poses.release(); m->d_local.release(); m->d_world.release();
+  m->d_valid.release(); m->d_lat.release(); m->d_coarse.release(); m->d_resp.release();
+  m->d_slow.release(); m->d_results.release(); m->d_dbg.release();
+  delete m;
+}
+
+int lslam_matcher_num_beams(const lslam_matcher* m) { return m ? m->g.n_beams : LSLAM_ERR_INVALID_ARGUMENT; }
+
+int lslam_matcher_grid_info(const lslam_matcher* m, int32_t out[8], double offset_xy[2]) {
+  if (!m) return LSLAM_ERR_INVALID_ARGUMENT;
+  const Geom& g = m->g;
+  out[0] = g.width; out[1] = g.height; out[2] = g.stride; out[3] = g.border; out[4] = g.border;
+  out[5] = g.roi_w; out[6] = g.roi_h; out[7] = g.kernel_size;
+  if (offset_xy) { offset_xy[0] = g.off_x; offset_xy[1] = g.off_y; }
+  return LSLAM_OK;
+}
+
+int lslam_matcher_get_grid_u8(lslam_matcher* m, uint8_t* out) {
+  if (!m || !out) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = m->ctx;
+  LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_grid, (size_t)m->g.data_size, hipMemcpyDeviceToHost, ctx->stream));
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSLAM_OK;
+}
+
+int lslam_matcher_get_kernel_u8(lslam_matcher* m, uint8_t* out) {
+  if (!m || !out) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = m->ctx;
+  LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_kernel, m->h_kernel.size(), hipMemcpyDeviceToHost, ctx->stream));
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSLAM_OK;
+}
+
+int lslam_matcher_set_grid_u8(lslam_matcher* m, const uint8_t* grid, const double offset_xy[2]) {
+  if (!m || !grid || !offset_xy) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = m->ctx;
+  LSLAM_HIP(ctx, hipMemcpyAsync(m->d_grid, grid, (size_t)m->g.data_size, hipMemcpyHostToDevice, ctx->stream));
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  m->g.off_x = offset_xy[0];
+  m->g.off_y = offset_xy[1];
+  return LSLAM_OK;
+}
+
+int lslam_matcher_set_grid_u8_dev(lslam_matcher* m, const uint8_t* grid_dev, const double offset_xy[2]) {
+  if (!m || !grid_dev || !offset_xy) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = m->ctx;
+  if (grid_dev != m->d_grid)
+    LSLAM_HIP(ctx, hipMemcpyAsync(m->d_grid, grid_dev, (size_t)m->g.data_size, hipMemcpyDeviceToDevice, ctx->stream));
+  m->g.off_x = offset_xy[0];
+  m->g.off_y = offset_xy[1];
+  return LSLAM_OK;
+}
+
+void* lslam_matcher_grid_dev_ptr(lslam_matcher* m) { return m ? (void*)m->d_grid : nullptr; }
+
+int lslam_matcher_set_base_scans(lslam_matcher* m, int B, const double* ranges, int stride,
+                                 const double* sensor_poses, const double center[3]) {
+  if (!m || !center || B < 0 || (B > 0 && (!ranges || !sensor_poses))) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = m->ctx;
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  Geom& g = m->g;
+  // Mapper.cpp:212-220: offset = scanPose - 0.5*(roi-1)*resolution
+  g.off_x = center[0] - (0.5 * (g.roi_w - 1) * (1.0 / g.scale));
+  g.off_y = center[1] - (0.5 * (g.roi_h - 1) * (1.0 / g.scale));
+  LSLAM_HIP(ctx, hipMemsetAsync(m->d_grid, 0, (size_t)g.data_size, ctx->stream));  // Grid::Clear (Mapper.cpp:701)
+  if (B == 0 || g.n_beams == 0) {
+    LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LSLAM_OK;
+  }
+  int rc = upload_scans(m, B, ranges, stride, sensor_poses);
+  if (rc) return rc;
+  const int n = g.n_beams, total = B * n;
+  LSLAM_HIP(ctx, m->d_world.reserve((size_t)total));
+  LSLAM_HIP(ctx, m->d_valid.reserve((size_t)total));
+  launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((n + 255) / 256, B), dim3(256), 0,
+         (const double*)m->d_ranges64.p, n, (const double*)m->d_poses.p, g, (double2*)nullptr, m->d_world.p);
+  launch(ctx, "find_valid", k_find_valid, dim3((B + 63) / 64), dim3(64), 0, B, n, (const double2*)m->d_world.p,
+         center[0], center[1], m->d_valid.p);
+  if (m->kernel_center_only) {
+    launch(ctx, "mark_occupied", k_mark_occupied, dim3((total + 255) / 256), dim3(256), 0, total,
+           (const double2*)m->d_world.p, (const uint8_t*)m->d_valid.p, g, m->d_grid);
+    launch(ctx, "smear", k_smear, dim3((total + 255) / 256), dim3(256), 0, total, (const double2*)m->d_world.p,
+           (const uint8_t*)m->d_valid.p, g, (const uint8_t*)m->d_kernel, m->d_grid);
+  } else {
+    launch(ctx, "add_scans_serial", k_add_scans_serial, dim3(1), dim3(64), 0, total, (const double2*)m->d_world.p,
+           (const uint8_t*)m->d_valid.p, g, (const uint8_t*)m->d_kernel, m->d_grid);
+  }
+  LSLAM_HIP(ctx, hipGetLastError());
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSLAM_OK;
+}
+
+int lslam_matcher_match_batch(lslam_matcher* m, int S, const double* ranges, int stride, const double* poses,
+                              int do_penalize, int do_refine, lslam_match_result* out) {
+  if (!m || S < 0 || (S > 0 && (!ranges || !poses || !out))) return LSLAM_ERR_INVALID_ARGUMENT;
+  if (S == 0) return LSLAM_OK;
+  lslam_context* ctx = m->ctx;
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = upload_scans(m, S, ranges, stride, poses);
+  if (rc) return rc;
+  LSLAM_HIP(ctx, m->d_results.reserve(S));
+  rc = match_batch_impl<double>(m, S, m->d_ranges64.p, std::max(m->g.n_beams, 1), m->d_poses.p, do_penalize,
+                                do_refine, m->d_results.p, nullptr, 0);
+  if (rc) return rc;
+  LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_results.p, (size_t)S * sizeof(lslam_match_result), hipMemcpyDeviceToHost,
+                                ctx->stream));
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSLAM_OK;
+}
+
+int lslam_matcher_match_batch_dev_f32(lslam_matcher* m, int S, const float* ranges_dev, int stride,
+                                      const double* poses_dev, int do_penalize, int do_refine,
+                                      lslam_match_result* out_dev) {
+  if (!m || S < 0 || (S > 0 && (!ranges_dev || !poses_dev || !out_dev))) return LSLAM_ERR_INVALID_ARGUMENT;
+  if (stride < m->g.n_beams) return m->ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "ranges_stride < num_beams");
+  return match_batch_impl<float>(m, S, ranges_dev, stride, poses_dev, do_penalize, do_refine, out_dev, nullptr, 0);
+}
+
+int lslam_matcher_match_batch_dev_f64(lslam_matcher* m, int S, const double* ranges_dev, int stride,
+                                      const double* poses_dev, int do_penalize, int do_refine,
+                                      lslam_match_result* out_dev) {
+  if (!m || S < 0 || (S > 0 && (!ranges_dev || !poses_dev || !out_dev))) return LSLAM_ERR_INVALID_ARGUMENT;
+  if (stride < m->g.n_beams) return m->ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "ranges_stride < num_beams");
+  return match_batch_impl<double>(m, S, ranges_dev, stride, poses_dev, do_penalize, do_refine, out_dev, nullptr, 0);
+}
+
+int lslam_matcher_match_scan(lslam_matcher* m, int n_base, const double* base_ranges, int stride,
+                             const double* base_poses, const double* q_ranges, const double q_pose[3],
+                             int do_penalize, int do_refine, lslam_match_result* out) {
+  if (!m || !q_ranges || !q_pose || !out) return LSLAM_ERR_INVALID_ARGUMENT;
+  if (m->g.n_beams != 0) {  // a scan without readings returns before AddScans (Mapper.cpp:199-209)
+    int rc = lslam_matcher_set_base_scans(m, n_base, base_ranges, stride, base_poses, q_pose);
+    if (rc) return rc;
+  }
+  return lslam_matcher_match_batch(m, 1, q_ranges, std::max(m->g.n_beams, 1), q_pose, do_penalize, do_refine, out);
+}
+
+int lslam_matcher_debug_lookup_table(lslam_matcher* m, const double* ranges, const double pose[3],
+                                     double angle_center, double angle_offset, double angle_res,
+                                     int32_t* out, int* n_angles_out) {
+  if (!m || !ranges || !pose || !n_angles_out) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = m->ctx;
+  const Geom g = m->g;
+  int na = n_angles_of(angle_offset, angle_res);
+  *n_angles_out = na;
+  if (!out || g.n_beams == 0) return LSLAM_OK;
+  int rc = upload_scans(m, 1, ranges, g.n_beams, pose);
+  if (rc) return rc;
+  LSLAM_HIP(ctx, m->d_local.reserve((size_t)g.n_beams));
+  LSLAM_HIP(ctx, m->d_dbg.reserve((size_t)na * g.n_beams));
+  launch(ctx, "scan_prep", k_scan_prep<double>, dim3((g.n_beams + 255) / 256, 1), dim3(256), 0,
+         (const double*)m->d_ranges64.p, g.n_beams, (const double*)m->d_poses.p, g, m->d_local.p, (double2*)nullptr);
+  launch(ctx, "debug_table", k_debug_table, dim3((g.n_beams + 255) / 256, na), dim3(256), 0, g,
+         (const double2*)m->d_local.p, angle_center, angle_offset, angle_res, na, m->d_dbg.p);
+  LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_dbg.p, (size_t)na * g.n_beams * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                ctx->stream));
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSLAM_OK;
+}
+
+int lslam_matcher_debug_coarse_sums(lslam_matcher* m, const double* ranges, const double pose[3], int32_t* out,
+                                    int* nx, int* ny, int* na, int force_generic) {
+  if (!m || !ranges || !pose) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = m->ctx;
+  const Geom g = m->g;
+  const double res = 1.0 / g.scale;
+  double off = 0.5 * ((double)g.probs_side - 1) * res;
+  int lx = lattice_count(off, 2 * res);
+  int la = n_angles_of(m->cfg.coarse_search_angle_offset, m->cfg.coarse_angle_resolution);
+  if (nx) *nx = lx;
+  if (ny) *ny = lx;
+  if (na) *na = la;
+  if (!out || g.n_beams == 0) return LSLAM_OK;
+  int rc = upload_scans(m, 1, ranges, g.n_beams, pose);
+  if (rc) return rc;
+  LSLAM_HIP(ctx, m->d_results.reserve(1));
+  LSLAM_HIP(ctx, m->d_dbg.reserve((size_t)lx * lx * la));
+  rc = match_batch_impl<double>(m, 1, m->d_ranges64.p, g.n_beams, m->d_poses.p, 1, 0, m->d_results.p, m->d_dbg.p,
+                                force_generic);
+  if (rc) return rc;
+  LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_dbg.p, (size_t)lx * lx * la * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                ctx->stream));
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSLAM_OK;
+}
+
+int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges, const double pose[3],
+                                   const double viewpoint[2], uint8_t* out) {
+  if (!m || !ranges || !pose || !viewpoint || !out) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = m->ctx;
+  const Geom g = m->g;
+  if (g.n_beams == 0) return LSLAM_OK;
+  int rc = upload_scans(m, 1, ranges, g.n_beams, pose);
+  if (rc) return rc;
+  LSLAM_HIP(ctx, m->d_world.reserve((size_t)g.n_beams));
+  LSLAM_HIP(ctx, m->d_valid.reserve((size_t)g.n_beams));
+  launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((g.n_beams + 255) / 256, 1), dim3(256), 0,
+         (const double*)m->d_ranges64.p, g.n_beams, (const double*)m->d_poses.p, g, (double2*)nullptr, m->d_world.p);
+  launch(ctx, "find_valid", k_find_valid, dim3(1), dim3(64), 0, 1, g.n_beams, (const double2*)m->d_world.p,
+         viewpoint[0], viewpoint[1], m->d_valid.p);
+  LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_valid.p, (size_t)g.n_beams, hipMemcpyDeviceToHost, ctx->stream));
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSLAM_OK;
+}
+
+}  // extern "C"

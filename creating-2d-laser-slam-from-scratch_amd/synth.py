@@ -229,3 +229,37 @@ def make_match_workload(
     )
     q_poses = perturb(truth, err_xy, err_th, seed + 1000)
     return MatchWorkload(laser, base_ranges, base_poses, q_ranges, q_poses, truth, anchor.copy())
+
+
+def hector_points(ranges_f32: np.ndarray, laser: Laser, scale_to_map: float, min_dist: float = 0.4,
+                  max_dist: float = 30.0, use_max: float = 20.0) -> np.ndarray:
+    """LaserScan -> Hector DataContainer points (float32, MAP-CELL units, robot frame).
+
+    Follows what the reference node feeds the map with (hector_slam.cc:193,320-362):
+    laser_geometry projection r*(cos a, sin a) in float32, the node's distance filters, then
+    * scaleToMap.  Laser mounted at the base origin (origo = 0), z filter passes.
+    """
+    r = np.asarray(ranges_f32, dtype=np.float32)
+    a = (laser.angle_min + np.arange(len(r)) * laser.angle_increment).astype(np.float32)
+    x = (r * np.cos(a).astype(np.float32)).astype(np.float32)
+    y = (r * np.sin(a).astype(np.float32)).astype(np.float32)
+    d2 = x * x + y * y
+    ok = np.isfinite(r) & (d2 > np.float32(min_dist * min_dist)) & (d2 < np.float32(max_dist * max_dist))
+    ok &= ~((x < 0) & (d2 < np.float32(0.5)))
+    ok &= ~(d2 > np.float32(use_max * use_max))
+    pts = np.stack([x[ok], y[ok]], axis=1) * np.float32(scale_to_map)
+    return np.ascontiguousarray(pts, dtype=np.float32)
+
+
+def hector_points_metres(ranges_f32: np.ndarray, laser: Laser) -> np.ndarray:
+    """LaserScan -> points in METRES as lesson4's make_hector_map demo builds them
+    (hector_mapping.cc:138-165): float angle accumulated by += angle_increment."""
+    r = np.asarray(ranges_f32, dtype=np.float32)
+    out = []
+    angle = np.float32(laser.angle_min)
+    max_r = np.float32(laser.range_max) - np.float32(0.1)
+    for d in r:
+        if np.isfinite(d) and d > np.float32(laser.range_min) and d < max_r:
+            out.append((np.float32(math.cos(float(angle)) * float(d)), np.float32(math.sin(float(angle)) * float(d))))
+        angle = np.float32(angle + np.float32(laser.angle_increment))
+    return np.asarray(out, dtype=np.float32).reshape(-1, 2)

@@ -1,0 +1,239 @@
+/*
+ * lslam_gpu.h -- C ABI of the MI355X-native 2-D laser SLAM front-end hot path
+ * (Karto-style correlative scan matcher + Hector-style Bresenham log-odds grid update).
+ *
+ * This is the drop-in boundary.  The reference (xiangli0608/Creating-2D-laser-slam-from-scratch)
+ * has no FFI for this path -- its seams are C++ classes -- so every entry point below names the
+ * reference interface it stands in for (file:line relative to the reference repo; short names:
+ *   Mapper.h/Karto.h = lesson6/lib/open_karto/include/open_karto/..., Mapper.cpp = .../src/Mapper.cpp,
+ *   H/ = lesson4/include/lesson4/hector_mapping/).
+ * INTEGRATION.md shows the adapter a maintainer of the reference would add on top of it.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.  Opaque handles.
+ *  - Every call returns LSLAM_OK (0) or a negative lslam_status; lslam_last_error() gives text.
+ *    No exception ever crosses the boundary (the reference throws karto::Exception /
+ *    std::runtime_error, Mapper.cpp:444-447,484-487, Karto.h:4488-4499; those surface as
+ *    per-scan `status` in lslam_match_result or as the call's return code).
+ *  - Poses are (x [m], y [m], heading [rad]).  Matcher poses are SENSOR poses
+ *    (LocalizedRangeScan::GetSensorPose, Karto.h:5280); lslam_sensor_pose_from_robot /
+ *    lslam_robot_pose_from_sensor convert (Karto.h:5289-5313).
+ *  - "host" entry points take host pointers and are synchronous.  "_dev" entry points take
+ *    device (HBM) pointers, only enqueue work on the context's HIP stream and return; use
+ *    lslam_synchronize() or your own event on lslam_stream().
+ *  - A context is bound to one GPU and is not thread-safe, like the reference's matcher
+ *    (one grid + one lookup per ScanMatcher instance, Mapper.h:1273-1278).
+ *  - There is NO CPU fallback: without a usable gfx950 device lslam_create fails.
+ */
+#ifndef LSLAM_GPU_H
+#define LSLAM_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSLAM_ABI_VERSION 1
+
+typedef enum lslam_status {
+  LSLAM_OK = 0,
+  LSLAM_ERR_INVALID_ARGUMENT = -1, /* ScanMatcher::Create returning NULL (Mapper.cpp:130-145) */
+  LSLAM_ERR_NO_DEVICE = -2,
+  LSLAM_ERR_INDEX_OUT_OF_RANGE = -3,  /* karto::Exception from Grid::GridIndex (Karto.h:4488-4499) */
+  LSLAM_ERR_PROBABILITY_SEARCH = -4,  /* "Index out of range in probability search" (Mapper.cpp:444-447) */
+  LSLAM_ERR_NO_BEST_POSE = -5,        /* "Unable to find best position" (Mapper.cpp:484-487) */
+  LSLAM_ERR_HIP = -6,
+  LSLAM_ERR_SMEAR_DEVIATION = -7,     /* CalculateKernel range check (Mapper.h:1041-1053) */
+  LSLAM_ERR_UNSUPPORTED = -8
+} lslam_status;
+
+typedef struct lslam_context lslam_context;
+typedef struct lslam_matcher lslam_matcher;
+typedef struct lslam_map lslam_map;
+
+/* ---------------------------------------------------------------------------------------- */
+/* context                                                                                  */
+/* ---------------------------------------------------------------------------------------- */
+int lslam_abi_version(void);
+/* device = HIP device ordinal.  Fails (LSLAM_ERR_NO_DEVICE) if no GPU is visible. */
+int lslam_create(int device, lslam_context** out);
+void lslam_destroy(lslam_context* ctx);
+const char* lslam_last_error(const lslam_context* ctx); /* ctx may be NULL: last global error */
+int lslam_synchronize(lslam_context* ctx);
+void* lslam_stream(lslam_context* ctx); /* the hipStream_t all work of this context runs on */
+/* device memory helpers for callers without their own allocator (bench / tests) */
+int lslam_dev_alloc(lslam_context* ctx, size_t bytes, void** out);
+int lslam_dev_free(lslam_context* ctx, void* p);
+int lslam_dev_upload(lslam_context* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int lslam_dev_download(lslam_context* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* per-kernel HIP-event timing of subsequent calls (bench.py's roofline numbers).
+ * lslam_profile_read returns the number of records written: name (<=31 chars), launches, total ms */
+typedef struct lslam_kernel_time {
+  char name[32];
+  int64_t launches;
+  double total_ms;
+} lslam_kernel_time;
+int lslam_profile_enable(lslam_context* ctx, int on);
+int lslam_profile_reset(lslam_context* ctx);
+int lslam_profile_read(lslam_context* ctx, lslam_kernel_time* out, int capacity);
+
+/* ---------------------------------------------------------------------------------------- */
+/* Karto correlative scan matcher  (replaces karto::ScanMatcher, Mapper.h:1127-1279)        */
+/* ---------------------------------------------------------------------------------------- */
+typedef struct lslam_matcher_config {
+  double search_size;                /* ScanMatcher::Create searchSize   (Mapper.h:1139-1143) */
+  double resolution;                 /*                      resolution                        */
+  double smear_deviation;            /*                      smearDeviation                    */
+  double range_threshold;            /*                      rangeThreshold                    */
+  /* the Mapper parameters the matcher reads through friend access (Mapper.cpp:206,238-256,
+   * 279-280,405-411).  The two variance penalties are VARIANCES: Mapper::setParam*VariancePenalty
+   * squares what the ROS node passes (Mapper.cpp:1919-1927). */
+  double coarse_search_angle_offset; /* m_pCoarseSearchAngleOffset */
+  double coarse_angle_resolution;    /* m_pCoarseAngleResolution   */
+  double fine_search_angle_offset;   /* m_pFineSearchAngleOffset   */
+  double distance_variance_penalty;  /* m_pDistanceVariancePenalty */
+  double angle_variance_penalty;     /* m_pAngleVariancePenalty    */
+  double minimum_distance_penalty;   /* m_pMinimumDistancePenalty  */
+  double minimum_angle_penalty;      /* m_pMinimumAnglePenalty     */
+  int32_t use_response_expansion;    /* m_pUseResponseExpansion    */
+  int32_t reserved;
+} lslam_matcher_config;
+
+/* karto::LaserRangeFinder parameters the hot path reads (Karto.h:4127-4137, karto_slam.cc:384-395) */
+typedef struct lslam_laser {
+  double minimum_angle, maximum_angle, angular_resolution;
+  double minimum_range, maximum_range, range_threshold;
+  double offset_x, offset_y, offset_heading; /* Sensor::SetOffsetPose (karto_slam.cc:387-389) */
+} lslam_laser;
+
+/* Pose2 mean + response + Matrix3 covariance of one match (Mapper.h:1155-1159): 104 B padded to 112 */
+typedef struct lslam_match_result {
+  double pose[3];       /* rMean: best SENSOR pose */
+  double response;      /* return value of MatchScan, in [0,1] */
+  double covariance[9]; /* rCovariance, row-major 3x3 */
+  int32_t status;       /* LSLAM_OK or the lslam_status the reference would have thrown */
+  int32_t flags;        /* bit0: response expansion was used */
+} lslam_match_result;
+
+/* default parameters of the library (Mapper.cpp:1572-1647) */
+void lslam_matcher_config_defaults(lslam_matcher_config* cfg);
+
+/* ScanMatcher::Create (Mapper.h:1139-1143, Mapper.cpp:126-172): allocates the correlation grid,
+ * smear kernel and workspaces in HBM.  Invalid parameters -> LSLAM_ERR_INVALID_ARGUMENT (the
+ * reference returns NULL) / LSLAM_ERR_SMEAR_DEVIATION (the reference throws). */
+int lslam_matcher_create(lslam_context* ctx, const lslam_matcher_config* cfg,
+                         const lslam_laser* laser, lslam_matcher** out);
+void lslam_matcher_destroy(lslam_matcher* m); /* ~ScanMatcher (Mapper.cpp:119-124) */
+
+/* LaserRangeFinder::GetNumberOfRangeReadings (Karto.h:4152-4161): round((max-min)/res), no +1 */
+int lslam_matcher_num_beams(const lslam_matcher* m);
+/* GetCorrelationGrid() geometry (Mapper.h:1226): out[8] = width,height,widthStep,roi_x,roi_y,
+ * roi_w,roi_h,kernel_size ; offset_xy = CoordinateConverter offset of the current grid */
+int lslam_matcher_grid_info(const lslam_matcher* m, int32_t out[8], double offset_xy[2]);
+/* GetCorrelationGrid()->GetDataPointer() contents: height*widthStep bytes */
+int lslam_matcher_get_grid_u8(lslam_matcher* m, uint8_t* out_host);
+int lslam_matcher_get_kernel_u8(lslam_matcher* m, uint8_t* out_host);
+/* shared-grid mode: install a prebuilt correlation grid (same geometry) + its offset */
+int lslam_matcher_set_grid_u8(lslam_matcher* m, const uint8_t* grid_host, const double offset_xy[2]);
+/* same, from a device buffer (used to replicate one rank's grid after an RCCL broadcast) */
+int lslam_matcher_set_grid_u8_dev(lslam_matcher* m, const uint8_t* grid_dev, const double offset_xy[2]);
+/* device address of the grid bytes (height*widthStep), e.g. as an RCCL broadcast buffer */
+void* lslam_matcher_grid_dev_ptr(lslam_matcher* m);
+
+/* LocalizedRangeScan::GetSensorAt / SetSensorPose (Karto.h:5280-5313), host-side, double */
+void lslam_sensor_pose_from_robot(const lslam_laser* laser, const double robot[3], double sensor[3]);
+void lslam_robot_pose_from_sensor(const lslam_laser* laser, const double sensor[3], double robot[3]);
+
+/* MatchScan steps 1-4 + AddScans (Mapper.cpp:212-225,699-748): recentre the grid on
+ * center_pose, clear it, rasterise + smear the valid points (FindValidPoints, :756-811, viewpoint =
+ * center position) of n_scans base scans.  ranges: n_scans rows of `ranges_stride` doubles
+ * (>= num_beams used), sensor_poses: n_scans*3. */
+int lslam_matcher_set_base_scans(lslam_matcher* m, int n_scans, const double* ranges,
+                                 int ranges_stride, const double* sensor_poses,
+                                 const double center_pose[3]);
+
+/* ScanMatcher::MatchScan (Mapper.h:1155-1159, Mapper.cpp:184-291), complete: rebuild the grid
+ * from the base scans around the query's sensor pose, coarse + (expansion) + fine search. */
+int lslam_matcher_match_scan(lslam_matcher* m, int n_base, const double* base_ranges,
+                             int ranges_stride, const double* base_sensor_poses,
+                             const double* query_ranges, const double query_sensor_pose[3],
+                             int do_penalize, int do_refine, lslam_match_result* out);
+
+/* The search part of MatchScan (Mapper.cpp:227-290 = CorrelateScan coarse/expansion/fine,
+ * Mapper.h:1177-1186) for n_scans INDEPENDENT scans against the CURRENT grid (batched
+ * many-scan mode; n_scans = 1 is the single-scan case).  Host pointers, synchronous. */
+int lslam_matcher_match_batch(lslam_matcher* m, int n_scans, const double* ranges,
+                              int ranges_stride, const double* sensor_poses, int do_penalize,
+                              int do_refine, lslam_match_result* out);
+/* Same with everything resident in HBM: float32 ranges exactly as a sensor_msgs/LaserScan
+ * carries them (widened to double on the device like karto_slam.cc:428-433), results written
+ * to out_dev.  Asynchronous on the context stream. */
+int lslam_matcher_match_batch_dev_f32(lslam_matcher* m, int n_scans, const float* ranges_dev,
+                                      int ranges_stride, const double* sensor_poses_dev,
+                                      int do_penalize, int do_refine,
+                                      lslam_match_result* out_dev);
+int lslam_matcher_match_batch_dev_f64(lslam_matcher* m, int n_scans, const double* ranges_dev,
+                                      int ranges_stride, const double* sensor_poses_dev,
+                                      int do_penalize, int do_refine,
+                                      lslam_match_result* out_dev);
+
+/* ---- inspection hooks used by the parity tests (intermediate state of the reference) ---- */
+/* GridIndexLookup::ComputeOffsets (Karto.h:6409-6501) for one scan: out = n_angles*num_beams
+ * int32 (INT_MAX = INVALID_SCAN); returns n_angles in *n_angles_out */
+int lslam_matcher_debug_lookup_table(lslam_matcher* m, const double* ranges,
+                                     const double sensor_pose[3], double angle_center,
+                                     double angle_offset, double angle_resolution,
+                                     int32_t* out_host, int* n_angles_out);
+/* integer numerators of GetResponse (Mapper.cpp:819-856) over the COARSE lattice of one scan
+ * against the current grid, order y,x,angle; returns counts through nx,ny,na */
+int lslam_matcher_debug_coarse_sums(lslam_matcher* m, const double* ranges,
+                                    const double sensor_pose[3], int32_t* out_host, int* nx,
+                                    int* ny, int* na, int force_generic_kernel);
+/* FindValidPoints mask (Mapper.cpp:756-811) of one scan: out[num_beams] bytes, 1 = kept */
+int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges,
+                                   const double sensor_pose[3], const double viewpoint[2],
+                                   uint8_t* out_host);
+
+/* ---------------------------------------------------------------------------------------- */
+/* Hector log-odds occupancy grid  (replaces hectorslam::OccGridMapBase<LogOddsCell,...>,    */
+/* H/map/OccGridMapBase.h, H/map/GridMapLogOdds.h, H/map/GridMapBase.h)                      */
+/* ---------------------------------------------------------------------------------------- */
+/* GridMapBase ctor (H/map/GridMapBase.h:54-67) x MapRepMultiMap pyramid (H/slam_main/
+ * MapRepMultiMap.h:50-93): level i has size>>i cells of cell_length*2^i.
+ * top-left offset as in H/map/GridMapBase.h:270-286. */
+int lslam_map_create(lslam_context* ctx, int size_x, int size_y, float cell_length,
+                     float offset_x, float offset_y, int levels, lslam_map** out);
+void lslam_map_destroy(lslam_map* map);
+int lslam_map_reset(lslam_map* map);                         /* GridMapBase::reset (:95-110) */
+int lslam_map_set_update_factor_free(lslam_map* map, float p);     /* H/map/OccGridMapBase.h:103-106 */
+int lslam_map_set_update_factor_occupied(lslam_map* map, float p); /* :108-111 */
+int lslam_map_levels(const lslam_map* map);
+int lslam_map_size(const lslam_map* map, int level, int* size_x, int* size_y);
+float lslam_map_scale_to_map(const lslam_map* map, int level); /* getScaleToMap (:292-295) */
+/* OccGridMapBase::updateByScan (H/map/OccGridMapBase.h:118-168) on every pyramid level, level
+ * i using points*(1/2^i) like DataPointContainer::setFrom (H/scan/DataPointContainer.h:46-58).
+ * points_xy: n points in LEVEL-0 MAP-CELL units, robot frame (hector_slam.cc:320-362);
+ * origo_xy: DataContainer origo; pose_world: (x[m], y[m], heading). */
+int lslam_map_update_by_scan(lslam_map* map, const float* points_xy, int n,
+                             const float origo_xy[2], const float pose_world[3]);
+int lslam_map_update_by_scan_dev(lslam_map* map, const float* points_xy_dev, int n,
+                                 const float origo_xy[2], const float pose_world[3]);
+/* OccGridMapBase::updateByScanJustOnce (H/map/OccGridMapBase.h:175-217): the lesson4
+ * make_hector_map demo variant -- points in METRES, begin cell and 1/0.05 scale hard-coded by
+ * the reference (we take them as parameters; pass 800,800,0.05 for the literal behaviour). */
+int lslam_map_update_just_once(lslam_map* map, const float* points_xy, int n,
+                               const float origo_xy[2], float begin_x, float begin_y,
+                               double metres_per_cell);
+/* LogOddsCell::logOddsVal of every cell, row-major y*size_x+x (H/map/GridMapLogOdds.h:85) */
+int lslam_map_read_logodds(lslam_map* map, int level, float* out_host);
+/* nav_msgs/OccupancyGrid data as hector_slam.cc:287-304 / hector_mapping.cc:186-200 publish
+ * it: free(<0) -> 0, occupied(>0) -> 100, else -1 */
+int lslam_map_read_occupancy_i8(lslam_map* map, int level, int8_t* out_host);
+void* lslam_map_cells_dev_ptr(lslam_map* map, int level); /* float log-odds plane in HBM */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSLAM_GPU_H */

@@ -1,0 +1,51 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's Hector log-odds grid update.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *
+ * Parity status: PARITY UNPINNED at the Eigen boundary.  lesson4 cannot be compiled here (Eigen
+ * and ROS are absent), the reference ships no tests or golden vectors, so this
+ * file restates H/map/OccGridMapBase.h:118-330, H/map/GridMapLogOdds.h:37-161,
+ * H/map/GridMapBase.h:270-286 in plain float32 C.  Eigen is used there only for 2-D affine
+ * multiplies and int/float casts; we assume the coefficient order (m00*x + m01*y) + t with one
+ * rounding per operation (no FMA: the reference builds lesson4 for baseline x86-64, -O0).  The
+ * integer part (Bresenham traversal, once-per-scan cell semantics) is exact by construction.
+ *
+ * Citations: H/ = /root/reference/lesson4/include/lesson4/hector_mapping/.
+ */
+#ifndef HECTOR_ORACLE_H
+#define HECTOR_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hor_map hor_map;
+
+/* GridMapBase ctor (H/map/GridMapBase.h:54-67): one level */
+hor_map* hor_create(int size_x, int size_y, float cell_length, float offset_x, float offset_y);
+void hor_destroy(hor_map* m);
+void hor_reset(hor_map* m);                           /* clear() (H/map/GridMapBase.h:102-110) */
+void hor_set_update_free_factor(hor_map* m, float p); /* H/map/GridMapLogOdds.h:140-143 */
+void hor_set_update_occupied_factor(hor_map* m, float p);
+float hor_scale_to_map(const hor_map* m);
+/* OccGridMapBase::updateByScan (H/map/OccGridMapBase.h:118-168); points in map-cell units */
+void hor_update_by_scan(hor_map* m, const float* points_xy, int n, const float origo_xy[2],
+                        const float pose_world[3]);
+/* OccGridMapBase::updateByScanJustOnce (H/map/OccGridMapBase.h:175-217); points in metres */
+void hor_update_just_once(hor_map* m, const float* points_xy, int n, const float origo_xy[2],
+                          float begin_x, float begin_y, double metres_per_cell);
+void hor_read_logodds(const hor_map* m, float* out);
+void hor_read_update_index(const hor_map* m, int32_t* out);
+/* publish conversion (hector_slam.cc:287-304): free -> 0, occupied -> 100, else -1 */
+void hor_read_occupancy_i8(const hor_map* m, int8_t* out);
+/* number of cells traversed (free marks incl. repeats + endpoints) by the last update: the
+ * "cell-updates" unit of BASELINE.md §4 */
+int64_t hor_last_cell_visits(const hor_map* m);
+
+/* DataPointContainer::setFrom factor for pyramid level i (H/slam_main/MapRepMultiMap.h:161) */
+float hor_level_factor(int level);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -490,3 +490,94 @@ class PortKarto:
 
     def running_scans(self) -> int:
         return self.L.kor_frontend_running_scans(self.fe)
+
+
+class PortHector:
+    """oracle/hector_oracle.c: one level of the reference's log-odds map."""
+
+    _L = None
+
+    @classmethod
+    def lib(cls):
+        if cls._L is None:
+            path = HERE / "libhector_oracle.so"
+            if not path.exists():
+                build("libhector_oracle.so")
+            L = C.CDLL(str(path))
+            vp = C.c_void_p
+            L.hor_create.restype = vp
+            L.hor_create.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]
+            L.hor_destroy.argtypes = [vp]
+            L.hor_reset.argtypes = [vp]
+            L.hor_set_update_free_factor.argtypes = [vp, C.c_float]
+            L.hor_set_update_occupied_factor.argtypes = [vp, C.c_float]
+            L.hor_scale_to_map.restype = C.c_float
+            L.hor_scale_to_map.argtypes = [vp]
+            L.hor_update_by_scan.argtypes = [vp, vp, C.c_int, vp, vp]
+            L.hor_update_just_once.argtypes = [vp, vp, C.c_int, vp, C.c_float, C.c_float, C.c_double]
+            L.hor_read_logodds.argtypes = [vp, vp]
+            L.hor_read_update_index.argtypes = [vp, vp]
+            L.hor_read_occupancy_i8.argtypes = [vp, vp]
+            L.hor_last_cell_visits.restype = C.c_int64
+            L.hor_last_cell_visits.argtypes = [vp]
+            L.hor_level_factor.restype = C.c_float
+            L.hor_level_factor.argtypes = [C.c_int]
+            cls._L = L
+        return cls._L
+
+    def __init__(self, size_x, size_y, cell_length, offset=(0.0, 0.0)):
+        self.L = self.lib()
+        self.sx, self.sy = size_x, size_y
+        self.h = self.L.hor_create(size_x, size_y, cell_length, offset[0], offset[1])
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.hor_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.L.hor_reset(self.h)
+
+    def setUpdateFreeFactor(self, p):
+        self.L.hor_set_update_free_factor(self.h, p)
+
+    def setUpdateOccupiedFactor(self, p):
+        self.L.hor_set_update_occupied_factor(self.h, p)
+
+    def getScaleToMap(self):
+        return self.L.hor_scale_to_map(self.h)
+
+    def updateByScan(self, points_xy, origo_xy, pose_world):
+        p = np.ascontiguousarray(points_xy, dtype=np.float32).reshape(-1, 2)
+        o = np.ascontiguousarray(origo_xy, dtype=np.float32)
+        w = np.ascontiguousarray(pose_world, dtype=np.float32)
+        self.L.hor_update_by_scan(self.h, p.ctypes.data, p.shape[0], o.ctypes.data, w.ctypes.data)
+
+    def updateByScanJustOnce(self, points_xy_m, origo_xy=(0.0, 0.0), begin=(800.0, 800.0), metres_per_cell=0.05):
+        p = np.ascontiguousarray(points_xy_m, dtype=np.float32).reshape(-1, 2)
+        o = np.ascontiguousarray(origo_xy, dtype=np.float32)
+        self.L.hor_update_just_once(self.h, p.ctypes.data, p.shape[0], o.ctypes.data, begin[0], begin[1],
+                                    metres_per_cell)
+
+    def logodds(self):
+        out = np.zeros((self.sy, self.sx), dtype=np.float32)
+        self.L.hor_read_logodds(self.h, out.ctypes.data)
+        return out
+
+    def occupancy_i8(self):
+        out = np.zeros((self.sy, self.sx), dtype=np.int8)
+        self.L.hor_read_occupancy_i8(self.h, out.ctypes.data)
+        return out
+
+    def last_cell_visits(self) -> int:
+        return self.L.hor_last_cell_visits(self.h)
+
+    @classmethod
+    def level_factor(cls, level: int) -> float:
+        return cls.lib().hor_level_factor(level)

@@ -1,0 +1,131 @@
+"""GPU parity tests of the Hector log-odds Bresenham map update against the CPU restatement
+(oracle/hector_oracle.c).  The map is float32: same operations in the same per-cell order, so the
+log-odds planes must be BIT-EXACT, and the published int8 occupancy identical."""
+import math
+
+import numpy as np
+import pytest
+
+from lslam_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def scans_for_map(n_scans=6, seed=3, map_cells=1000, cell=0.05):
+    world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=seed)
+    laser = synth.Laser()
+    path = synth.trajectory(world, n_scans, step=0.45, seed=seed, bounds=8.0)
+    rng = np.random.default_rng(seed)
+    out = []
+    for p in path:
+        r = synth.cast_scan(world, p, laser, 0.01, 0.01, rng)
+        out.append((synth.hector_points(r, laser, 1.0 / cell), p.astype(np.float32)))
+    return out
+
+
+def test_update_by_scan_bit_exact(ctx, oracle_lib):
+    n, cell = 1000, 0.05
+    off = (n * cell * 0.5, n * cell * 0.5)  # MapRepMultiMap mid offset (MapRepMultiMap.h:62-66)
+    cpu = oracle_lib.PortHector(n, n, cell, off)
+    gpu = api.OccGridMap(ctx, n, n, cell, off, levels=1)
+    for m in (cpu, gpu):
+        m.setUpdateFreeFactor(0.4)
+        m.setUpdateOccupiedFactor(0.9)  # hector_slam.cc:144-145
+    assert gpu.getScaleToMap() == cpu.getScaleToMap()
+    for pts, pose in scans_for_map():
+        assert len(pts) > 500
+        cpu.updateByScan(pts, (0.0, 0.0), pose)
+        gpu.updateByScan(pts, (0.0, 0.0), pose)
+        a, b = cpu.logodds(), gpu.logodds()
+        assert (a != 0).sum() > 10000
+        assert a.tobytes() == b.tobytes()
+    assert np.array_equal(cpu.occupancy_i8(), gpu.occupancy_i8())
+    occ = gpu.occupancy_i8()
+    assert {int(v) for v in np.unique(occ)} == {-1, 0, 100}
+
+
+def test_repeated_scans_hit_the_occupied_clamp(ctx, oracle_lib):
+    """logOdds < 50 clamp applies to occupied updates only (GridMapLogOdds.h:108-114)."""
+    n, cell = 400, 0.05
+    off = (10.0, 10.0)
+    cpu = oracle_lib.PortHector(n, n, cell, off)
+    gpu = api.OccGridMap(ctx, n, n, cell, off)
+    for m in (cpu, gpu):
+        m.setUpdateOccupiedFactor(0.999)  # ln(999) ~ 6.9 per hit -> clamp after 8 scans
+    (pts, pose) = scans_for_map(1, seed=7, map_cells=n)[0]
+    pose = np.array([0.0, 0.0, 0.3], dtype=np.float32)
+    pts = pts[(np.abs(pts) < 150).all(axis=1)]
+    for _ in range(12):
+        cpu.updateByScan(pts, (0.0, 0.0), pose)
+        gpu.updateByScan(pts, (0.0, 0.0), pose)
+    a, b = cpu.logodds(), gpu.logodds()
+    assert a.max() >= 50.0 and a.max() < 50.0 + 7.0
+    assert a.tobytes() == b.tobytes()
+
+
+def test_free_then_occupied_same_scan(ctx, oracle_lib):
+    """A cell crossed by an earlier beam and hit by a later one gets (v+free)-free then +occ;
+    hit first and crossed later gets +occ only (OccGridMapBase.h:316-330)."""
+    n, cell = 200, 0.05
+    cpu = oracle_lib.PortHector(n, n, cell, (5.0, 5.0))
+    gpu = api.OccGridMap(ctx, n, n, cell, (5.0, 5.0))
+    # beams along +x of different lengths, both orders, plus duplicates and a zero-length beam
+    pts = np.array([[40, 0], [20, 0], [10, 0], [30, 0], [30, 0], [0.2, 0.1], [-15, 25], [-15, 25], [-7.5, 12.5],
+                    [500, 0], [0, -60]], dtype=np.float32)
+    pose = np.array([0.0, 0.0, 0.0], dtype=np.float32)
+    for k in range(3):
+        cpu.updateByScan(pts, (0.0, 0.0), pose)
+        gpu.updateByScan(pts, (0.0, 0.0), pose)
+        assert cpu.logodds().tobytes() == gpu.logodds().tobytes()
+        pts = pts[::-1].copy()  # reverse beam order next round
+
+
+def test_pyramid_levels(ctx, oracle_lib):
+    """MapRepMultiMap: level i = size>>i, cell*2^i, points*(1/2^i) (MapRepMultiMap.h:57-93,174-191)."""
+    n, cell, levels = 512, 0.05, 3
+    off = (n * cell * 0.5, n * cell * 0.5)
+    gpu = api.OccGridMap(ctx, n, n, cell, off, levels=levels)
+    cpus = [oracle_lib.PortHector(n >> i, n >> i, cell * 2 ** i, off) for i in range(levels)]
+    assert gpu.levels == levels
+    for pts, pose in scans_for_map(3, seed=9, map_cells=n):
+        pts = pts[(np.abs(pts) < 200).all(axis=1)]
+        pose = (pose * np.float32(0.2)).astype(np.float32)
+        gpu.updateByScan(pts, (1.5, -0.5), pose)
+        for i, c in enumerate(cpus):
+            f = np.float32(oracle_lib.PortHector.level_factor(i))
+            if i == 0:
+                c.updateByScan(pts, (1.5, -0.5), pose)
+            else:
+                c.updateByScan(pts * f, np.array([1.5, -0.5], dtype=np.float32) * f, pose)
+    for i, c in enumerate(cpus):
+        assert gpu.size(i) == (n >> i, n >> i)
+        assert c.logodds().tobytes() == gpu.logodds(i).tobytes()
+
+
+def test_update_just_once_demo_variant(ctx, oracle_lib):
+    """lesson4 make_hector_map: fresh 1600x1600 map per scan, begin (800,800), metres/0.05."""
+    laser = synth.Laser()
+    world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=2)
+    r = synth.cast_scan(world, (1.0, -2.0, 0.4), laser)
+    pts = synth.hector_points_metres(r, laser)
+    cpu = oracle_lib.PortHector(1600, 1600, 0.05, (0.0, 0.0))
+    gpu = api.OccGridMap(ctx, 1600, 1600, 0.05, (0.0, 0.0))
+    cpu.updateByScanJustOnce(pts)
+    gpu.updateByScanJustOnce(pts)
+    a = cpu.logodds()
+    assert (a > 0).sum() > 300 and (a < 0).sum() > 10000
+    assert a.tobytes() == gpu.logodds().tobytes()
+
+
+def test_out_of_map_beams_are_dropped(ctx, oracle_lib):
+    n, cell = 100, 0.1
+    cpu = oracle_lib.PortHector(n, n, cell, (5.0, 5.0))
+    gpu = api.OccGridMap(ctx, n, n, cell, (5.0, 5.0))
+    pts = np.array([[200, 0], [-200, 3], [10, 10], [0, 49.4], [0, 49.6], [49.4, 0]], dtype=np.float32)
+    for pose in ((0, 0, 0), (4.9, 0, 0), (20.0, 0, 0)):  # last: begin cell outside the map
+        pose = np.array(pose, dtype=np.float32)
+        cpu.updateByScan(pts, (0, 0), pose)
+        gpu.updateByScan(pts, (0, 0), pose)
+    assert cpu.logodds().tobytes() == gpu.logodds().tobytes()
+    # empty scan is legal
+    gpu.updateByScan(np.zeros((0, 2), np.float32), (0, 0), np.zeros(3, np.float32))
