@@ -10,5 +10,6 @@ it through the repo-root alias module::
 from . import build as build  # noqa: F401
 from . import synth as synth  # noqa: F401
 from . import api as api  # noqa: F401
+from . import shard as shard  # noqa: F401
 
 __all__ = ["api", "synth", "build"]

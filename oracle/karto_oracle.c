@@ -603,6 +603,59 @@ int kor_probs(const kor_matcher* m, double* out) {
   return m->probs_side;
 }
 
+/* Matrix3::InverseFast by cofactors (Karto.h:2460-2493), tolerance 1e-14 as Inverse() passes it */
+static int mat3_inverse(const double m[9], double inv[9]) {
+  inv[0] = m[4] * m[8] - m[5] * m[7];
+  inv[1] = m[2] * m[7] - m[1] * m[8];
+  inv[2] = m[1] * m[5] - m[2] * m[4];
+  inv[3] = m[5] * m[6] - m[3] * m[8];
+  inv[4] = m[0] * m[8] - m[2] * m[6];
+  inv[5] = m[2] * m[3] - m[0] * m[5];
+  inv[6] = m[3] * m[7] - m[4] * m[6];
+  inv[7] = m[1] * m[6] - m[0] * m[7];
+  inv[8] = m[0] * m[4] - m[1] * m[3];
+  double det = m[0] * inv[0] + m[1] * inv[3] + m[2] * inv[6];
+  if (fabs(det) <= 1e-14) return 0;
+  double id = 1.0 / det;
+  for (int i = 0; i < 9; i++) inv[i] *= id;
+  return 1;
+}
+/* Matrix3 operator* (Karto.h:2552-2568) */
+static void mat3_mul(const double a[9], const double b[9], double out[9]) {
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++)
+      out[3 * r + c] = a[3 * r] * b[c] + a[3 * r + 1] * b[3 + c] + a[3 * r + 2] * b[6 + c];
+}
+/* MapperGraph::ComputeWeightedMean (Mapper.cpp:1288-1330): AddEdges ends with
+ * SetSensorPose(ComputeWeightedMean(means, covariances)) (Mapper.cpp:969-972), so even a single
+ * (mean, covariance) pair passes through inverse(inverse(C)) * inverse(C) * pose. */
+static void weighted_mean(int n, const double* means, const double* covs, double out[3]) {
+  double sum[9] = {0};
+  double* inv = (double*)malloc(sizeof(double) * 9 * (size_t)n);
+  for (int i = 0; i < n; i++) {
+    mat3_inverse(covs + 9 * i, inv + 9 * i);
+    for (int k = 0; k < 9; k++) sum[k] += inv[9 * i + k];
+  }
+  double ios[9];
+  mat3_inverse(sum, ios);
+  double ax = 0.0, ay = 0.0, ah = 0.0, tx = 0.0, ty = 0.0;
+  for (int i = 0; i < n; i++) {
+    const double* p = means + 3 * i;
+    tx += cos(p[2]);
+    ty += sin(p[2]);
+    double w[9];
+    mat3_mul(ios, inv + 9 * i, w);
+    double wx = w[0] * p[0] + w[1] * p[1] + w[2] * p[2]; /* Matrix3 * Pose2 (Karto.h:2574-2583) */
+    double wy = w[3] * p[0] + w[4] * p[1] + w[5] * p[2];
+    double wh = w[6] * p[0] + w[7] * p[1] + w[8] * p[2];
+    ax += wx; ay += wy;                                   /* Pose2 operator+= (Karto.h:2117-2121) */
+    ah = normalize_angle(ah + wh);
+  }
+  free(inv);
+  tx /= n; ty /= n;
+  out[0] = ax; out[1] = ay; out[2] = atan2(ty, tx);
+}
+
 /* ------------------------------------------------------------------------------------------- */
 struct kor_frontend {
   kor_matcher* m;
@@ -672,6 +725,13 @@ int kor_frontend_process(kor_frontend* f, const double* ranges, const double odo
     free(sposes);
     if (status) return status;
     kor_robot_pose_from_sensor(m, mean, corrected); /* SetSensorPose(bestPose) (:2044) */
+    /* AddEdges (Mapper.cpp:957-972): means = {GetSensorPose()}, covariances = {covariance}; near
+     * chains (graph traversal, LinkNearChains) are host-side back-end work and not restated: the
+     * harness trajectories do not revisit, so no near chain exists. */
+    double sp[3], wm[3];
+    kor_sensor_pose_from_robot(m, corrected, sp);
+    weighted_mean(1, sp, cov, wm);
+    kor_robot_pose_from_sensor(m, wm, corrected);
   }
   /* AddRunningScan (Mapper.h:1365-1386) */
   memcpy(f->run_ranges + (size_t)f->n_run * f->n_ranges, ranges, sizeof(double) * f->n_ranges);

@@ -133,6 +133,10 @@ class RefKarto:
         L.kref_occupancy_grid.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.kref_last_error.restype = C.c_char_p
         L.kref_last_error.argtypes = [C.c_void_p]
+        L.kref_set_base_scans.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.kref_match_fixed_grid.restype = C.c_double
+        L.kref_match_fixed_grid.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.kref_round.restype = C.c_double
         L.kref_round.argtypes = [C.c_double]
         self.L = L
@@ -182,6 +186,27 @@ class RefKarto:
                                       qr.shape[1], qr.ctypes.data, qp.ctypes.data, n,
                                       poses.ctypes.data, resp.ctypes.data)
         return sec, poses, resp
+
+    def set_base_scans(self, base_ranges, base_poses, center_pose):
+        """shared-grid mode: the reference's AddScans around an explicit centre pose."""
+        br = np.ascontiguousarray(base_ranges, dtype=np.float64)
+        bp = np.ascontiguousarray(base_poses, dtype=np.float64)
+        c = np.ascontiguousarray(center_pose, dtype=np.float64)
+        rc = self.L.kref_set_base_scans(self.h, br.shape[0], br.ctypes.data, bp.ctypes.data, br.shape[1], c.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(self.L.kref_last_error(self.h).decode())
+
+    def match_fixed_grid(self, q_ranges, q_poses, do_penalize=True, do_refine=True):
+        """coarse+fine CorrelateScan of n scans vs the current grid -> (sec/scan, poses, covs, resp)."""
+        qr = np.ascontiguousarray(q_ranges, dtype=np.float64).reshape(-1, np.shape(q_ranges)[-1])
+        qp = np.ascontiguousarray(q_poses, dtype=np.float64).reshape(-1, 3)
+        n = qr.shape[0]
+        poses, covs, resp = np.zeros((n, 3)), np.zeros((n, 3, 3)), np.zeros(n)
+        sec = self.L.kref_match_fixed_grid(self.h, qr.shape[1], qr.ctypes.data, qp.ctypes.data, n, int(do_penalize),
+                                           int(do_refine), poses.ctypes.data, covs.ctypes.data, resp.ctypes.data)
+        if sec < 0:
+            raise RuntimeError("reference threw inside CorrelateScan")
+        return sec, poses, covs, resp
 
     def grid_info(self):
         i = np.zeros(8, dtype=np.int32)

@@ -395,6 +395,90 @@ int kref_occupancy_grid(void* h, double resolution, int* dims /* w,h */, double*
   return 0;
 }
 
+// ---- shared-grid ("batched many-scan") mode on the reference's own functions -------------------
+// MatchScan steps 1-4 + AddScans (Mapper.cpp:212-225) around an explicit centre pose: the private
+// AddScans is the reference's; only the centre is ours.
+int kref_set_base_scans(void* h, int n_base, const double* base_ranges, const double* base_poses,
+                        int n_ranges, const double* center_pose) {
+  KRef* k = (KRef*)h;
+  try {
+    for (auto* s : k->owned) delete s;
+    k->owned.clear();
+    LocalizedRangeScanVector base;
+    for (int i = 0; i < n_base; i++) {
+      LocalizedRangeScan* s = make_scan(k, base_ranges + (size_t)i * n_ranges, n_ranges, base_poses + 3 * i);
+      k->owned.push_back(s);
+      base.push_back(s);
+    }
+    CorrelationGrid* g = k->matcher->m_pCorrelationGrid;
+    Rectangle2<kt_int32s> roi = g->GetROI();
+    Vector2<kt_double> offset;
+    offset.SetX(center_pose[0] - (0.5 * (roi.GetWidth() - 1) * g->GetResolution()));
+    offset.SetY(center_pose[1] - (0.5 * (roi.GetHeight() - 1) * g->GetResolution()));
+    g->GetCoordinateConverter()->SetOffset(offset);
+    k->matcher->AddScans(base, Vector2<kt_double>(center_pose[0], center_pose[1]));
+    return 0;
+  } catch (std::exception& e) {
+    k->err = e.what();
+    return -1;
+  } catch (karto::Exception& e) {
+    k->err = e.GetErrorMessage();
+    return -2;
+  }
+}
+
+// The search part of MatchScan (Mapper.cpp:227-282) against the CURRENT grid, spelled with the
+// reference's public CorrelateScan (Mapper.h:1177-1186).  Returns seconds per scan over the n
+// queries (steady_clock around the loop only).
+double kref_match_fixed_grid(void* h, int n_ranges, const double* q_ranges_all, const double* q_poses_all,
+                             int n_queries, int do_penalize, int do_refine, double* out_poses,
+                             double* out_covs, double* out_resp) {
+  KRef* k = (KRef*)h;
+  ScanMatcher* sm = k->matcher;
+  Mapper* mp = k->mapper;
+  std::vector<LocalizedRangeScan*> qs;
+  for (int i = 0; i < n_queries; i++)
+    qs.push_back(make_scan(k, q_ranges_all + (size_t)i * n_ranges, n_ranges, q_poses_all + 3 * i));
+  CorrelationGrid* g = sm->m_pCorrelationGrid;
+  double total = 0.0;
+  try {
+    for (int i = 0; i < n_queries; i++) {
+      qs[i]->GetPointReadings();  // LocalizedRangeScan::Update outside the timed region
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n_queries; i++) {
+      LocalizedRangeScan* pScan = qs[i];
+      Pose2 scanPose = pScan->GetSensorPose();
+      Pose2 mean;
+      Matrix3 cov;
+      cov.SetToIdentity();
+      Vector2<kt_double> searchDimensions(sm->m_pSearchSpaceProbs->GetWidth(), sm->m_pSearchSpaceProbs->GetHeight());
+      Vector2<kt_double> coarseSearchOffset(0.5 * (searchDimensions.GetX() - 1) * g->GetResolution(),
+                                            0.5 * (searchDimensions.GetY() - 1) * g->GetResolution());
+      Vector2<kt_double> coarseSearchResolution(2 * g->GetResolution(), 2 * g->GetResolution());
+      kt_double best = sm->CorrelateScan(pScan, scanPose, coarseSearchOffset, coarseSearchResolution,
+                                         mp->m_pCoarseSearchAngleOffset->GetValue(),
+                                         mp->m_pCoarseAngleResolution->GetValue(), do_penalize != 0, mean, cov, false);
+      if (do_refine) {
+        Vector2<kt_double> fineSearchOffset(coarseSearchResolution * 0.5);
+        Vector2<kt_double> fineSearchResolution(g->GetResolution(), g->GetResolution());
+        best = sm->CorrelateScan(pScan, mean, fineSearchOffset, fineSearchResolution,
+                                 0.5 * mp->m_pCoarseAngleResolution->GetValue(),
+                                 mp->m_pFineSearchAngleOffset->GetValue(), do_penalize != 0, mean, cov, true);
+      }
+      if (out_poses) { out_poses[3 * i] = mean.GetX(); out_poses[3 * i + 1] = mean.GetY(); out_poses[3 * i + 2] = mean.GetHeading(); }
+      if (out_covs) for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) out_covs[9 * i + 3 * r + c] = cov(r, c);
+      if (out_resp) out_resp[i] = best;
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    total = std::chrono::duration<double>(t1 - t0).count();
+  } catch (...) {
+    total = -1.0;
+  }
+  for (auto* q : qs) delete q;
+  return total / std::max(1, n_queries);
+}
+
 const char* kref_last_error(void* h) { return ((KRef*)h)->err.c_str(); }
 
 int kref_sizeof_pose2() { return (int)sizeof(Pose2); }

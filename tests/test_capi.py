@@ -1,0 +1,69 @@
+"""The C-ABI library loads and exports every symbol include/lslam_gpu.h declares; without a GPU
+the product fails loudly instead of falling back to anything.  CPU only (no compute calls)."""
+import ctypes
+import pathlib
+import re
+
+import pytest
+
+from lslam_amd import api, build
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def declared_functions():
+    text = (ROOT / "include" / "lslam_gpu.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lslam_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    names = declared_functions()
+    assert len(names) >= 40
+    L = ctypes.CDLL(str(build.build_library()))
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_abi_version_and_struct_sizes():
+    L = api.lib()
+    assert L.lslam_abi_version() == 1
+    assert ctypes.sizeof(api.MatchResult) == 112  # 104 B padded to 112
+    assert ctypes.sizeof(api.MatcherConfig) == 96
+    assert ctypes.sizeof(api.LaserParams) == 72
+    cfg = api.MatcherConfig()
+    L.lslam_matcher_config_defaults(ctypes.byref(cfg))
+    assert (cfg.search_size, cfg.resolution, cfg.smear_deviation) == (0.3, 0.01, 0.03)  # Mapper.cpp:1572-1586
+    assert cfg.use_response_expansion == 0
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(api.LslamError) as e:
+        api.Context(0)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under the package or include/ may reference it."""
+    pkg = ROOT / "creating-2d-laser-slam-from-scratch_amd"
+    for p in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.hpp")) + [ROOT / "include" / "lslam_gpu.h"]:
+        s = p.read_text()
+        assert "pyoracle" not in s and "karto_oracle" not in s and "hector_oracle" not in s and "libkarto_ref" not in s, p
+
+
+def test_pose_helpers_host_only():
+    """lslam_sensor_pose_from_robot / robot_pose_from_sensor are host fp64 and need no GPU."""
+    import numpy as np
+
+    L = api.lib()
+    lp = api.LaserParams(-2.0, 2.0, 0.01, 0.1, 30.0, 12.0, 0.2, -0.1, 0.3)
+    robot = np.array([1.0, 2.0, 0.5])
+    sensor, back = np.zeros(3), np.zeros(3)
+    L.lslam_sensor_pose_from_robot(ctypes.byref(lp), robot.ctypes.data, sensor.ctypes.data)
+    L.lslam_robot_pose_from_sensor(ctypes.byref(lp), sensor.ctypes.data, back.ctypes.data)
+    assert np.allclose(back, robot, atol=1e-12)
+    assert abs(sensor[2] - 0.8) < 1e-15
