@@ -151,7 +151,7 @@ def main():
     if dom_name:
         launches, total_ms = prof[dom_name]
         avg_ms = total_ms / max(launches, 1)
-        per_launch_bytes = (coarse_bytes if dom_name == "resp_lattice2" else match_bytes) * B
+        per_launch_bytes = (coarse_bytes if dom_name == "resp_rows_coarse" else match_bytes) * B
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         tfile = ROOT / "profiles" / "traffic.json"  # PMC HBM bytes per launch of the same command (see profiles/README.md)

@@ -8,8 +8,8 @@
 // Device pipeline of one batch of S independent scans against the resident correlation grid:
 //   k_scan_prep      S*N threads   ranges -> scan-frame points (Karto.h:5384-5388, 6423-6434)
 //   k_pass_setup     S threads     lattice cell coordinates of the pass (Mapper.cpp:339-386)
-//   k_resp_lattice2  S*nA waves    ** hot kernel ** all nX*nY response sums of one (scan, angle)
-//                                  for a uniform 2-cell lattice (Mapper.cpp:373-424, 819-856)
+//   k_resp_rows      S*nA waves    ** hot kernel ** all nX*nY response sums of one (scan, angle)
+//                                  for a uniform lattice (Mapper.cpp:373-424, 819-856)
 //   k_resp_generic   work list     same sums for arbitrary lattices (fine pass, fall-back)
 //   k_reduce_coarse  S blocks      penalties, max, tie average, positional covariance
 //   k_reduce_fine    S blocks      same + angular covariance (Mapper.cpp:431-506, 535-692)
@@ -157,72 +157,104 @@ __global__ void k_pass_setup(int S, Geom g, PassCfg pc, const double* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
-// k_resp_lattice2 -- THE HOT KERNEL.
-// One wave = one (scan, angle[, beam slice]).  Each lane owns beams lane, lane+64, ...; for a
-// beam it computes the lookup-table offset on the fly (no table round trip through HBM), then
-// reads the beam's whole candidate neighbourhood -- NY rows of 4*NXD bytes, the 2-cell lattice
-// lives on the even byte offsets of each row -- with unaligned dwordx4/x2 loads and accumulates
-// TWO candidates per VALU op in packed 16-bit fields (dword & 0x00FF00FF).  The per-lane packed
-// partials are transposed through LDS and reduced to the exact int32 response numerators.
-// No MFMA: this is a gather/compare path (byte gathers out of an L2-resident 4 MB grid).
-// Grid bounds: the reference skips a byte iff its FLAT index is outside [0,dataSize)
-// (Mapper.cpp:841-845); zero guard bands around the grid make partially overhanging rows exact.
+// k_deinterleave: F_q[m] = G[2m+q].  On the coarse lattice (2-cell steps) the candidates of one
+// beam sit on every second byte of a grid row; splitting the grid by the parity of the FLAT index
+// (widthStep is even, so this is also the x parity) makes them CONTIGUOUS bytes of F_q, and the
+// reference's 1-D bounds rule idx in [0,dataSize) becomes m in [0,dataSize/2).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_deinterleave(const uint8_t* __restrict__ grid, uint8_t* __restrict__ f0, uint8_t* __restrict__ f1, int n8) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n8) return;
+  uint2 v = ((const uint2*)grid)[t];
+  // bytes b0..b7 -> even: b0 b2 b4 b6, odd: b1 b3 b5 b7
+  uint32_t e = (v.x & 0xFFu) | ((v.x >> 8) & 0xFF00u) | ((v.y & 0xFFu) << 16) | ((v.y << 8) & 0xFF000000u);
+  uint32_t o = ((v.x >> 8) & 0xFFu) | ((v.x >> 16) & 0xFF00u) | ((v.y << 8) & 0xFF0000u) | (v.y & 0xFF000000u);
+  ((uint32_t*)f0)[t] = e;
+  ((uint32_t*)f1)[t] = o;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_resp_rows -- THE HOT KERNEL.
+// Exact response numerators (Mapper.cpp:819-856) of every candidate position of a uniform
+// lattice for one (scan, angle): one wave64 per (scan, angle[, beam slice]).
+//   STEP 2 (coarse pass): sources are the parity planes F_0/F_1 of the grid, a lattice row is nX
+//                         contiguous bytes of F_(base&1) starting at base>>1;
+//   STEP 1 (fine pass)  : the source is the grid itself.
+// Each lane owns beams lane, lane+64, ...; for a beam it computes the lookup-table offset on the fly
+// in fp64 (no table round trip through HBM), loads the beam's whole candidate neighbourhood --
+// NY rows of 4*NXD contiguous bytes, one unaligned load per row, branch-free (rows wholly outside
+// the valid index range read the zero guard band) -- and accumulates FOUR candidates per loaded
+// dword in packed 16-bit fields.  The per-lane packed partials are transposed through LDS and
+// reduced to exact int32 sums, written angle-major so the stores coalesce.
+// No MFMA: this is a gather/compare path over an L2-resident 4 MB grid.
+// Block -> (scan, angle) mapping keeps all angles of a scan on one XCD (block b runs on XCD b%8),
+// so a scan's 17 KB of scan-frame points is fetched into ONE L2 instead of eight.
 // ------------------------------------------------------------------------------------------
 template <int NXD, int NYC>
 __global__ void __launch_bounds__(64)
-k_resp_lattice2(const uint8_t* __restrict__ grid, Geom g, PassCfg pc,
-                const Lattice* __restrict__ lat, const double2* __restrict__ local,
-                int32_t* __restrict__ resp, size_t resp_stride, int beam_slices) {
-  __shared__ uint32_t red[NXD * NYC][65];
+k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int step, int limit, Geom g,
+            PassCfg pc, const Lattice* __restrict__ lat, const double2* __restrict__ local,
+            int32_t* __restrict__ resp, size_t resp_stride, int beam_slices, int S) {
+  constexpr int NW = NXD * NYC * 2;
+  __shared__ uint32_t red[NW][65];
   const int lane = threadIdx.x;
   int w = blockIdx.x;
   const int slice = w % beam_slices;
   w /= beam_slices;
-  const int a = w % pc.na;
-  const int s = w / pc.na;
+  const int xcd = w & 7, r = w >> 3;
+  const int s = (r / pc.na) * 8 + xcd;
+  const int a = r % pc.na;
+  if (s >= S) return;
   const Lattice& L = lat[s];
-  if (!L.active || L.status != 0 || L.step_x != 2 || L.step_y != 2) return;
+  if (!L.active || L.status != 0 || L.step_x != step || L.step_y != step) return;
 
   const double angle = (L.center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;  // Mapper.cpp:390-393
   const double cosine = cos(angle), sine = sin(angle);                         // Karto.h:6465-6466
   const int pos00 = L.gx[0] + L.gy[0] * g.stride;
   const double2* lp = local + (size_t)s * g.n_beams;
-  const int row_step = 2 * g.stride;
+  const int ncand = pc.nx * pc.ny;
+  const int shift = step == 2 ? 1 : 0;
 
   for (int j0 = 0; j0 < pc.ny; j0 += NYC) {
-    uint32_t acc[NYC][NXD];
+    uint32_t acc[NYC][NXD][2];
 #pragma unroll
     for (int j = 0; j < NYC; j++)
 #pragma unroll
-      for (int k = 0; k < NXD; k++) acc[j][k] = 0u;
+      for (int k = 0; k < NXD; k++) acc[j][k][0] = acc[j][k][1] = 0u;
 
     for (int b = lane + 64 * slice; b < g.n_beams; b += 64 * beam_slices) {
       double2 p = lp[b];
       const bool beam_ok = !isnan(p.x);  // NaN = INVALID_SCAN
       int t = lookup_offset(p.x, p.y, cosine, sine, g.off_x, g.off_y, g.scale, g.stride);
-      long long base = (long long)pos00 + t + (long long)j0 * row_step;
-      // Branch-free: rows that lie wholly outside [0,dataSize) (or belong to an invalid beam)
-      // read the zero guard band instead, so all 2*NYC loads of a beam are in flight together.
+      long long base = (long long)pos00 + t;
+      const uint8_t* src = (shift && (base & 1)) ? src1 : src0;
+      long long m0 = (base >> shift) + (long long)j0 * g.stride;  // arithmetic shift = floor
       uint32_t d[NYC][NXD];
 #pragma unroll
       for (int j = 0; j < NYC; j++) {
-        long long rs = base + (long long)j * row_step;
-        bool ok = beam_ok && (j0 + j < pc.ny) && rs >= -(long long)(4 * NXD) && rs < (long long)g.data_size;
-        const uint8_t* src = grid + (ok ? rs : -(long long)kGuard);
-        __builtin_memcpy(d[j], src, 4 * NXD);
+        long long rs = m0 + (long long)j * g.stride;
+        bool ok = beam_ok && (j0 + j < pc.ny) && rs >= -(long long)(4 * NXD) && rs < (long long)limit;
+        __builtin_memcpy(d[j], src + (ok ? rs : -(long long)kGuard), 4 * NXD);
       }
 #pragma unroll
       for (int j = 0; j < NYC; j++)
 #pragma unroll
-        for (int k = 0; k < NXD; k++) acc[j][k] += d[j][k] & 0x00FF00FFu;
+        for (int k = 0; k < NXD; k++) {
+          acc[j][k][0] += d[j][k] & 0x00FF00FFu;         // candidates 4k, 4k+2
+          acc[j][k][1] += (d[j][k] >> 8) & 0x00FF00FFu;  // candidates 4k+1, 4k+3
+        }
     }
     // transpose through LDS, then lane i reduces packed word i over the 64 lanes
 #pragma unroll
     for (int j = 0; j < NYC; j++)
 #pragma unroll
-      for (int k = 0; k < NXD; k++) red[j * NXD + k][lane] = acc[j][k];
+      for (int k = 0; k < NXD; k++) {
+        red[(j * NXD + k) * 2 + 0][lane] = acc[j][k][0];
+        red[(j * NXD + k) * 2 + 1][lane] = acc[j][k][1];
+      }
     __syncthreads();
-    for (int idx = lane; idx < NXD * NYC; idx += 64) {
+    for (int idx = lane; idx < NW; idx += 64) {
       uint32_t lo = 0, hi = 0;
 #pragma unroll 8
       for (int k = 0; k < 64; k++) {
@@ -230,15 +262,16 @@ k_resp_lattice2(const uint8_t* __restrict__ grid, Geom g, PassCfg pc,
         lo += v & 0xFFFFu;
         hi += v >> 16;
       }
-      int j = j0 + idx / NXD, i = 2 * (idx % NXD);
+      const int par = idx & 1, jk = idx >> 1;
+      const int j = j0 + jk / NXD, i = 4 * (jk % NXD) + par;
       if (j < pc.ny) {
-        int32_t* o = resp + (size_t)s * resp_stride + ((size_t)j * pc.nx + i) * pc.na + a;
+        int32_t* o = resp + (size_t)s * resp_stride + (size_t)a * ncand + (size_t)j * pc.nx + i;
         if (beam_slices == 1) {
           if (i < pc.nx) o[0] = (int32_t)lo;
-          if (i + 1 < pc.nx) o[pc.na] = (int32_t)hi;
+          if (i + 2 < pc.nx) o[2] = (int32_t)hi;
         } else {
           if (i < pc.nx) atomicAdd(o, (int32_t)lo);
-          if (i + 1 < pc.nx) atomicAdd(o + pc.na, (int32_t)hi);
+          if (i + 2 < pc.nx) atomicAdd(o + 2, (int32_t)hi);
         }
       }
     }
@@ -297,7 +330,7 @@ k_resp_generic(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, const Latti
       int v = acc[q];
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
       int f = c * kPosChunk + q;
-      if (lane == 0 && f < np) resp[(size_t)s * resp_stride + (size_t)f * pc.na + a] = v;
+      if (lane == 0 && f < np) resp[(size_t)s * resp_stride + (size_t)a * np + f] = v;
     }
   }
 }
@@ -377,16 +410,18 @@ __device__ int tie_average(const uint32_t* mask, int total, const PassCfg& pc, c
 }
 
 // ------------------------------------------------------------------------------------------
-// k_reduce_coarse: one block per scan (Mapper.cpp:431-501, 535-630)
+// k_reduce_coarse: one block per scan (Mapper.cpp:431-501, 535-630).  Response numerators are
+// stored angle-major (resp[a*ncand + c]); the reference's candidate order k = c*nA + a (y, x,
+// angle) is what the tie mask and every ordered loop use.  Dynamic LDS:
+//   [CACHE ? total : 0] doubles penalised responses | ncand doubles | side^2 doubles | mask words
 // ------------------------------------------------------------------------------------------
+template <bool CACHE>
 __global__ void __launch_bounds__(256)
 k_reduce_coarse(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ lat,
                 const int32_t* __restrict__ resp, size_t resp_stride, CoarseOut* __restrict__ out,
                 int use_expansion, int pass_index) {
+  extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double sh[256];
-  __shared__ double latmax[kMaxLattice * kMaxLattice];
-  __shared__ double probs[kMaxProbsSide * kMaxProbsSide];
-  __shared__ uint32_t mask[(kMaxLattice * kMaxLattice * kMaxAngles + 31) / 32];
   const int s = blockIdx.x, tid = threadIdx.x;
   const Lattice& L = lat[s];
   if (!L.active) return;
@@ -394,36 +429,45 @@ k_reduce_coarse(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ la
     if (tid == 0) { out[s].status = L.status; out[s].expand = 0; out[s].best = 0.0; }
     return;
   }
-  const int total = pc.nx * pc.ny * pc.na;
+  const int ncand = pc.nx * pc.ny;
+  const int total = ncand * pc.na;
+  const int words = (total + 31) / 32;
+  double* presp = (double*)smem;
+  double* latmax = presp + (CACHE ? total : 0);
+  double* probs = latmax + ncand;
+  uint32_t* mask = (uint32_t*)(probs + g.probs_side * g.probs_side);
   const int32_t* r = resp + (size_t)s * resp_stride;
   const double center[3] = {L.center[0], L.center[1], L.center[2]};
+  auto value = [&](int k) -> double {
+    if (CACHE) return presp[k];
+    const int a = k % pc.na, c = k / pc.na;
+    return penalized(r[a * ncand + c], cand_of(k, pc, center), center, g.n_beams, sc);
+  };
 
   double lm = -1.0;  // bestResponse starts at -1 (Mapper.cpp:431)
-  for (int k = tid; k < total; k += 256) {
-    double v = penalized(r[k], cand_of(k, pc, center), center, g.n_beams, sc);
+  for (int t = tid; t < total; t += 256) {  // storage order: coalesced reads
+    const int a = t / ncand, c = t - a * ncand;
+    const int k = c * pc.na + a;
+    double v = penalized(r[t], cand_of(k, pc, center), center, g.n_beams, sc);
+    if (CACHE) presp[k] = v;
     lm = lm > v ? lm : v;
   }
-  const double best = block_max(lm, sh, tid, 256);
+  for (int wd = tid; wd < words; wd += 256) mask[wd] = 0u;
+  for (int c = tid; c < g.probs_side * g.probs_side; c += 256) probs[c] = 0.0;  // Clear (:329)
+  const double best = block_max(lm, sh, tid, 256);  // contains the barriers that publish presp/mask
 
   // best response per lattice cell over all angles (what the reference max-merges into
   // m_pSearchSpaceProbs, Mapper.cpp:437-450)
-  for (int c = tid; c < pc.nx * pc.ny; c += 256) {
+  for (int c = tid; c < ncand; c += 256) {
     double m = -1.0;
     for (int a = 0; a < pc.na; a++) {
-      int k = c * pc.na + a;
-      double v = penalized(r[k], cand_of(k, pc, center), center, g.n_beams, sc);
+      double v = value(c * pc.na + a);
       m = m > v ? m : v;
     }
     latmax[c] = m;
   }
-  const int words = (total + 31) / 32;
-  for (int wd = tid; wd < words; wd += 256) mask[wd] = 0u;
-  for (int c = tid; c < g.probs_side * g.probs_side; c += 256) probs[c] = 0.0;  // Clear (:329)
-  __syncthreads();
-  for (int k = tid; k < total; k += 256) {
-    double v = penalized(r[k], cand_of(k, pc, center), center, g.n_beams, sc);
-    if (double_equal(v, best)) atomicOr(&mask[k >> 5], 1u << (k & 31));
-  }
+  for (int k = tid; k < total; k += 256)
+    if (double_equal(value(k), best)) atomicOr(&mask[k >> 5], 1u << (k & 31));
   __syncthreads();
   if (tid != 0) return;
 
@@ -433,7 +477,7 @@ k_reduce_coarse(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ la
   o.pad = 0;
   // search-space probability grid: offset = searchCenter - searchSpaceOffset (:332-333)
   const double p_off_x = center[0] - pc.off_x, p_off_y = center[1] - pc.off_y;
-  for (int c = 0; c < pc.nx * pc.ny && o.status == 0; c++) {
+  for (int c = 0; c < ncand && o.status == 0; c++) {
     int xi = c % pc.nx, yi = c / pc.nx;
     double wx = center[0] + (-pc.off_x + (uint32_t)xi * pc.res_x);
     double wy = center[1] + (-pc.off_y + (uint32_t)yi * pc.res_y);
@@ -500,19 +544,20 @@ k_reduce_coarse(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ la
 // ------------------------------------------------------------------------------------------
 // k_reduce_fine: one block per scan: max + tie average of the fine lattice, then
 // ComputeAngularCovariance (Mapper.cpp:641-692): nA more response sums at the best cell,
-// gathered by the whole block; final result record.
+// gathered by the whole block; final result record.  Dynamic LDS: mask words.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc,
               const Lattice* __restrict__ lat, const int32_t* __restrict__ resp, size_t resp_stride,
               const double2* __restrict__ local, const CoarseOut* __restrict__ coarse,
               lslam_match_result* __restrict__ out, int do_refine) {
+  extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double sh[256];
-  __shared__ uint32_t mask[(kMaxLattice * kMaxLattice * kMaxAngles + 31) / 32];
   __shared__ int32_t asum[kMaxAngles];
   __shared__ double s_avg[3];
   __shared__ double s_best;
   __shared__ int s_status, s_pos;
+  uint32_t* mask = (uint32_t*)smem;
   const int s = blockIdx.x, tid = threadIdx.x;
   const CoarseOut& co = coarse[s];
   if (!do_refine || co.status != 0) {
@@ -538,23 +583,25 @@ k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc
     }
     return;
   }
-  const int total = pc.nx * pc.ny * pc.na;
+  const int ncand = pc.nx * pc.ny;
+  const int total = ncand * pc.na;
   const int32_t* r = resp + (size_t)s * resp_stride;
   const double center[3] = {L.center[0], L.center[1], L.center[2]};
+  auto value = [&](int k) -> double {
+    const int a = k % pc.na, c = k / pc.na;
+    return penalized(r[a * ncand + c], cand_of(k, pc, center), center, g.n_beams, sc);
+  };
   double lm = -1.0;
   for (int k = tid; k < total; k += 256) {
-    double v = penalized(r[k], cand_of(k, pc, center), center, g.n_beams, sc);
+    double v = value(k);
     lm = lm > v ? lm : v;
   }
-  const double best = block_max(lm, sh, tid, 256);
   const int words = (total + 31) / 32;
   for (int wd = tid; wd < words; wd += 256) mask[wd] = 0u;
   if (tid < kMaxAngles) asum[tid] = 0;
-  __syncthreads();
-  for (int k = tid; k < total; k += 256) {
-    double v = penalized(r[k], cand_of(k, pc, center), center, g.n_beams, sc);
-    if (double_equal(v, best)) atomicOr(&mask[k >> 5], 1u << (k & 31));
-  }
+  const double best = block_max(lm, sh, tid, 256);
+  for (int k = tid; k < total; k += 256)
+    if (double_equal(value(k), best)) atomicOr(&mask[k >> 5], 1u << (k & 31));
   __syncthreads();
   if (tid == 0) {
     double avg[3] = {0, 0, 0};
@@ -574,22 +621,30 @@ k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc
   }
   __syncthreads();
   if (s_status == 0) {
-    // GetResponse(angleIndex, gridIndex) for every fine angle at the best cell (:663-666)
-    const double2* lp = local + (size_t)s * g.n_beams;
-    const int pos = s_pos;
-    for (int a = 0; a < pc.na; a++) {
-      double angle = (center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;
-      double cosine = cos(angle), sine = sin(angle);
-      int32_t part = 0;
-      for (int b = tid; b < g.n_beams; b += 256) {
-        double2 p = lp[b];
-        if (isnan(p.x)) continue;
-        int t = lookup_offset(p.x, p.y, cosine, sine, g.off_x, g.off_y, g.scale, g.stride);
-        long long idx = (long long)pos + t;
-        if (idx >= 0 && idx < g.data_size) part += grid[idx];
+    // GetResponse(angleIndex, gridIndex) for every fine angle at the best cell (:663-666).
+    // Usually that cell is one of the fine lattice cells whose numerators are already there.
+    int hit = -1;
+    for (int c = 0; c < ncand; c++)
+      if (L.gx[c % pc.nx] + L.gy[c / pc.nx] * g.stride == s_pos) hit = c;
+    if (hit >= 0) {
+      if (tid < pc.na) asum[tid] = r[tid * ncand + hit];
+    } else {
+      const double2* lp = local + (size_t)s * g.n_beams;
+      const int pos = s_pos;
+      for (int a = 0; a < pc.na; a++) {
+        double angle = (center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;
+        double cosine = cos(angle), sine = sin(angle);
+        int32_t part = 0;
+        for (int b = tid; b < g.n_beams; b += 256) {
+          double2 p = lp[b];
+          if (isnan(p.x)) continue;
+          int t = lookup_offset(p.x, p.y, cosine, sine, g.off_x, g.off_y, g.scale, g.stride);
+          long long idx = (long long)pos + t;
+          if (idx >= 0 && idx < g.data_size) part += grid[idx];
+        }
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if ((tid & 63) == 0) atomicAdd(&asum[a], part);
       }
-      for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-      if ((tid & 63) == 0) atomicAdd(&asum[a], part);
     }
   }
   __syncthreads();
@@ -772,6 +827,9 @@ struct lslam_matcher {
   uint8_t* d_grid_alloc = nullptr;  // kGuard + data_size + kGuard
   uint8_t* d_grid = nullptr;        // d_grid_alloc + kGuard
   uint8_t* d_kernel = nullptr;
+  uint8_t* d_sub_alloc = nullptr;   // two parity planes F_0, F_1, each kGuard + data_size/2 + kGuard
+  uint8_t* d_sub[2] = {nullptr, nullptr};
+  bool sub_dirty = true;            // the planes lag behind d_grid
   // workspaces
   DevBuf<double> d_ranges64;
   DevBuf<double> d_poses;
@@ -854,33 +912,48 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   launch(ctx, "scan_prep", k_scan_prep<RT>, dim3((g.n_beams + 255) / 256, S), dim3(256), 0, d_ranges,
          stride, d_poses, g, m->d_local.p, (double2*)nullptr);
 
-  // fast-kernel selection: 2-cell lattice that fits the packed accumulators
-  auto run_coarse = [&](const PassCfg& p, int pass_index) -> int {
-    const bool fast6 = !force_generic && p.nx <= 12;
-    const bool fast8 = !force_generic && !fast6 && p.nx <= 16;
+  if (m->sub_dirty) {  // refresh the parity planes of the grid (coarse pass source)
+    launch(ctx, "deinterleave", k_deinterleave, dim3((g.data_size / 8 + 255) / 256), dim3(256), 0,
+           (const uint8_t*)m->d_grid, m->d_sub[0], m->d_sub[1], g.data_size / 8);
+    m->sub_dirty = false;
+  }
+  auto reduce_lds = [&](const PassCfg& p, bool cache) -> size_t {
+    size_t total = (size_t)p.nx * p.ny * p.na;
+    return (cache ? total * 8 : 0) + (size_t)p.nx * p.ny * 8 + (size_t)g.probs_side * g.probs_side * 8 +
+           ((total + 31) / 32) * 4 + 16;
+  };
+  // response numerators of one pass: packed row kernel for uniform lattices (step 2 on the parity
+  // planes, step 1 on the grid), generic kernel for everything else
+  auto run_responses = [&](const PassCfg& p, int step, const char* name) -> int {
+    const int variant = force_generic ? 0 : (p.nx <= 4 && p.ny <= 4) ? 1 : (p.nx <= 12) ? 2 : (p.nx <= 16) ? 3 : 0;
     LSLAM_HIP(ctx, hipMemsetAsync(m->d_slow.p, 0, sizeof(int), ctx->stream));
     int* slow_cnt = m->d_slow.p;
     int* slow_list = m->d_slow.p + 1;
     launch(ctx, "pass_setup", k_pass_setup, dim3((S + 127) / 128), dim3(128), 0, S, g, p, d_poses,
-           (const CoarseOut*)m->d_coarse.p, m->d_lat.p, (fast6 || fast8) ? slow_list : (int*)nullptr,
-           slow_cnt, 2);
-    if (fast6 || fast8) {
+           (const CoarseOut*)m->d_coarse.p, m->d_lat.p, variant ? slow_list : (int*)nullptr, slow_cnt, step);
+    if (variant) {
       // small batches: split the beams of one (scan, angle) over several waves to fill the chip
       int slices = 1;
-      long long waves = (long long)S * p.na;
+      const long long waves = (long long)((S + 7) / 8) * 8 * p.na;
       while (slices < 8 && waves * slices < 2048) slices *= 2;
       if (slices > 1)
         LSLAM_HIP(ctx, hipMemsetAsync(m->d_resp.p, 0, (size_t)S * resp_stride * sizeof(int32_t), ctx->stream));
       dim3 grid((unsigned)(waves * slices));
-      if (fast6)
-        launch(ctx, "resp_lattice2", k_resp_lattice2<6, 11>, grid, dim3(64), 0, (const uint8_t*)m->d_grid, g, p,
-               (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices);
+      const uint8_t* s0 = step == 2 ? m->d_sub[0] : m->d_grid;
+      const uint8_t* s1 = step == 2 ? m->d_sub[1] : m->d_grid;
+      const int limit = step == 2 ? g.data_size / 2 : g.data_size;
+      if (variant == 1)
+        launch(ctx, name, k_resp_rows<1, 4>, grid, dim3(64), 0, s0, s1, step, limit, g, p, (const Lattice*)m->d_lat.p,
+               (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S);
+      else if (variant == 2)
+        launch(ctx, name, k_resp_rows<3, 11>, grid, dim3(64), 0, s0, s1, step, limit, g, p, (const Lattice*)m->d_lat.p,
+               (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S);
       else
-        launch(ctx, "resp_lattice2", k_resp_lattice2<8, 8>, grid, dim3(64), 0, (const uint8_t*)m->d_grid, g, p,
-               (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices);
-      // scans with a non-uniform lattice (rounding on a cell boundary) take the generic kernel
-      launch(ctx, "resp_generic_fallback", k_resp_generic, dim3(256), dim3(64), 0, (const uint8_t*)m->d_grid, g,
-             p, (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S,
+        launch(ctx, name, k_resp_rows<4, 8>, grid, dim3(64), 0, s0, s1, step, limit, g, p, (const Lattice*)m->d_lat.p,
+               (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S);
+      // scans whose lattice is not uniform (a coordinate rounds on a cell boundary) take the generic kernel
+      launch(ctx, "resp_generic_fallback", k_resp_generic, dim3(128), dim3(64), 0, (const uint8_t*)m->d_grid, g, p,
+             (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S,
              (const int*)slow_list, (const int*)slow_cnt);
     } else {
       int chunks = (p.nx * p.ny + kPosChunk - 1) / kPosChunk;
@@ -889,12 +962,23 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
              (const uint8_t*)m->d_grid, g, p, (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p,
              m->d_resp.p, resp_stride, S, (const int*)nullptr, (const int*)nullptr);
     }
+    return LSLAM_OK;
+  };
+  auto run_coarse = [&](const PassCfg& p, int pass_index) -> int {
+    int rc = run_responses(p, 2, "resp_rows_coarse");
+    if (rc) return rc;
     if (dbg_coarse_sums && pass_index == 0)
       LSLAM_HIP(ctx, hipMemcpyAsync(dbg_coarse_sums, m->d_resp.p, (size_t)p.nx * p.ny * p.na * sizeof(int32_t),
                                     hipMemcpyDeviceToDevice, ctx->stream));
-    launch(ctx, "reduce_coarse", k_reduce_coarse, dim3(S), dim3(256), 0, g, p, sc, (const Lattice*)m->d_lat.p,
-           (const int32_t*)m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion,
-           pass_index);
+    const bool cache = reduce_lds(p, true) <= 60 * 1024;
+    if (cache)
+      launch(ctx, "reduce_coarse", k_reduce_coarse<true>, dim3(S), dim3(256), reduce_lds(p, true), g, p, sc,
+             (const Lattice*)m->d_lat.p, (const int32_t*)m->d_resp.p, resp_stride, m->d_coarse.p,
+             (int)m->cfg.use_response_expansion, pass_index);
+    else
+      launch(ctx, "reduce_coarse", k_reduce_coarse<false>, dim3(S), dim3(256), reduce_lds(p, false), g, p, sc,
+             (const Lattice*)m->d_lat.p, (const int32_t*)m->d_resp.p, resp_stride, m->d_coarse.p,
+             (int)m->cfg.use_response_expansion, pass_index);
     return LSLAM_OK;
   };
 
@@ -905,17 +989,12 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     if (rc) return rc;
   }
   if (do_refine) {
-    launch(ctx, "pass_setup", k_pass_setup, dim3((S + 127) / 128), dim3(128), 0, S, g, pf, d_poses,
-           (const CoarseOut*)m->d_coarse.p, m->d_lat.p, (int*)nullptr, (int*)nullptr, 1);
-    int chunks = (pf.nx * pf.ny + kPosChunk - 1) / kPosChunk;
-    long long items = (long long)S * pf.na * chunks;
-    launch(ctx, "resp_fine", k_resp_generic, dim3((unsigned)std::min<long long>(items, 1 << 20)), dim3(64), 0,
-           (const uint8_t*)m->d_grid, g, pf, (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p,
-           resp_stride, S, (const int*)nullptr, (const int*)nullptr);
+    rc = run_responses(pf, 1, "resp_rows_fine");
+    if (rc) return rc;
   }
-  launch(ctx, "reduce_fine", k_reduce_fine, dim3(S), dim3(256), 0, (const uint8_t*)m->d_grid, g, pf, sc,
-         (const Lattice*)m->d_lat.p, (const int32_t*)m->d_resp.p, resp_stride, (const double2*)m->d_local.p,
-         (const CoarseOut*)m->d_coarse.p, d_out, do_refine);
+  launch(ctx, "reduce_fine", k_reduce_fine, dim3(S), dim3(256), (size_t)(((size_t)pf.nx * pf.ny * pf.na + 31) / 32) * 4 + 16,
+         (const uint8_t*)m->d_grid, g, pf, sc, (const Lattice*)m->d_lat.p, (const int32_t*)m->d_resp.p, resp_stride,
+         (const double2*)m->d_local.p, (const CoarseOut*)m->d_coarse.p, d_out, do_refine);
   LSLAM_HIP(ctx, hipGetLastError());
   return LSLAM_OK;
 }
@@ -1036,6 +1115,16 @@ int lslam_matcher_create(lslam_context* ctx, const lslam_matcher_config* cfg, co
     return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the correlation grid in HBM");
   }
   m->d_grid = m->d_grid_alloc + kGuard;
+  const size_t plane = (size_t)g.data_size / 2 + 2 * kGuard;  // data_size is a multiple of 8
+  if (hipMalloc((void**)&m->d_sub_alloc, 2 * plane) != hipSuccess) {
+    (void)hipFree(m->d_grid_alloc);
+    (void)hipFree(m->d_kernel);
+    delete m;
+    return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the grid parity planes in HBM");
+  }
+  m->d_sub[0] = m->d_sub_alloc + kGuard;
+  m->d_sub[1] = m->d_sub_alloc + plane + kGuard;
+  (void)hipMemsetAsync(m->d_sub_alloc, 0, 2 * plane, ctx->stream);
   (void)hipMemsetAsync(m->d_grid_alloc, 0, (size_t)g.data_size + 2 * kGuard, ctx->stream);
   (void)hipMemcpyAsync(m->d_kernel, m->h_kernel.data(), m->h_kernel.size(), hipMemcpyHostToDevice, ctx->stream);
   (void)hipStreamSynchronize(ctx->stream);
@@ -1049,6 +1138,7 @@ void lslam_matcher_destroy(lslam_matcher* m) {
   (void)hipStreamSynchronize(m->ctx->stream);
   (void)hipFree(m->d_grid_alloc);
   (void)hipFree(m->d_kernel);
+  (void)hipFree(m->d_sub_alloc);
   m->d_ranges64.release(); m->d_poses.release(); m->d_local.release(); m->d_world.release();
   m->d_valid.release(); m->d_lat.release(); m->d_coarse.release(); m->d_resp.release();
   m->d_slow.release(); m->d_results.release(); m->d_dbg.release();
@@ -1089,6 +1179,7 @@ int lslam_matcher_set_grid_u8(lslam_matcher* m, const uint8_t* grid, const doubl
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   m->g.off_x = offset_xy[0];
   m->g.off_y = offset_xy[1];
+  m->sub_dirty = true;
   return LSLAM_OK;
 }
 
@@ -1099,6 +1190,7 @@ int lslam_matcher_set_grid_u8_dev(lslam_matcher* m, const uint8_t* grid_dev, con
     LSLAM_HIP(ctx, hipMemcpyAsync(m->d_grid, grid_dev, (size_t)m->g.data_size, hipMemcpyDeviceToDevice, ctx->stream));
   m->g.off_x = offset_xy[0];
   m->g.off_y = offset_xy[1];
+  m->sub_dirty = true;
   return LSLAM_OK;
 }
 
@@ -1114,6 +1206,7 @@ int lslam_matcher_set_base_scans(lslam_matcher* m, int B, const double* ranges, 
   g.off_x = center[0] - (0.5 * (g.roi_w - 1) * (1.0 / g.scale));
   g.off_y = center[1] - (0.5 * (g.roi_h - 1) * (1.0 / g.scale));
   LSLAM_HIP(ctx, hipMemsetAsync(m->d_grid, 0, (size_t)g.data_size, ctx->stream));  // Grid::Clear (Mapper.cpp:701)
+  m->sub_dirty = true;
   if (B == 0 || g.n_beams == 0) {
     LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LSLAM_OK;
@@ -1229,9 +1322,13 @@ int lslam_matcher_debug_coarse_sums(lslam_matcher* m, const double* ranges, cons
   rc = match_batch_impl<double>(m, 1, m->d_ranges64.p, g.n_beams, m->d_poses.p, 1, 0, m->d_results.p, m->d_dbg.p,
                                 force_generic);
   if (rc) return rc;
-  LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_dbg.p, (size_t)lx * lx * la * sizeof(int32_t), hipMemcpyDeviceToHost,
+  std::vector<int32_t> tmp((size_t)lx * lx * la);
+  LSLAM_HIP(ctx, hipMemcpyAsync(tmp.data(), m->d_dbg.p, tmp.size() * sizeof(int32_t), hipMemcpyDeviceToHost,
                                 ctx->stream));
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int ncand = lx * lx;  // device layout is angle-major; the reference order is y, x, angle
+  for (int a = 0; a < la; a++)
+    for (int c = 0; c < ncand; c++) out[(size_t)c * la + a] = tmp[(size_t)a * ncand + c];
   return LSLAM_OK;
 }
 

@@ -34,13 +34,16 @@ int main(int argc, char**) {
   double resp = m->MatchScan(q, {base}, mean, cov);
   std::printf("response %.3f mean %.3f %.3f %.3f\n", resp, mean.x, mean.y, mean.heading);
   if (!(resp > 0.2 && std::fabs(mean.x - 0.2) < 0.06)) return 3;
-  lslam::MapRepGpu map(ctx, 0.05f, 256, 256, 2, 0.5f, 0.5f);
-  float pts[4] = {40.f, 0.f, 0.f, 30.f}, origo[2] = {0, 0}, pose[3] = {0, 0, 0};
-  map.updateByScan(pts, 2, origo, pose);
-  std::vector<float> lo(256 * 256);
-  map.readLogOdds(0, lo.data());
-  int nz = 0; for (float v : lo) nz += v != 0.f;
-  std::printf("nonzero cells %d\n", nz);
+  int nz = 0;
+  {  // handles must be released before their context
+    lslam::MapRepGpu map(ctx, 0.05f, 256, 256, 2, 0.5f, 0.5f);
+    float pts[4] = {40.f, 0.f, 0.f, 30.f}, origo[2] = {0, 0}, pose[3] = {0, 0, 0};
+    map.updateByScan(pts, 2, origo, pose);
+    std::vector<float> lo(256 * 256);
+    map.readLogOdds(0, lo.data());
+    for (float v : lo) nz += v != 0.f;
+    std::printf("nonzero cells %d\n", nz);
+  }
   delete m;
   lslam_destroy(ctx);
   return nz == 71 ? 0 : 4;
