@@ -175,6 +175,36 @@ k_deinterleave(const uint8_t* __restrict__ grid, uint8_t* __restrict__ f0, uint8
 }
 
 // ------------------------------------------------------------------------------------------
+// k_row_occupancy: exact skip mask for the row loads of k_resp_rows.  Only ~0.4 % of the grid is
+// non-zero, so most candidate rows of most beams sum zeros.  bit(x, y) = any G_flat[f .. f+kOccWin-1]
+// != 0 for f = x + y*widthStep (flat index, out-of-range bytes count as zero, y from -1).
+// Stored TRANSPOSED (column-major, 32 consecutive y per word) so one 8-byte read gives a beam the
+// bits of all its lattice rows (rows are 1 or 2 grid rows apart, same column).  A row whose bit is
+// clear contributes nothing to any candidate -> skipping its load is exact, not an approximation.
+// ------------------------------------------------------------------------------------------
+constexpr int kOccWin = 21;  // row span covered by one bit: step*(nX-1)+1 grid bytes must fit (coarse 2*10+1 = 21)
+__global__ void __launch_bounds__(256)
+k_row_occupancy(const uint8_t* __restrict__ grid, int stride, int height, int data_size, int win,
+                uint32_t* __restrict__ occ_t, int words_per_col) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;  // column (flat index mod widthStep)
+  int wq = blockIdx.y;                            // word index along y
+  if (x >= stride || wq >= words_per_col) return;
+  uint32_t bits = 0;
+  for (int b = 0; b < 32; b++) {
+    int y = wq * 32 + b - 1;  // bit 0 of word 0 is y = -1
+    if (y > height) break;
+    long long f = (long long)x + (long long)y * stride;
+    bool any = false;
+    for (int k = 0; k < win; k++) {
+      long long idx = f + k;
+      if (idx >= 0 && idx < data_size && grid[idx] != 0) { any = true; break; }
+    }
+    if (any) bits |= 1u << b;
+  }
+  occ_t[(size_t)x * words_per_col + wq] = bits;
+}
+
+// ------------------------------------------------------------------------------------------
 // k_resp_rows -- THE HOT KERNEL.
 // Exact response numerators (Mapper.cpp:819-856) of every candidate position of a uniform
 // lattice for one (scan, angle): one wave64 per (scan, angle[, beam slice]).
@@ -195,7 +225,8 @@ template <int NXD, int NYC>
 __global__ void __launch_bounds__(64)
 k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int step, int limit, Geom g,
             PassCfg pc, const Lattice* __restrict__ lat, const double2* __restrict__ local,
-            int32_t* __restrict__ resp, size_t resp_stride, int beam_slices, int S) {
+            int32_t* __restrict__ resp, size_t resp_stride, int beam_slices, int S,
+            const uint32_t* __restrict__ occ_t, int occ_wpc) {
   constexpr int NW = NXD * NYC * 2;
   __shared__ uint32_t red[NW][65];
   const int lane = threadIdx.x;
@@ -230,12 +261,27 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       long long base = (long long)pos00 + t;
       const uint8_t* src = (shift && (base & 1)) ? src1 : src0;
       long long m0 = (base >> shift) + (long long)j0 * g.stride;  // arithmetic shift = floor
+      // row-occupancy bits of this beam's lattice rows (bit j*step <-> lattice row j0+j)
+      unsigned long long rowbits = ~0ull;
+      if (occ_t) {
+        long long f0 = base + (long long)j0 * step * g.stride;
+        long long y = f0 >= 0 ? f0 / g.stride : -((-f0 + g.stride - 1) / g.stride);  // floor
+        int x = (int)(f0 - y * g.stride);
+        if (y >= -1 && y + (long long)step * (NYC - 1) <= (long long)g.height) {
+          const uint32_t* col = occ_t + (size_t)x * occ_wpc + ((y + 1) >> 5);
+          unsigned long long two = (unsigned long long)col[0] | ((unsigned long long)col[1] << 32);
+          rowbits = two >> ((y + 1) & 31);
+        }
+      }
       uint32_t d[NYC][NXD];
 #pragma unroll
       for (int j = 0; j < NYC; j++) {
+#pragma unroll
+        for (int k = 0; k < NXD; k++) d[j][k] = 0u;
         long long rs = m0 + (long long)j * g.stride;
-        bool ok = beam_ok && (j0 + j < pc.ny) && rs >= -(long long)(4 * NXD) && rs < (long long)limit;
-        __builtin_memcpy(d[j], src + (ok ? rs : -(long long)kGuard), 4 * NXD);
+        bool ok = beam_ok && (j0 + j < pc.ny) && rs >= -(long long)(4 * NXD) && rs < (long long)limit &&
+                  ((rowbits >> (j * step)) & 1ull);
+        if (ok) __builtin_memcpy(d[j], src + rs, 4 * NXD);
       }
 #pragma unroll
       for (int j = 0; j < NYC; j++)
@@ -830,6 +876,9 @@ struct lslam_matcher {
   uint8_t* d_sub_alloc = nullptr;   // two parity planes F_0, F_1, each kGuard + data_size/2 + kGuard
   uint8_t* d_sub[2] = {nullptr, nullptr};
   bool sub_dirty = true;            // the planes lag behind d_grid
+  bool use_row_occupancy = true;
+  uint32_t* d_occ_t = nullptr;      // transposed row-occupancy bitmap (k_row_occupancy)
+  int occ_wpc = 0;
   // workspaces
   DevBuf<double> d_ranges64;
   DevBuf<double> d_poses;
@@ -915,6 +964,8 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   if (m->sub_dirty) {  // refresh the parity planes of the grid (coarse pass source)
     launch(ctx, "deinterleave", k_deinterleave, dim3((g.data_size / 8 + 255) / 256), dim3(256), 0,
            (const uint8_t*)m->d_grid, m->d_sub[0], m->d_sub[1], g.data_size / 8);
+    launch(ctx, "row_occupancy", k_row_occupancy, dim3((g.stride + 255) / 256, m->occ_wpc), dim3(256), 0,
+           (const uint8_t*)m->d_grid, g.stride, g.height, g.data_size, kOccWin, m->d_occ_t, m->occ_wpc);
     m->sub_dirty = false;
   }
   auto reduce_lds = [&](const PassCfg& p, bool cache) -> size_t {
@@ -942,15 +993,17 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       const uint8_t* s0 = step == 2 ? m->d_sub[0] : m->d_grid;
       const uint8_t* s1 = step == 2 ? m->d_sub[1] : m->d_grid;
       const int limit = step == 2 ? g.data_size / 2 : g.data_size;
+      // the bitmap covers row spans of kOccWin grid bytes: step*(nX-1)+1 must fit
+      const uint32_t* occ = (m->use_row_occupancy && step * (p.nx - 1) + 1 <= kOccWin) ? m->d_occ_t : (const uint32_t*)nullptr;
       if (variant == 1)
         launch(ctx, name, k_resp_rows<1, 4>, grid, dim3(64), 0, s0, s1, step, limit, g, p, (const Lattice*)m->d_lat.p,
-               (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S);
+               (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc);
       else if (variant == 2)
         launch(ctx, name, k_resp_rows<3, 11>, grid, dim3(64), 0, s0, s1, step, limit, g, p, (const Lattice*)m->d_lat.p,
-               (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S);
+               (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc);
       else
         launch(ctx, name, k_resp_rows<4, 8>, grid, dim3(64), 0, s0, s1, step, limit, g, p, (const Lattice*)m->d_lat.p,
-               (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S);
+               (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc);
       // scans whose lattice is not uniform (a coordinate rounds on a cell boundary) take the generic kernel
       launch(ctx, "resp_generic_fallback", k_resp_generic, dim3(128), dim3(64), 0, (const uint8_t*)m->d_grid, g, p,
              (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S,
@@ -1122,6 +1175,14 @@ int lslam_matcher_create(lslam_context* ctx, const lslam_matcher_config* cfg, co
     delete m;
     return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the grid parity planes in HBM");
   }
+  m->occ_wpc = (g.height + 2 + 63) / 32 + 1;
+  if (hipMalloc((void**)&m->d_occ_t, (size_t)g.stride * m->occ_wpc * sizeof(uint32_t)) != hipSuccess) {
+    (void)hipFree(m->d_grid_alloc);
+    (void)hipFree(m->d_kernel);
+    (void)hipFree(m->d_sub_alloc);
+    delete m;
+    return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the row-occupancy bitmap in HBM");
+  }
   m->d_sub[0] = m->d_sub_alloc + kGuard;
   m->d_sub[1] = m->d_sub_alloc + plane + kGuard;
   (void)hipMemsetAsync(m->d_sub_alloc, 0, 2 * plane, ctx->stream);
@@ -1139,6 +1200,7 @@ void lslam_matcher_destroy(lslam_matcher* m) {
   (void)hipFree(m->d_grid_alloc);
   (void)hipFree(m->d_kernel);
   (void)hipFree(m->d_sub_alloc);
+  (void)hipFree(m->d_occ_t);
   m->d_ranges64.release(); m->d_poses.release(); m->d_local.release(); m->d_world.release();
   m->d_valid.release(); m->d_lat.release(); m->d_coarse.release(); m->d_resp.release();
   m->d_slow.release(); m->d_results.release(); m->d_dbg.release();
