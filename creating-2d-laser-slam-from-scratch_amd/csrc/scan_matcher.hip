@@ -183,23 +183,55 @@ k_deinterleave(const uint8_t* __restrict__ grid, uint8_t* __restrict__ f0, uint8
 // clear contributes nothing to any candidate -> skipping its load is exact, not an approximation.
 // ------------------------------------------------------------------------------------------
 constexpr int kOccWin = 21;  // row span covered by one bit: step*(nX-1)+1 grid bytes must fit (coarse 2*10+1 = 21)
+
+// pass A: flat non-zero bitmap, one bit per grid byte (thread per 32 bytes, coalesced)
 __global__ void __launch_bounds__(256)
-k_row_occupancy(const uint8_t* __restrict__ grid, int stride, int height, int data_size, int win,
+k_nonzero_bits(const uint8_t* __restrict__ grid, int data_size, uint32_t* __restrict__ nz, int n_words) {
+  int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  uint32_t bits = 0;
+  const long long f0 = (long long)w * 32;
+  if (f0 + 32 <= data_size) {
+    const uint4* p = (const uint4*)(grid + f0);  // grid base is 16-byte aligned (kGuard = 256)
+    uint4 a = p[0], b = p[1];
+    const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      uint32_t d = v[k];
+      bits |= ((d & 0xFFu) ? 1u : 0u) << (4 * k);
+      bits |= ((d & 0xFF00u) ? 1u : 0u) << (4 * k + 1);
+      bits |= ((d & 0xFF0000u) ? 1u : 0u) << (4 * k + 2);
+      bits |= ((d & 0xFF000000u) ? 1u : 0u) << (4 * k + 3);
+    }
+  } else {
+    for (int k = 0; k < 32; k++)
+      if (f0 + k < data_size && grid[f0 + k] != 0) bits |= 1u << k;
+  }
+  nz[w] = bits;
+}
+
+// pass B: bit(x, y) = any of the kOccWin flat bits starting at f = x + y*widthStep, written transposed
+__global__ void __launch_bounds__(256)
+k_row_occupancy(const uint32_t* __restrict__ nz, int n_words, int stride, int height, int win,
                 uint32_t* __restrict__ occ_t, int words_per_col) {
   int x = blockIdx.x * blockDim.x + threadIdx.x;  // column (flat index mod widthStep)
   int wq = blockIdx.y;                            // word index along y
   if (x >= stride || wq >= words_per_col) return;
+  const unsigned long long wmask = (1ull << win) - 1ull;
   uint32_t bits = 0;
   for (int b = 0; b < 32; b++) {
     int y = wq * 32 + b - 1;  // bit 0 of word 0 is y = -1
     if (y > height) break;
-    long long f = (long long)x + (long long)y * stride;
-    bool any = false;
-    for (int k = 0; k < win; k++) {
-      long long idx = f + k;
-      if (idx >= 0 && idx < data_size && grid[idx] != 0) { any = true; break; }
-    }
-    if (any) bits |= 1u << b;
+    long long f = (long long)x + (long long)y * stride;  // may be negative for y = -1
+    long long w0 = f >> 5;                                // floor
+    int sh = (int)(f & 31);
+    // 96-bit window of flat bits starting at word w0 (out-of-range words are zero)
+    unsigned long long lo = 0, hi = 0;
+    if (w0 >= 0 && w0 < n_words) lo = nz[w0];
+    if (w0 + 1 >= 0 && w0 + 1 < n_words) lo |= (unsigned long long)nz[w0 + 1] << 32;
+    if (w0 + 2 >= 0 && w0 + 2 < n_words) hi = nz[w0 + 2];
+    unsigned long long window = (lo >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
+    if (window & wmask) bits |= 1u << b;
   }
   occ_t[(size_t)x * words_per_col + wq] = bits;
 }
@@ -741,50 +773,90 @@ __global__ void k_result_no_readings(int S, const double* poses, double coarse_a
 // ------------------------------------------------------------------------------------------
 // correlation-grid construction (AddScans, Mapper.cpp:699-748)
 // ------------------------------------------------------------------------------------------
-// FindValidPoints (Mapper.cpp:756-811) is a sequential scan with a lagging iterator: one thread
-// per base scan walks its points; valid[] marks the points the reference would push_back.
-__global__ void k_find_valid(int B, int n, const double2* __restrict__ world, double vx, double vy,
-                             uint8_t* __restrict__ valid) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= B) return;
-  const double2* p = world + (size_t)s * n;
-  uint8_t* v = valid + (size_t)s * n;
-  for (int i = 0; i < n; i++) v[i] = 0;
-  const double min_sq = ksq(0.1);
-  int trailing = 0;
-  bool first_time = true;
-  double fx = 0.0, fy = 0.0;
-  for (int i = 0; i < n; i++) {
-    double cx = p[i].x, cy = p[i].y;
-    if (first_time && !isnan(cx) && !isnan(cy)) {
-      fx = cx; fy = cy; first_time = false;
-    }
-    double dx = fx - cx, dy = fy - cy;
-    if (ksq(dx) + ksq(dy) > min_sq) {
-      double a = vy - fy;
-      double b = fx - vx;
-      double c = fy * vx - fx * vy;
-      double ss = cx * a + cy * b + c;
-      fx = cx; fy = cy;
-      if (ss < 0.0) {
-        trailing = i;
-      } else {
-        for (; trailing != i; ++trailing) v[trailing] = 1;
-      }
-    }
+// FindValidPoints (Mapper.cpp:756-811) is a sequential scan with a lagging iterator.  One wave per
+// base scan, points staged in LDS (coalesced); valid[] marks the points the reference would
+// push_back.  Base scans live in a ring of `cap` slots (streaming front-end); slot of window entry
+// b = (ring_start + b) % cap.
+// Parallel form of the same walk.  The reference's loop only carries two things from one point to
+// the next: the anchor `firstPoint` (replaced by the first later point farther than 10 cm) and the
+// lagging iterator, which always ends up at the new anchor; the run [old anchor, new anchor) is kept
+// iff the side test ss >= 0 (the very first run starts at index 0).  So:
+//   (1) every thread finds the successor next[i] of "its" point as if it were an anchor,
+//   (2) one thread follows the anchor chain through next[] (a few hundred LDS reads),
+//   (3) every chain link evaluates its side test and marks its run -- in parallel.
+// Every fp64 expression is the reference's.
+__global__ void __launch_bounds__(256)
+k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, double vx, double vy,
+             uint8_t* __restrict__ valid, int use_lds, int* __restrict__ scratch) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ int s_first, s_len;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const double2* gp = world + (size_t)((ring_start + b) % cap) * n;
+  uint8_t* gv = valid + (size_t)b * n;
+  const double2* p = gp;
+  uint8_t* v = gv;
+  int *next, *chain;
+  if (use_lds) {
+    double2* lp = (double2*)smem;
+    next = (int*)(lp + n);
+    chain = next + n;
+    uint8_t* lv = (uint8_t*)(chain + n);
+    for (int i = tid; i < n; i += 256) { lp[i] = gp[i]; lv[i] = 0; }
+    p = lp;
+    v = lv;
+  } else {
+    next = scratch + (size_t)b * 2 * n;
+    chain = next + n;
+    for (int i = tid; i < n; i += 256) gv[i] = 0;
   }
+  if (tid == 0) { s_first = n; s_len = 0; }
+  __syncthreads();
+  const double min_sq = ksq(0.1);
+  for (int i = tid; i < n; i += 256) {
+    const double fx = p[i].x, fy = p[i].y;
+    if (!isnan(fx) && !isnan(fy)) atomicMin(&s_first, i);  // first anchor (Mapper.cpp:774-778)
+    int j = i + 1;
+    for (; j < n; j++) {
+      double dx = fx - p[j].x, dy = fy - p[j].y;
+      if (ksq(dx) + ksq(dy) > min_sq) break;  // :780-781
+    }
+    next[i] = j;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int len = 0;
+    for (int a = s_first; a < n; a = next[a]) chain[len++] = a;
+    s_len = len;
+  }
+  __syncthreads();
+  const int len = s_len;
+  for (int k = tid; k + 1 < len; k += 256) {
+    const int a = chain[k], f = chain[k + 1];
+    const double fx = p[a].x, fy = p[a].y, cx = p[f].x, cy = p[f].y;
+    const double aa = vy - fy;  // :788-791
+    const double bb = fx - vx;
+    const double cc = fy * vx - fx * vy;
+    const double ss = cx * aa + cy * bb + cc;
+    if (!(ss < 0.0))            // :796-806
+      for (int t = (k == 0 ? 0 : a); t < f; t++) v[t] = 1;
+  }
+  __syncthreads();
+  if (use_lds)
+    for (int i = tid; i < n; i += 256) gv[i] = v[i];
 }
 
-// Pass 1: occupied cells (AddScan, Mapper.cpp:723-740).  Racing byte stores all write 100.
-__global__ void __launch_bounds__(256)
-k_mark_occupied(int total, const double2* __restrict__ world, const uint8_t* __restrict__ valid, Geom g,
-                uint8_t* __restrict__ grid) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total || !valid[i]) return;
-  int gx = world_to_grid(world[i].x, g.off_x, g.scale);
-  int gy = world_to_grid(world[i].y, g.off_y, g.scale);
-  if (gx < 0 || gx >= g.roi_w || gy < 0 || gy >= g.roi_h) return;  // IsUpTo on the ROI (:724-729)
-  grid[(size_t)(gx + g.border) + (size_t)(gy + g.border) * g.stride] = (uint8_t)kOccupied;
+// returns true iff THIS thread changed byte idx to v (CAS on the containing aligned word)
+__device__ __forceinline__ bool atomic_set_u8(uint8_t* base, size_t idx, uint32_t v) {
+  uint32_t* w = (uint32_t*)(base + (idx & ~(size_t)3));
+  const int sh = (int)(idx & 3) * 8;
+  uint32_t old = *w;
+  for (;;) {
+    if (((old >> sh) & 0xFFu) == v) return false;
+    uint32_t want = (old & ~(0xFFu << sh)) | (v << sh);
+    uint32_t prev = atomicCAS(w, old, want);
+    if (prev == old) return true;
+    old = prev;
+  }
 }
 
 __device__ __forceinline__ void atomic_max_u8(uint8_t* base, size_t idx, uint32_t v) {
@@ -799,37 +871,45 @@ __device__ __forceinline__ void atomic_max_u8(uint8_t* base, size_t idx, uint32_
   }
 }
 
-// Pass 2: SmearPoint (Mapper.h:971-1005) as a max-merge scatter.  Order-independent because the
-// kernel's only 100 is its centre (checked at create time; otherwise k_add_scans_serial runs).
+// AddScan (Mapper.cpp:716-748) for every valid point of every base scan in parallel: the thread
+// that turns a cell into 100 ("not already occupied", :734-740) smears it (SmearPoint,
+// Mapper.h:971-1005) as a max-merge scatter.  Order-independent because the kernel's only 100 is
+// its centre (checked at create time; otherwise k_add_scans_serial runs).
 __global__ void __launch_bounds__(256)
-k_smear(int total, const double2* __restrict__ world, const uint8_t* __restrict__ valid, Geom g,
-        const uint8_t* __restrict__ kernel, uint8_t* __restrict__ grid) {
+k_mark_smear(int B, int n, const double2* __restrict__ world, int ring_start, int cap,
+             const uint8_t* __restrict__ valid, Geom g, const uint8_t* __restrict__ kernel,
+             uint8_t* __restrict__ grid) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total || !valid[i]) return;
-  int gx = world_to_grid(world[i].x, g.off_x, g.scale);
-  int gy = world_to_grid(world[i].y, g.off_y, g.scale);
-  if (gx < 0 || gx >= g.roi_w || gy < 0 || gy >= g.roi_h) return;
+  int b = blockIdx.y;
+  if (i >= n || !valid[(size_t)b * n + i]) return;
+  double2 p = world[(size_t)((ring_start + b) % cap) * n + i];
+  int gx = world_to_grid(p.x, g.off_x, g.scale);
+  int gy = world_to_grid(p.y, g.off_y, g.scale);
+  if (gx < 0 || gx >= g.roi_w || gy < 0 || gy >= g.roi_h) return;  // IsUpTo on the ROI (:724-729)
+  size_t idx = (size_t)(gx + g.border) + (size_t)(gy + g.border) * g.stride;
+  if (!atomic_set_u8(grid, idx, (uint32_t)kOccupied)) return;  // value already set (:734-738)
   const int hk = g.kernel_size / 2;
   for (int j = -hk; j <= hk; j++) {
     size_t row = (size_t)(gx + g.border) + (size_t)(gy + j + g.border) * g.stride;
     for (int k = -hk; k <= hk; k++) {
       uint32_t kv = kernel[(k + hk) + g.kernel_size * (j + hk)];
-      if (kv) atomic_max_u8(grid, row + k, kv);
+      if (kv && (j || k)) atomic_max_u8(grid, row + k, kv);
     }
   }
 }
 
 // Exact sequential AddScans for smear kernels that contain 100 off-centre (then "already
 // occupied -> skip" makes the result order dependent, Mapper.cpp:734-738).  One thread.
-__global__ void k_add_scans_serial(int total, const double2* __restrict__ world,
+__global__ void k_add_scans_serial(int B, int n, const double2* __restrict__ world, int ring_start, int cap,
                                    const uint8_t* __restrict__ valid, Geom g,
                                    const uint8_t* __restrict__ kernel, uint8_t* __restrict__ grid) {
   if (blockIdx.x || threadIdx.x) return;
   const int hk = g.kernel_size / 2;
-  for (int i = 0; i < total; i++) {
+  for (int i = 0; i < B * n; i++) {
     if (!valid[i]) continue;
-    int gx = world_to_grid(world[i].x, g.off_x, g.scale);
-    int gy = world_to_grid(world[i].y, g.off_y, g.scale);
+    const double2 wp = world[(size_t)((ring_start + i / n) % cap) * n + (i % n)];
+    int gx = world_to_grid(wp.x, g.off_x, g.scale);
+    int gy = world_to_grid(wp.y, g.off_y, g.scale);
     if (gx < 0 || gx >= g.roi_w || gy < 0 || gy >= g.roi_h) continue;
     size_t idx = (size_t)(gx + g.border) + (size_t)(gy + g.border) * g.stride;
     if (grid[idx] == kOccupied) continue;
@@ -879,11 +959,14 @@ struct lslam_matcher {
   bool use_row_occupancy = true;
   uint32_t* d_occ_t = nullptr;      // transposed row-occupancy bitmap (k_row_occupancy)
   int occ_wpc = 0;
+  uint32_t* d_nz = nullptr;         // flat non-zero bitmap, one bit per grid byte (k_nonzero_bits)
+  int nz_words = 0;
   // workspaces
   DevBuf<double> d_ranges64;
   DevBuf<double> d_poses;
   DevBuf<double2> d_local, d_world;
   DevBuf<uint8_t> d_valid;
+  DevBuf<int> d_fv_scratch;
   DevBuf<Lattice> d_lat;
   DevBuf<CoarseOut> d_coarse;
   DevBuf<int32_t> d_resp;
@@ -964,8 +1047,10 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   if (m->sub_dirty) {  // refresh the parity planes of the grid (coarse pass source)
     launch(ctx, "deinterleave", k_deinterleave, dim3((g.data_size / 8 + 255) / 256), dim3(256), 0,
            (const uint8_t*)m->d_grid, m->d_sub[0], m->d_sub[1], g.data_size / 8);
+    launch(ctx, "nonzero_bits", k_nonzero_bits, dim3((m->nz_words + 255) / 256), dim3(256), 0,
+           (const uint8_t*)m->d_grid, g.data_size, m->d_nz, m->nz_words);
     launch(ctx, "row_occupancy", k_row_occupancy, dim3((g.stride + 255) / 256, m->occ_wpc), dim3(256), 0,
-           (const uint8_t*)m->d_grid, g.stride, g.height, g.data_size, kOccWin, m->d_occ_t, m->occ_wpc);
+           (const uint32_t*)m->d_nz, m->nz_words, g.stride, g.height, kOccWin, m->d_occ_t, m->occ_wpc);
     m->sub_dirty = false;
   }
   auto reduce_lds = [&](const PassCfg& p, bool cache) -> size_t {
@@ -1048,6 +1133,34 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   launch(ctx, "reduce_fine", k_reduce_fine, dim3(S), dim3(256), (size_t)(((size_t)pf.nx * pf.ny * pf.na + 31) / 32) * 4 + 16,
          (const uint8_t*)m->d_grid, g, pf, sc, (const Lattice*)m->d_lat.p, (const int32_t*)m->d_resp.p, resp_stride,
          (const double2*)m->d_local.p, (const CoarseOut*)m->d_coarse.p, d_out, do_refine);
+  LSLAM_HIP(ctx, hipGetLastError());
+  return LSLAM_OK;
+}
+
+// AddScans on the device (Mapper.cpp:699-748) from world points already resident in HBM:
+// recentre, clear, FindValidPoints, mark + smear.  `world` is a ring of `cap` scans of n points.
+int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, int B, int cap, const double center[3]) {
+  lslam_context* ctx = m->ctx;
+  Geom& g = m->g;
+  // Mapper.cpp:212-220: offset = scanPose - 0.5*(roi-1)*resolution
+  g.off_x = center[0] - (0.5 * (g.roi_w - 1) * (1.0 / g.scale));
+  g.off_y = center[1] - (0.5 * (g.roi_h - 1) * (1.0 / g.scale));
+  LSLAM_HIP(ctx, hipMemsetAsync(m->d_grid, 0, (size_t)g.data_size, ctx->stream));  // Grid::Clear (Mapper.cpp:701)
+  m->sub_dirty = true;
+  const int n = g.n_beams;
+  if (B <= 0 || n <= 0) return LSLAM_OK;
+  LSLAM_HIP(ctx, m->d_valid.reserve((size_t)B * n));
+  const size_t lds = (size_t)n * (sizeof(double2) + 9) + 16;
+  const int use_lds = lds <= 60 * 1024;
+  if (!use_lds) LSLAM_HIP(ctx, m->d_fv_scratch.reserve((size_t)B * 2 * n));
+  launch(ctx, "find_valid", k_find_valid, dim3(B), dim3(256), use_lds ? lds : 0, n, d_world, ring_start, cap,
+         center[0], center[1], m->d_valid.p, use_lds, m->d_fv_scratch.p);
+  if (m->kernel_center_only)
+    launch(ctx, "mark_smear", k_mark_smear, dim3((n + 255) / 256, B), dim3(256), 0, B, n, d_world, ring_start, cap,
+           (const uint8_t*)m->d_valid.p, g, (const uint8_t*)m->d_kernel, m->d_grid);
+  else
+    launch(ctx, "add_scans_serial", k_add_scans_serial, dim3(1), dim3(64), 0, B, n, d_world, ring_start, cap,
+           (const uint8_t*)m->d_valid.p, g, (const uint8_t*)m->d_kernel, m->d_grid);
   LSLAM_HIP(ctx, hipGetLastError());
   return LSLAM_OK;
 }
@@ -1176,7 +1289,9 @@ int lslam_matcher_create(lslam_context* ctx, const lslam_matcher_config* cfg, co
     return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the grid parity planes in HBM");
   }
   m->occ_wpc = (g.height + 2 + 63) / 32 + 1;
-  if (hipMalloc((void**)&m->d_occ_t, (size_t)g.stride * m->occ_wpc * sizeof(uint32_t)) != hipSuccess) {
+  m->nz_words = (g.data_size + 31) / 32;
+  if (hipMalloc((void**)&m->d_occ_t, (size_t)g.stride * m->occ_wpc * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc((void**)&m->d_nz, (size_t)m->nz_words * sizeof(uint32_t)) != hipSuccess) {
     (void)hipFree(m->d_grid_alloc);
     (void)hipFree(m->d_kernel);
     (void)hipFree(m->d_sub_alloc);
@@ -1201,8 +1316,9 @@ void lslam_matcher_destroy(lslam_matcher* m) {
   (void)hipFree(m->d_kernel);
   (void)hipFree(m->d_sub_alloc);
   (void)hipFree(m->d_occ_t);
+  (void)hipFree(m->d_nz);
   m->d_ranges64.release(); m->d_poses.release(); m->d_local.release(); m->d_world.release();
-  m->d_valid.release(); m->d_lat.release(); m->d_coarse.release(); m->d_resp.release();
+  m->d_valid.release(); m->d_fv_scratch.release(); m->d_lat.release(); m->d_coarse.release(); m->d_resp.release();
   m->d_slow.release(); m->d_results.release(); m->d_dbg.release();
   delete m;
 }
@@ -1263,35 +1379,17 @@ int lslam_matcher_set_base_scans(lslam_matcher* m, int B, const double* ranges, 
   if (!m || !center || B < 0 || (B > 0 && (!ranges || !sensor_poses))) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_context* ctx = m->ctx;
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
-  Geom& g = m->g;
-  // Mapper.cpp:212-220: offset = scanPose - 0.5*(roi-1)*resolution
-  g.off_x = center[0] - (0.5 * (g.roi_w - 1) * (1.0 / g.scale));
-  g.off_y = center[1] - (0.5 * (g.roi_h - 1) * (1.0 / g.scale));
-  LSLAM_HIP(ctx, hipMemsetAsync(m->d_grid, 0, (size_t)g.data_size, ctx->stream));  // Grid::Clear (Mapper.cpp:701)
-  m->sub_dirty = true;
-  if (B == 0 || g.n_beams == 0) {
-    LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return LSLAM_OK;
+  const Geom& g = m->g;
+  const int n = g.n_beams;
+  if (B > 0 && n > 0) {
+    int rc = upload_scans(m, B, ranges, stride, sensor_poses);
+    if (rc) return rc;
+    LSLAM_HIP(ctx, m->d_world.reserve((size_t)B * n));
+    launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((n + 255) / 256, B), dim3(256), 0,
+           (const double*)m->d_ranges64.p, n, (const double*)m->d_poses.p, g, (double2*)nullptr, m->d_world.p);
   }
-  int rc = upload_scans(m, B, ranges, stride, sensor_poses);
+  int rc = rebuild_grid_dev(m, m->d_world.p, 0, B, B > 0 ? B : 1, center);
   if (rc) return rc;
-  const int n = g.n_beams, total = B * n;
-  LSLAM_HIP(ctx, m->d_world.reserve((size_t)total));
-  LSLAM_HIP(ctx, m->d_valid.reserve((size_t)total));
-  launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((n + 255) / 256, B), dim3(256), 0,
-         (const double*)m->d_ranges64.p, n, (const double*)m->d_poses.p, g, (double2*)nullptr, m->d_world.p);
-  launch(ctx, "find_valid", k_find_valid, dim3((B + 63) / 64), dim3(64), 0, B, n, (const double2*)m->d_world.p,
-         center[0], center[1], m->d_valid.p);
-  if (m->kernel_center_only) {
-    launch(ctx, "mark_occupied", k_mark_occupied, dim3((total + 255) / 256), dim3(256), 0, total,
-           (const double2*)m->d_world.p, (const uint8_t*)m->d_valid.p, g, m->d_grid);
-    launch(ctx, "smear", k_smear, dim3((total + 255) / 256), dim3(256), 0, total, (const double2*)m->d_world.p,
-           (const uint8_t*)m->d_valid.p, g, (const uint8_t*)m->d_kernel, m->d_grid);
-  } else {
-    launch(ctx, "add_scans_serial", k_add_scans_serial, dim3(1), dim3(64), 0, total, (const double2*)m->d_world.p,
-           (const uint8_t*)m->d_valid.p, g, (const uint8_t*)m->d_kernel, m->d_grid);
-  }
-  LSLAM_HIP(ctx, hipGetLastError());
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return LSLAM_OK;
 }
@@ -1406,8 +1504,13 @@ int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges, const
   LSLAM_HIP(ctx, m->d_valid.reserve((size_t)g.n_beams));
   launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((g.n_beams + 255) / 256, 1), dim3(256), 0,
          (const double*)m->d_ranges64.p, g.n_beams, (const double*)m->d_poses.p, g, (double2*)nullptr, m->d_world.p);
-  launch(ctx, "find_valid", k_find_valid, dim3(1), dim3(64), 0, 1, g.n_beams, (const double2*)m->d_world.p,
-         viewpoint[0], viewpoint[1], m->d_valid.p);
+  {
+    const size_t lds = (size_t)g.n_beams * (sizeof(double2) + 9) + 16;
+    const int use_lds = lds <= 60 * 1024;
+    if (!use_lds) LSLAM_HIP(ctx, m->d_fv_scratch.reserve((size_t)2 * g.n_beams));
+    launch(ctx, "find_valid", k_find_valid, dim3(1), dim3(256), use_lds ? lds : 0, g.n_beams,
+           (const double2*)m->d_world.p, 0, 1, viewpoint[0], viewpoint[1], m->d_valid.p, use_lds, m->d_fv_scratch.p);
+  }
   LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_valid.p, (size_t)g.n_beams, hipMemcpyDeviceToHost, ctx->stream));
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return LSLAM_OK;
