@@ -175,6 +175,12 @@ def lib() -> C.CDLL:
     L.lslam_matcher_debug_coarse_sums.argtypes = [vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32),
                                                   C.POINTER(i32), i32]
     L.lslam_matcher_debug_valid_mask.argtypes = [vp, vp, vp, vp, vp]
+    L.lslam_frontend_create.argtypes = [vp, i32, dbl, dbl, dbl, C.POINTER(vp)]
+    L.lslam_frontend_destroy.argtypes = [vp]
+    L.lslam_frontend_destroy.restype = None
+    L.lslam_frontend_reset.argtypes = [vp]
+    L.lslam_frontend_process.argtypes = [vp, vp, i32, vp, C.POINTER(i32), vp, vp, C.POINTER(dbl)]
+    L.lslam_frontend_running_scans.argtypes = [vp]
     L.lslam_map_create.argtypes = [vp, i32, i32, C.c_float, C.c_float, C.c_float, i32, C.POINTER(vp)]
     L.lslam_map_destroy.argtypes = [vp]
     L.lslam_map_destroy.restype = None
@@ -409,6 +415,44 @@ class ScanMatcher:
         self.ctx.check(self.L.lslam_matcher_debug_valid_mask(self.h, r.ctypes.data, p.ctypes.data, v.ctypes.data,
                                                              out.ctypes.data))
         return out
+
+
+class FrontEnd:
+    """Pose path of karto::Mapper::Process with a device-resident running-scan window."""
+
+    def __init__(self, matcher: ScanMatcher, scan_buffer_size=70, scan_buffer_max_distance=20.0,
+                 min_travel_distance=0.2, min_travel_heading=math.radians(10.0)):
+        self.m, self.ctx, self.L = matcher, matcher.ctx, matcher.L
+        h = C.c_void_p()
+        self.ctx.check(self.L.lslam_frontend_create(matcher.h, scan_buffer_size, scan_buffer_max_distance,
+                                                    min_travel_distance, min_travel_heading, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lslam_frontend_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def Process(self, ranges, odom_pose):
+        """-> (processed, corrected robot pose, covariance 3x3, response)"""
+        r, o = _f64(ranges), _f64(odom_pose)
+        ok, resp = C.c_int(), C.c_double()
+        pose, cov = np.zeros(3), np.zeros(9)
+        self.ctx.check(self.L.lslam_frontend_process(self.h, r.ctypes.data, r.shape[0], o.ctypes.data, C.byref(ok),
+                                                     pose.ctypes.data, cov.ctypes.data, C.byref(resp)))
+        return bool(ok.value), pose, cov.reshape(3, 3), resp.value
+
+    def running_scans(self) -> int:
+        return self.L.lslam_frontend_running_scans(self.h)
+
+    def reset(self):
+        self.ctx.check(self.L.lslam_frontend_reset(self.h))
 
 
 class OccGridMap:

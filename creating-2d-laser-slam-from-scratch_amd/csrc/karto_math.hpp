@@ -131,4 +131,80 @@ LSLAM_HD int32_t lookup_offset(double lx, double ly, double cosine, double sine,
   return gx + gy * stride;
 }
 
+// karto::Transform(rPose1, rPose2) (Karto.h:2870-2873, 2909-2935) and TransformPose (:2881-2887)
+struct PoseXform {
+  Rot2 rot;
+  double tx, ty, th;
+};
+LSLAM_HD PoseXform pose_xform(const double p1[3], const double p2[3]) {
+  PoseXform t;
+  if (p1[0] == p2[0] && p1[1] == p2[1] && p1[2] == p2[2]) {  // :2911-2917
+    t.rot = rot_identity();
+    t.tx = t.ty = t.th = 0.0;
+    return t;
+  }
+  t.rot = rot_z(p2[2] - p1[2]);  // :2920
+  if (p1[0] != 0.0 || p1[1] != 0.0) {  // :2925-2928: rPose2 - m_Rotation * rPose1
+    double rx, ry;
+    rot_apply(t.rot, p1[0], p1[1], p1[2], rx, ry);
+    t.tx = p2[0] - rx;
+    t.ty = p2[1] - ry;
+  } else {
+    t.tx = p2[0];
+    t.ty = p2[1];
+  }
+  t.th = p2[2] - p1[2];  // :2934
+  return t;
+}
+LSLAM_HD void pose_xform_apply(const PoseXform& t, const double src[3], double out[3]) {
+  double rx, ry;
+  rot_apply(t.rot, src[0], src[1], src[2], rx, ry);
+  out[0] = t.tx + rx;
+  out[1] = t.ty + ry;
+  out[2] = normalize_angle(src[2] + t.th);
+}
+
+// Matrix3::InverseFast by cofactors with Inverse()'s 1e-14 tolerance (Karto.h:2445-2493)
+LSLAM_HD bool mat3_inverse(const double m[9], double inv[9]) {
+  inv[0] = m[4] * m[8] - m[5] * m[7];
+  inv[1] = m[2] * m[7] - m[1] * m[8];
+  inv[2] = m[1] * m[5] - m[2] * m[4];
+  inv[3] = m[5] * m[6] - m[3] * m[8];
+  inv[4] = m[0] * m[8] - m[2] * m[6];
+  inv[5] = m[2] * m[3] - m[0] * m[5];
+  inv[6] = m[3] * m[7] - m[4] * m[6];
+  inv[7] = m[1] * m[6] - m[0] * m[7];
+  inv[8] = m[0] * m[4] - m[1] * m[3];
+  double det = m[0] * inv[0] + m[1] * inv[3] + m[2] * inv[6];
+  if (fabs(det) <= 1e-14) return false;
+  double id = 1.0 / det;
+  for (int i = 0; i < 9; i++) inv[i] *= id;
+  return true;
+}
+// Matrix3 operator* (Karto.h:2552-2568)
+LSLAM_HD void mat3_mul(const double a[9], const double b[9], double out[9]) {
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++)
+      out[3 * r + c] = a[3 * r] * b[c] + a[3 * r + 1] * b[3 + c] + a[3 * r + 2] * b[6 + c];
+}
+// MapperGraph::ComputeWeightedMean for ONE (mean, covariance) pair (Mapper.cpp:1288-1330): what
+// AddEdges' closing SetSensorPose(ComputeWeightedMean(...)) (Mapper.cpp:969-972) applies when no
+// near chain contributes.
+LSLAM_HD void weighted_mean_single(const double mean[3], const double cov[9], double out[3]) {
+  double inv[9], ios[9], w[9];
+  mat3_inverse(cov, inv);
+  double sum[9];
+  for (int i = 0; i < 9; i++) sum[i] = 0.0 + inv[i];  // zero matrix += inverse (Mapper.cpp:1296-1303)
+  mat3_inverse(sum, ios);
+  double tx = cos(mean[2]), ty = sin(mean[2]);
+  mat3_mul(ios, inv, w);
+  double wx = w[0] * mean[0] + w[1] * mean[1] + w[2] * mean[2];  // Matrix3 * Pose2 (Karto.h:2574-2583)
+  double wy = w[3] * mean[0] + w[4] * mean[1] + w[5] * mean[2];
+  out[0] = 0.0 + wx;  // Pose2 operator+= on a default Pose2 (Karto.h:2117-2121)
+  out[1] = 0.0 + wy;
+  tx /= 1;
+  ty /= 1;
+  out[2] = atan2(ty, tx);
+}
+
 }  // namespace lslam

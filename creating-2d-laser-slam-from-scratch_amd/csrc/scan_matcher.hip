@@ -1517,3 +1517,5 @@ int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges, const
 }
 
 }  // extern "C"
+
+#include "frontend_impl.hpp"

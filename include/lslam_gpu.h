@@ -197,6 +197,26 @@ int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges,
                                    uint8_t* out_host);
 
 /* ---------------------------------------------------------------------------------------- */
+/* Streaming front-end: the pose path of karto::Mapper::Process (Mapper.cpp:1999-2079) with a  */
+/* device-resident running-scan window (replaces Mapper::Process as karto_slam.cc:444 calls it, */
+/* minus the pose graph, which stays on the host)                                              */
+/* ---------------------------------------------------------------------------------------- */
+typedef struct lslam_frontend lslam_frontend;
+/* scan_buffer_size / scan_buffer_max_distance: ScanBufferSize, ScanBufferMaximumScanDistance
+ * (Mapper.cpp:1501-1515); min_travel_*: MinimumTravelDistance / MinimumTravelHeading (:1480-1499).
+ * The matcher must outlive the front-end; its grid is rebuilt on every processed scan. */
+int lslam_frontend_create(lslam_matcher* m, int scan_buffer_size, double scan_buffer_max_distance,
+                          double min_travel_distance, double min_travel_heading, lslam_frontend** out);
+void lslam_frontend_destroy(lslam_frontend* f);
+int lslam_frontend_reset(lslam_frontend* f);
+/* One LaserScan in (ranges widened to double, odometric ROBOT pose), corrected ROBOT pose out.
+ * *processed = 0 when HasMovedEnough rejects the scan (Mapper.cpp:2028-2031).  covariance/response
+ * may be NULL. */
+int lslam_frontend_process(lslam_frontend* f, const double* ranges, int n_ranges, const double odom_pose[3],
+                           int* processed, double corrected_pose[3], double covariance[9], double* response);
+int lslam_frontend_running_scans(const lslam_frontend* f); /* ScanManager::GetRunningScans().size() */
+
+/* ---------------------------------------------------------------------------------------- */
 /* Hector log-odds occupancy grid  (replaces hectorslam::OccGridMapBase<LogOddsCell,...>,    */
 /* H/map/OccGridMapBase.h, H/map/GridMapLogOdds.h, H/map/GridMapBase.h)                      */
 /* ---------------------------------------------------------------------------------------- */
