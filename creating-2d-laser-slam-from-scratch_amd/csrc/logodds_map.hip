@@ -11,7 +11,8 @@
 // un-doing a free mark made earlier in the same scan (H/map/OccGridMapBase.h:302-330).  The only
 // order-dependent bit is whether (v + free) - free is applied to a hit cell, i.e. whether some
 // beam with a smaller index crossed the cell before the first beam that ends in it.
-// Device formulation (one thread per beam, two kernels, no atomics on the float plane):
+// Device formulation (one WAVE per beam, closed-form Bresenham cells, two kernels, no atomics on
+// the float plane):
 //   k_logodds_mark   walks the Bresenham line; atomicMax(free_key[cell]) along the ray and
 //                    atomicMax(occ_key[end]) where key = epoch<<12 | (4095-beam): for the current
 //                    epoch the max key is the SMALLEST beam index that touched the cell.
@@ -75,76 +76,84 @@ __device__ __forceinline__ Line beam_line(const LevelGeom& g, const float* __res
   return l;
 }
 
-// Bresenham traversal of H/map/OccGridMapBase.h:240-299: F(offset) for the start cell and the
-// abs_da-1 following cells (end point excluded).
-template <typename F>
-__device__ __forceinline__ void walk(const Line& l, int sx, F f) {
+// Bresenham traversal of H/map/OccGridMapBase.h:240-299 in CLOSED FORM.  The reference loop adds
+// abs_db to an error term that starts at abs_da/2 and takes a minor-axis step whenever it reaches
+// abs_da; since abs_db <= abs_da that is at most one minor step per major step, so after i major
+// steps exactly q(i) = floor((abs_da/2 + i*abs_db) / abs_da) minor steps were taken.  Cell i of the
+// ray (i = 0 .. abs_da-1, end point excluded) is therefore start + i*offset_a + q(i)*offset_b --
+// independent of the other cells, so a whole wave walks ONE ray, 64 cells at a time, instead of one
+// thread crawling it cell by cell with a dependent atomic per step.
+struct Ray {
+  unsigned start, abs_da, abs_db;
+  int offset_a, offset_b;
+};
+__device__ __forceinline__ Ray ray_of(const Line& l, int sx) {
   int dx = l.x1 - l.x0, dy = l.y1 - l.y0;
   unsigned abs_dx = (unsigned)abs(dx), abs_dy = (unsigned)abs(dy);
-  int offset_dx = dx > 0 ? 1 : -1;            // util::sign: sign(0) = -1
+  int offset_dx = dx > 0 ? 1 : -1;  // util::sign: sign(0) = -1
   int offset_dy = (dy > 0 ? 1 : -1) * sx;
-  unsigned offset = (unsigned)(l.y0 * sx + l.x0);
-  unsigned abs_da, abs_db;
-  int offset_a, offset_b;
+  Ray r;
+  r.start = (unsigned)(l.y0 * sx + l.x0);
   if (abs_dx >= abs_dy) {
-    abs_da = abs_dx; abs_db = abs_dy; offset_a = offset_dx; offset_b = offset_dy;
+    r.abs_da = abs_dx; r.abs_db = abs_dy; r.offset_a = offset_dx; r.offset_b = offset_dy;
   } else {
-    abs_da = abs_dy; abs_db = abs_dx; offset_a = offset_dy; offset_b = offset_dx;
+    r.abs_da = abs_dy; r.abs_db = abs_dx; r.offset_a = offset_dy; r.offset_b = offset_dx;
   }
-  int error_b = (int)(abs_da / 2);
-  f(offset);
-  unsigned end = abs_da - 1;
-  for (unsigned i = 0; i < end; ++i) {
-    offset += offset_a;
-    error_b += abs_db;
-    if ((unsigned)error_b >= abs_da) {
-      offset += offset_b;
-      error_b -= abs_da;
-    }
-    f(offset);
-  }
+  return r;
+}
+__device__ __forceinline__ unsigned ray_cell(const Ray& r, unsigned i) {
+  unsigned q = (unsigned)(((unsigned long long)(r.abs_da / 2) + (unsigned long long)i * r.abs_db) / r.abs_da);
+  return r.start + (unsigned)((int)i * r.offset_a) + (unsigned)((int)q * r.offset_b);
 }
 
+// one wave per beam
 __global__ void __launch_bounds__(256)
 k_logodds_mark(LevelGeom g, const float* __restrict__ pts, int n, uint32_t* __restrict__ free_key,
                uint32_t* __restrict__ occ_key) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= n) return;
   Line l = beam_line(g, pts, i);
   if (!l.valid) return;
   const uint32_t key = (g.epoch << kBeamBits) | (kBeamMask - (uint32_t)i);
-  walk(l, g.sx, [&](unsigned off) { atomicMax(&free_key[off], key); });
-  atomicMax(&occ_key[(unsigned)(l.y1 * g.sx + l.x1)], key);
+  const Ray r = ray_of(l, g.sx);
+  for (unsigned c = lane; c < r.abs_da; c += 64) atomicMax(&free_key[ray_cell(r, c)], key);
+  if (lane == 0) atomicMax(&occ_key[(unsigned)(l.y1 * g.sx + l.x1)], key);
 }
 
 __global__ void __launch_bounds__(256)
 k_logodds_apply(LevelGeom g, const float* __restrict__ pts, int n, const uint32_t* __restrict__ free_key,
                 const uint32_t* __restrict__ occ_key, float* __restrict__ logodds) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= n) return;
   Line l = beam_line(g, pts, i);
   if (!l.valid) return;
   const uint32_t me = kBeamMask - (uint32_t)i;
   const uint32_t ep = g.epoch;
+  const Ray r = ray_of(l, g.sx);
   // crossed cells: free once per scan unless some beam ends here (bresenhamCellFree, :302-313)
-  walk(l, g.sx, [&](unsigned off) {
+  for (unsigned c = lane; c < r.abs_da; c += 64) {
+    const unsigned off = ray_cell(r, c);
     uint32_t fk = free_key[off];
-    if ((fk & kBeamMask) != me) return;                 // not the first beam crossing this cell
-    if ((occ_key[off] >> kBeamBits) == ep) return;      // a hit cell: handled by its occ owner
+    if ((fk & kBeamMask) != me) continue;             // not the first beam crossing this cell
+    if ((occ_key[off] >> kBeamBits) == ep) continue;  // a hit cell: handled by its occ owner
     logodds[off] += g.lo_free;
-  });
+  }
   // end cell (bresenhamCellOcc, :316-330)
-  unsigned eoff = (unsigned)(l.y1 * g.sx + l.x1);
-  uint32_t ok = occ_key[eoff];
-  if ((ok & kBeamMask) == me) {  // first beam ending here
-    float v = logodds[eoff];
-    uint32_t fk = free_key[eoff];
-    if ((fk >> kBeamBits) == ep && (fk & kBeamMask) > me) {  // crossed by an EARLIER beam: free then unset
-      v += g.lo_free;
-      v -= g.lo_free;
+  if (lane == 0) {
+    unsigned eoff = (unsigned)(l.y1 * g.sx + l.x1);
+    uint32_t ok = occ_key[eoff];
+    if ((ok & kBeamMask) == me) {  // first beam ending here
+      float v = logodds[eoff];
+      uint32_t fk = free_key[eoff];
+      if ((fk >> kBeamBits) == ep && (fk & kBeamMask) > me) {  // crossed by an EARLIER beam: free then unset
+        v += g.lo_free;
+        v -= g.lo_free;
+      }
+      if (v < 50.0f) v += g.lo_occ;  // updateSetOccupied (H/map/GridMapLogOdds.h:108-114)
+      logodds[eoff] = v;
     }
-    if (v < 50.0f) v += g.lo_occ;  // updateSetOccupied (H/map/GridMapLogOdds.h:108-114)
-    logodds[eoff] = v;
   }
 }
 
@@ -235,7 +244,7 @@ int update_impl(lslam_map* map, const float* d_pts, int n, const float origo[2],
     g.bx = (int)(bxf + 0.5f);                   // :135
     g.by = (int)(byf + 0.5f);
     if (n > 0) {
-      dim3 grid((n + 255) / 256), block(256);
+      dim3 grid((n + 3) / 4), block(256);  // 4 waves per block, one wave per beam
       launch(ctx, "logodds_mark", k_logodds_mark, grid, block, 0, g, d_pts, n, L.d_free, L.d_occ);
       launch(ctx, "logodds_apply", k_logodds_apply, grid, block, 0, g, d_pts, n, (const uint32_t*)L.d_free,
              (const uint32_t*)L.d_occ, L.d_logodds);
