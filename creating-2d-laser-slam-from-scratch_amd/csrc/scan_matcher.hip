@@ -182,7 +182,7 @@ k_deinterleave(const uint8_t* __restrict__ grid, uint8_t* __restrict__ f0, uint8
 // bits of all its lattice rows (rows are 1 or 2 grid rows apart, same column).  A row whose bit is
 // clear contributes nothing to any candidate -> skipping its load is exact, not an approximation.
 // ------------------------------------------------------------------------------------------
-constexpr int kOccWin = 21;  // row span covered by one bit: step*(nX-1)+1 grid bytes must fit (coarse 2*10+1 = 21)
+constexpr int kOccWinMax = 63;  // widest row span one bit can summarise (window mask is 64-bit)
 
 // pass A: flat non-zero bitmap, one bit per grid byte (thread per 32 bytes, coalesced)
 __global__ void __launch_bounds__(256)
@@ -959,6 +959,7 @@ struct lslam_matcher {
   bool use_row_occupancy = true;
   uint32_t* d_occ_t = nullptr;      // transposed row-occupancy bitmap (k_row_occupancy)
   int occ_wpc = 0;
+  int occ_win = 21;                 // grid bytes summarised per bit = row span of the coarse lattice
   uint32_t* d_nz = nullptr;         // flat non-zero bitmap, one bit per grid byte (k_nonzero_bits)
   int nz_words = 0;
   // workspaces
@@ -1050,7 +1051,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     launch(ctx, "nonzero_bits", k_nonzero_bits, dim3((m->nz_words + 255) / 256), dim3(256), 0,
            (const uint8_t*)m->d_grid, g.data_size, m->d_nz, m->nz_words);
     launch(ctx, "row_occupancy", k_row_occupancy, dim3((g.stride + 255) / 256, m->occ_wpc), dim3(256), 0,
-           (const uint32_t*)m->d_nz, m->nz_words, g.stride, g.height, kOccWin, m->d_occ_t, m->occ_wpc);
+           (const uint32_t*)m->d_nz, m->nz_words, g.stride, g.height, m->occ_win, m->d_occ_t, m->occ_wpc);
     m->sub_dirty = false;
   }
   auto reduce_lds = [&](const PassCfg& p, bool cache) -> size_t {
@@ -1079,7 +1080,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       const uint8_t* s1 = step == 2 ? m->d_sub[1] : m->d_grid;
       const int limit = step == 2 ? g.data_size / 2 : g.data_size;
       // the bitmap covers row spans of kOccWin grid bytes: step*(nX-1)+1 must fit
-      const uint32_t* occ = (m->use_row_occupancy && step * (p.nx - 1) + 1 <= kOccWin) ? m->d_occ_t : (const uint32_t*)nullptr;
+      const uint32_t* occ = (m->use_row_occupancy && step * (p.nx - 1) + 1 <= m->occ_win) ? m->d_occ_t : (const uint32_t*)nullptr;
       if (variant == 1)
         launch(ctx, name, k_resp_rows<1, 4>, grid, dim3(64), 0, s0, s1, step, limit, g, p, (const Lattice*)m->d_lat.p,
                (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc);
@@ -1287,6 +1288,11 @@ int lslam_matcher_create(lslam_context* ctx, const lslam_matcher_config* cfg, co
     (void)hipFree(m->d_kernel);
     delete m;
     return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the grid parity planes in HBM");
+  }
+  {  // row span of the coarse lattice: 2-cell steps over nX candidates (Mapper.cpp:228-234)
+    const double res = 1.0 / g.scale;
+    const int nx = lattice_count(0.5 * ((double)g.probs_side - 1) * res, 2 * res);
+    m->occ_win = std::min(kOccWinMax, std::max(3, 2 * (nx - 1) + 1));
   }
   m->occ_wpc = (g.height + 2 + 63) / 32 + 1;
   m->nz_words = (g.data_size + 31) / 32;

@@ -277,3 +277,35 @@ def test_full_size_properties(ctx):
     own = gm.match_batch(wl.base_ranges[-1:], wl.base_poses[-1:])
     assert own["response"][0] > 0.5
     assert np.abs(own["pose"][0][:2] - wl.base_poses[-1][:2]).max() <= 0.05 + 1e-9
+
+
+def test_reference_indoor_default_config(ctx, oracle_lib):
+    """The configuration the reference ships (lesson6/config/mapper_params.yaml): 0.01 m cells,
+    0.3 m search space, 12 m range threshold -> 2445x2445 grid, 13x13 smear kernel, 16x16x21 coarse
+    lattice, response expansion on.  Exercises the <4,8> packed kernel, the wide smear and 31-byte rows."""
+    laser = synth.Laser(range_max=30.0)
+    kw = dict(search_size=0.3, resolution=0.01, smear_deviation=0.03, use_response_expansion=1)
+    port, gm = make_pair(ctx, oracle_lib, laser=laser, cfg_kw=kw, range_threshold=12.0)
+    assert gm.grid_info()["width"] == 2445 and gm.grid_info()["kernel_size"] == 13
+    world = synth.arena(size=24.0, n_axis=8, n_rot=3, seed=12)
+    wl = synth.make_match_workload(n_base=12, n_query=6, seed=12, laser=laser, world=world, err_xy=0.08,
+                                   err_th=math.radians(6.0), query_spread=0.5)
+    port.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    assert np.array_equal(gm.GetCorrelationGrid(), port.grid())
+    p0 = wl.query_poses[0]
+    _, _, _, st, sums = port.correlate_scan(wl.query_ranges[0], p0, p0, 0.15, 0.02, 0.349, 0.0349, True, False,
+                                            want_sums=True)
+    assert st == 0
+    assert np.array_equal(gm.coarse_sums(wl.query_ranges[0], p0), sums)
+    res = gm.match_batch(wl.query_ranges, wl.query_poses)
+    good = 0
+    for q in range(len(res)):
+        mean, cov, resp = port.match(wl.query_ranges[q], wl.query_poses[q])
+        _assert_result(res[q], mean, cov, resp)
+        good += resp > 0.3
+    assert good >= 3
+    # full MatchScan too (grid rebuilt with the 13x13 smear around the query)
+    mean, cov, resp = port.match_scan(wl.base_ranges, wl.base_poses, wl.query_ranges[1], wl.query_poses[1])
+    r, m, c = gm.MatchScan(wl.query_ranges[1], wl.query_poses[1], wl.base_ranges, wl.base_poses)
+    assert abs(r - resp) <= 1e-12 and np.abs(m - mean).max() <= POSE_TOL
