@@ -122,12 +122,17 @@ LSLAM_HD void beam_world_point(double sx, double sy, double sh, double min_angle
 // One lookup-table entry of GridIndexLookup::ComputeOffsets (Karto.h:6486-6496): local point
 // rotated by the candidate angle, WorldToGrid(offset + rGridOffset), base-class GridIndex
 // (no ROI, no bounds check).
-LSLAM_HD int32_t lookup_offset(double lx, double ly, double cosine, double sine, double off_x,
-                               double off_y, double scale, int stride) {
+LSLAM_HD void lookup_cell(double lx, double ly, double cosine, double sine, double off_x, double off_y,
+                          double scale, int& gx, int& gy) {
   double ox = cosine * lx - sine * ly;
   double oy = sine * lx + cosine * ly;
-  int gx = world_to_grid(ox + off_x, off_x, scale);
-  int gy = world_to_grid(oy + off_y, off_y, scale);
+  gx = world_to_grid(ox + off_x, off_x, scale);
+  gy = world_to_grid(oy + off_y, off_y, scale);
+}
+LSLAM_HD int32_t lookup_offset(double lx, double ly, double cosine, double sine, double off_x,
+                               double off_y, double scale, int stride) {
+  int gx, gy;
+  lookup_cell(lx, ly, cosine, sine, off_x, off_y, scale, gx, gy);
   return gx + gy * stride;
 }
 

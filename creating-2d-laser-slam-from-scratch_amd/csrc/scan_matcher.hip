@@ -260,7 +260,9 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
             int32_t* __restrict__ resp, size_t resp_stride, int beam_slices, int S,
             const uint32_t* __restrict__ occ_t, int occ_wpc) {
   constexpr int NW = NXD * NYC * 2;
+  constexpr int kQueue = 128;
   __shared__ uint32_t red[NW][65];
+  __shared__ int2 queue[kQueue];  // .x = first row index m0, .y = row mask | parity << 31
   const int lane = threadIdx.x;
   int w = blockIdx.x;
   const int slice = w % beam_slices;
@@ -274,10 +276,11 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
 
   const double angle = (L.center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;  // Mapper.cpp:390-393
   const double cosine = cos(angle), sine = sin(angle);                         // Karto.h:6465-6466
-  const int pos00 = L.gx[0] + L.gy[0] * g.stride;
+  const int X0 = L.gx[0], Y0 = L.gy[0];
   const double2* lp = local + (size_t)s * g.n_beams;
   const int ncand = pc.nx * pc.ny;
   const int shift = step == 2 ? 1 : 0;
+  const unsigned long long lane_lt = (1ull << lane) - 1ull;
 
   for (int j0 = 0; j0 < pc.ny; j0 += NYC) {
     uint32_t acc[NYC][NXD][2];
@@ -286,34 +289,17 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
 #pragma unroll
       for (int k = 0; k < NXD; k++) acc[j][k][0] = acc[j][k][1] = 0u;
 
-    for (int b = lane + 64 * slice; b < g.n_beams; b += 64 * beam_slices) {
-      double2 p = lp[b];
-      const bool beam_ok = !isnan(p.x);  // NaN = INVALID_SCAN
-      int t = lookup_offset(p.x, p.y, cosine, sine, g.off_x, g.off_y, g.scale, g.stride);
-      long long base = (long long)pos00 + t;
-      const uint8_t* src = (shift && (base & 1)) ? src1 : src0;
-      long long m0 = (base >> shift) + (long long)j0 * g.stride;  // arithmetic shift = floor
-      // row-occupancy bits of this beam's lattice rows (bit j*step <-> lattice row j0+j)
-      unsigned long long rowbits = ~0ull;
-      if (occ_t) {
-        long long f0 = base + (long long)j0 * step * g.stride;
-        long long y = f0 >= 0 ? f0 / g.stride : -((-f0 + g.stride - 1) / g.stride);  // floor
-        int x = (int)(f0 - y * g.stride);
-        if (y >= -1 && y + (long long)step * (NYC - 1) <= (long long)g.height) {
-          const uint32_t* col = occ_t + (size_t)x * occ_wpc + ((y + 1) >> 5);
-          unsigned long long two = (unsigned long long)col[0] | ((unsigned long long)col[1] << 32);
-          rowbits = two >> ((y + 1) & 31);
-        }
-      }
+    // Phase B: one queued beam per lane -- load the rows its mask names, accumulate 4 candidates per dword
+    auto drain = [&](int cnt) {
+      int2 e = lane < cnt ? queue[lane] : make_int2(0, 0);
+      const uint8_t* src = (e.y < 0) ? src1 : src0;
+      const uint32_t mask = (uint32_t)e.y & 0x7FFFFFFFu;
       uint32_t d[NYC][NXD];
 #pragma unroll
       for (int j = 0; j < NYC; j++) {
 #pragma unroll
         for (int k = 0; k < NXD; k++) d[j][k] = 0u;
-        long long rs = m0 + (long long)j * g.stride;
-        bool ok = beam_ok && (j0 + j < pc.ny) && rs >= -(long long)(4 * NXD) && rs < (long long)limit &&
-                  ((rowbits >> (j * step)) & 1ull);
-        if (ok) __builtin_memcpy(d[j], src + rs, 4 * NXD);
+        if ((mask >> j) & 1u) __builtin_memcpy(d[j], src + ((long long)e.x + (long long)j * g.stride), 4 * NXD);
       }
 #pragma unroll
       for (int j = 0; j < NYC; j++)
@@ -322,7 +308,70 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
           acc[j][k][0] += d[j][k] & 0x00FF00FFu;         // candidates 4k, 4k+2
           acc[j][k][1] += (d[j][k] >> 8) & 0x00FF00FFu;  // candidates 4k+1, 4k+3
         }
+    };
+
+    // Phase A: every beam -- table entry, row mask (bounds + exact row occupancy); survivors are queued
+    int qcount = 0;
+    const int rows_here = min(NYC, pc.ny - j0);
+    const uint32_t all_rows = rows_here >= 32 ? 0xFFFFFFFFu : ((1u << rows_here) - 1u);
+    for (int b0 = 64 * slice; b0 < g.n_beams; b0 += 64 * beam_slices) {
+      const int b = b0 + lane;
+      uint32_t mask = 0;
+      int m0i = 0, par = 0;
+      if (b < g.n_beams) {
+        double2 p = lp[b];
+        if (!isnan(p.x)) {  // NaN = INVALID_SCAN
+          int gx, gy;
+          lookup_cell(p.x, p.y, cosine, sine, g.off_x, g.off_y, g.scale, gx, gy);
+          const int t = gx + gy * g.stride;  // Karto.h:6494 (int32 like the reference)
+          const long long base = (long long)X0 + (long long)Y0 * g.stride + t + (long long)j0 * step * g.stride;
+          par = (int)(base & 1) & shift;
+          const long long m0 = base >> shift;  // arithmetic shift = floor
+          // rows inside the valid index range (the reference's 1-D check, Mapper.cpp:841-845)
+          if (m0 >= 0 && m0 + (long long)(rows_here - 1) * g.stride + 4 * NXD <= (long long)limit) {
+            mask = all_rows;
+          } else {
+            for (int j = 0; j < rows_here; j++) {
+              long long rs = m0 + (long long)j * g.stride;
+              if (rs >= -(long long)(4 * NXD) && rs < (long long)limit) mask |= 1u << j;
+            }
+          }
+          if (occ_t && mask) {  // exact row occupancy: bit j*step <-> lattice row j0+j
+            long long x = (long long)X0 + gx, y = (long long)Y0 + gy + (long long)j0 * step;
+            if (x < 0 || x >= g.stride) {  // flat index wrapped into a neighbouring row
+              y = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
+              x = base - y * g.stride;
+            }
+            if (y >= -1 && y + (long long)step * (NYC - 1) <= (long long)g.height) {
+              const uint32_t* col = occ_t + (size_t)x * occ_wpc + ((y + 1) >> 5);
+              unsigned long long two = (unsigned long long)col[0] | ((unsigned long long)col[1] << 32);
+              unsigned long long rowbits = two >> ((y + 1) & 31);
+              uint32_t keep = 0;
+#pragma unroll
+              for (int j = 0; j < NYC; j++) keep |= (uint32_t)((rowbits >> (j * step)) & 1ull) << j;
+              mask &= keep;
+            }
+          }
+          m0i = (int)m0;
+        }
+      }
+      const unsigned long long votes = __ballot(mask != 0);
+      if (mask) queue[qcount + __popcll(votes & lane_lt)] = make_int2(m0i, (int)(mask | ((uint32_t)par << 31)));
+      qcount += __popcll(votes);
+      __syncthreads();
+      if (qcount >= 64) {
+        drain(64);
+        __syncthreads();
+        int2 moved = (lane + 64 < qcount) ? queue[lane + 64] : make_int2(0, 0);
+        __syncthreads();
+        if (lane + 64 < qcount) queue[lane] = moved;
+        qcount -= 64;
+        __syncthreads();
+      }
     }
+    if (qcount > 0) drain(qcount);
+    __syncthreads();
+
     // transpose through LDS, then lane i reduces packed word i over the 64 lanes
 #pragma unroll
     for (int j = 0; j < NYC; j++)
@@ -340,8 +389,8 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
         lo += v & 0xFFFFu;
         hi += v >> 16;
       }
-      const int par = idx & 1, jk = idx >> 1;
-      const int j = j0 + jk / NXD, i = 4 * (jk % NXD) + par;
+      const int par2 = idx & 1, jk = idx >> 1;
+      const int j = j0 + jk / NXD, i = 4 * (jk % NXD) + par2;
       if (j < pc.ny) {
         int32_t* o = resp + (size_t)s * resp_stride + (size_t)a * ncand + (size_t)j * pc.nx + i;
         if (beam_slices == 1) {
