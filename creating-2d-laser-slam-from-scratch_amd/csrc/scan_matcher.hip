@@ -260,8 +260,10 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
             int32_t* __restrict__ resp, size_t resp_stride, int beam_slices, int S,
             const uint32_t* __restrict__ occ_t, int occ_wpc) {
   constexpr int NW = NXD * NYC * 2;
+  constexpr int kRedPasses = NW > 32 ? 2 : 1;
+  constexpr int NWC = (NW + kRedPasses - 1) / kRedPasses;
   constexpr int kQueue = 128;
-  __shared__ uint32_t red[NW][65];
+  __shared__ uint32_t red[NWC][65];
   __shared__ int2 queue[kQueue];  // .x = first row index m0, .y = row mask | parity << 31
   const int lane = threadIdx.x;
   int w = blockIdx.x;
@@ -372,37 +374,46 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
     if (qcount > 0) drain(qcount);
     __syncthreads();
 
-    // transpose through LDS, then lane i reduces packed word i over the 64 lanes
+    // transpose through LDS in kRedPasses slices (keeps LDS per wave small -> 4 waves/SIMD), then
+    // lane i reduces packed word i over the 64 lanes
 #pragma unroll
-    for (int j = 0; j < NYC; j++)
+    for (int pass = 0; pass < kRedPasses; pass++) {
 #pragma unroll
-      for (int k = 0; k < NXD; k++) {
-        red[(j * NXD + k) * 2 + 0][lane] = acc[j][k][0];
-        red[(j * NXD + k) * 2 + 1][lane] = acc[j][k][1];
-      }
-    __syncthreads();
-    for (int idx = lane; idx < NW; idx += 64) {
-      uint32_t lo = 0, hi = 0;
+      for (int j = 0; j < NYC; j++)
+#pragma unroll
+        for (int k = 0; k < NXD; k++)
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            const int wi = (j * NXD + k) * 2 + q;  // compile-time after unrolling
+            if (wi / NWC == pass) red[wi % NWC][lane] = acc[j][k][q];
+          }
+      __syncthreads();
+      for (int li = lane; li < NWC; li += 64) {
+        const int idx = pass * NWC + li;
+        if (idx < NW) {
+          uint32_t lo = 0, hi = 0;
 #pragma unroll 8
-      for (int k = 0; k < 64; k++) {
-        uint32_t v = red[idx][k];
-        lo += v & 0xFFFFu;
-        hi += v >> 16;
-      }
-      const int par2 = idx & 1, jk = idx >> 1;
-      const int j = j0 + jk / NXD, i = 4 * (jk % NXD) + par2;
-      if (j < pc.ny) {
-        int32_t* o = resp + (size_t)s * resp_stride + (size_t)a * ncand + (size_t)j * pc.nx + i;
-        if (beam_slices == 1) {
-          if (i < pc.nx) o[0] = (int32_t)lo;
-          if (i + 2 < pc.nx) o[2] = (int32_t)hi;
-        } else {
-          if (i < pc.nx) atomicAdd(o, (int32_t)lo);
-          if (i + 2 < pc.nx) atomicAdd(o + 2, (int32_t)hi);
+          for (int k = 0; k < 64; k++) {
+            uint32_t v = red[li][k];
+            lo += v & 0xFFFFu;
+            hi += v >> 16;
+          }
+          const int par2 = idx & 1, jk = idx >> 1;
+          const int j = j0 + jk / NXD, i = 4 * (jk % NXD) + par2;
+          if (j < pc.ny) {
+            int32_t* o = resp + (size_t)s * resp_stride + (size_t)a * ncand + (size_t)j * pc.nx + i;
+            if (beam_slices == 1) {
+              if (i < pc.nx) o[0] = (int32_t)lo;
+              if (i + 2 < pc.nx) o[2] = (int32_t)hi;
+            } else {
+              if (i < pc.nx) atomicAdd(o, (int32_t)lo);
+              if (i + 2 < pc.nx) atomicAdd(o + 2, (int32_t)hi);
+            }
+          }
         }
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 
