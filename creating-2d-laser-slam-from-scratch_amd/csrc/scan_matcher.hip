@@ -573,7 +573,11 @@ k_reduce_coarse(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ la
   double* presp = (double*)smem;
   double* latmax = presp + (CACHE ? total : 0);
   double* probs = latmax + ncand;
-  uint32_t* mask = (uint32_t*)(probs + g.probs_side * g.probs_side);
+  double* terms = probs + g.probs_side * g.probs_side;  // 4 per lattice cell
+  uint32_t* mask = (uint32_t*)(terms + 4 * ncand);
+  int* cell = (int*)(mask + words);
+  __shared__ double s_avg[3];
+  __shared__ int s_status;
   const int32_t* r = resp + (size_t)s * resp_stride;
   const double center[3] = {L.center[0], L.center[1], L.center[2]};
   auto value = [&](int k) -> double {
@@ -606,55 +610,65 @@ k_reduce_coarse(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ la
   }
   for (int k = tid; k < total; k += 256)
     if (double_equal(value(k), best)) atomicOr(&mask[k >> 5], 1u << (k & 31));
-  __syncthreads();
-  if (tid != 0) return;
-
-  CoarseOut o;
-  o.status = 0;
-  o.flags = pass_index > 0 ? 1 : 0;
-  o.pad = 0;
-  // search-space probability grid: offset = searchCenter - searchSpaceOffset (:332-333)
+  // search-space probability cell of every lattice position (offset = searchCenter -
+  // searchSpaceOffset, :332-333; WorldToGrid of the candidate position, :440) -- in parallel; only
+  // the order-sensitive merges and sums below stay on one thread
   const double p_off_x = center[0] - pc.off_x, p_off_y = center[1] - pc.off_y;
-  for (int c = 0; c < ncand && o.status == 0; c++) {
+  for (int c = tid; c < ncand; c += 256) {
     int xi = c % pc.nx, yi = c / pc.nx;
     double wx = center[0] + (-pc.off_x + (uint32_t)xi * pc.res_x);
     double wy = center[1] + (-pc.off_y + (uint32_t)yi * pc.res_y);
     int gx = world_to_grid(wx, p_off_x, g.scale), gy = world_to_grid(wy, p_off_y, g.scale);
-    if (gx < 0 || gx >= g.probs_side || gy < 0 || gy >= g.probs_side) {
-      o.status = LSLAM_ERR_PROBABILITY_SEARCH;
-      break;
-    }
-    double* p = &probs[gy * g.probs_side + gx];
-    *p = latmax[c] > *p ? latmax[c] : *p;
+    cell[c] = (gx < 0 || gx >= g.probs_side || gy < 0 || gy >= g.probs_side) ? -1 : gy * g.probs_side + gx;
   }
-  double avg[3] = {0, 0, 0};
-  if (o.status == 0 && tie_average(mask, total, pc, center, avg) == 0) o.status = LSLAM_ERR_NO_BEST_POSE;
+  __syncthreads();
+  if (tid == 0) {
+    int st = 0;
+    for (int c = 0; c < ncand; c++) {  // *ptr = max(response, *ptr) in candidate order (:443-449)
+      if (cell[c] < 0) { st = LSLAM_ERR_PROBABILITY_SEARCH; break; }
+      double* p = &probs[cell[c]];
+      *p = latmax[c] > *p ? latmax[c] : *p;
+    }
+    double avg[3] = {0, 0, 0};
+    if (st == 0 && tie_average(mask, total, pc, center, avg) == 0) st = LSLAM_ERR_NO_BEST_POSE;
+    s_avg[0] = avg[0]; s_avg[1] = avg[1]; s_avg[2] = avg[2];
+    s_status = st;
+  }
+  __syncthreads();
+  // ComputePositionalCovariance terms (Mapper.cpp:573-594), one lattice cell per thread; the
+  // running sums are then accumulated in the reference's order by one thread
+  const double dx = s_avg[0] - center[0], dy = s_avg[1] - center[1];
+  for (int c = tid; c < ncand; c += 256) {
+    int xi = c % pc.nx, yi = c / pc.nx;
+    double x = -pc.off_x + (uint32_t)xi * pc.res_x;
+    double y = -pc.off_y + (uint32_t)yi * pc.res_y;
+    double rr = cell[c] >= 0 ? probs[cell[c]] : 0.0;
+    terms[4 * c + 0] = rr;
+    terms[4 * c + 1] = (ksq(x - dx) * rr);
+    terms[4 * c + 2] = ((x - dx) * (y - dy) * rr);
+    terms[4 * c + 3] = (ksq(y - dy) * rr);
+  }
+  __syncthreads();
+  if (tid != 0) return;
 
-  // ComputePositionalCovariance (Mapper.cpp:535-630)
+  CoarseOut o;
+  o.status = s_status;
+  o.flags = pass_index > 0 ? 1 : 0;
+  o.pad = 0;
+  const double avg[3] = {s_avg[0], s_avg[1], s_avg[2]};
   double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   if (o.status == 0) {
     if (best < kTol) {
       cov[0] = kMaxVariance; cov[4] = kMaxVariance; cov[8] = 4 * ksq(pc.ang_res);
     } else {
       double axx = 0, axy = 0, ayy = 0, norm = 0;
-      double dx = avg[0] - center[0], dy = avg[1] - center[1];
-      for (int yi = 0; yi < pc.ny && o.status == 0; yi++) {
-        double y = -pc.off_y + (uint32_t)yi * pc.res_y;
-        for (int xi = 0; xi < pc.nx; xi++) {
-          double x = -pc.off_x + (uint32_t)xi * pc.res_x;
-          int gx = world_to_grid(center[0] + x, p_off_x, g.scale);
-          int gy = world_to_grid(center[1] + y, p_off_y, g.scale);
-          if (gx < 0 || gx >= g.probs_side || gy < 0 || gy >= g.probs_side) {
-            o.status = LSLAM_ERR_INDEX_OUT_OF_RANGE;
-            break;
-          }
-          double rr = probs[gy * g.probs_side + gx];
-          if (rr >= (best - 0.1)) {
-            norm += rr;
-            axx += (ksq(x - dx) * rr);
-            axy += ((x - dx) * (y - dy) * rr);
-            ayy += (ksq(y - dy) * rr);
-          }
+      for (int c = 0; c < ncand; c++) {  // y outer, x inner = candidate-cell order
+        double rr = terms[4 * c];
+        if (rr >= (best - 0.1)) {
+          norm += rr;
+          axx += terms[4 * c + 1];
+          axy += terms[4 * c + 2];
+          ayy += terms[4 * c + 3];
         }
       }
       if (norm > kTol) {
@@ -1116,7 +1130,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   }
   auto reduce_lds = [&](const PassCfg& p, bool cache) -> size_t {
     size_t total = (size_t)p.nx * p.ny * p.na;
-    return (cache ? total * 8 : 0) + (size_t)p.nx * p.ny * 8 + (size_t)g.probs_side * g.probs_side * 8 +
+    return (cache ? total * 8 : 0) + (size_t)p.nx * p.ny * (8 + 32 + 4) + (size_t)g.probs_side * g.probs_side * 8 +
            ((total + 31) / 32) * 4 + 16;
   };
   // response numerators of one pass: packed row kernel for uniform lattices (step 2 on the parity
