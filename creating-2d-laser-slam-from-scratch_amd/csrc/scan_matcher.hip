@@ -1154,7 +1154,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       const uint8_t* s1 = step == 2 ? m->d_sub[1] : m->d_grid;
       const int limit = step == 2 ? g.data_size / 2 : g.data_size;
       // the bitmap covers row spans of kOccWin grid bytes: step*(nX-1)+1 must fit
-      const uint32_t* occ = (m->use_row_occupancy && step * (p.nx - 1) + 1 <= m->occ_win) ? m->d_occ_t : (const uint32_t*)nullptr;
+      const uint32_t* occ = (m->use_row_occupancy && step == 2 && step * (p.nx - 1) + 1 <= m->occ_win) ? m->d_occ_t : (const uint32_t*)nullptr;
       if (variant == 1)
         launch(ctx, name, k_resp_rows<1, 4>, grid, dim3(64), 0, s0, s1, step, limit, g, p, (const Lattice*)m->d_lat.p,
                (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc);
