@@ -142,6 +142,46 @@ class GpuScanMatcher {
   std::vector<double> ranges_, poses_;
 };
 
+// Pose path of karto::Mapper::Process (Mapper.cpp:1999-2079) with a device-resident running-scan
+// window: what SlamKarto::addScan calls per LaserScan (karto_slam.cc:444).  The pose graph
+// (vertices, edges, loop closure) stays with the reference's host code.
+class GpuFrontEnd {
+ public:
+  // scanBufferSize / scanBufferMaximumScanDistance / minimumTravelDistance / minimumTravelHeading:
+  // the Mapper parameters of the same names (Mapper.cpp:1480-1515)
+  GpuFrontEnd(lslam_context* ctx, GpuScanMatcher& matcher, int scanBufferSize, double scanBufferMaximumScanDistance,
+              double minimumTravelDistance, double minimumTravelHeading)
+      : ctx_(ctx) {
+    int rc = lslam_frontend_create(matcher.handle(), scanBufferSize, scanBufferMaximumScanDistance,
+                                   minimumTravelDistance, minimumTravelHeading, &h_);
+    if (rc != LSLAM_OK) throw std::runtime_error(lslam_last_error(ctx));
+  }
+  ~GpuFrontEnd() { lslam_frontend_destroy(h_); }
+  GpuFrontEnd(const GpuFrontEnd&) = delete;
+  GpuFrontEnd& operator=(const GpuFrontEnd&) = delete;
+
+  // kt_bool Process(LocalizedRangeScan*): ranges + odometric robot pose in; returns whether the scan
+  // was processed (HasMovedEnough) and its corrected robot pose (GetCorrectedPose) / covariance
+  bool Process(const double* ranges, int nRanges, const Pose2& odometricPose, Pose2& correctedPose,
+               Matrix3* covariance = nullptr, double* response = nullptr) {
+    const double o[3] = {odometricPose.x, odometricPose.y, odometricPose.heading};
+    double c[3], cov[9];
+    int processed = 0;
+    int rc = lslam_frontend_process(h_, ranges, nRanges, o, &processed, c, cov, response);
+    if (rc != LSLAM_OK) throw MatcherError(rc, lslam_last_error(ctx_));
+    correctedPose = Pose2{c[0], c[1], c[2]};
+    if (covariance && processed)
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) covariance->m[i][j] = cov[3 * i + j];
+    return processed != 0;
+  }
+  int RunningScans() const { return lslam_frontend_running_scans(h_); }
+
+ private:
+  lslam_context* ctx_;
+  lslam_frontend* h_ = nullptr;
+};
+
 // update side of hectorslam::MapRepresentationInterface (the Gauss-Newton matchData is next-row #2)
 class MapRepGpu {
  public:
