@@ -63,12 +63,21 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X GPU (no CPU fallback)")
+    # one process per GPU; LSLAM_BENCH_BACKEND=gloo lets the N>1 control flow be exercised on a 1-GPU box
+    backend = os.environ.get("LSLAM_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and distributed and local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPUs visible")
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     import lslam  # noqa: F401
     from lslam_amd import api, synth, shard
@@ -85,7 +94,7 @@ def main():
     if args.broadcast_grid and distributed:
         if rank == 0:
             gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
-        shard.broadcast_grid(gm, dev, src=0)  # RCCL broadcast of the 4 MB grid
+        shard.broadcast_grid(gm, dev if backend == "nccl" else torch.device("cpu"), src=0)  # RCCL broadcast of the 4 MB grid
     else:
         gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)  # redundant build: cheaper than the broadcast
     B = args.batch
@@ -112,11 +121,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    ctx.synchronize()
-    torch.cuda.synchronize()
+    barrier()  # stream + device sync, then the RCCL barrier: the timed region is bracketed on both sides
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ctx.profile(False)
@@ -126,7 +134,7 @@ def main():
     res_np = results.cpu().numpy().view(api.RESULT_DTYPE).reshape(-1)
     n_ok = int((res_np["status"] == 0).sum())
     if distributed:
-        gathered = shard.all_gather_results(results, world)
+        gathered = shard.all_gather_results(results if backend == "nccl" else results.cpu(), world)
         n_ok_all = int((gathered.cpu().numpy().view(api.RESULT_DTYPE)["status"] == 0).sum())
     else:
         n_ok_all = n_ok
