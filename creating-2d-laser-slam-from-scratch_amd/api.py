@@ -14,8 +14,8 @@ There is NO CPU fallback here: if the shared library or a GPU is missing, constr
 from __future__ import annotations
 
 import ctypes as C
-import dataclasses
 import math
+import weakref
 
 import numpy as np
 
@@ -181,6 +181,12 @@ def lib() -> C.CDLL:
     L.lslam_frontend_reset.argtypes = [vp]
     L.lslam_frontend_process.argtypes = [vp, vp, i32, vp, C.POINTER(i32), vp, vp, C.POINTER(dbl)]
     L.lslam_frontend_running_scans.argtypes = [vp]
+    L.lslam_occgrid_create_from_scans.argtypes = [vp, C.POINTER(LaserParams), i32, vp, i32, vp, dbl, C.POINTER(vp)]
+    L.lslam_occgrid_destroy.argtypes = [vp]
+    L.lslam_occgrid_destroy.restype = None
+    L.lslam_occgrid_info.argtypes = [vp, vp, vp, C.POINTER(dbl)]
+    L.lslam_occgrid_read_u8.argtypes = [vp, vp]
+    L.lslam_occgrid_read_ros_i8.argtypes = [vp, vp]
     L.lslam_map_create.argtypes = [vp, i32, i32, C.c_float, C.c_float, C.c_float, i32, C.POINTER(vp)]
     L.lslam_map_destroy.argtypes = [vp]
     L.lslam_map_destroy.restype = None
@@ -217,6 +223,10 @@ class Context:
             raise LslamError(rc, self.L.lslam_last_error(None).decode())
         self.h = h
         self.device = device
+        self._children = weakref.WeakSet()  # handles that must be released before the context
+
+    def _adopt(self, child):
+        self._children.add(child)
 
     def check(self, rc: int):
         if rc != LSLAM_OK:
@@ -224,6 +234,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for child in list(self._children):  # matcher / map / grid handles hold a pointer to the context
+                child.close()
             self.L.lslam_destroy(self.h)
             self.h = None
 
@@ -277,6 +289,8 @@ class ScanMatcher:
         h = C.c_void_p()
         ctx.check(self.L.lslam_matcher_create(ctx.h, C.byref(cfg), C.byref(laser), C.byref(h)))
         self.h = h
+        self._frontends = weakref.WeakSet()
+        ctx._adopt(self)
 
     # reference spelling
     @classmethod
@@ -291,6 +305,8 @@ class ScanMatcher:
 
     def close(self):
         if getattr(self, "h", None):
+            for fe in list(self._frontends):  # a front-end borrows its matcher
+                fe.close()
             self.L.lslam_matcher_destroy(self.h)
             self.h = None
 
@@ -427,6 +443,7 @@ class FrontEnd:
         self.ctx.check(self.L.lslam_frontend_create(matcher.h, scan_buffer_size, scan_buffer_max_distance,
                                                     min_travel_distance, min_travel_heading, C.byref(h)))
         self.h = h
+        matcher._frontends.add(self)
 
     def close(self):
         if getattr(self, "h", None):
@@ -455,6 +472,54 @@ class FrontEnd:
         self.ctx.check(self.L.lslam_frontend_reset(self.h))
 
 
+class OccupancyGrid:
+    """karto::OccupancyGrid (hit/pass counters) built on the GPU from scans at sensor poses."""
+
+    def __init__(self, ctx: Context, h):
+        self.ctx, self.L, self.h = ctx, ctx.L, h
+        ctx._adopt(self)
+
+    @classmethod
+    def CreateFromScans(cls, ctx: Context, laser: LaserParams, ranges, sensor_poses, resolution: float):
+        """OccupancyGrid::CreateFromScans; None where the reference returns NULL (no scans)."""
+        r, p = _f64(ranges), _f64(sensor_poses)
+        r = r.reshape(-1, r.shape[-1]) if r.size else r.reshape(0, 1)
+        if r.shape[0] == 0:
+            return None
+        h = C.c_void_p()
+        ctx.check(ctx.L.lslam_occgrid_create_from_scans(ctx.h, C.byref(laser), r.shape[0], r.ctypes.data, r.shape[1],
+                                                        p.ctypes.data, resolution, C.byref(h)))
+        return cls(ctx, h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lslam_occgrid_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        d, off, res = np.zeros(2, dtype=np.int32), np.zeros(2), C.c_double()
+        self.ctx.check(self.L.lslam_occgrid_info(self.h, d.ctypes.data, off.ctypes.data, C.byref(res)))
+        return int(d[0]), int(d[1]), off, res.value
+
+    def data(self) -> np.ndarray:
+        w, h, _, _ = self.info()
+        out = np.zeros((h, w), dtype=np.uint8)
+        self.ctx.check(self.L.lslam_occgrid_read_u8(self.h, out.ctypes.data))
+        return out
+
+    def ros_data(self) -> np.ndarray:
+        w, h, _, _ = self.info()
+        out = np.zeros((h, w), dtype=np.int8)
+        self.ctx.check(self.L.lslam_occgrid_read_ros_i8(self.h, out.ctypes.data))
+        return out
+
+
 class OccGridMap:
     """hectorslam log-odds occupancy grid pyramid on the GPU (OccGridMapBase / MapRepMultiMap)."""
 
@@ -464,6 +529,7 @@ class OccGridMap:
         h = C.c_void_p()
         ctx.check(self.L.lslam_map_create(ctx.h, size_x, size_y, cell_length, offset[0], offset[1], levels, C.byref(h)))
         self.h = h
+        ctx._adopt(self)
 
     def close(self):
         if getattr(self, "h", None):

@@ -14,17 +14,30 @@ import subprocess
 PKG = pathlib.Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "liblslam_gpu.so"
-SOURCES = ["context.hip", "scan_matcher.hip", "logodds_map.hip"]
+SOURCES = ["context.hip", "scan_matcher.hip", "logodds_map.hip", "occupancy_grid.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wno-unused-result"]
 
 
+STAMP = PKG / "liblslam_gpu.so.srchash"
+
+
+def _source_hash() -> str:
+    """Content hash of everything the library is built from (mtimes do not survive a snapshot copy)."""
+    import hashlib
+
+    h = hashlib.sha256(" ".join(FLAGS + SOURCES).encode())
+    deps = sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.hpp")) + [PKG.parent / "include" / "lslam_gpu.h"]
+    for p in deps:
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()
+
+
 def _stale() -> bool:
-    if not LIB.exists():
+    if not LIB.exists() or not STAMP.exists():
         return True
-    t = LIB.stat().st_mtime
-    deps = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + [PKG.parent / "include" / "lslam_gpu.h"]
-    return any(p.stat().st_mtime > t for p in deps)
+    return STAMP.read_text().strip() != _source_hash()
 
 
 def build_library(force: bool = False, verbose: bool = False) -> pathlib.Path:
@@ -43,4 +56,5 @@ def build_library(force: bool = False, verbose: bool = False) -> pathlib.Path:
         print(r.stdout + r.stderr)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed building liblslam_gpu.so")
+    STAMP.write_text(_source_hash() + "\n")
     return LIB

@@ -217,6 +217,24 @@ int lslam_frontend_process(lslam_frontend* f, const double* ranges, int n_ranges
 int lslam_frontend_running_scans(const lslam_frontend* f); /* ScanManager::GetRunningScans().size() */
 
 /* ---------------------------------------------------------------------------------------- */
+/* Karto hit/pass-counter occupancy grid (replaces karto::OccupancyGrid::CreateFromScans,     */
+/* Karto.h:5659-5673, as SlamKarto::updateMap calls it, karto_slam.cc:507-581)                */
+/* ---------------------------------------------------------------------------------------- */
+typedef struct lslam_occgrid lslam_occgrid;
+/* n_scans scans (rows of `ranges_stride` doubles) at SENSOR poses; the grid is sized by
+ * ComputeDimensions (Karto.h:5799-5817).  No scans -> LSLAM_ERR_INVALID_ARGUMENT (reference: NULL). */
+int lslam_occgrid_create_from_scans(lslam_context* ctx, const lslam_laser* laser, int n_scans, const double* ranges,
+                                    int ranges_stride, const double* sensor_poses, double resolution,
+                                    lslam_occgrid** out);
+void lslam_occgrid_destroy(lslam_occgrid* og);
+/* GetWidth/GetHeight, CoordinateConverter offset, resolution */
+int lslam_occgrid_info(const lslam_occgrid* og, int32_t dims[2], double offset_xy[2], double* resolution);
+/* GetValue(x,y): 0 unknown, 100 occupied, 255 free (GridStates, Karto.h:4193-4198); row-major y*w+x */
+int lslam_occgrid_read_u8(lslam_occgrid* og, uint8_t* out_host);
+/* nav_msgs/OccupancyGrid data as karto_slam.cc:546-569 fills it: -1 unknown, 100 occupied, 0 free */
+int lslam_occgrid_read_ros_i8(lslam_occgrid* og, int8_t* out_host);
+
+/* ---------------------------------------------------------------------------------------- */
 /* Hector log-odds occupancy grid  (replaces hectorslam::OccGridMapBase<LogOddsCell,...>,    */
 /* H/map/OccGridMapBase.h, H/map/GridMapLogOdds.h, H/map/GridMapBase.h)                      */
 /* ---------------------------------------------------------------------------------------- */

@@ -603,6 +603,103 @@ int kor_probs(const kor_matcher* m, double* out) {
   return m->probs_side;
 }
 
+/* ------------------------------------------------------------------------------------------- */
+/* karto::OccupancyGrid (Karto.h:5609-6039) */
+typedef struct { int w, h, stride; double scale, ox, oy; uint32_t *pass, *hit; } occ_t;
+
+/* Grid<T>::TraceLine (Karto.h:4680-4745) with the pass-count increment */
+static void occ_trace_line(occ_t* g, int x0, int y0, int x1, int y1) {
+  int steep = abs(y1 - y0) > abs(x1 - x0);
+  int t;
+  if (steep) { t = x0; x0 = y0; y0 = t; t = x1; x1 = y1; y1 = t; }
+  if (x0 > x1) { t = x0; x0 = x1; x1 = t; t = y0; y0 = y1; y1 = t; }
+  int delta_x = x1 - x0, delta_y = abs(y1 - y0), error = 0, y = y0;
+  int ystep = y0 < y1 ? 1 : -1;
+  for (int x = x0; x <= x1; x++) {
+    int px = steep ? y : x, py = steep ? x : y;
+    error += delta_y;
+    if (2 * error >= delta_x) { y += ystep; error -= delta_x; }
+    if (is_up_to(px, g->w) && is_up_to(py, g->h)) g->pass[px + py * g->stride]++;
+  }
+}
+
+int kor_occgrid_from_scans(const kor_matcher* m, int n_scans, const double* ranges, int ranges_stride,
+                           const double* sposes, double resolution, int32_t dims[2], double offset_xy[2],
+                           uint8_t* out) {
+  if (n_scans <= 0) return -1; /* rScans.empty() -> NULL (Karto.h:5661-5664) */
+  const int n = m->n_beams;
+  const double thr = m->laser.range_threshold, rmin = m->laser.minimum_range, rmax = m->laser.maximum_range;
+  double* pts = (double*)malloc(sizeof(double) * 2 * (size_t)(n > 0 ? n : 1));
+  /* ComputeDimensions (Karto.h:5799-5817): union of the scans' bounding boxes; a scan's box holds its
+   * sensor position and its FILTERED readings (minRange <= r <= rangeThreshold, Karto.h:5382,5418-5424) */
+  double mnx = 999999999999999999.99999, mny = mnx, mxx = -mnx, mxy = -mnx; /* Karto.h:2765 */
+  for (int s = 0; s < n_scans; s++) {
+    const double* sp = sposes + 3 * s;
+    const double* r = ranges + (size_t)s * ranges_stride;
+    kor_point_readings(m, r, sp, pts);
+    double bnx = 999999999999999999.99999, bny = bnx, bxx = -bnx, bxy = -bnx;
+#define ADDPT(X, Y) do { if ((X) < bnx) bnx = (X); if ((Y) < bny) bny = (Y); if ((X) > bxx) bxx = (X); if ((Y) > bxy) bxy = (Y); } while (0)
+    ADDPT(sp[0], sp[1]);
+    for (int i = 0; i < n; i++)
+      if (r[i] >= rmin && r[i] <= thr) ADDPT(pts[2 * i], pts[2 * i + 1]);
+#undef ADDPT
+    /* boundingBox.Add(scanBox): Add(min), Add(max) (Karto.h:2824-2828) */
+    const double bx[2] = {bnx, bxx}, by[2] = {bny, bxy};
+    for (int c = 0; c < 2; c++) {
+      if (bx[c] < mnx) mnx = bx[c];
+      if (by[c] < mny) mny = by[c];
+      if (bx[c] > mxx) mxx = bx[c];
+      if (by[c] > mxy) mxy = by[c];
+    }
+  }
+  occ_t g;
+  g.scale = 1.0 / resolution;
+  g.w = (int)kround((mxx - mnx) * g.scale);
+  g.h = (int)kround((mxy - mny) * g.scale);
+  g.ox = mnx; g.oy = mny;
+  dims[0] = g.w; dims[1] = g.h;
+  offset_xy[0] = mnx; offset_xy[1] = mny;
+  if (!out) { free(pts); return 0; }
+  g.stride = (g.w + 7) & ~7; /* Grid<kt_int32u>::Resize (Karto.h:4442) */
+  size_t cells = (size_t)g.stride * (g.h > 0 ? g.h : 0);
+  g.pass = (uint32_t*)calloc(cells ? cells : 1, sizeof(uint32_t));
+  g.hit = (uint32_t*)calloc(cells ? cells : 1, sizeof(uint32_t));
+  for (int s = 0; s < n_scans; s++) { /* AddScan (Karto.h:5851-5895) */
+    const double* sp = sposes + 3 * s;
+    const double* r = ranges + (size_t)s * ranges_stride;
+    kor_point_readings(m, r, sp, pts);
+    for (int i = 0; i < n; i++) {
+      double px = pts[2 * i], py = pts[2 * i + 1], rr = r[i];
+      int end_valid = rr < (thr - KT_TOLERANCE);
+      if (rr <= rmin || rr >= rmax || isnan(rr)) continue;
+      if (rr >= thr) {
+        double ratio = thr / rr;
+        double dx = px - sp[0], dy = py - sp[1];
+        px = sp[0] + ratio * dx;
+        py = sp[1] + ratio * dy;
+      }
+      int fx, fy, tx, ty; /* RayTrace (Karto.h:5907-5942) */
+      world_to_grid(sp[0], sp[1], g.ox, g.oy, g.scale, &fx, &fy);
+      world_to_grid(px, py, g.ox, g.oy, g.scale, &tx, &ty);
+      occ_trace_line(&g, fx, fy, tx, ty);
+      if (end_valid && is_up_to(tx, g.w) && is_up_to(ty, g.h)) {
+        g.pass[tx + ty * g.stride]++;
+        g.hit[tx + ty * g.stride]++;
+      }
+    }
+  }
+  /* Update / UpdateCell (Karto.h:5950-5990): MinPassThrough = 2, OccupancyThreshold = 0.1 (:5636-5637) */
+  for (int y = 0; y < g.h; y++)
+    for (int x = 0; x < g.w; x++) {
+      uint32_t pc = g.pass[x + y * g.stride], hc = g.hit[x + y * g.stride];
+      uint8_t v = 0;
+      if (pc > 2) v = ((double)hc / (double)pc > 0.1) ? 100 : 255;
+      out[(size_t)y * g.w + x] = v;
+    }
+  free(g.pass); free(g.hit); free(pts);
+  return 0;
+}
+
 /* Matrix3::InverseFast by cofactors (Karto.h:2460-2493), tolerance 1e-14 as Inverse() passes it */
 static int mat3_inverse(const double m[9], double inv[9]) {
   inv[0] = m[4] * m[8] - m[5] * m[7];

@@ -101,6 +101,14 @@ double kor_match_scan(kor_matcher* m, int n_base, const double* base_ranges, int
 /* last coarse pass' search-space probability grid (Mapper.cpp:431-451): side*side doubles */
 int kor_probs(const kor_matcher* m, double* out);
 
+/* karto::OccupancyGrid::CreateFromScans (Karto.h:5659-5990): hit/pass-counter occupancy grid of
+ * scans at SENSOR poses (lesson6's published map, karto_slam.cc:507-581).  Two-call protocol:
+ * out == NULL fills dims/offset only.  Cell values: 0 unknown, 100 occupied, 255 free.
+ * returns 0, or -1 when there are no scans (the reference returns NULL). */
+int kor_occgrid_from_scans(const kor_matcher* m, int n_scans, const double* ranges, int ranges_stride,
+                           const double* sensor_poses, double resolution, int32_t dims[2],
+                           double offset_xy[2], uint8_t* out);
+
 /* ---- streaming front-end: the pose-relevant part of Mapper::Process (Mapper.cpp:1999-2079) ----
  * lastTransform propagation (:2021-2025), HasMovedEnough (:2087-2120, time test omitted: the
  * harness has no clock), MatchScan vs the running window (:2040), SetSensorPose (:2044),

@@ -137,6 +137,7 @@ class RefKarto:
         L.kref_match_fixed_grid.restype = C.c_double
         L.kref_match_fixed_grid.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                             C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kref_occgrid_from_scans.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.kref_round.restype = C.c_double
         L.kref_round.argtypes = [C.c_double]
         self.L = L
@@ -285,6 +286,20 @@ class RefKarto:
         self.L.kref_occupancy_grid(self.h, resolution, d.ctypes.data, off.ctypes.data, out.ctypes.data)
         return out, off
 
+    def occgrid_from_scans(self, ranges, poses, resolution):
+        """OccupancyGrid::CreateFromScans of explicit scans at ROBOT poses -> (grid[h,w] u8, offset)."""
+        r = np.ascontiguousarray(ranges, dtype=np.float64)
+        p = np.ascontiguousarray(poses, dtype=np.float64)
+        d, off = np.zeros(2, dtype=np.int32), np.zeros(2)
+        rc = self.L.kref_occgrid_from_scans(self.h, r.shape[0], r.ctypes.data, p.ctypes.data, r.shape[1], resolution,
+                                            d.ctypes.data, off.ctypes.data, None)
+        if rc != 0:
+            return None, None
+        out = np.zeros((d[1], d[0]), dtype=np.uint8)
+        self.L.kref_occgrid_from_scans(self.h, r.shape[0], r.ctypes.data, p.ctypes.data, r.shape[1], resolution,
+                                       d.ctypes.data, off.ctypes.data, out.ctypes.data)
+        return out, off
+
     def round(self, v: float) -> float:
         return self.L.kref_round(v)
 
@@ -349,6 +364,7 @@ class PortKarto:
         L.kor_match_scan.restype = C.c_double
         L.kor_match_scan.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
         L.kor_probs.argtypes = [vp, vp]
+        L.kor_occgrid_from_scans.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_double, vp, vp, vp]
         L.kor_frontend_create.restype = vp
         L.kor_frontend_create.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double]
         L.kor_frontend_destroy.argtypes = [vp]
@@ -496,6 +512,19 @@ class PortKarto:
         out = np.zeros((side, side))
         self.L.kor_probs(self.h, out.ctypes.data)
         return out
+
+    def occgrid_from_scans(self, ranges, sensor_poses, resolution):
+        r = np.ascontiguousarray(ranges, dtype=np.float64)
+        p = np.ascontiguousarray(sensor_poses, dtype=np.float64)
+        d, off = np.zeros(2, dtype=np.int32), np.zeros(2)
+        rc = self.L.kor_occgrid_from_scans(self.h, r.shape[0], r.ctypes.data, r.shape[1], p.ctypes.data, resolution,
+                                           d.ctypes.data, off.ctypes.data, None)
+        if rc != 0:
+            return None, None
+        out = np.zeros((d[1], d[0]), dtype=np.uint8)
+        self.L.kor_occgrid_from_scans(self.h, r.shape[0], r.ctypes.data, r.shape[1], p.ctypes.data, resolution,
+                                      d.ctypes.data, off.ctypes.data, out.ctypes.data)
+        return out, off
 
     # streaming front-end
     def frontend(self):

@@ -479,6 +479,39 @@ double kref_match_fixed_grid(void* h, int n_ranges, const double* q_ranges_all, 
   return total / std::max(1, n_queries);
 }
 
+// OccupancyGrid::CreateFromScans (Karto.h:5659-5673) on explicit scans at explicit ROBOT poses:
+// the published map of lesson6 (karto_slam.cc:507-581).  Two-call protocol: out == NULL -> dims only.
+int kref_occgrid_from_scans(void* h, int n_scans, const double* ranges, const double* poses, int n_ranges,
+                            double resolution, int* dims /* w,h */, double* offset_xy, uint8_t* out) {
+  KRef* k = (KRef*)h;
+  try {
+    LocalizedRangeScanVector scans;
+    for (int i = 0; i < n_scans; i++) scans.push_back(make_scan(k, ranges + (size_t)i * n_ranges, n_ranges, poses + 3 * i));
+    OccupancyGrid* g = OccupancyGrid::CreateFromScans(scans, resolution);
+    int rc = 0;
+    if (!g) {
+      rc = -1;
+    } else {
+      dims[0] = g->GetWidth();
+      dims[1] = g->GetHeight();
+      offset_xy[0] = g->GetCoordinateConverter()->GetOffset().GetX();
+      offset_xy[1] = g->GetCoordinateConverter()->GetOffset().GetY();
+      if (out)
+        for (int y = 0; y < g->GetHeight(); y++)
+          for (int x = 0; x < g->GetWidth(); x++) out[(size_t)y * g->GetWidth() + x] = g->GetValue(Vector2<kt_int32s>(x, y));
+      delete g;
+    }
+    for (auto* s : scans) delete s;
+    return rc;
+  } catch (std::exception& e) {
+    k->err = e.what();
+    return -2;
+  } catch (karto::Exception& e) {
+    k->err = e.GetErrorMessage();
+    return -3;
+  }
+}
+
 const char* kref_last_error(void* h) { return ((KRef*)h)->err.c_str(); }
 
 int kref_sizeof_pose2() { return (int)sizeof(Pose2); }

@@ -165,3 +165,14 @@ def test_streaming_front_end(po):
         assert ref.running_scans() == port.running_scans()
         n_proc += ok
     assert 10 < n_proc < 40 and port.running_scans() <= 8
+
+
+def test_occupancy_grid_counters(po, workload):
+    """karto::OccupancyGrid::CreateFromScans (next-row #1)."""
+    wl = workload
+    for thr, res in ((20.0, 0.05), (49.5, 0.05), (12.0, 0.1)):
+        ref, port = pair(po, range_threshold=thr)
+        a, oa = ref.occgrid_from_scans(wl.base_ranges, wl.base_poses, res)
+        b, ob = port.occgrid_from_scans(wl.base_ranges, wl.base_poses, res)
+        assert a.shape == b.shape and np.array_equal(oa, ob)
+        assert (a == 100).sum() > 100 and np.array_equal(a, b)
