@@ -26,9 +26,10 @@ using namespace lslam;
 
 namespace {
 
-constexpr int kMaxLattice = 32;   // nX, nY per pass handled by the reduce kernels
+constexpr int kMaxLattice = 128;  // nX, nY per pass (loop-closure matcher: 101 x 101, Mapper.cpp:862-871)
 constexpr int kMaxAngles = 128;   // nA per pass
-constexpr int kMaxProbsSide = 63; // search-space probability grid side
+constexpr int kMaxProbsSide = 255; // search-space probability grid side (loop closure: 201)
+constexpr int kDenseMaxNx = 112;   // widest lattice row the dense kernel covers (7 lanes x 16 candidates)
 constexpr int kGuard = 256;       // zero bytes before/after the grid: unaligned row loads may overhang
 
 struct Geom {
@@ -694,6 +695,295 @@ k_reduce_coarse(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ la
 }
 
 // ------------------------------------------------------------------------------------------
+// Large lattices (the loop-closure matcher: search space 8-15 m -> 81..151 positions per side x 21
+// angles = 140-480 k candidates per match, Mapper.cpp:862-871, 976-1051).  Here the candidate
+// window of a beam is hundreds of cells wide and the windows of ALL candidates overlap almost
+// completely, so the work is turned around: one wave owns a tile of lattice rows of one
+// (scan, angle) and streams every beam's window through it.  Lane (r, k) loads 16 contiguous
+// parity-plane bytes = 16 neighbouring candidates of lattice row r -- adjacent lanes read adjacent
+// bytes, so a row is one coalesced 112-byte access -- and accumulates them in packed 16-bit
+// fields, flushed to 32-bit registers every 256 beams (255 * 256 < 2^16).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_table_big(int S, Geom g, PassCfg pc, const Lattice* __restrict__ lat, const double2* __restrict__ local,
+            int32_t* __restrict__ tbl) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int a = blockIdx.y, s = blockIdx.z;
+  if (b >= g.n_beams) return;
+  const Lattice& L = lat[s];
+  int32_t v = kInvalidScan;
+  if (L.active && L.status == 0) {
+    const double angle = (L.center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;
+    const double2 p = local[(size_t)s * g.n_beams + b];
+    if (!isnan(p.x)) v = lookup_offset(p.x, p.y, cos(angle), sin(angle), g.off_x, g.off_y, g.scale, g.stride);
+  }
+  tbl[((size_t)s * pc.na + a) * g.n_beams + b] = v;
+}
+
+constexpr int kDenseT = 4;  // row slots per lane
+__global__ void __launch_bounds__(64)
+k_resp_dense(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int limit, Geom g, PassCfg pc,
+             const Lattice* __restrict__ lat, const int32_t* __restrict__ tbl, int32_t* __restrict__ resp,
+             size_t resp_stride, int n_tiles, int beam_slices) {
+  const int lane = threadIdx.x;
+  int w = blockIdx.x;
+  const int slice = w % beam_slices; w /= beam_slices;
+  const int tile = w % n_tiles; w /= n_tiles;
+  const int a = w % pc.na;
+  const int s = w / pc.na;
+  const Lattice& L = lat[s];
+  if (!L.active || L.status != 0 || L.step_x != 2 || L.step_y != 2) return;
+  const int lpr = (pc.nx + 15) / 16;  // lanes per lattice row
+  const int rpw = 64 / lpr;           // lattice rows per wave-wide load
+  const int r = lane / lpr, k = lane % lpr;
+  const bool lane_on = r < rpw;
+  const int j_base = tile * rpw * kDenseT;
+  const long long pos00 = (long long)L.gx[0] + (long long)L.gy[0] * g.stride;
+  const int32_t* trow = tbl + ((size_t)s * pc.na + a) * g.n_beams;
+  const int per = (g.n_beams + beam_slices - 1) / beam_slices;
+  const int b_lo = slice * per, b_hi = min(g.n_beams, b_lo + per);
+
+  uint32_t acc[kDenseT][16];
+#pragma unroll
+  for (int t = 0; t < kDenseT; t++)
+#pragma unroll
+    for (int c = 0; c < 16; c++) acc[t][c] = 0u;
+
+  for (int b0 = b_lo; b0 < b_hi; b0 += 256) {
+    uint32_t pe[kDenseT][4], po[kDenseT][4];
+#pragma unroll
+    for (int t = 0; t < kDenseT; t++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) pe[t][q] = po[t][q] = 0u;
+    const int b1 = min(b_hi, b0 + 256);
+    for (int b = b0; b < b1; b++) {
+      const int32_t tv = trow[b];  // wave-uniform
+      if (tv == kInvalidScan) continue;
+      const long long base = pos00 + tv;
+      const uint8_t* src = (base & 1) ? src1 : src0;
+      const long long m0 = (base >> 1) + 16 * k;
+      uint4 d[kDenseT];
+#pragma unroll
+      for (int t = 0; t < kDenseT; t++) {
+        const int j = j_base + t * rpw + r;
+        const long long m = m0 + (long long)j * g.stride;
+        d[t] = make_uint4(0u, 0u, 0u, 0u);
+        if (lane_on && j < pc.ny && m + 16 > 0 && m < (long long)limit) __builtin_memcpy(&d[t], src + m, 16);
+      }
+#pragma unroll
+      for (int t = 0; t < kDenseT; t++) {
+        const uint32_t dw[4] = {d[t].x, d[t].y, d[t].z, d[t].w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          pe[t][q] += dw[q] & 0x00FF00FFu;
+          po[t][q] += (dw[q] >> 8) & 0x00FF00FFu;
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kDenseT; t++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        acc[t][4 * q + 0] += pe[t][q] & 0xFFFFu;
+        acc[t][4 * q + 2] += pe[t][q] >> 16;
+        acc[t][4 * q + 1] += po[t][q] & 0xFFFFu;
+        acc[t][4 * q + 3] += po[t][q] >> 16;
+      }
+  }
+  if (!lane_on) return;
+  const int ncand = pc.nx * pc.ny;
+#pragma unroll
+  for (int t = 0; t < kDenseT; t++) {
+    const int j = j_base + t * rpw + r;
+    if (j >= pc.ny) continue;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      const int i = 16 * k + c;
+      if (i >= pc.nx) continue;
+      int32_t* o = resp + (size_t)s * resp_stride + (size_t)a * ncand + (size_t)j * pc.nx + i;
+      if (beam_slices == 1) *o = (int32_t)acc[t][c];
+      else atomicAdd(o, (int32_t)acc[t][c]);
+    }
+  }
+}
+
+// Reduce of a large coarse lattice (block per scan, global scratch instead of LDS): same steps as
+// k_reduce_coarse.  scratch per scan: latmax[ncand] | probs[side^2] (as uint64 bit patterns: all
+// responses are >= 0, so unsigned integer max == double max) | terms[4*ncand] | mask words
+__global__ void __launch_bounds__(256)
+k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ lat,
+                    const int32_t* __restrict__ resp, size_t resp_stride, CoarseOut* __restrict__ out,
+                    int use_expansion, int pass_index, double* __restrict__ scratch, size_t scratch_stride) {
+  constexpr int kList = 2048;
+  __shared__ double sh[256];
+  __shared__ double chunk[4 * 256];
+  __shared__ int s_list[kList];
+  __shared__ int s_nlist, s_status;
+  __shared__ double s_avg[3];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const Lattice& L = lat[s];
+  if (!L.active) return;
+  if (L.status != 0) {
+    if (tid == 0) { out[s].status = L.status; out[s].expand = 0; out[s].best = 0.0; }
+    return;
+  }
+  const int ncand = pc.nx * pc.ny, total = ncand * pc.na, words = (total + 31) / 32;
+  const int side2 = g.probs_side * g.probs_side;
+  double* latmax = scratch + (size_t)s * scratch_stride;
+  unsigned long long* probs = (unsigned long long*)(latmax + ncand);
+  double* terms = (double*)(probs + side2);
+  uint32_t* mask = (uint32_t*)(terms + 4 * (size_t)ncand);
+  const int32_t* r = resp + (size_t)s * resp_stride;
+  const double center[3] = {L.center[0], L.center[1], L.center[2]};
+  auto value = [&](int c, int a) -> double {
+    return penalized(r[a * ncand + c], cand_of(c * pc.na + a, pc, center), center, g.n_beams, sc);
+  };
+  double lm = -1.0;
+  for (int c = tid; c < ncand; c += 256) {
+    double m = -1.0;
+    for (int a = 0; a < pc.na; a++) {
+      double v = value(c, a);
+      m = m > v ? m : v;
+    }
+    latmax[c] = m;
+    lm = lm > m ? lm : m;
+  }
+  for (int wd = tid; wd < words; wd += 256) mask[wd] = 0u;
+  for (int c = tid; c < side2; c += 256) probs[c] = 0ull;  // Clear (:329) (+0.0)
+  if (tid == 0) { s_nlist = 0; s_status = 0; }
+  const double best = block_max(lm, sh, tid, 256);
+  for (int c = tid; c < ncand; c += 256) {
+    if (latmax[c] + kTol < best) continue;  // no angle of this cell can tie
+    for (int a = 0; a < pc.na; a++)
+      if (double_equal(value(c, a), best)) {
+        const int k = c * pc.na + a;
+        atomicOr(&mask[k >> 5], 1u << (k & 31));
+      }
+  }
+  // search-space probabilities (:437-450): max-merge is order independent -> parallel integer max
+  const double p_off_x = center[0] - pc.off_x, p_off_y = center[1] - pc.off_y;
+  for (int c = tid; c < ncand; c += 256) {
+    int xi = c % pc.nx, yi = c / pc.nx;
+    double wx = center[0] + (-pc.off_x + (uint32_t)xi * pc.res_x);
+    double wy = center[1] + (-pc.off_y + (uint32_t)yi * pc.res_y);
+    int gx = world_to_grid(wx, p_off_x, g.scale), gy = world_to_grid(wy, p_off_y, g.scale);
+    if (gx < 0 || gx >= g.probs_side || gy < 0 || gy >= g.probs_side) {
+      s_status = LSLAM_ERR_PROBABILITY_SEARCH;
+    } else {
+      double v = latmax[c] > 0.0 ? latmax[c] : 0.0;
+      atomicMax(&probs[gy * g.probs_side + gx], (unsigned long long)__double_as_longlong(v));
+    }
+    terms[4 * (size_t)c] = (double)(gy * g.probs_side + gx);  // remember the cell for the covariance pass
+  }
+  // mask / probs were updated with device-scope atomics (served by L2): agent-scope fence so the plain
+  // loads below cannot hit stale lines of this CU's vector L1
+  __threadfence();
+  __syncthreads();
+  // non-empty mask words, in ascending order
+  for (int wd = tid; wd < words; wd += 256)
+    if (mask[wd]) {
+      int pos = atomicAdd(&s_nlist, 1);
+      if (pos < kList) s_list[pos] = wd;
+    }
+  __syncthreads();
+  if (tid == 0) {
+    int st = s_status;
+    double ax = 0, ay = 0, tx = 0, ty = 0;
+    int cnt = 0;
+    auto visit_word = [&](int wd) {
+      uint32_t mbits = mask[wd];
+      while (mbits) {
+        int bit = __ffs(mbits) - 1;
+        mbits &= mbits - 1;
+        Cand cd = cand_of(wd * 32 + bit, pc, center);
+        double h = normalize_angle(cd.angle);
+        ax += center[0] + cd.x; ay += center[1] + cd.y;
+        tx += cos(h); ty += sin(h);
+        cnt++;
+      }
+    };
+    if (s_nlist <= kList) {
+      const int nl = s_nlist;
+      for (int i = 1; i < nl; i++) {  // insertion sort: a handful of entries
+        int v = s_list[i], j = i - 1;
+        while (j >= 0 && s_list[j] > v) { s_list[j + 1] = s_list[j]; j--; }
+        s_list[j + 1] = v;
+      }
+      for (int i = 0; i < nl; i++) visit_word(s_list[i]);
+    } else {
+      for (int wd = 0; wd < words; wd++) visit_word(wd);
+    }
+    if (st == 0 && cnt == 0) st = LSLAM_ERR_NO_BEST_POSE;
+    if (cnt) { ax /= cnt; ay /= cnt; tx /= cnt; ty /= cnt; }
+    s_avg[0] = ax; s_avg[1] = ay; s_avg[2] = cnt ? atan2(ty, tx) : 0.0;
+    s_status = st;
+  }
+  __syncthreads();
+  const double dx = s_avg[0] - center[0], dy = s_avg[1] - center[1];
+  for (int c = tid; c < ncand; c += 256) {
+    int xi = c % pc.nx, yi = c / pc.nx;
+    double x = -pc.off_x + (uint32_t)xi * pc.res_x;
+    double y = -pc.off_y + (uint32_t)yi * pc.res_y;
+    int cell = (int)terms[4 * (size_t)c];
+    double rr = (cell >= 0 && cell < side2) ? __longlong_as_double((long long)probs[cell]) : 0.0;
+    terms[4 * (size_t)c + 0] = rr;
+    terms[4 * (size_t)c + 1] = (ksq(x - dx) * rr);
+    terms[4 * (size_t)c + 2] = ((x - dx) * (y - dy) * rr);
+    terms[4 * (size_t)c + 3] = (ksq(y - dy) * rr);
+  }
+  __syncthreads();
+  // ordered accumulation (:573-594): chunks of 256 cells staged in LDS, summed by one thread
+  double axx = 0, axy = 0, ayy = 0, norm = 0;
+  for (int c0 = 0; c0 < ncand; c0 += 256) {
+    if (c0 + tid < ncand)
+      for (int q = 0; q < 4; q++) chunk[4 * tid + q] = terms[4 * (size_t)(c0 + tid) + q];
+    __syncthreads();
+    if (tid == 0) {
+      const int n = min(256, ncand - c0);
+      for (int i = 0; i < n; i++) {
+        double rr = chunk[4 * i];
+        if (rr >= (best - 0.1)) {
+          norm += rr;
+          axx += chunk[4 * i + 1];
+          axy += chunk[4 * i + 2];
+          ayy += chunk[4 * i + 3];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid != 0) return;
+  CoarseOut o;
+  o.status = s_status;
+  o.flags = pass_index > 0 ? 1 : 0;
+  o.pad = 0;
+  double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (o.status == 0) {
+    if (best < kTol) {
+      cov[0] = kMaxVariance; cov[4] = kMaxVariance; cov[8] = 4 * ksq(pc.ang_res);
+    } else {
+      if (norm > kTol) {
+        double vxx = axx / norm, vxy = axy / norm, vyy = ayy / norm;
+        double vthth = 4 * ksq(pc.ang_res);
+        double min_xx = 0.1 * ksq(pc.res_x), min_yy = 0.1 * ksq(pc.res_y);
+        vxx = vxx > min_xx ? vxx : min_xx;
+        vyy = vyy > min_yy ? vyy : min_yy;
+        double mult = 1.0 / best;
+        cov[0] = vxx * mult; cov[1] = vxy * mult; cov[3] = vxy * mult; cov[4] = vyy * mult;
+        cov[8] = vthth;
+      }
+      if (double_equal(cov[0], 0.0)) cov[0] = kMaxVariance;
+      if (double_equal(cov[4], 0.0)) cov[4] = kMaxVariance;
+    }
+  }
+  o.mean[0] = s_avg[0]; o.mean[1] = s_avg[1]; o.mean[2] = s_avg[2];
+  for (int i = 0; i < 9; i++) o.cov[i] = cov[i];
+  o.best = best > 1.0 ? 1.0 : best;
+  o.expand = (use_expansion && o.status == 0 && pass_index < 3 && double_equal(o.best, 0.0)) ? 1 : 0;
+  out[s] = o;
+}
+
+// ------------------------------------------------------------------------------------------
 // k_reduce_fine: one block per scan: max + tie average of the fine lattice, then
 // ComputeAngularCovariance (Mapper.cpp:641-692): nA more response sums at the best cell,
 // gathered by the whole block; final result record.  Dynamic LDS: mask words.
@@ -1046,6 +1336,8 @@ struct lslam_matcher {
   DevBuf<CoarseOut> d_coarse;
   DevBuf<int32_t> d_resp;
   DevBuf<int> d_slow;  // [0] = count, [1..] = list
+  DevBuf<int32_t> d_tbl;     // large lattices: materialised lookup tables [S][nA][N]
+  DevBuf<double> d_big;      // large lattices: reduce scratch
   DevBuf<lslam_match_result> d_results;
   DevBuf<int32_t> d_dbg;
 };
@@ -1177,7 +1469,43 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     }
     return LSLAM_OK;
   };
+  auto run_coarse_big = [&](const PassCfg& p, int pass_index) -> int {
+    // dense kernel for uniform lattices; scans with a non-uniform lattice fall to the generic kernel
+    LSLAM_HIP(ctx, hipMemsetAsync(m->d_slow.p, 0, sizeof(int), ctx->stream));
+    int* slow_cnt = m->d_slow.p;
+    int* slow_list = m->d_slow.p + 1;
+    launch(ctx, "pass_setup", k_pass_setup, dim3((S + 127) / 128), dim3(128), 0, S, g, p, d_poses,
+           (const CoarseOut*)m->d_coarse.p, m->d_lat.p, slow_list, slow_cnt, 2);
+    LSLAM_HIP(ctx, m->d_tbl.reserve((size_t)S * p.na * g.n_beams));
+    launch(ctx, "table_big", k_table_big, dim3((g.n_beams + 255) / 256, p.na, S), dim3(256), 0, S, g, p,
+           (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_tbl.p);
+    const int lpr = (p.nx + 15) / 16, rpw = 64 / lpr;
+    const int n_tiles = (p.ny + rpw * kDenseT - 1) / (rpw * kDenseT);
+    int slices = 1;
+    while (slices < 8 && (long long)S * p.na * n_tiles * slices < 1024) slices *= 2;
+    if (slices > 1)
+      LSLAM_HIP(ctx, hipMemsetAsync(m->d_resp.p, 0, (size_t)S * resp_stride * sizeof(int32_t), ctx->stream));
+    launch(ctx, "resp_dense", k_resp_dense, dim3((unsigned)((long long)S * p.na * n_tiles * slices)), dim3(64), 0,
+           (const uint8_t*)m->d_sub[0], (const uint8_t*)m->d_sub[1], g.data_size / 2, g, p, (const Lattice*)m->d_lat.p,
+           (const int32_t*)m->d_tbl.p, m->d_resp.p, resp_stride, n_tiles, slices);
+    launch(ctx, "resp_generic_fallback", k_resp_generic, dim3(256), dim3(64), 0, (const uint8_t*)m->d_grid, g, p,
+           (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S,
+           (const int*)slow_list, (const int*)slow_cnt);
+    if (dbg_coarse_sums && pass_index == 0)
+      LSLAM_HIP(ctx, hipMemcpyAsync(dbg_coarse_sums, m->d_resp.p, (size_t)p.nx * p.ny * p.na * sizeof(int32_t),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+    const size_t ncand = (size_t)p.nx * p.ny, total = ncand * p.na;
+    const size_t stride = ncand + (size_t)g.probs_side * g.probs_side + 4 * ncand + (total + 63) / 64 + 8;  // doubles
+    LSLAM_HIP(ctx, m->d_big.reserve((size_t)S * stride));
+    launch(ctx, "reduce_coarse_big", k_reduce_coarse_big, dim3(S), dim3(256), 0, g, p, sc, (const Lattice*)m->d_lat.p,
+           (const int32_t*)m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
+           m->d_big.p, stride);
+    return LSLAM_OK;
+  };
   auto run_coarse = [&](const PassCfg& p, int pass_index) -> int {
+    if (!force_generic && p.nx > 16 && p.nx <= kDenseMaxNx) return run_coarse_big(p, pass_index);
+    if (p.nx > 32 || p.ny > 32 || g.probs_side > 63)
+      return ctx->fail(LSLAM_ERR_UNSUPPORTED, "lattice %dx%d is outside the built kernels", p.nx, p.ny);
     int rc = run_responses(p, 2, "resp_rows_coarse");
     if (rc) return rc;
     if (dbg_coarse_sums && pass_index == 0)
@@ -1399,7 +1727,7 @@ void lslam_matcher_destroy(lslam_matcher* m) {
   (void)hipFree(m->d_nz);
   m->d_ranges64.release(); m->d_poses.release(); m->d_local.release(); m->d_world.release();
   m->d_valid.release(); m->d_fv_scratch.release(); m->d_lat.release(); m->d_coarse.release(); m->d_resp.release();
-  m->d_slow.release(); m->d_results.release(); m->d_dbg.release();
+  m->d_slow.release(); m->d_tbl.release(); m->d_big.release(); m->d_results.release(); m->d_dbg.release();
   delete m;
 }
 

@@ -309,3 +309,34 @@ def test_reference_indoor_default_config(ctx, oracle_lib):
     mean, cov, resp = port.match_scan(wl.base_ranges, wl.base_poses, wl.query_ranges[1], wl.query_poses[1])
     r, m, c = gm.MatchScan(wl.query_ranges[1], wl.query_poses[1], wl.base_ranges, wl.base_poses)
     assert abs(r - resp) <= 1e-12 and np.abs(m - mean).max() <= POSE_TOL
+
+
+@pytest.mark.parametrize("search_size,nx", [(8.0, 81), (10.0, 101)])
+def test_loop_closure_size_lattice(ctx, oracle_lib, search_size, nx):
+    """Next-row #3: the loop-closure matcher instance (Mapper.cpp:862-871): search space 8 m (library
+    default) / 10 m (mapper_params.yaml) at 0.05 m -> 81^2 / 101^2 positions x 21 angles, coarse pass
+    only and no odometry penalty (TryCloseLoop, Mapper.cpp:991).  Dense big-lattice kernel."""
+    laser = synth.Laser(range_max=30.0)
+    kw = dict(search_size=search_size, resolution=0.05, smear_deviation=0.03)
+    port, gm = make_pair(ctx, oracle_lib, laser=laser, cfg_kw=kw, range_threshold=12.0)
+    world = synth.arena(size=40.0, n_axis=12, n_rot=4, seed=14)
+    wl = synth.make_match_workload(n_base=16, n_query=3, seed=14, laser=laser, world=world, err_xy=2.0,
+                                   err_th=math.radians(12.0), query_spread=1.0)
+    port.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    assert np.array_equal(gm.GetCorrelationGrid(), port.grid())
+    p0 = wl.query_poses[0]
+    off = 0.5 * (round(search_size / 0.05)) * 0.05
+    _, _, _, st, sums = port.correlate_scan(wl.query_ranges[0], p0, p0, off, 0.1, 0.349, 0.0349, False, False,
+                                            want_sums=True)
+    assert st == 0 and sums.shape == (nx, nx, 21) and sums.any()
+    assert np.array_equal(gm.coarse_sums(wl.query_ranges[0], p0), sums)
+    res = gm.match_batch(wl.query_ranges, wl.query_poses, doPenalize=False, doRefineMatch=False)
+    for q in range(len(res)):
+        mean, cov, resp = port.match(wl.query_ranges[q], wl.query_poses[q], False, False)
+        _assert_result(res[q], mean, cov, resp)
+    # with refinement too (TryCloseLoop's second, fine MatchScan uses the sequential matcher; this only checks
+    # that a fine pass behind a big coarse lattice works)
+    res = gm.match_batch(wl.query_ranges[:1], wl.query_poses[:1], doPenalize=False, doRefineMatch=True)
+    mean, cov, resp = port.match(wl.query_ranges[0], wl.query_poses[0], False, True)
+    _assert_result(res[0], mean, cov, resp)
