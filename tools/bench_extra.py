@@ -147,17 +147,51 @@ def cfg5_streaming(ctx, n_scans):
     return res
 
 
+def loop_closure(ctx, n_queries):
+    """Next-row #3: loop-closure matcher instance, 10 m search space @0.05 m -> 101x101x21 candidates,
+    coarse pass only, no penalty (TryCloseLoop, Mapper.cpp:991)."""
+    laser = synth.Laser(range_max=30.0)
+    world = synth.arena(size=40.0, n_axis=12, n_rot=4, seed=14)
+    wl = synth.make_match_workload(n_base=30, n_query=8, seed=14, laser=laser, world=world, err_xy=2.0,
+                                   err_th=math.radians(12.0), query_spread=1.0)
+    cfg = api.baseline_config(search_size=10.0, range_threshold=12.0)
+    gm = api.ScanMatcher(ctx, cfg, api.laser_params(laser, 12.0))
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    idx = np.arange(n_queries) % 8
+    r, p = wl.query_ranges[idx], wl.query_poses[idx]
+    gm.match_batch(r[:2], p[:2], doPenalize=False, doRefineMatch=False)
+    t0 = time.perf_counter()
+    one = [gm.match_batch(r[i:i + 1], p[i:i + 1], doPenalize=False, doRefineMatch=False)[0] for i in range(min(16, n_queries))]
+    lat_s = (time.perf_counter() - t0) / min(16, n_queries)
+    t0 = time.perf_counter()
+    res = gm.match_batch(r, p, doPenalize=False, doRefineMatch=False)
+    gpu_s = time.perf_counter() - t0
+    out = {"config": "loop-closure coarse match: 101x101x21 candidates x 1081 beams (231 M byte gathers per match)",
+           "queries": n_queries, "gpu_batched_ms_per_match": round(1e3 * gpu_s / n_queries, 4),
+           "gpu_single_ms_per_match": round(1e3 * lat_s, 4)}
+    port = po.PortKarto(po.default_cfg(search_size=10.0), po.laser_struct(laser, 12.0))
+    port.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    k = min(4, n_queries)
+    t0 = time.perf_counter()
+    cpu = [port.match(r[i], p[i], False, False) for i in range(k)]
+    out["cpu_port_ms_per_match"] = round(1e3 * (time.perf_counter() - t0) / k, 2)
+    out["max_pose_err"] = float(max(np.abs(res["pose"][i] - cpu[i][0]).max() for i in range(k)))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--map-scans", type=int, default=1000)
     ap.add_argument("--single", type=int, default=200)
     ap.add_argument("--stream", type=int, default=1000)
+    ap.add_argument("--loop", type=int, default=64)
     args = ap.parse_args()
     po.build("restate")
     ctx = api.Context(0)
     print(json.dumps(cfg2_map_update(ctx, args.map_scans)))
     print(json.dumps(cfg3_single_scan(ctx, args.single)))
     print(json.dumps(cfg5_streaming(ctx, args.stream)))
+    print(json.dumps(loop_closure(ctx, args.loop)))
 
 
 if __name__ == "__main__":
