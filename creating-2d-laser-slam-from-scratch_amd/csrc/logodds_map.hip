@@ -20,6 +20,7 @@
 //                    it) applies exactly the float operations the sequential reference applies.
 // HBM-bound integer/byte work: coalescing comes from neighbouring beams crossing neighbouring
 // cells; nothing here is GEMM-shaped.
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -162,6 +163,130 @@ __global__ void k_occupancy_i8(const float* __restrict__ v, int8_t* __restrict__
   if (i >= n) return;
   float x = v[i];
   out[i] = x < 0.0f ? (int8_t)0 : (x > 0.0f ? (int8_t)100 : (int8_t)-1);  // hector_slam.cc:287-304
+}
+
+// ------------------------------------------------------------------------------------------
+// Hector Gauss-Newton scan-to-map matcher (next-row #2): MapRepMultiMap::matchData
+// (H/slam_main/MapRepMultiMap.h:144-167) -> ScanMatcher::matchData / estimateTransformationLogLh
+// (H/matcher/ScanMatcher.h:60-139) -> OccGridMapUtil::getCompleteHessianDerivs /
+// interpMapValueWithDerivatives (H/map/OccGridMapUtil.h:77-228).  One block per scan walks all
+// pyramid levels and iterations: every thread evaluates the bilinear map value + gradient of its
+// points and their 9 Hessian/gradient terms in fp32 (parallel), ONE thread then adds the terms in
+// point order -- the reference accumulates H and dTr sequentially in fp32, so the order is part of
+// the result -- and solves the 3x3 system.  The probability cache of the reference
+// (GridMapCacheArray) is a pure memoisation and has no device counterpart.
+// ------------------------------------------------------------------------------------------
+constexpr int kGnMaxLevels = 8;
+struct GnLevels {
+  int n_levels;
+  int sx[kGnMaxLevels], sy[kGnMaxLevels];
+  float scale[kGnMaxLevels], t_x[kGnMaxLevels], t_y[kGnMaxLevels];
+  const float* logodds[kGnMaxLevels];
+};
+
+__device__ __forceinline__ float gn_prob(const float* lo, int index) {  // getGridProbability (GridMapLogOdds.h:123-127)
+  float odds = (float)exp((double)lo[index]);
+  return odds / (odds + 1.0f);
+}
+
+__device__ __forceinline__ float gn_cof3(const float* m, int i, int j) {
+  int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m[3 * i1 + j1] * m[3 * i2 + j2] - m[3 * i1 + j2] * m[3 * i2 + j1];
+}
+
+__global__ void __launch_bounds__(256)
+k_gn_match(GnLevels lv, const float* __restrict__ pts, int n, float bx, float by, float bth,
+           float* __restrict__ out /* pose[3] + H[9] */) {
+  extern __shared__ float terms[];  // [n][9]
+  __shared__ float s_est[3];
+  const int tid = threadIdx.x;
+  float tmp0 = bx, tmp1 = by, tmp2 = bth;
+  float Hlast[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int L = lv.n_levels - 1; L >= 0; --L) {
+    if (n == 0) continue;
+    const float* lo = lv.logodds[L];
+    const int sx = lv.sx[L], sy = lv.sy[L];
+    const float sc = lv.scale[L];
+    const float factor = L == 0 ? 1.0f : (float)(1.0 / pow(2.0, (double)L));
+    const int iters = 1 + (L == 0 ? 5 : 3);
+    if (tid == 0) {  // getMapCoordsPose (GridMapBase.h:238-242)
+      s_est[0] = (sc * tmp0 + 0.0f * tmp1) + lv.t_x[L];
+      s_est[1] = (0.0f * tmp0 + sc * tmp1) + lv.t_y[L];
+      s_est[2] = tmp2;
+    }
+    __syncthreads();
+    for (int it = 0; it < iters; it++) {
+      const float e0 = s_est[0], e1 = s_est[1], e2 = s_est[2];
+      const float c = (float)cos((double)e2), s = (float)sin((double)e2);  // Rotation2Df + sinRot/cosRot (:85-88)
+      const float lim_x = (float)sx - 2.0f, lim_y = (float)sy - 2.0f;     // MapDimensionProperties.h:66-70
+      for (int i = tid; i < n; i += 256) {
+        const float px = pts[2 * i] * factor, py = pts[2 * i + 1] * factor;
+        const float cx = (c * px + (-s) * py) + e0;
+        const float cy = (s * px + c * py) + e1;
+        float v = 0.0f, gxv = 0.0f, gyv = 0.0f;
+        if (!(cx < 0.0f || cx > lim_x || cy < 0.0f || cy > lim_y)) {  // pointOutOfMapBounds (:60-63)
+          const int ix = (int)cx, iy = (int)cy;
+          const float fx = cx - (float)ix, fy = cy - (float)iy;
+          const int index = iy * sx + ix;
+          const float i0 = gn_prob(lo, index), i1 = gn_prob(lo, index + 1);
+          const float i2 = gn_prob(lo, index + sx), i3 = gn_prob(lo, index + sx + 1);
+          const float dx1 = i0 - i1, dx2 = i2 - i3, dy1 = i0 - i2, dy2 = i1 - i3;
+          const float xi = 1.0f - fx, yi = 1.0f - fy;
+          v = ((i0 * xi + i1 * fx) * (yi)) + ((i2 * xi + i3 * fx) * (fy));
+          gxv = -((dx1 * yi) + (dx2 * fy));
+          gyv = -((dy1 * xi) + (dy2 * fx));
+        }
+        const float funVal = 1.0f - v;
+        const float rotDeriv = ((-s * px - c * py) * gxv + (c * px - s * py) * gyv);
+        float* t = terms + 9 * i;
+        t[0] = gxv * funVal; t[1] = gyv * funVal; t[2] = rotDeriv * funVal;
+        t[3] = gxv * gxv; t[4] = gyv * gyv; t[5] = rotDeriv * rotDeriv;
+        t[6] = gxv * gyv; t[7] = gxv * rotDeriv; t[8] = gyv * rotDeriv;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float d0 = 0, d1 = 0, d2 = 0, h00 = 0, h11 = 0, h22 = 0, h01 = 0, h02 = 0, h12 = 0;
+        for (int i = 0; i < n; i++) {  // sequential fp32 accumulation, point order (:94-126)
+          const float* t = terms + 9 * i;
+          d0 += t[0]; d1 += t[1]; d2 += t[2];
+          h00 += t[3]; h11 += t[4]; h22 += t[5]; h01 += t[6]; h02 += t[7]; h12 += t[8];
+        }
+        float H[9] = {h00, h01, h02, h01, h11, h12, h02, h12, h22};
+        for (int q = 0; q < 9; q++) Hlast[q] = H[q];
+        if (h00 != 0.0f && h11 != 0.0f) {  // estimateTransformationLogLh (ScanMatcher.h:113-133)
+          const float c0 = gn_cof3(H, 0, 0), c1 = gn_cof3(H, 1, 0), c2 = gn_cof3(H, 2, 0);
+          const float det = c0 * H[0] + (c1 * H[3] + c2 * H[6]);
+          const float invdet = 1.0f / det;
+          const float Hi[9] = {c0 * invdet, c1 * invdet, c2 * invdet,
+                               gn_cof3(H, 0, 1) * invdet, gn_cof3(H, 1, 1) * invdet, gn_cof3(H, 2, 1) * invdet,
+                               gn_cof3(H, 0, 2) * invdet, gn_cof3(H, 1, 2) * invdet, gn_cof3(H, 2, 2) * invdet};
+          float sd[3];
+          for (int r = 0; r < 3; r++) sd[r] = (Hi[3 * r] * d0 + Hi[3 * r + 1] * d1) + Hi[3 * r + 2] * d2;
+          if (sd[2] > 0.2f) sd[2] = 0.2f; else if (sd[2] < -0.2f) sd[2] = -0.2f;
+          s_est[0] += sd[0]; s_est[1] += sd[1]; s_est[2] += sd[2];
+        }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      // util::normalize_angle (UtilFunctions.h:36-48), double arithmetic with M_PI
+      const double two_pi = 2.0f * 3.14159265358979323846;
+      float a = (float)fmod(fmod((double)s_est[2], two_pi) + two_pi, two_pi);
+      if ((double)a > 3.14159265358979323846) a = (float)((double)a - two_pi);
+      // getWorldCoordsPose: worldTmap = mapTworld.inverse() (GridMapBase.h:229-233, 285)
+      const float invdet = 1.0f / (sc * sc - 0.0f * 0.0f);
+      const float l00 = sc * invdet, l01 = -0.0f * invdet, l10 = -0.0f * invdet, l11 = sc * invdet;
+      const float wt0 = -(l00 * lv.t_x[L] + l01 * lv.t_y[L]), wt1 = -(l10 * lv.t_x[L] + l11 * lv.t_y[L]);
+      tmp0 = (l00 * s_est[0] + l01 * s_est[1]) + wt0;
+      tmp1 = (l10 * s_est[0] + l11 * s_est[1]) + wt1;
+      tmp2 = a;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    out[0] = tmp0; out[1] = tmp1; out[2] = tmp2;
+    for (int q = 0; q < 9; q++) out[3 + q] = Hlast[q];
+  }
 }
 
 float prob_to_logodds(float prob) {  // H/map/GridMapLogOdds.h:151-155 (log() is the double overload)
@@ -380,6 +505,39 @@ int lslam_map_update_just_once(lslam_map* map, const float* pts, int n, const fl
   int rc = update_impl(map, map->d_pts.p, n, origo, pose, 1, begin_x, begin_y, metres_per_cell);
   if (rc) return rc;
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSLAM_OK;
+}
+
+int lslam_map_match_data(lslam_map* map, const float* pts, int n, const float begin_world[3], float out_pose[3],
+                         float out_cov[9]) {
+  if (!map || n < 0 || (n > 0 && !pts) || !begin_world || !out_pose) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = map->ctx;
+  if ((int)map->levels.size() > kGnMaxLevels)
+    return ctx->fail(LSLAM_ERR_UNSUPPORTED, "at most %d pyramid levels", kGnMaxLevels);
+  if ((size_t)n * 9 * sizeof(float) > 150 * 1024)
+    return ctx->fail(LSLAM_ERR_UNSUPPORTED, "at most %d points per scan in matchData", (int)(150 * 1024 / 36));
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  LSLAM_HIP(ctx, map->d_pts.reserve((size_t)2 * (n > 0 ? n : 1) + 16));
+  float* d_out = map->d_pts.p + (size_t)2 * (n > 0 ? n : 1);
+  if (n > 0)
+    LSLAM_HIP(ctx, hipMemcpyAsync(map->d_pts.p, pts, (size_t)2 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  GnLevels lv;
+  lv.n_levels = (int)map->levels.size();
+  for (int i = 0; i < lv.n_levels; i++) {
+    const Level& L = map->levels[i];
+    lv.sx[i] = L.sx; lv.sy[i] = L.sy; lv.scale[i] = L.scale_to_map; lv.t_x[i] = L.t_x; lv.t_y[i] = L.t_y;
+    lv.logodds[i] = L.d_logodds;
+  }
+  const size_t lds = (size_t)std::max(n, 1) * 9 * sizeof(float);
+  if (lds > 64 * 1024)
+    LSLAM_HIP(ctx, hipFuncSetAttribute((const void*)k_gn_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  launch(ctx, "gn_match", k_gn_match, dim3(1), dim3(256), lds, lv, (const float*)map->d_pts.p, n, begin_world[0],
+         begin_world[1], begin_world[2], d_out);
+  float host[12];
+  LSLAM_HIP(ctx, hipMemcpyAsync(host, d_out, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 3; i++) out_pose[i] = host[i];
+  if (out_cov) for (int i = 0; i < 9; i++) out_cov[i] = host[3 + i];
   return LSLAM_OK;
 }
 

@@ -182,7 +182,7 @@ class GpuFrontEnd {
   lslam_frontend* h_ = nullptr;
 };
 
-// update side of hectorslam::MapRepresentationInterface (the Gauss-Newton matchData is next-row #2)
+// hectorslam::MapRepresentationInterface on the GPU: matchData + updateByScan
 class MapRepGpu {
  public:
   // MapRepMultiMap(mapResolution, mapSizeX, mapSizeY, numDepth, startCoords)
@@ -208,6 +208,11 @@ class MapRepGpu {
   // units), origo = DataContainer::getOrigo()
   void updateByScan(const float* pointsXY, int n, const float origo[2], const float robotPoseWorld[3]) {
     int rc = lslam_map_update_by_scan(h_, pointsXY, n, origo, robotPoseWorld);
+    if (rc != LSLAM_OK) throw std::runtime_error(lslam_last_error(ctx_));
+  }
+  // Eigen::Vector3f matchData(beginEstimateWorld, dataContainer, covMatrix)
+  void matchData(const float beginEstimateWorld[3], const float* pointsXY, int n, float outPose[3], float outCov[9]) {
+    int rc = lslam_map_match_data(h_, pointsXY, n, beginEstimateWorld, outPose, outCov);
     if (rc != LSLAM_OK) throw std::runtime_error(lslam_last_error(ctx_));
   }
   // getGridMap(level) contents: log-odds plane / the int8 data of nav_msgs::OccupancyGrid

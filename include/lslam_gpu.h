@@ -264,6 +264,13 @@ int lslam_map_update_by_scan_dev(lslam_map* map, const float* points_xy_dev, int
 int lslam_map_update_just_once(lslam_map* map, const float* points_xy, int n,
                                const float origo_xy[2], float begin_x, float begin_y,
                                double metres_per_cell);
+/* MapRepresentationInterface::matchData (H/slam_main/MapRepresentationInterface.h:58-60) =
+ * MapRepMultiMap::matchData (H/slam_main/MapRepMultiMap.h:144-167): coarse-to-fine Gauss-Newton
+ * scan-to-map matching on the pyramid.  points_xy as for updateByScan (level-0 map-cell units);
+ * begin_world = beginEstimateWorld; out_cov = covMatrix (the last Hessian, ScanMatcher.h:82-86).
+ * n = 0 returns begin_world unchanged (ScanMatcher.h:96). */
+int lslam_map_match_data(lslam_map* map, const float* points_xy, int n, const float begin_world[3],
+                         float out_pose[3], float out_cov[9]);
 /* LogOddsCell::logOddsVal of every cell, row-major y*size_x+x (H/map/GridMapLogOdds.h:85) */
 int lslam_map_read_logodds(lslam_map* map, int level, float* out_host);
 /* nav_msgs/OccupancyGrid data as hector_slam.cc:287-304 / hector_mapping.cc:186-200 publish

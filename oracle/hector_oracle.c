@@ -148,3 +148,110 @@ void hor_read_occupancy_i8(const hor_map* m, int8_t* out) {
   }
 }
 int64_t hor_last_cell_visits(const hor_map* m) { return m->visits; }
+
+/* ------------------------------------------------------------------------------------------- */
+/* Gauss-Newton scan-to-map matcher (next-row #2) */
+static float grid_probability(const hor_map* m, int index) { /* H/map/GridMapLogOdds.h:123-127 */
+  float odds = (float)exp((double)m->cells[index].v);
+  return odds / (odds + 1.0f);
+}
+
+/* interpMapValueWithDerivatives (H/map/OccGridMapUtil.h:139-228); limits = dims - 2 (MapDimensionProperties.h:66-70) */
+static void interp_with_derivs(const hor_map* m, float cx, float cy, float out[3]) {
+  float lim_x = (float)m->sx - 2.0f, lim_y = (float)m->sy - 2.0f;
+  if (cx < 0.0f || cx > lim_x || cy < 0.0f || cy > lim_y) { out[0] = out[1] = out[2] = 0.0f; return; }
+  int ix = (int)cx, iy = (int)cy;
+  float fx = cx - (float)ix, fy = cy - (float)iy;
+  int index = iy * m->sx + ix;
+  float i0 = grid_probability(m, index);
+  float i1 = grid_probability(m, index + 1);
+  float i2 = grid_probability(m, index + m->sx);
+  float i3 = grid_probability(m, index + m->sx + 1);
+  float dx1 = i0 - i1, dx2 = i2 - i3, dy1 = i0 - i2, dy2 = i1 - i3;
+  float xi = 1.0f - fx, yi = 1.0f - fy;
+  out[0] = ((i0 * xi + i1 * fx) * (yi)) + ((i2 * xi + i3 * fx) * (fy));
+  out[1] = -((dx1 * yi) + (dx2 * fy));
+  out[2] = -((dy1 * xi) + (dy2 * fx));
+}
+
+static float cof3(const float* m, int i, int j) { /* Eigen cofactor_3x3 */
+  int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m[3 * i1 + j1] * m[3 * i2 + j2] - m[3 * i1 + j2] * m[3 * i2 + j1];
+}
+static void inverse3(const float* m, float* r) { /* Eigen compute_inverse<Matrix3f> */
+  float c0 = cof3(m, 0, 0), c1 = cof3(m, 1, 0), c2 = cof3(m, 2, 0);
+  float det = c0 * m[0] + (c1 * m[3] + c2 * m[6]);
+  float invdet = 1.0f / det;
+  r[0] = c0 * invdet; r[1] = c1 * invdet; r[2] = c2 * invdet;
+  r[3] = cof3(m, 0, 1) * invdet; r[4] = cof3(m, 1, 1) * invdet; r[5] = cof3(m, 2, 1) * invdet;
+  r[6] = cof3(m, 0, 2) * invdet; r[7] = cof3(m, 1, 2) * invdet; r[8] = cof3(m, 2, 2) * invdet;
+}
+
+static float normalize_angle_f(float angle) { /* H/util/UtilFunctions.h:36-48 (double arithmetic, M_PI) */
+  const double two_pi = 2.0f * 3.14159265358979323846;
+  float a = (float)fmod(fmod((double)angle, two_pi) + two_pi, two_pi);
+  if ((double)a > 3.14159265358979323846) a = (float)((double)a - two_pi);
+  return a;
+}
+
+/* getCompleteHessianDerivs (H/map/OccGridMapUtil.h:77-132) */
+static void hessian_derivs(const hor_map* m, const float pose[3], const float* pts, float factor, int n, float H[9], float dTr[3]) {
+  float c = cosf(pose[2]), s = sinf(pose[2]); /* Rotation2Df of getTransformForState (:437-440) */
+  float sinRot = (float)sin((double)pose[2]), cosRot = (float)cos((double)pose[2]); /* :87-88 */
+  memset(H, 0, 9 * sizeof(float));
+  dTr[0] = dTr[1] = dTr[2] = 0.0f;
+  for (int i = 0; i < n; i++) {
+    float px = pts[2 * i] * factor, py = pts[2 * i + 1] * factor;
+    float tx = (c * px + (-s) * py) + pose[0];
+    float ty = (s * px + c * py) + pose[1];
+    float t[3];
+    interp_with_derivs(m, tx, ty, t);
+    float funVal = 1.0f - t[0];
+    dTr[0] += t[1] * funVal;
+    dTr[1] += t[2] * funVal;
+    float rotDeriv = ((-sinRot * px - cosRot * py) * t[1] + (cosRot * px - sinRot * py) * t[2]);
+    dTr[2] += rotDeriv * funVal;
+    H[0] += t[1] * t[1];
+    H[4] += t[2] * t[2];
+    H[8] += rotDeriv * rotDeriv;
+    H[1] += t[1] * t[2];
+    H[2] += t[1] * rotDeriv;
+    H[5] += t[2] * rotDeriv;
+  }
+  H[3] = H[1]; H[6] = H[2]; H[7] = H[5];
+}
+
+void hor_match_data(hor_map* const* levels, int n_levels, const float* pts, int n, const float begin_world[3],
+                    float out_pose[3], float out_cov[9]) {
+  float tmp[3] = {begin_world[0], begin_world[1], begin_world[2]};
+  for (int lv = n_levels - 1; lv >= 0; --lv) { /* MapRepMultiMap.h:151-165 */
+    const hor_map* m = levels[lv];
+    float factor = lv == 0 ? 1.0f : hor_level_factor(lv);
+    int max_iter = lv == 0 ? 5 : 3;
+    if (n == 0) continue; /* matchData returns beginEstimateWorld (ScanMatcher.h:96) */
+    /* getMapCoordsPose */
+    float sc = m->scale_to_map;
+    float est[3] = {(sc * tmp[0] + 0.0f * tmp[1]) + m->t_x, (0.0f * tmp[0] + sc * tmp[1]) + m->t_y, tmp[2]};
+    float H[9], dTr[3];
+    for (int it = 0; it < 1 + max_iter; it++) { /* ScanMatcher.h:73-80 */
+      hessian_derivs(m, est, pts, factor, n, H, dTr);
+      if (H[0] != 0.0f && H[4] != 0.0f) {
+        float Hi[9], sd[3];
+        inverse3(H, Hi);
+        for (int r = 0; r < 3; r++) sd[r] = (Hi[3 * r] * dTr[0] + Hi[3 * r + 1] * dTr[1]) + Hi[3 * r + 2] * dTr[2];
+        if (sd[2] > 0.2f) sd[2] = 0.2f; else if (sd[2] < -0.2f) sd[2] = -0.2f;
+        est[0] += sd[0]; est[1] += sd[1]; est[2] += sd[2];
+      }
+    }
+    est[2] = normalize_angle_f(est[2]);
+    memcpy(out_cov, H, sizeof H);
+    /* getWorldCoordsPose: worldTmap = mapTworld.inverse() (H/map/GridMapBase.h:285) */
+    float invdet = 1.0f / (sc * sc - 0.0f * 0.0f);
+    float l00 = sc * invdet, l01 = -0.0f * invdet, l10 = -0.0f * invdet, l11 = sc * invdet;
+    float wt0 = -(l00 * m->t_x + l01 * m->t_y), wt1 = -(l10 * m->t_x + l11 * m->t_y);
+    tmp[0] = (l00 * est[0] + l01 * est[1]) + wt0;
+    tmp[1] = (l10 * est[0] + l11 * est[1]) + wt1;
+    tmp[2] = est[2];
+  }
+  out_pose[0] = tmp[0]; out_pose[1] = tmp[1]; out_pose[2] = tmp[2];
+}

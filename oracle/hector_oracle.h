@@ -42,6 +42,16 @@ void hor_read_occupancy_i8(const hor_map* m, int8_t* out);
  * "cell-updates" unit of BASELINE.md §4 */
 int64_t hor_last_cell_visits(const hor_map* m);
 
+/* MapRepMultiMap::matchData (H/slam_main/MapRepMultiMap.h:144-167) over `n_levels` maps (level i =
+ * cell_length*2^i): coarse-to-fine Gauss-Newton scan-to-map matching (H/matcher/ScanMatcher.h:60-139,
+ * H/map/OccGridMapUtil.h:77-228), 3 (+1) iterations per coarse level, 5 (+1) on level 0.
+ * points: level-0 map-cell units.  out_cov = the last Hessian H (ScanMatcher.h:82-86).
+ * Eigen evaluation orders assumed (UNPINNED): 3x3 inverse by cofactors with
+ * det = c0*m00 + (c1*m10 + c2*m20); matrix*vector as ((a*x + b*y) + c*z); Affine2f inverse via the
+ * 2x2 cofactor inverse and translation = -(Linv * t). */
+void hor_match_data(hor_map* const* levels, int n_levels, const float* points_xy, int n,
+                    const float begin_world[3], float out_pose[3], float out_cov[9]);
+
 /* DataPointContainer::setFrom factor for pyramid level i (H/slam_main/MapRepMultiMap.h:161) */
 float hor_level_factor(int level);
 

@@ -574,6 +574,7 @@ class PortHector:
             L.hor_read_occupancy_i8.argtypes = [vp, vp]
             L.hor_last_cell_visits.restype = C.c_int64
             L.hor_last_cell_visits.argtypes = [vp]
+            L.hor_match_data.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp]
             L.hor_level_factor.restype = C.c_float
             L.hor_level_factor.argtypes = [C.c_int]
             cls._L = L
@@ -631,6 +632,17 @@ class PortHector:
 
     def last_cell_visits(self) -> int:
         return self.L.hor_last_cell_visits(self.h)
+
+    @classmethod
+    def match_data(cls, levels, points_xy, begin_world):
+        """MapRepMultiMap::matchData over a list of PortHector levels -> (pose[3], H[3,3])."""
+        L = cls.lib()
+        arr = (C.c_void_p * len(levels))(*[lv.h for lv in levels])
+        p = np.ascontiguousarray(points_xy, dtype=np.float32).reshape(-1, 2)
+        b = np.ascontiguousarray(begin_world, dtype=np.float32)
+        pose, cov = np.zeros(3, dtype=np.float32), np.zeros(9, dtype=np.float32)
+        L.hor_match_data(arr, len(levels), p.ctypes.data, p.shape[0], b.ctypes.data, pose.ctypes.data, cov.ctypes.data)
+        return pose, cov.reshape(3, 3)
 
     @classmethod
     def level_factor(cls, level: int) -> float:

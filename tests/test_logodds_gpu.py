@@ -129,3 +129,44 @@ def test_out_of_map_beams_are_dropped(ctx, oracle_lib):
     assert cpu.logodds().tobytes() == gpu.logodds().tobytes()
     # empty scan is legal
     gpu.updateByScan(np.zeros((0, 2), np.float32), (0, 0), np.zeros(3, np.float32))
+
+
+def test_gauss_newton_match_data(ctx, oracle_lib):
+    """Next-row #2: MapRepMultiMap::matchData (coarse-to-fine Gauss-Newton on the 3-level pyramid) --
+    the lesson4 front-end loop matchData -> updateByScan, GPU vs the restated oracle.  fp32 with the
+    reference's sequential accumulation order; tolerance 1e-4 (map units are metres / radians)."""
+    laser = synth.Laser()
+    n, cell, levels = 1024, 0.05, 3
+    off = (n * cell * 0.5, n * cell * 0.5)
+    world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=3)
+    cpus = [oracle_lib.PortHector(n >> i, n >> i, cell * 2 ** i, off) for i in range(levels)]
+    gpu = api.OccGridMap(ctx, n, n, cell, off, levels=levels)
+    for m in cpus + [gpu]:
+        m.setUpdateOccupiedFactor(0.9)
+    path = synth.trajectory(world, 14, step=0.3, seed=3, bounds=6.0)
+    rng = np.random.default_rng(1)
+    worst = 0.0
+    for k, t in enumerate(path):
+        r = synth.cast_scan(world, t, laser, 0.01, 0.0, rng)
+        pts = synth.hector_points(r, laser, 1.0 / cell, use_max=20.0)
+        if k == 0:
+            pose_c = pose_g = t.astype(np.float32)
+        else:
+            hint = (t + np.array([0.08, -0.06, 0.03])).astype(np.float32)
+            pose_c, H_c = oracle_lib.PortHector.match_data(cpus, pts, hint)
+            pose_g, H_g = gpu.matchData(hint, pts)
+            d = float(np.abs(pose_c - pose_g).max())
+            worst = max(worst, d)
+            assert d <= 1e-4, (k, pose_c, pose_g)
+            assert np.abs(H_c - H_g).max() <= 1e-3 * max(1.0, float(np.abs(H_c).max()))
+            assert np.hypot(*(pose_g[:2] - t[:2])) < 0.03  # it converges to the truth from an 10 cm / 1.7 deg hint
+        for i, c in enumerate(cpus):  # keep both maps identical: update both with the ORACLE pose
+            f = np.float32(oracle_lib.PortHector.level_factor(i))
+            c.updateByScan(pts if i == 0 else pts * f, (0.0, 0.0), pose_c)
+        gpu.updateByScan(pts, (0.0, 0.0), pose_c)
+    for i, c in enumerate(cpus):
+        assert c.logodds().tobytes() == gpu.logodds(i).tobytes()
+    print("max |pose_gpu - pose_oracle| =", worst)
+    # empty scan: beginEstimateWorld comes back unchanged
+    p, _ = gpu.matchData(np.array([1.0, 2.0, 0.3], np.float32), np.zeros((0, 2), np.float32))
+    assert np.array_equal(p, np.array([1.0, 2.0, 0.3], np.float32))
