@@ -1,0 +1,55 @@
+"""Randomised parity sweep: different lasers (beam counts not multiples of 64), batch sizes (1 -> the
+beam-sliced atomics path, larger -> one wave per (scan, angle)), poses anywhere in the grid
+including the rim (rows leaving the flat index range, occupancy columns wrapping), random invalid
+readings.  Integer response sums must be bit-exact, results within 1e-9 of the CPU oracle."""
+import math
+
+import numpy as np
+import pytest
+
+from lslam_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_ranges,inc_deg,seed", [(360, 1.0, 1), (1081, 0.25, 2), (721, 0.5, 3), (1080, 0.3333, 4)])
+def test_random_sweep(ctx, oracle_lib, n_ranges, inc_deg, seed):
+    rng = np.random.default_rng(seed)
+    laser = synth.Laser(n_ranges=n_ranges, angle_min=math.radians(-0.5 * (n_ranges - 1) * inc_deg),
+                        angle_increment=math.radians(inc_deg), range_max=40.0)
+    thr = 30.0
+    port = oracle_lib.PortKarto(oracle_lib.default_cfg(), oracle_lib.laser_struct(laser, thr))
+    gm = api.ScanMatcher(ctx, api.baseline_config(range_threshold=thr), api.laser_params(laser, thr))
+    world = synth.arena(size=50.0, n_axis=14, n_rot=5, seed=seed)
+    wl = synth.make_match_workload(n_base=16, n_query=24, seed=seed, laser=laser, world=world, query_spread=4.0)
+    port.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    assert np.array_equal(gm.GetCorrelationGrid(), port.grid())
+    ranges, poses = wl.query_ranges.copy(), wl.query_poses.copy()
+    # random invalid readings and a few poses pushed to the rim / far corners of the grid
+    mask = rng.random(ranges.shape) < 0.03
+    ranges[mask] = np.where(rng.random(mask.sum()) < 0.5, np.nan, np.inf)
+    half = 0.5 * 0.05 * (gm.grid_info()["roi_w"] - 1)
+    for i, (fx, fy) in enumerate([(0.97, 0.0), (-0.97, 0.97), (0.0, -0.985), (0.985, 0.985)]):
+        poses[i, 0] = wl.center_pose[0] + fx * half
+        poses[i, 1] = wl.center_pose[1] + fy * half
+        poses[i, 2] = rng.uniform(-math.pi, math.pi)
+    # integer numerators, fast and generic kernels, single scan (beam-sliced atomics)
+    for q in (0, 1, 5, 9):
+        p = poses[q]
+        _, _, _, st, sums = port.correlate_scan(ranges[q], p, p, 0.5, 0.1, 0.349, 0.0349, True, False, want_sums=True)
+        assert st == 0
+        assert np.array_equal(gm.coarse_sums(ranges[q], p), sums)
+        assert np.array_equal(gm.coarse_sums(ranges[q], p, force_generic=True), sums)
+    # whole batch, then odd-sized sub-batches (S = 1, 3, 7 take different wave decompositions)
+    res = gm.match_batch(ranges, poses)
+    exp = [port.match(ranges[q], poses[q]) for q in range(len(ranges))]
+    for q, (mean, cov, resp) in enumerate(exp):
+        assert res["status"][q] == 0
+        assert np.abs(res["pose"][q][:2] - mean[:2]).max() <= 1e-9
+        assert abs(math.remainder(res["pose"][q][2] - mean[2], 2 * math.pi)) <= 1e-9
+        assert abs(res["response"][q] - resp) <= 1e-12
+        assert np.abs(res["covariance"][q] - cov).max() <= 1e-9 * max(1.0, np.abs(cov).max())
+    for S in (1, 3, 7):
+        sub = gm.match_batch(ranges[:S], poses[:S])
+        assert sub.tobytes() == res[:S].tobytes()
