@@ -297,19 +297,25 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       int2 e = lane < cnt ? queue[lane] : make_int2(0, 0);
       const uint8_t* src = (e.y < 0) ? src1 : src0;
       const uint32_t mask = (uint32_t)e.y & 0x7FFFFFFFu;
-      uint32_t d[NYC][NXD];
+      // dword-ALIGNED loads of NXD+1 words covering the row, realigned in registers: the planes and
+      // widthStep are multiples of 4, so every row of a beam has the same byte phase
+      const uint32_t sh = (uint32_t)e.x & 3u;
+      const long long a0 = (long long)e.x - (long long)sh;
+      uint32_t wv[NYC][NXD + 1];
 #pragma unroll
       for (int j = 0; j < NYC; j++) {
 #pragma unroll
-        for (int k = 0; k < NXD; k++) d[j][k] = 0u;
-        if ((mask >> j) & 1u) __builtin_memcpy(d[j], src + ((long long)e.x + (long long)j * g.stride), 4 * NXD);
+        for (int k = 0; k <= NXD; k++) wv[j][k] = 0u;
+        if ((mask >> j) & 1u)
+          __builtin_memcpy(wv[j], __builtin_assume_aligned(src + (a0 + (long long)j * g.stride), 4), 4 * (NXD + 1));
       }
 #pragma unroll
       for (int j = 0; j < NYC; j++)
 #pragma unroll
         for (int k = 0; k < NXD; k++) {
-          acc[j][k][0] += d[j][k] & 0x00FF00FFu;         // candidates 4k, 4k+2
-          acc[j][k][1] += (d[j][k] >> 8) & 0x00FF00FFu;  // candidates 4k+1, 4k+3
+          const uint32_t dw = __builtin_amdgcn_alignbyte(wv[j][k + 1], wv[j][k], sh);
+          acc[j][k][0] += dw & 0x00FF00FFu;         // candidates 4k, 4k+2
+          acc[j][k][1] += (dw >> 8) & 0x00FF00FFu;  // candidates 4k+1, 4k+3
         }
     };
 
