@@ -14,6 +14,7 @@ There is NO CPU fallback here: if the shared library or a GPU is missing, constr
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 import weakref
 
@@ -131,7 +132,9 @@ def lib() -> C.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = _build.build_library()
+    # LSLAM_GPU_LIB: developer override naming a prebuilt variant of the library (kernel A/B runs,
+    # tools/ab_variants.py); it is still the HIP library -- there is no CPU fallback behind it
+    path = os.environ.get("LSLAM_GPU_LIB") or _build.build_library()
     L = C.CDLL(str(path))
     vp, i32, dbl = C.c_void_p, C.c_int, C.c_double
     L.lslam_abi_version.restype = i32

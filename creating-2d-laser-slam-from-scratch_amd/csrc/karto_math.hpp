@@ -129,6 +129,20 @@ LSLAM_HD void lookup_cell(double lx, double ly, double cosine, double sine, doub
   gx = world_to_grid(ox + off_x, off_x, scale);
   gy = world_to_grid(oy + off_y, off_y, scale);
 }
+// Same cell through a cheaper rounding: (int)math::Round(v) == sign(v) * (int)(|v| + 0.5) -- the
+// conversion truncates, |v| + 0.5 >= 0, and ceil(v - 0.5) == -floor(-v + 0.5) (round-to-nearest is
+// symmetric) -- identical to lookup_cell for |v| < 2^31.
+LSLAM_HD int kround_i32(double v) {
+  const int i = (int)(fabs(v) + 0.5);
+  return v < 0.0 ? -i : i;
+}
+LSLAM_HD void lookup_cell_i32(double lx, double ly, double cosine, double sine, double off_x, double off_y,
+                              double scale, int& gx, int& gy) {
+  double ox = cosine * lx - sine * ly;
+  double oy = sine * lx + cosine * ly;
+  gx = kround_i32(((ox + off_x) - off_x) * scale);
+  gy = kround_i32(((oy + off_y) - off_y) * scale);
+}
 LSLAM_HD int32_t lookup_offset(double lx, double ly, double cosine, double sine, double off_x,
                                double off_y, double scale, int stride) {
   int gx, gy;

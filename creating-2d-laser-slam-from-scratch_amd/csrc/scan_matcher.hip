@@ -53,6 +53,8 @@ struct SearchCfg {
   int do_penalize;
 };
 
+constexpr int kMaxGridSide = 32768;  // widthStep and height: dataSize <= 2^30, flat indices stay int32
+
 struct Lattice {  // per scan, per pass
   double center[3];
   int gx[kMaxLattice], gy[kMaxLattice];  // full-grid cell coordinates (ROI offset included)
@@ -263,7 +265,11 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
   constexpr int NW = NXD * NYC * 2;
   constexpr int kRedPasses = NW > 32 ? 2 : 1;
   constexpr int NWC = (NW + kRedPasses - 1) / kRedPasses;
-  constexpr int kQueue = 128;
+#ifndef LSLAM_U
+#define LSLAM_U 2
+#endif
+  constexpr int U = LSLAM_U;           // beam chunks (of 64) in flight per phase-A iteration
+  constexpr int kQueue = 64 * (U + 1);
   __shared__ uint32_t red[NWC][65];
   __shared__ int2 queue[kQueue];  // .x = first row index m0, .y = row mask | parity << 31
   const int lane = threadIdx.x;
@@ -284,6 +290,8 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
   const int ncand = pc.nx * pc.ny;
   const int shift = step == 2 ? 1 : 0;
   const unsigned long long lane_lt = (1ull << lane) - 1ull;
+  const int bstride = 64 * beam_slices;
+  constexpr uint32_t kNoOcc = 0xFFFFFFFFu;
 
   for (int j0 = 0; j0 < pc.ny; j0 += NYC) {
     uint32_t acc[NYC][NXD][2];
@@ -293,14 +301,22 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       for (int k = 0; k < NXD; k++) acc[j][k][0] = acc[j][k][1] = 0u;
 
     // Phase B: one queued beam per lane -- load the rows its mask names, accumulate 4 candidates per dword
-    auto drain = [&](int cnt) {
-      int2 e = lane < cnt ? queue[lane] : make_int2(0, 0);
+    auto drain = [&](int head, int cnt) {
+      int2 e = lane < cnt ? queue[head + lane] : make_int2(0, 0);
+#ifdef LSLAM_EXP_NODRAIN
+      acc[0][0][0] += e.x + e.y;
+      return;
+#endif
       const uint8_t* src = (e.y < 0) ? src1 : src0;
       const uint32_t mask = (uint32_t)e.y & 0x7FFFFFFFu;
       // dword-ALIGNED loads of NXD+1 words covering the row, realigned in registers: the planes and
       // widthStep are multiples of 4, so every row of a beam has the same byte phase
       const uint32_t sh = (uint32_t)e.x & 3u;
       const long long a0 = (long long)e.x - (long long)sh;
+      // v_perm_b32 selectors: bytes sh+0 / sh+2 (even candidates) and sh+1 / sh+3 (odd) of the word pair,
+      // each zero-extended into a 16-bit field (0x0C selects the constant 0)
+      const uint32_t sel_e = 0x0C020C00u + sh * 0x00010001u;
+      const uint32_t sel_o = 0x0C030C01u + sh * 0x00010001u;
       uint32_t wv[NYC][NXD + 1];
 #pragma unroll
       for (int j = 0; j < NYC; j++) {
@@ -313,72 +329,118 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       for (int j = 0; j < NYC; j++)
 #pragma unroll
         for (int k = 0; k < NXD; k++) {
-          const uint32_t dw = __builtin_amdgcn_alignbyte(wv[j][k + 1], wv[j][k], sh);
-          acc[j][k][0] += dw & 0x00FF00FFu;         // candidates 4k, 4k+2
-          acc[j][k][1] += (dw >> 8) & 0x00FF00FFu;  // candidates 4k+1, 4k+3
+          acc[j][k][0] += __builtin_amdgcn_perm(wv[j][k + 1], wv[j][k], sel_e);  // candidates 4k, 4k+2
+          acc[j][k][1] += __builtin_amdgcn_perm(wv[j][k + 1], wv[j][k], sel_o);  // candidates 4k+1, 4k+3
         }
     };
 
-    // Phase A: every beam -- table entry, row mask (bounds + exact row occupancy); survivors are queued
+    // Phase A: every beam -- table entry, row mask (bounds + exact row occupancy); survivors are queued.
+    // U chunks of 64 beams per iteration with their loads issued together.  The lattice lies inside
+    // the grid (k_pass_setup) and the grid has <= 2^30 cells, so for a beam whose table cell is
+    // within +-2^15 cells every index below is exact in int32 (24-bit multiplies, no 64-bit
+    // compares); any other beam takes the 64-bit path.
     int qcount = 0;
     const int rows_here = min(NYC, pc.ny - j0);
     const uint32_t all_rows = rows_here >= 32 ? 0xFFFFFFFFu : ((1u << rows_here) - 1u);
-    for (int b0 = 64 * slice; b0 < g.n_beams; b0 += 64 * beam_slices) {
-      const int b = b0 + lane;
-      uint32_t mask = 0;
-      int m0i = 0, par = 0;
-      if (b < g.n_beams) {
-        double2 p = lp[b];
-        if (!isnan(p.x)) {  // NaN = INVALID_SCAN
+    const int B0 = X0 + Y0 * g.stride + j0 * step * g.stride;
+    const int Yb = Y0 + j0 * step;
+    const int m0_max = limit - ((rows_here - 1) * g.stride + 4 * NXD);  // whole neighbourhood in range
+    const int y1_max = g.height + 1 - step * (NYC - 1);                 // y+1 range of the occupancy window
+    for (int b0 = 64 * slice; b0 < g.n_beams; b0 += bstride * U) {
+      double2 p[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) p[u] = lp[min(b0 + u * bstride + lane, g.n_beams - 1)];
+      uint32_t mask[U], par[U], osh[U];
+      int m0i[U];
+      uint32_t col[U];  // word index into occ_t
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        mask[u] = 0u, par[u] = 0u, osh[u] = kNoOcc, m0i[u] = 0, col[u] = 0u;
+        if (b0 + u * bstride >= g.n_beams) continue;  // wave-uniform
+        const int b = b0 + u * bstride + lane;
+        if (b < g.n_beams && !isnan(p[u].x)) {  // NaN = INVALID_SCAN
           int gx, gy;
-          lookup_cell(p.x, p.y, cosine, sine, g.off_x, g.off_y, g.scale, gx, gy);
-          const int t = gx + gy * g.stride;  // Karto.h:6494 (int32 like the reference)
-          const long long base = (long long)X0 + (long long)Y0 * g.stride + t + (long long)j0 * step * g.stride;
-          par = (int)(base & 1) & shift;
-          const long long m0 = base >> shift;  // arithmetic shift = floor
-          // rows inside the valid index range (the reference's 1-D check, Mapper.cpp:841-845)
-          if (m0 >= 0 && m0 + (long long)(rows_here - 1) * g.stride + 4 * NXD <= (long long)limit) {
-            mask = all_rows;
+          lookup_cell_i32(p[u].x, p[u].y, cosine, sine, g.off_x, g.off_y, g.scale, gx, gy);
+          if ((((uint32_t)(gx + 32768)) | ((uint32_t)(gy + 32768))) < 65536u) {
+            const int base = B0 + gx + __mul24(gy, g.stride);  // Karto.h:6494 + Mapper.cpp:838
+            par[u] = (uint32_t)(base & shift);
+            const int m0 = base >> shift;  // arithmetic shift = floor
+            uint32_t mk = 0;
+            // rows inside the valid index range (the reference's 1-D check, Mapper.cpp:841-845)
+            if (m0 >= 0 && m0 <= m0_max) {
+              mk = all_rows;
+            } else {
+              for (int j = 0; j < rows_here; j++) {
+                const int rs = m0 + j * g.stride;
+                if (rs >= -(4 * NXD) && rs < limit) mk |= 1u << j;
+              }
+            }
+            if (occ_t && mk) {  // exact row occupancy: bit j*step <-> lattice row j0+j
+              int x = X0 + gx, y = Yb + gy;
+              if ((uint32_t)x >= (uint32_t)g.stride) {  // flat index wrapped into a neighbouring row
+                y = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
+                x = base - y * g.stride;
+              }
+              if (y >= -1 && y + 1 <= y1_max) {
+                col[u] = (uint32_t)__mul24(x, occ_wpc) + (uint32_t)((y + 1) >> 5);
+                osh[u] = (uint32_t)((y + 1) & 31);
+              }
+            }
+            mask[u] = mk;
+            m0i[u] = m0;
           } else {
+            const int t = gx + gy * g.stride;  // int32 like the reference
+            const long long base = (long long)B0 + t;
+            par[u] = (uint32_t)((int)(base & 1) & shift);
+            const long long m0 = base >> shift;
+            uint32_t mk = 0;
             for (int j = 0; j < rows_here; j++) {
               long long rs = m0 + (long long)j * g.stride;
-              if (rs >= -(long long)(4 * NXD) && rs < (long long)limit) mask |= 1u << j;
+              if (rs >= -(long long)(4 * NXD) && rs < (long long)limit) mk |= 1u << j;
             }
+            mask[u] = mk;  // no occupancy pruning on this path
+            m0i[u] = (int)m0;
           }
-          if (occ_t && mask) {  // exact row occupancy: bit j*step <-> lattice row j0+j
-            long long x = (long long)X0 + gx, y = (long long)Y0 + gy + (long long)j0 * step;
-            if (x < 0 || x >= g.stride) {  // flat index wrapped into a neighbouring row
-              y = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
-              x = base - y * g.stride;
-            }
-            if (y >= -1 && y + (long long)step * (NYC - 1) <= (long long)g.height) {
-              const uint32_t* col = occ_t + (size_t)x * occ_wpc + ((y + 1) >> 5);
-              unsigned long long two = (unsigned long long)col[0] | ((unsigned long long)col[1] << 32);
-              unsigned long long rowbits = two >> ((y + 1) & 31);
-              uint32_t keep = 0;
-#pragma unroll
-              for (int j = 0; j < NYC; j++) keep |= (uint32_t)((rowbits >> (j * step)) & 1ull) << j;
-              mask &= keep;
-            }
-          }
-          m0i = (int)m0;
         }
       }
-      const unsigned long long votes = __ballot(mask != 0);
-      if (mask) queue[qcount + __popcll(votes & lane_lt)] = make_int2(m0i, (int)(mask | ((uint32_t)par << 31)));
-      qcount += __popcll(votes);
+      if (occ_t) {
+        unsigned long long two[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          two[u] = (unsigned long long)occ_t[col[u]] | ((unsigned long long)occ_t[(size_t)col[u] + 1] << 32);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          static_assert(2 * (NYC - 1) < 32, "occupancy window must fit 32 bits");
+          uint32_t keep = (uint32_t)(two[u] >> (osh[u] & 31u));  // bit j*step <-> row j
+          if (shift) {  // gather the even bits
+            keep &= 0x55555555u;
+            keep = (keep | (keep >> 1)) & 0x33333333u;
+            keep = (keep | (keep >> 2)) & 0x0F0F0F0Fu;
+            keep = (keep | (keep >> 4)) & 0x00FF00FFu;
+            keep = (keep | (keep >> 8)) & 0x0000FFFFu;
+          }
+          if (osh[u] != kNoOcc) mask[u] &= keep;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const unsigned long long votes = __ballot(mask[u] != 0);
+        if (mask[u]) queue[qcount + __popcll(votes & lane_lt)] = make_int2(m0i[u], (int)(mask[u] | (par[u] << 31)));
+        qcount += __popcll(votes);
+      }
       __syncthreads();
       if (qcount >= 64) {
-        drain(64);
+        int head = 0;
+        for (; qcount - head >= 64; head += 64) drain(head, 64);
+        const int rest = qcount - head;
+        int2 moved = lane < rest ? queue[head + lane] : make_int2(0, 0);
         __syncthreads();
-        int2 moved = (lane + 64 < qcount) ? queue[lane + 64] : make_int2(0, 0);
-        __syncthreads();
-        if (lane + 64 < qcount) queue[lane] = moved;
-        qcount -= 64;
+        if (lane < rest) queue[lane] = moved;
+        qcount = rest;
         __syncthreads();
       }
     }
-    if (qcount > 0) drain(qcount);
+    if (qcount > 0) drain(0, qcount);
     __syncthreads();
 
     // transpose through LDS in kRedPasses slices (keeps LDS per wave small -> 4 waves/SIMD), then
@@ -1658,6 +1720,11 @@ int lslam_matcher_create(lslam_context* ctx, const lslam_matcher_config* cfg, co
   g.roi_w = g.roi_h = grid_size;
   g.width = g.height = grid_size + 2 * g.border;  // Mapper.h:1018
   g.stride = (g.width + 7) & ~7;                   // Karto.h:4442
+  if (g.stride > kMaxGridSide || g.height > kMaxGridSide) {  // keeps every flat index inside int32 (k_resp_rows)
+    delete m;
+    return ctx->fail(LSLAM_ERR_UNSUPPORTED, "correlation grid of %dx%d cells exceeds the built limit %d per side",
+                     g.width, g.height, kMaxGridSide);
+  }
   g.data_size = g.stride * g.height;
   g.scale = 1.0 / cfg->resolution;  // Mapper.h:1020
   g.off_x = g.off_y = 0.0;
