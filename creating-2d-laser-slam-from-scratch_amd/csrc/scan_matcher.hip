@@ -256,8 +256,11 @@ k_row_occupancy(const uint32_t* __restrict__ nz, int n_words, int stride, int he
 // Block -> (scan, angle) mapping keeps all angles of a scan on one XCD (block b runs on XCD b%8),
 // so a scan's 17 KB of scan-frame points is fetched into ONE L2 instead of eight.
 // ------------------------------------------------------------------------------------------
+#ifndef LSLAM_WAVES
+#define LSLAM_WAVES 1
+#endif
 template <int NXD, int NYC>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LSLAM_WAVES, 8)))
 k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int step, int limit, Geom g,
             PassCfg pc, const Lattice* __restrict__ lat, const double2* __restrict__ local,
             int32_t* __restrict__ resp, size_t resp_stride, int beam_slices, int S,
@@ -266,7 +269,7 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
   constexpr int kRedPasses = NW > 32 ? 2 : 1;
   constexpr int NWC = (NW + kRedPasses - 1) / kRedPasses;
 #ifndef LSLAM_U
-#define LSLAM_U 2
+#define LSLAM_U 1
 #endif
   constexpr int U = LSLAM_U;           // beam chunks (of 64) in flight per phase-A iteration
   constexpr int kQueue = 64 * (U + 1);
@@ -322,8 +325,9 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       for (int j = 0; j < NYC; j++) {
 #pragma unroll
         for (int k = 0; k <= NXD; k++) wv[j][k] = 0u;
-        if ((mask >> j) & 1u)
-          __builtin_memcpy(wv[j], __builtin_assume_aligned(src + (a0 + (long long)j * g.stride), 4), 4 * (NXD + 1));
+        // a masked row reads the zero guard band instead: straight-line loads beat exec-masked ones
+        const uint8_t* ad = ((mask >> j) & 1u) ? src + (a0 + (long long)j * g.stride) : src0 - 64;
+        __builtin_memcpy(wv[j], __builtin_assume_aligned(ad, 4), 4 * (NXD + 1));
       }
 #pragma unroll
       for (int j = 0; j < NYC; j++)
