@@ -53,6 +53,7 @@ struct SearchCfg {
   int do_penalize;
 };
 
+constexpr int kTileMinWaves = 2048;  // below this the fine pass stays on k_resp_rows (beam slices fill the chip)
 constexpr int kMaxGridSide = 32768;  // widthStep and height: dataSize <= 2^30, flat indices stay int32
 
 struct Lattice {  // per scan, per pass
@@ -488,6 +489,113 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       __syncthreads();
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fine pass on 4x4 cell blocks.  The fine lattice of MatchScan is always 3x3 cells at 1-cell steps
+// (Mapper.cpp:276-281: offset = coarse resolution / 2 = one cell), so a beam's nine candidates are a
+// 3x3 patch of the grid.  k_tile4 stores, for every EVEN (X, Y), the 16 bytes
+//     T[Y/2][X/2][r][c] = G_flat[(Y + r) * widthStep + X + c]   (0 outside [0, dataSize))
+// -- overlapping 4x4 blocks, 4x the grid in HBM, built once per grid change -- so the patch with
+// top-left cell (x, y) lies inside block (x & ~1, y & ~1) and ONE aligned 16-byte load per beam
+// replaces three row loads.  Blocks are defined on the FLAT index, like the reference's 1-D bounds
+// rule (Mapper.cpp:841-845): an x that runs past widthStep continues in the next row.
+// ------------------------------------------------------------------------------------------
+constexpr int kTileYPad = 4;  // blocks start at Y = -4: flat indices of row y = -3 can wrap into row 0
+
+__global__ void __launch_bounds__(256)
+k_tile4(const uint8_t* __restrict__ grid, int stride, int data_size, uint4* __restrict__ tiles, int tile_cols,
+        int tile_rows) {
+  const int ux = blockIdx.x * blockDim.x + threadIdx.x, uy = blockIdx.y;
+  if (ux >= tile_cols || uy >= tile_rows) return;
+  const long long idx0 = (long long)(2 * uy - kTileYPad) * stride + 2 * ux;  // even: pairs are in or out together
+  uint32_t w[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const long long i = idx0 + (long long)r * stride;
+    uint32_t lo = 0, hi = 0;
+    if (i >= 0 && i < data_size) lo = *reinterpret_cast<const uint16_t*>(grid + i);
+    if (i + 2 >= 0 && i + 2 < data_size) hi = *reinterpret_cast<const uint16_t*>(grid + i + 2);
+    w[r] = lo | (hi << 16);
+  }
+  tiles[(size_t)uy * tile_cols + ux] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += (uint32_t)__shfl_xor((int)v, m);
+  return v;
+}
+
+// One wave64 per (scan, angle); lanes stride over the beams.  Same exact numerators as
+// k_resp_rows<1,4> at step 1 (Mapper.cpp:819-856), written resp[s][a][j*3+i].
+__global__ void __launch_bounds__(64)
+k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc, const Lattice* __restrict__ lat,
+             const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int S) {
+  const int lane = threadIdx.x;
+  const int w = blockIdx.x;
+  const int xcd = w & 7, r = w >> 3;
+  const int s = (r / pc.na) * 8 + xcd;  // all angles of a scan on one XCD, like k_resp_rows
+  const int a = r % pc.na;
+  if (s >= S) return;
+  const Lattice& L = lat[s];
+  if (!L.active || L.status != 0 || L.step_x != 1 || L.step_y != 1) return;
+
+  const double angle = (L.center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;  // Mapper.cpp:390-393
+  const double cosine = cos(angle), sine = sin(angle);                         // Karto.h:6465-6466
+  const int X0 = L.gx[0], Y0 = L.gy[0];
+  const int B0 = X0 + Y0 * g.stride;
+  const double2* lp = local + (size_t)s * g.n_beams;
+  // packed 16-bit fields: e[j] = candidates (0,j) | (2,j) << 16; o01 = (1,0) | (1,1) << 16; o2 = (1,2)
+  uint32_t e0 = 0, e1 = 0, e2 = 0, o01 = 0, o2 = 0;
+  double2 p = lp[min(lane, g.n_beams - 1)];
+  for (int b = lane; b < g.n_beams; b += 64) {
+    const double2 pn = lp[min(b + 64, g.n_beams - 1)];  // next point in flight while this one is used
+    if (!isnan(p.x)) {  // NaN = INVALID_SCAN
+      int gx, gy;
+      lookup_cell_i32(p.x, p.y, cosine, sine, g.off_x, g.off_y, g.scale, gx, gy);
+      int x, y;
+      bool ok;
+      if ((((uint32_t)(gx + 32768)) | ((uint32_t)(gy + 32768))) < 65536u) {  // all int32-exact, see k_resp_rows
+        x = X0 + gx, y = Y0 + gy;
+        if ((uint32_t)x >= (uint32_t)g.stride) {  // flat index wrapped into a neighbouring row
+          const int base = B0 + gx + __mul24(gy, g.stride);
+          y = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
+          x = base - y * g.stride;
+        }
+        ok = y >= -3 && y < g.height;
+      } else {
+        const long long base = (long long)B0 + (int)(gx + gy * g.stride);  // int32 table offset like the reference
+        const long long yl = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
+        ok = yl >= -3 && yl < g.height;
+        y = ok ? (int)yl : 0;
+        x = ok ? (int)(base - yl * g.stride) : 0;
+      }
+      if (ok) {
+        const uint4 t = tiles[(size_t)((y + kTileYPad) >> 1) * tile_cols + (x >> 1)];
+        const uint32_t dx = (uint32_t)x & 1u;
+        const bool dy = (y & 1) != 0;
+        const uint32_t r0 = dy ? t.y : t.x, r1 = dy ? t.z : t.y, r2 = dy ? t.w : t.z;
+        const uint32_t sel_e = 0x0C020C00u + dx * 0x00010001u;  // bytes dx, dx+2 of one row
+        const uint32_t sel_o = 0x0C050C01u + dx * 0x00010001u;  // byte dx+1 of src1 (low) and of src0 (high)
+        e0 += __builtin_amdgcn_perm(r0, r0, sel_e);
+        e1 += __builtin_amdgcn_perm(r1, r1, sel_e);
+        e2 += __builtin_amdgcn_perm(r2, r2, sel_e);
+        o01 += __builtin_amdgcn_perm(r1, r0, sel_o);
+        o2 += __builtin_amdgcn_perm(r2, r2, 0x0C0C0C01u + dx);
+      }
+    }
+    p = pn;
+  }
+  uint32_t tot[9];
+  tot[0] = wave_sum(e0 & 0xFFFFu), tot[1] = wave_sum(o01 & 0xFFFFu), tot[2] = wave_sum(e0 >> 16);
+  tot[3] = wave_sum(e1 & 0xFFFFu), tot[4] = wave_sum(o01 >> 16), tot[5] = wave_sum(e1 >> 16);
+  tot[6] = wave_sum(e2 & 0xFFFFu), tot[7] = wave_sum(o2), tot[8] = wave_sum(e2 >> 16);
+  uint32_t mine = 0;
+#pragma unroll
+  for (int c = 0; c < 9; c++)
+    if (lane == c) mine = tot[c];
+  if (lane < 9) resp[(size_t)s * resp_stride + (size_t)a * 9 + lane] = (int32_t)mine;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1398,6 +1506,9 @@ struct lslam_matcher {
   int occ_win = 21;                 // grid bytes summarised per bit = row span of the coarse lattice
   uint32_t* d_nz = nullptr;         // flat non-zero bitmap, one bit per grid byte (k_nonzero_bits)
   int nz_words = 0;
+  uint4* d_tiles = nullptr;         // overlapping 4x4 cell blocks (k_tile4), allocated on first batch use
+  int tile_cols = 0, tile_rows = 0;
+  bool tile_dirty = true, tile_failed = false;
   // workspaces
   DevBuf<double> d_ranges64;
   DevBuf<double> d_poses;
@@ -1506,10 +1617,34 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     int* slow_list = m->d_slow.p + 1;
     launch(ctx, "pass_setup", k_pass_setup, dim3((S + 127) / 128), dim3(128), 0, S, g, p, d_poses,
            (const CoarseOut*)m->d_coarse.p, m->d_lat.p, variant ? slow_list : (int*)nullptr, slow_cnt, step);
-    if (variant) {
+    const long long waves = (long long)((S + 7) / 8) * 8 * p.na;
+    // fine pass of a batch big enough to fill the chip: one 16-byte load per beam from the 4x4 blocks
+    bool tiled = variant == 1 && step == 1 && p.nx == 3 && p.ny == 3 && waves >= kTileMinWaves &&
+                 g.n_beams <= 16384 && !m->tile_failed;
+    if (tiled && !m->d_tiles) {
+      m->tile_cols = g.stride / 2;
+      m->tile_rows = (g.height + 1) / 2 + kTileYPad / 2 + 1;
+      if (hipMalloc((void**)&m->d_tiles, (size_t)m->tile_cols * m->tile_rows * sizeof(uint4)) != hipSuccess) {
+        (void)hipGetLastError();
+        m->d_tiles = nullptr;
+        m->tile_failed = true;  // not enough HBM for the 4x copy: keep to the row kernel
+        tiled = false;
+      }
+    }
+    if (tiled) {
+      if (m->tile_dirty) {
+        launch(ctx, "tile4", k_tile4, dim3((m->tile_cols + 255) / 256, m->tile_rows), dim3(256), 0,
+               (const uint8_t*)m->d_grid, g.stride, g.data_size, m->d_tiles, m->tile_cols, m->tile_rows);
+        m->tile_dirty = false;
+      }
+      launch(ctx, "resp_tile_fine", k_resp_tile3, dim3((unsigned)waves), dim3(64), 0, (const uint4*)m->d_tiles, m->tile_cols, g, p,
+             (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S);
+      launch(ctx, "resp_generic_fallback", k_resp_generic, dim3(128), dim3(64), 0, (const uint8_t*)m->d_grid, g, p,
+             (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S,
+             (const int*)slow_list, (const int*)slow_cnt);
+    } else if (variant) {
       // small batches: split the beams of one (scan, angle) over several waves to fill the chip
       int slices = 1;
-      const long long waves = (long long)((S + 7) / 8) * 8 * p.na;
       while (slices < 8 && waves * slices < 2048) slices *= 2;
       if (slices > 1)
         LSLAM_HIP(ctx, hipMemsetAsync(m->d_resp.p, 0, (size_t)S * resp_stride * sizeof(int32_t), ctx->stream));
@@ -1621,7 +1756,7 @@ int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, i
   g.off_x = center[0] - (0.5 * (g.roi_w - 1) * (1.0 / g.scale));
   g.off_y = center[1] - (0.5 * (g.roi_h - 1) * (1.0 / g.scale));
   LSLAM_HIP(ctx, hipMemsetAsync(m->d_grid, 0, (size_t)g.data_size, ctx->stream));  // Grid::Clear (Mapper.cpp:701)
-  m->sub_dirty = true;
+  m->sub_dirty = m->tile_dirty = true;
   const int n = g.n_beams;
   if (B <= 0 || n <= 0) return LSLAM_OK;
   LSLAM_HIP(ctx, m->d_valid.reserve((size_t)B * n));
@@ -1802,6 +1937,7 @@ void lslam_matcher_destroy(lslam_matcher* m) {
   (void)hipFree(m->d_sub_alloc);
   (void)hipFree(m->d_occ_t);
   (void)hipFree(m->d_nz);
+  (void)hipFree(m->d_tiles);
   m->d_ranges64.release(); m->d_poses.release(); m->d_local.release(); m->d_world.release();
   m->d_valid.release(); m->d_fv_scratch.release(); m->d_lat.release(); m->d_coarse.release(); m->d_resp.release();
   m->d_slow.release(); m->d_tbl.release(); m->d_big.release(); m->d_results.release(); m->d_dbg.release();
@@ -1842,7 +1978,7 @@ int lslam_matcher_set_grid_u8(lslam_matcher* m, const uint8_t* grid, const doubl
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   m->g.off_x = offset_xy[0];
   m->g.off_y = offset_xy[1];
-  m->sub_dirty = true;
+  m->sub_dirty = m->tile_dirty = true;
   return LSLAM_OK;
 }
 
@@ -1853,7 +1989,7 @@ int lslam_matcher_set_grid_u8_dev(lslam_matcher* m, const uint8_t* grid_dev, con
     LSLAM_HIP(ctx, hipMemcpyAsync(m->d_grid, grid_dev, (size_t)m->g.data_size, hipMemcpyDeviceToDevice, ctx->stream));
   m->g.off_x = offset_xy[0];
   m->g.off_y = offset_xy[1];
-  m->sub_dirty = true;
+  m->sub_dirty = m->tile_dirty = true;
   return LSLAM_OK;
 }
 

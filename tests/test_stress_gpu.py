@@ -53,3 +53,12 @@ def test_random_sweep(ctx, oracle_lib, n_ranges, inc_deg, seed):
     for S in (1, 3, 7):
         sub = gm.match_batch(ranges[:S], poses[:S])
         assert sub.tobytes() == res[:S].tobytes()
+    # a batch big enough for the fine pass to switch to the 4x4-block kernel (k_resp_tile3): the same
+    # scans tiled 8x must give byte-identical results to the row-kernel batch above
+    ctx.profile(True)
+    ctx.profile_reset()
+    big = gm.match_batch(np.tile(ranges, (8, 1)), np.tile(poses, (8, 1)))
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    assert "resp_tile_fine" in prof and "resp_rows_fine" not in prof
+    assert big.tobytes() == np.tile(res, 8).tobytes()

@@ -46,7 +46,7 @@ def run(steps):
             d = json.loads(r.stdout.strip().splitlines()[-1])
             k = d["kernel_ms_per_step"]
             print(f"{so.stem:24s} {d['value']:12.0f}/s  step {d['ms_per_step']:.4f} ms  coarse {k.get('resp_rows_coarse', 0):.4f}"
-                  f"  fine {k.get('resp_rows_fine', 0):.4f}  err {d['cpu_baseline']['max_pose_err_vs_gpu']:.2e}")
+                  f"  fine {k.get('resp_tile_fine', k.get('resp_rows_fine', 0)):.4f}  err {d['cpu_baseline']['max_pose_err_vs_gpu']:.2e}")
         except Exception as e:  # noqa: BLE001
             print(so.stem, "FAILED", e, r.stderr[-400:])
 
