@@ -53,6 +53,7 @@ struct SearchCfg {
   int do_penalize;
 };
 
+constexpr int kMaxBeamsPerLane = 32;  // k_resp_rows: 8 lanes x 32 beams x 255 < 2^16 (packed DPP reduce)
 constexpr int kTileMinWaves = 2048;  // below this the fine pass stays on k_resp_rows (beam slices fill the chip)
 constexpr int kMaxGridSide = 32768;  // widthStep and height: dataSize <= 2^30, flat indices stay int32
 
@@ -110,53 +111,73 @@ k_scan_prep(const RT* __restrict__ ranges, int stride, const double* __restrict_
 // (Mapper.cpp:339-386): each lattice coordinate is rounded on its own, exactly like the reference
 // (the fine pass is centred on a possibly off-lattice tie average).
 // ------------------------------------------------------------------------------------------
-__global__ void k_pass_setup(int S, Geom g, PassCfg pc, const double* __restrict__ poses,
-                             const CoarseOut* __restrict__ coarse, Lattice* __restrict__ lat,
-                             int* __restrict__ slow_list, int* __restrict__ slow_count,
-                             int want_step) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(64)
+k_pass_setup(int S, Geom g, PassCfg pc, const double* __restrict__ poses, const CoarseOut* __restrict__ coarse,
+             Lattice* __restrict__ lat, double2* __restrict__ cossin, int* __restrict__ slow_list,
+             int* __restrict__ slow_count, int want_step) {
+  // one wave per scan: lane i owns lattice coordinates i, i+64 and candidate angles i, i+64
+  const int s = blockIdx.x, lane = threadIdx.x;
   if (s >= S) return;
-  Lattice L;
-  L.status = 0;
-  L.active = 1;
+  double center[3];
+  int active = 1;
   if (pc.mode == 0) {
-    L.center[0] = poses[3 * s]; L.center[1] = poses[3 * s + 1]; L.center[2] = poses[3 * s + 2];
+    center[0] = poses[3 * s]; center[1] = poses[3 * s + 1]; center[2] = poses[3 * s + 2];
   } else if (pc.mode == 1) {
-    L.center[0] = poses[3 * s]; L.center[1] = poses[3 * s + 1]; L.center[2] = poses[3 * s + 2];
-    L.active = coarse[s].expand && coarse[s].status == 0;
+    center[0] = poses[3 * s]; center[1] = poses[3 * s + 1]; center[2] = poses[3 * s + 2];
+    active = coarse[s].expand && coarse[s].status == 0;
   } else {
-    L.center[0] = coarse[s].mean[0]; L.center[1] = coarse[s].mean[1]; L.center[2] = coarse[s].mean[2];
-    L.active = coarse[s].status == 0;
+    center[0] = coarse[s].mean[0]; center[1] = coarse[s].mean[1]; center[2] = coarse[s].mean[2];
+    active = coarse[s].status == 0;
   }
-  double start_x = -pc.off_x, start_y = -pc.off_y;
-  for (int i = 0; i < kMaxLattice; i++) L.gx[i] = L.gy[i] = 0;
-  for (int i = 0; i < pc.nx; i++) {
+  const double start_x = -pc.off_x, start_y = -pc.off_y;
+  auto cell_x = [&](int i) {
     double x = start_x + (uint32_t)i * pc.res_x;
-    double npx = L.center[0] + x;
-    int c = world_to_grid(npx, g.off_x, g.scale) + g.border;  // CorrelationGrid::GridIndex adds the ROI
-    if (c < 0 || c >= g.width) L.status = LSLAM_ERR_INDEX_OUT_OF_RANGE;
-    L.gx[i] = c;
-  }
-  for (int j = 0; j < pc.ny; j++) {
+    double npx = center[0] + x;
+    return world_to_grid(npx, g.off_x, g.scale) + g.border;  // CorrelationGrid::GridIndex adds the ROI
+  };
+  auto cell_y = [&](int j) {
     double y = start_y + (uint32_t)j * pc.res_y;
-    double npy = L.center[1] + y;
-    int c = world_to_grid(npy, g.off_y, g.scale) + g.border;
-    if (c < 0 || c >= g.height) L.status = LSLAM_ERR_INDEX_OUT_OF_RANGE;
-    L.gy[j] = c;
+    double npy = center[1] + y;
+    return world_to_grid(npy, g.off_y, g.scale) + g.border;
+  };
+  const int stx0 = pc.nx > 1 ? cell_x(1) - cell_x(0) : want_step;
+  const int sty0 = pc.ny > 1 ? cell_y(1) - cell_y(0) : want_step;
+  bool out_of_range = false, uneven_x = false, uneven_y = false;
+  Lattice& L = lat[s];
+  for (int i = lane; i < kMaxLattice; i += 64) {
+    int cx = 0, cy = 0;
+    if (i < pc.nx) {
+      cx = cell_x(i);
+      out_of_range |= cx < 0 || cx >= g.width;
+      if (i >= 1) uneven_x |= cx - cell_x(i - 1) != stx0;
+    }
+    if (i < pc.ny) {
+      cy = cell_y(i);
+      out_of_range |= cy < 0 || cy >= g.height;
+      if (i >= 1) uneven_y |= cy - cell_y(i - 1) != sty0;
+    }
+    L.gx[i] = cx;
+    L.gy[i] = cy;
   }
-  int stx = pc.nx > 1 ? L.gx[1] - L.gx[0] : want_step;
-  int sty = pc.ny > 1 ? L.gy[1] - L.gy[0] : want_step;
-  for (int i = 1; i < pc.nx; i++)
-    if (L.gx[i] - L.gx[i - 1] != stx) stx = 0;
-  for (int j = 1; j < pc.ny; j++)
-    if (L.gy[j] - L.gy[j - 1] != sty) sty = 0;
-  L.step_x = stx;
-  L.step_y = sty;
-  lat[s] = L;
-  // scans the fast lattice kernel cannot take go to the generic kernel's work list
-  if (slow_list && L.active && L.status == 0 && !(stx == want_step && sty == want_step)) {
-    int k = atomicAdd(slow_count, 1);
-    slow_list[k] = s;
+  // cos/sin of every candidate angle, computed once here instead of once per response wave
+  // (Mapper.cpp:390-393, Karto.h:6465-6466)
+  for (int a = lane; a < pc.na; a += 64) {
+    const double angle = (center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;
+    cossin[(size_t)s * kMaxAngles + a] = make_double2(cos(angle), sin(angle));
+  }
+  const int status = __any(out_of_range) ? LSLAM_ERR_INDEX_OUT_OF_RANGE : 0;
+  const int stx = __any(uneven_x) ? 0 : stx0, sty = __any(uneven_y) ? 0 : sty0;
+  if (lane == 0) {
+    L.center[0] = center[0]; L.center[1] = center[1]; L.center[2] = center[2];
+    L.step_x = stx;
+    L.step_y = sty;
+    L.status = status;
+    L.active = active;
+    // scans the fast lattice kernel cannot take go to the generic kernel's work list
+    if (slow_list && active && status == 0 && !(stx == want_step && sty == want_step)) {
+      int k = atomicAdd(slow_count, 1);
+      slow_list[k] = s;
+    }
   }
 }
 
@@ -263,18 +284,16 @@ k_row_occupancy(const uint32_t* __restrict__ nz, int n_words, int stride, int he
 template <int NXD, int NYC>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LSLAM_WAVES, 8)))
 k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int step, int limit, Geom g,
-            PassCfg pc, const Lattice* __restrict__ lat, const double2* __restrict__ local,
-            int32_t* __restrict__ resp, size_t resp_stride, int beam_slices, int S,
-            const uint32_t* __restrict__ occ_t, int occ_wpc) {
+            PassCfg pc, const Lattice* __restrict__ lat, const double2* __restrict__ cossin,
+            const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int beam_slices,
+            int S, const uint32_t* __restrict__ occ_t, int occ_wpc) {
   constexpr int NW = NXD * NYC * 2;
-  constexpr int kRedPasses = NW > 32 ? 2 : 1;
-  constexpr int NWC = (NW + kRedPasses - 1) / kRedPasses;
 #ifndef LSLAM_U
 #define LSLAM_U 1
 #endif
   constexpr int U = LSLAM_U;           // beam chunks (of 64) in flight per phase-A iteration
   constexpr int kQueue = 64 * (U + 1);
-  __shared__ uint32_t red[NWC][65];
+  __shared__ __align__(16) uint32_t red[NW][8];  // [packed word][group of 8 lanes]
   __shared__ int2 queue[kQueue];  // .x = first row index m0, .y = row mask | parity << 31
   const int lane = threadIdx.x;
   int w = blockIdx.x;
@@ -287,8 +306,8 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
   const Lattice& L = lat[s];
   if (!L.active || L.status != 0 || L.step_x != step || L.step_y != step) return;
 
-  const double angle = (L.center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;  // Mapper.cpp:390-393
-  const double cosine = cos(angle), sine = sin(angle);                         // Karto.h:6465-6466
+  const double2 cs = cossin[(size_t)s * kMaxAngles + a];  // of (center - ang_off) + a * ang_res (k_pass_setup)
+  const double cosine = cs.x, sine = cs.y;
   const int X0 = L.gx[0], Y0 = L.gy[0];
   const double2* lp = local + (size_t)s * g.n_beams;
   const int ncand = pc.nx * pc.ny;
@@ -448,46 +467,45 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
     if (qcount > 0) drain(0, qcount);
     __syncthreads();
 
-    // transpose through LDS in kRedPasses slices (keeps LDS per wave small -> 4 waves/SIMD), then
-    // lane i reduces packed word i over the 64 lanes
+    // Reduce over the wave.  A lane saw at most kMaxBeamsPerLane beams (the host slices longer scans),
+    // so three packed DPP adds -- lanes xor 1, xor 2, then the mirrored quad -- leave every group of 8
+    // lanes holding its 16-bit field sums without overflow; the 8 group partials of each packed word
+    // go through 2 KB of LDS to one lane, which unpacks them into exact int32 sums.
 #pragma unroll
-    for (int pass = 0; pass < kRedPasses; pass++) {
+    for (int j = 0; j < NYC; j++)
 #pragma unroll
-      for (int j = 0; j < NYC; j++)
+      for (int k = 0; k < NXD; k++)
 #pragma unroll
-        for (int k = 0; k < NXD; k++)
+        for (int q = 0; q < 2; q++) {
+          uint32_t v = acc[j][k][q];
+          v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+          v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+          v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+          if ((lane & 7) == 0) red[(j * NXD + k) * 2 + q][lane >> 3] = v;
+        }
+    __syncthreads();
+    for (int idx = lane; idx < NW; idx += 64) {
+      uint32_t lo = 0, hi = 0;
 #pragma unroll
-          for (int q = 0; q < 2; q++) {
-            const int wi = (j * NXD + k) * 2 + q;  // compile-time after unrolling
-            if (wi / NWC == pass) red[wi % NWC][lane] = acc[j][k][q];
-          }
-      __syncthreads();
-      for (int li = lane; li < NWC; li += 64) {
-        const int idx = pass * NWC + li;
-        if (idx < NW) {
-          uint32_t lo = 0, hi = 0;
-#pragma unroll 8
-          for (int k = 0; k < 64; k++) {
-            uint32_t v = red[li][k];
-            lo += v & 0xFFFFu;
-            hi += v >> 16;
-          }
-          const int par2 = idx & 1, jk = idx >> 1;
-          const int j = j0 + jk / NXD, i = 4 * (jk % NXD) + par2;
-          if (j < pc.ny) {
-            int32_t* o = resp + (size_t)s * resp_stride + (size_t)a * ncand + (size_t)j * pc.nx + i;
-            if (beam_slices == 1) {
-              if (i < pc.nx) o[0] = (int32_t)lo;
-              if (i + 2 < pc.nx) o[2] = (int32_t)hi;
-            } else {
-              if (i < pc.nx) atomicAdd(o, (int32_t)lo);
-              if (i + 2 < pc.nx) atomicAdd(o + 2, (int32_t)hi);
-            }
-          }
+      for (int k = 0; k < 8; k++) {
+        const uint32_t v = red[idx][k];
+        lo += v & 0xFFFFu;
+        hi += v >> 16;
+      }
+      const int par2 = idx & 1, jk = idx >> 1;
+      const int j = j0 + jk / NXD, i = 4 * (jk % NXD) + par2;
+      if (j < pc.ny) {
+        int32_t* o = resp + (size_t)s * resp_stride + (size_t)a * ncand + (size_t)j * pc.nx + i;
+        if (beam_slices == 1) {
+          if (i < pc.nx) o[0] = (int32_t)lo;
+          if (i + 2 < pc.nx) o[2] = (int32_t)hi;
+        } else {
+          if (i < pc.nx) atomicAdd(o, (int32_t)lo);
+          if (i + 2 < pc.nx) atomicAdd(o + 2, (int32_t)hi);
         }
       }
-      __syncthreads();
     }
+    __syncthreads();
   }
 }
 
@@ -531,7 +549,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // k_resp_rows<1,4> at step 1 (Mapper.cpp:819-856), written resp[s][a][j*3+i].
 __global__ void __launch_bounds__(64)
 k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc, const Lattice* __restrict__ lat,
-             const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int S) {
+             const double2* __restrict__ cossin, const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int S) {
   const int lane = threadIdx.x;
   const int w = blockIdx.x;
   const int xcd = w & 7, r = w >> 3;
@@ -541,8 +559,8 @@ k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc,
   const Lattice& L = lat[s];
   if (!L.active || L.status != 0 || L.step_x != 1 || L.step_y != 1) return;
 
-  const double angle = (L.center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;  // Mapper.cpp:390-393
-  const double cosine = cos(angle), sine = sin(angle);                         // Karto.h:6465-6466
+  const double2 cs = cossin[(size_t)s * kMaxAngles + a];  // of (center - ang_off) + a * ang_res (k_pass_setup)
+  const double cosine = cs.x, sine = cs.y;
   const int X0 = L.gx[0], Y0 = L.gy[0];
   const int B0 = X0 + Y0 * g.stride;
   const double2* lp = local + (size_t)s * g.n_beams;
@@ -1516,6 +1534,7 @@ struct lslam_matcher {
   DevBuf<uint8_t> d_valid;
   DevBuf<int> d_fv_scratch;
   DevBuf<Lattice> d_lat;
+  DevBuf<double2> d_cossin;  // [S][kMaxAngles] cos/sin of the pass's candidate angles (k_pass_setup)
   DevBuf<CoarseOut> d_coarse;
   DevBuf<int32_t> d_resp;
   DevBuf<int> d_slow;  // [0] = count, [1..] = list
@@ -1584,6 +1603,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
 
   LSLAM_HIP(ctx, m->d_local.reserve((size_t)S * g.n_beams));
   LSLAM_HIP(ctx, m->d_lat.reserve(S));
+  LSLAM_HIP(ctx, m->d_cossin.reserve((size_t)S * kMaxAngles));
   LSLAM_HIP(ctx, m->d_coarse.reserve(S));
   LSLAM_HIP(ctx, m->d_resp.reserve((size_t)S * resp_stride));
   LSLAM_HIP(ctx, m->d_slow.reserve((size_t)S + 1));
@@ -1615,8 +1635,8 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     LSLAM_HIP(ctx, hipMemsetAsync(m->d_slow.p, 0, sizeof(int), ctx->stream));
     int* slow_cnt = m->d_slow.p;
     int* slow_list = m->d_slow.p + 1;
-    launch(ctx, "pass_setup", k_pass_setup, dim3((S + 127) / 128), dim3(128), 0, S, g, p, d_poses,
-           (const CoarseOut*)m->d_coarse.p, m->d_lat.p, variant ? slow_list : (int*)nullptr, slow_cnt, step);
+    launch(ctx, "pass_setup", k_pass_setup, dim3(S), dim3(64), 0, S, g, p, d_poses,
+           (const CoarseOut*)m->d_coarse.p, m->d_lat.p, m->d_cossin.p, variant ? slow_list : (int*)nullptr, slow_cnt, step);
     const long long waves = (long long)((S + 7) / 8) * 8 * p.na;
     // fine pass of a batch big enough to fill the chip: one 16-byte load per beam from the 4x4 blocks
     bool tiled = variant == 1 && step == 1 && p.nx == 3 && p.ny == 3 && waves >= kTileMinWaves &&
@@ -1638,7 +1658,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
         m->tile_dirty = false;
       }
       launch(ctx, "resp_tile_fine", k_resp_tile3, dim3((unsigned)waves), dim3(64), 0, (const uint4*)m->d_tiles, m->tile_cols, g, p,
-             (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S);
+             (const Lattice*)m->d_lat.p, (const double2*)m->d_cossin.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S);
       launch(ctx, "resp_generic_fallback", k_resp_generic, dim3(128), dim3(64), 0, (const uint8_t*)m->d_grid, g, p,
              (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S,
              (const int*)slow_list, (const int*)slow_cnt);
@@ -1646,6 +1666,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       // small batches: split the beams of one (scan, angle) over several waves to fill the chip
       int slices = 1;
       while (slices < 8 && waves * slices < 2048) slices *= 2;
+      while ((g.n_beams + 64 * slices - 1) / (64 * slices) > kMaxBeamsPerLane) slices *= 2;  // packed 16-bit sums
       if (slices > 1)
         LSLAM_HIP(ctx, hipMemsetAsync(m->d_resp.p, 0, (size_t)S * resp_stride * sizeof(int32_t), ctx->stream));
       dim3 grid((unsigned)(waves * slices));
@@ -1656,13 +1677,13 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       const uint32_t* occ = (m->use_row_occupancy && step == 2 && step * (p.nx - 1) + 1 <= m->occ_win) ? m->d_occ_t : (const uint32_t*)nullptr;
       if (variant == 1)
         launch(ctx, name, k_resp_rows<1, 4>, grid, dim3(64), 0, s0, s1, step, limit, g, p, (const Lattice*)m->d_lat.p,
-               (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc);
+               (const double2*)m->d_cossin.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc);
       else if (variant == 2)
         launch(ctx, name, k_resp_rows<3, 11>, grid, dim3(64), 0, s0, s1, step, limit, g, p, (const Lattice*)m->d_lat.p,
-               (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc);
+               (const double2*)m->d_cossin.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc);
       else
         launch(ctx, name, k_resp_rows<4, 8>, grid, dim3(64), 0, s0, s1, step, limit, g, p, (const Lattice*)m->d_lat.p,
-               (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc);
+               (const double2*)m->d_cossin.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc);
       // scans whose lattice is not uniform (a coordinate rounds on a cell boundary) take the generic kernel
       launch(ctx, "resp_generic_fallback", k_resp_generic, dim3(128), dim3(64), 0, (const uint8_t*)m->d_grid, g, p,
              (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S,
@@ -1681,8 +1702,8 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     LSLAM_HIP(ctx, hipMemsetAsync(m->d_slow.p, 0, sizeof(int), ctx->stream));
     int* slow_cnt = m->d_slow.p;
     int* slow_list = m->d_slow.p + 1;
-    launch(ctx, "pass_setup", k_pass_setup, dim3((S + 127) / 128), dim3(128), 0, S, g, p, d_poses,
-           (const CoarseOut*)m->d_coarse.p, m->d_lat.p, slow_list, slow_cnt, 2);
+    launch(ctx, "pass_setup", k_pass_setup, dim3(S), dim3(64), 0, S, g, p, d_poses,
+           (const CoarseOut*)m->d_coarse.p, m->d_lat.p, m->d_cossin.p, slow_list, slow_cnt, 2);
     LSLAM_HIP(ctx, m->d_tbl.reserve((size_t)S * p.na * g.n_beams));
     launch(ctx, "table_big", k_table_big, dim3((g.n_beams + 255) / 256, p.na, S), dim3(256), 0, S, g, p,
            (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_tbl.p);
@@ -1939,7 +1960,7 @@ void lslam_matcher_destroy(lslam_matcher* m) {
   (void)hipFree(m->d_nz);
   (void)hipFree(m->d_tiles);
   m->d_ranges64.release(); m->d_poses.release(); m->d_local.release(); m->d_world.release();
-  m->d_valid.release(); m->d_fv_scratch.release(); m->d_lat.release(); m->d_coarse.release(); m->d_resp.release();
+  m->d_valid.release(); m->d_fv_scratch.release(); m->d_lat.release(); m->d_cossin.release(); m->d_coarse.release(); m->d_resp.release();
   m->d_slow.release(); m->d_tbl.release(); m->d_big.release(); m->d_results.release(); m->d_dbg.release();
   delete m;
 }
