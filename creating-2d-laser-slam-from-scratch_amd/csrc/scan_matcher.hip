@@ -53,6 +53,7 @@ struct SearchCfg {
   int do_penalize;
 };
 
+constexpr int kRowZero = 64;  // k_resp_rows: row-load offset 0 = 64 zero guard bytes in front of plane 0
 constexpr int kMaxBeamsPerLane = 32;  // k_resp_rows: 8 lanes x 32 beams x 255 < 2^16 (packed DPP reduce)
 constexpr int kTileMinWaves = 2048;  // below this the fine pass stays on k_resp_rows (beam slices fill the chip)
 constexpr int kMaxGridSide = 32768;  // widthStep and height: dataSize <= 2^30, flat indices stay int32
@@ -236,16 +237,19 @@ k_nonzero_bits(const uint8_t* __restrict__ grid, int data_size, uint32_t* __rest
 }
 
 // pass B: bit(x, y) = any of the kOccWin flat bits starting at f = x + y*widthStep, written transposed
+// and SPLIT BY ROW PARITY: column x holds two bitmaps, bit h of bitmap E <-> row y = 2h + E - 1, so
+// the rows y0, y0+2, ... of the coarse lattice are consecutive bits (no bit gather in k_resp_rows).
 __global__ void __launch_bounds__(256)
 k_row_occupancy(const uint32_t* __restrict__ nz, int n_words, int stride, int height, int win,
-                uint32_t* __restrict__ occ_t, int words_per_col) {
+                uint32_t* __restrict__ occ_t, int words_per_half) {
   int x = blockIdx.x * blockDim.x + threadIdx.x;  // column (flat index mod widthStep)
-  int wq = blockIdx.y;                            // word index along y
-  if (x >= stride || wq >= words_per_col) return;
+  int wq = blockIdx.y;                            // word index: [parity][word along y]
+  if (x >= stride || wq >= 2 * words_per_half) return;
+  const int E = wq / words_per_half, w2 = wq - E * words_per_half;
   const unsigned long long wmask = (1ull << win) - 1ull;
   uint32_t bits = 0;
   for (int b = 0; b < 32; b++) {
-    int y = wq * 32 + b - 1;  // bit 0 of word 0 is y = -1
+    int y = 2 * (w2 * 32 + b) + E - 1;  // bit 0 of bitmap 0 is y = -1
     if (y > height) break;
     long long f = (long long)x + (long long)y * stride;  // may be negative for y = -1
     long long w0 = f >> 5;                                // floor
@@ -258,7 +262,7 @@ k_row_occupancy(const uint32_t* __restrict__ nz, int n_words, int stride, int he
     unsigned long long window = (lo >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
     if (window & wmask) bits |= 1u << b;
   }
-  occ_t[(size_t)x * words_per_col + wq] = bits;
+  occ_t[(size_t)x * (2 * words_per_half) + wq] = bits;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -268,33 +272,30 @@ k_row_occupancy(const uint32_t* __restrict__ nz, int n_words, int stride, int he
 //   STEP 2 (coarse pass): sources are the parity planes F_0/F_1 of the grid, a lattice row is nX
 //                         contiguous bytes of F_(base&1) starting at base>>1;
 //   STEP 1 (fine pass)  : the source is the grid itself.
-// Each lane owns beams lane, lane+64, ...; for a beam it computes the lookup-table offset on the fly
-// in fp64 (no table round trip through HBM), loads the beam's whole candidate neighbourhood --
-// NY rows of 4*NXD contiguous bytes, one unaligned load per row, branch-free (rows wholly outside
-// the valid index range read the zero guard band) -- and accumulates FOUR candidates per loaded
-// dword in packed 16-bit fields.  The per-lane packed partials are transposed through LDS and
-// reduced to exact int32 sums, written angle-major so the stores coalesce.
+// Phase A (every beam; lane = beam): the lookup-table cell on the fly in fp64 (no table round trip
+// through HBM; cos/sin of the angle come from k_pass_setup), the flat index in int32, the rows
+// inside the reference's 1-D index range, and -- coarse pass -- the exact row-occupancy bits; a beam
+// with at least one live row is pushed on a circular LDS queue (wave ballot compaction).
+// Phase B (every 64 queued beams; lane = beam): one dword-aligned 16-byte load per lattice row
+// (a dead row reads the zero guard band instead, so the loads are straight-line), realigned with
+// v_perm_b32 into FOUR candidates per dword in packed 16-bit fields.
+// Epilogue: three packed DPP adds reduce over groups of 8 lanes, 2 KB of LDS brings the 8 partials of
+// each packed word to one lane, which writes exact int32 sums angle-major (coalesced).
 // No MFMA: this is a gather/compare path over an L2-resident 4 MB grid.
 // Block -> (scan, angle) mapping keeps all angles of a scan on one XCD (block b runs on XCD b%8),
 // so a scan's 17 KB of scan-frame points is fetched into ONE L2 instead of eight.
 // ------------------------------------------------------------------------------------------
-#ifndef LSLAM_WAVES
-#define LSLAM_WAVES 1
-#endif
 template <int NXD, int NYC>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LSLAM_WAVES, 8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))  // <= 128 VGPRs
 k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int step, int limit, Geom g,
             PassCfg pc, const Lattice* __restrict__ lat, const double2* __restrict__ cossin,
             const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int beam_slices,
             int S, const uint32_t* __restrict__ occ_t, int occ_wpc) {
   constexpr int NW = NXD * NYC * 2;
-#ifndef LSLAM_U
-#define LSLAM_U 1
-#endif
-  constexpr int U = LSLAM_U;           // beam chunks (of 64) in flight per phase-A iteration
-  constexpr int kQueue = 64 * (U + 1);
+  constexpr int kQueue = 128;
+  static_assert(NYC <= 16 && 2 * (NYC - 1) < 32, "row mask / occupancy window width");
   __shared__ __align__(16) uint32_t red[NW][8];  // [packed word][group of 8 lanes]
-  __shared__ int2 queue[kQueue];  // .x = first row index m0, .y = row mask | parity << 31
+  __shared__ int2 queue[kQueue];  // circular; .x = first row index m0, .y = row mask | parity << 31
   const int lane = threadIdx.x;
   int w = blockIdx.x;
   const int slice = w % beam_slices;
@@ -312,9 +313,11 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
   const double2* lp = local + (size_t)s * g.n_beams;
   const int ncand = pc.nx * pc.ny;
   const int shift = step == 2 ? 1 : 0;
-  const unsigned long long lane_lt = (1ull << lane) - 1ull;
   const int bstride = 64 * beam_slices;
-  constexpr uint32_t kNoOcc = 0xFFFFFFFFu;
+  // row loads address zbase + 32-bit offset: offset 0 is the zero guard band in front of plane 0
+  const uint8_t* zbase = src0 - kRowZero;
+  const uint32_t plane_delta = (uint32_t)(src1 - src0);
+  const int occ_wph = occ_wpc >> 1;  // words per (column, row parity)
 
   for (int j0 = 0; j0 < pc.ny; j0 += NYC) {
     uint32_t acc[NYC][NXD][2];
@@ -325,17 +328,11 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
 
     // Phase B: one queued beam per lane -- load the rows its mask names, accumulate 4 candidates per dword
     auto drain = [&](int head, int cnt) {
-      int2 e = lane < cnt ? queue[head + lane] : make_int2(0, 0);
-#ifdef LSLAM_EXP_NODRAIN
-      acc[0][0][0] += e.x + e.y;
-      return;
-#endif
-      const uint8_t* src = (e.y < 0) ? src1 : src0;
-      const uint32_t mask = (uint32_t)e.y & 0x7FFFFFFFu;
+      const int2 e = lane < cnt ? queue[(head + lane) & (kQueue - 1)] : make_int2(0, 0);
       // dword-ALIGNED loads of NXD+1 words covering the row, realigned in registers: the planes and
       // widthStep are multiples of 4, so every row of a beam has the same byte phase
       const uint32_t sh = (uint32_t)e.x & 3u;
-      const long long a0 = (long long)e.x - (long long)sh;
+      uint32_t cur = ((uint32_t)e.x & ~3u) + (uint32_t)kRowZero + (e.y < 0 ? plane_delta : 0u);
       // v_perm_b32 selectors: bytes sh+0 / sh+2 (even candidates) and sh+1 / sh+3 (odd) of the word pair,
       // each zero-extended into a 16-bit field (0x0C selects the constant 0)
       const uint32_t sel_e = 0x0C020C00u + sh * 0x00010001u;
@@ -343,11 +340,10 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       uint32_t wv[NYC][NXD + 1];
 #pragma unroll
       for (int j = 0; j < NYC; j++) {
-#pragma unroll
-        for (int k = 0; k <= NXD; k++) wv[j][k] = 0u;
-        // a masked row reads the zero guard band instead: straight-line loads beat exec-masked ones
-        const uint8_t* ad = ((mask >> j) & 1u) ? src + (a0 + (long long)j * g.stride) : src0 - 64;
-        __builtin_memcpy(wv[j], __builtin_assume_aligned(ad, 4), 4 * (NXD + 1));
+        // a masked row reads the zeros at offset 0 instead: straight-line loads beat exec-masked ones
+        const uint32_t off = cur & (uint32_t)__builtin_amdgcn_sbfe(e.y, j, 1);
+        __builtin_memcpy(wv[j], __builtin_assume_aligned(zbase + off, 4), 4 * (NXD + 1));
+        cur += (uint32_t)g.stride;
       }
 #pragma unroll
       for (int j = 0; j < NYC; j++)
@@ -359,112 +355,88 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
     };
 
     // Phase A: every beam -- table entry, row mask (bounds + exact row occupancy); survivors are queued.
-    // U chunks of 64 beams per iteration with their loads issued together.  The lattice lies inside
-    // the grid (k_pass_setup) and the grid has <= 2^30 cells, so for a beam whose table cell is
-    // within +-2^15 cells every index below is exact in int32 (24-bit multiplies, no 64-bit
-    // compares); any other beam takes the 64-bit path.
-    int qcount = 0;
+    // The lattice lies inside the grid (k_pass_setup) and the grid has <= 2^30 cells, so for a beam whose
+    // table cell is within +-2^15 cells every index below is exact in int32 (24-bit multiplies, unsigned
+    // range compares); any other beam takes the 64-bit path.
+    int qcount = 0, qhead = 0;
     const int rows_here = min(NYC, pc.ny - j0);
-    const uint32_t all_rows = rows_here >= 32 ? 0xFFFFFFFFu : ((1u << rows_here) - 1u);
+    const uint32_t all_rows = (1u << rows_here) - 1u;
     const int B0 = X0 + Y0 * g.stride + j0 * step * g.stride;
-    const int Yb = Y0 + j0 * step;
+    const int Yb1 = Y0 + j0 * step + 1;
     const int m0_max = limit - ((rows_here - 1) * g.stride + 4 * NXD);  // whole neighbourhood in range
     const int y1_max = g.height + 1 - step * (NYC - 1);                 // y+1 range of the occupancy window
-    for (int b0 = 64 * slice; b0 < g.n_beams; b0 += bstride * U) {
-      double2 p[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) p[u] = lp[min(b0 + u * bstride + lane, g.n_beams - 1)];
-      uint32_t mask[U], par[U], osh[U];
-      int m0i[U];
-      uint32_t col[U];  // word index into occ_t
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        mask[u] = 0u, par[u] = 0u, osh[u] = kNoOcc, m0i[u] = 0, col[u] = 0u;
-        if (b0 + u * bstride >= g.n_beams) continue;  // wave-uniform
-        const int b = b0 + u * bstride + lane;
-        if (b < g.n_beams && !isnan(p[u].x)) {  // NaN = INVALID_SCAN
-          int gx, gy;
-          lookup_cell_i32(p[u].x, p[u].y, cosine, sine, g.off_x, g.off_y, g.scale, gx, gy);
-          if ((((uint32_t)(gx + 32768)) | ((uint32_t)(gy + 32768))) < 65536u) {
-            const int base = B0 + gx + __mul24(gy, g.stride);  // Karto.h:6494 + Mapper.cpp:838
-            par[u] = (uint32_t)(base & shift);
-            const int m0 = base >> shift;  // arithmetic shift = floor
-            uint32_t mk = 0;
-            // rows inside the valid index range (the reference's 1-D check, Mapper.cpp:841-845)
-            if (m0 >= 0 && m0 <= m0_max) {
-              mk = all_rows;
-            } else {
-              for (int j = 0; j < rows_here; j++) {
-                const int rs = m0 + j * g.stride;
-                if (rs >= -(4 * NXD) && rs < limit) mk |= 1u << j;
-              }
-            }
-            if (occ_t && mk) {  // exact row occupancy: bit j*step <-> lattice row j0+j
-              int x = X0 + gx, y = Yb + gy;
-              if ((uint32_t)x >= (uint32_t)g.stride) {  // flat index wrapped into a neighbouring row
-                y = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
-                x = base - y * g.stride;
-              }
-              if (y >= -1 && y + 1 <= y1_max) {
-                col[u] = (uint32_t)__mul24(x, occ_wpc) + (uint32_t)((y + 1) >> 5);
-                osh[u] = (uint32_t)((y + 1) & 31);
-              }
-            }
-            mask[u] = mk;
-            m0i[u] = m0;
+    for (int b0 = 64 * slice; b0 < g.n_beams; b0 += bstride) {
+      const int b = b0 + lane;
+      const double2 p = lp[min(b, g.n_beams - 1)];
+      uint32_t mask = 0u, par = 0u, col = 0u, osh = 0u;
+      int m0i = 0;
+      bool have_occ = false;
+      // NaN = INVALID_SCAN (k_scan_prep writes both coordinates); testing both keeps the point ONE 16-byte load
+      if ((b < g.n_beams) & !isnan(p.x) & !isnan(p.y)) {
+        // ComputeOffsets + WorldToGrid (Karto.h:6465-6494, 4237-4252): identical fp64 expression tree;
+        // (int)math::Round(v) taken as trunc(copysign(|v| + 0.5, v))
+        const double ox = cosine * p.x - sine * p.y, oy = sine * p.x + cosine * p.y;
+        const double vx = ((ox + g.off_x) - g.off_x) * g.scale, vy = ((oy + g.off_y) - g.off_y) * g.scale;
+        const double ax = fabs(vx) + 0.5, ay = fabs(vy) + 0.5;
+        const int gx = (int)copysign(ax, vx), gy = (int)copysign(ay, vy);
+        if (fmax(ax, ay) < 32768.0) {  // |gx|, |gy| < 2^15
+          const int base = B0 + gx + __mul24(gy, g.stride);  // Karto.h:6494 + Mapper.cpp:838
+          par = (uint32_t)(base & shift);
+          const int m0 = base >> shift;  // arithmetic shift = floor
+          // rows inside the valid index range (the reference's 1-D check, Mapper.cpp:841-845)
+          if (m0_max >= 0 && (uint32_t)m0 <= (uint32_t)m0_max) {
+            mask = all_rows;
           } else {
-            const int t = gx + gy * g.stride;  // int32 like the reference
-            const long long base = (long long)B0 + t;
-            par[u] = (uint32_t)((int)(base & 1) & shift);
-            const long long m0 = base >> shift;
-            uint32_t mk = 0;
             for (int j = 0; j < rows_here; j++) {
-              long long rs = m0 + (long long)j * g.stride;
-              if (rs >= -(long long)(4 * NXD) && rs < (long long)limit) mk |= 1u << j;
+              const int rs = m0 + j * g.stride;
+              if (rs >= -(4 * NXD) && rs < limit) mask |= 1u << j;
             }
-            mask[u] = mk;  // no occupancy pruning on this path
-            m0i[u] = (int)m0;
           }
+          if (occ_t) {  // exact row occupancy (step 2): lattice rows are consecutive bits of one parity
+            int x = X0 + gx, y1 = Yb1 + gy;
+            if ((uint32_t)x >= (uint32_t)g.stride) {  // flat index wrapped into a neighbouring row
+              const int y = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
+              x = base - y * g.stride;
+              y1 = y + 1;
+            }
+            if ((uint32_t)y1 <= (uint32_t)y1_max) {
+              have_occ = true;
+              col = (uint32_t)__mul24(2 * x + (y1 & 1), occ_wph) + ((uint32_t)y1 >> 6);
+              osh = ((uint32_t)y1 >> 1) & 31u;
+            }
+          }
+          m0i = m0;
+        } else {
+          const int t = gx + gy * g.stride;  // int32 like the reference
+          const long long base = (long long)B0 + t;
+          par = (uint32_t)((int)(base & 1) & shift);
+          const long long m0 = base >> shift;
+          for (int j = 0; j < rows_here; j++) {
+            long long rs = m0 + (long long)j * g.stride;
+            if (rs >= -(long long)(4 * NXD) && rs < (long long)limit) mask |= 1u << j;
+          }
+          m0i = (int)m0;  // no occupancy pruning on this path
         }
       }
       if (occ_t) {
-        unsigned long long two[U];
-#pragma unroll
-        for (int u = 0; u < U; u++)
-          two[u] = (unsigned long long)occ_t[col[u]] | ((unsigned long long)occ_t[(size_t)col[u] + 1] << 32);
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          static_assert(2 * (NYC - 1) < 32, "occupancy window must fit 32 bits");
-          uint32_t keep = (uint32_t)(two[u] >> (osh[u] & 31u));  // bit j*step <-> row j
-          if (shift) {  // gather the even bits
-            keep &= 0x55555555u;
-            keep = (keep | (keep >> 1)) & 0x33333333u;
-            keep = (keep | (keep >> 2)) & 0x0F0F0F0Fu;
-            keep = (keep | (keep >> 4)) & 0x00FF00FFu;
-            keep = (keep | (keep >> 8)) & 0x0000FFFFu;
-          }
-          if (osh[u] != kNoOcc) mask[u] &= keep;
-        }
+        const uint32_t lo = occ_t[col], hi = occ_t[(size_t)col + 1];
+        const uint32_t keep = __builtin_amdgcn_alignbit(hi, lo, osh);  // bit j <-> lattice row j0 + j
+        mask &= have_occ ? keep : 0xFFFFFFFFu;
       }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const unsigned long long votes = __ballot(mask[u] != 0);
-        if (mask[u]) queue[qcount + __popcll(votes & lane_lt)] = make_int2(m0i[u], (int)(mask[u] | (par[u] << 31)));
-        qcount += __popcll(votes);
+      const unsigned long long votes = __ballot(mask != 0);
+      if (mask) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(votes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)votes, 0u));
+        queue[(qhead + qcount + rank) & (kQueue - 1)] = make_int2(m0i, (int)(mask | (par << 31)));
       }
+      qcount += __popcll(votes);
       __syncthreads();
       if (qcount >= 64) {
-        int head = 0;
-        for (; qcount - head >= 64; head += 64) drain(head, 64);
-        const int rest = qcount - head;
-        int2 moved = lane < rest ? queue[head + lane] : make_int2(0, 0);
-        __syncthreads();
-        if (lane < rest) queue[lane] = moved;
-        qcount = rest;
-        __syncthreads();
+        drain(qhead, 64);
+        qhead = (qhead + 64) & (kQueue - 1);
+        qcount -= 64;
       }
     }
-    if (qcount > 0) drain(0, qcount);
+    if (qcount > 0) drain(qhead, qcount);
     __syncthreads();
 
     // Reduce over the wave.  A lane saw at most kMaxBeamsPerLane beams (the host slices longer scans),
@@ -1620,7 +1592,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     launch(ctx, "nonzero_bits", k_nonzero_bits, dim3((m->nz_words + 255) / 256), dim3(256), 0,
            (const uint8_t*)m->d_grid, g.data_size, m->d_nz, m->nz_words);
     launch(ctx, "row_occupancy", k_row_occupancy, dim3((g.stride + 255) / 256, m->occ_wpc), dim3(256), 0,
-           (const uint32_t*)m->d_nz, m->nz_words, g.stride, g.height, m->occ_win, m->d_occ_t, m->occ_wpc);
+           (const uint32_t*)m->d_nz, m->nz_words, g.stride, g.height, m->occ_win, m->d_occ_t, m->occ_wpc / 2);
     m->sub_dirty = false;
   }
   auto reduce_lds = [&](const PassCfg& p, bool cache) -> size_t {
@@ -1929,7 +1901,7 @@ int lslam_matcher_create(lslam_context* ctx, const lslam_matcher_config* cfg, co
     const int nx = lattice_count(0.5 * ((double)g.probs_side - 1) * res, 2 * res);
     m->occ_win = std::min(kOccWinMax, std::max(3, 2 * (nx - 1) + 1));
   }
-  m->occ_wpc = (g.height + 2 + 63) / 32 + 1;
+  m->occ_wpc = 2 * (((g.height + 2) / 2 + 1 + 31) / 32 + 1);  // two row-parity bitmaps per column, +1 word each for the 64-bit read
   m->nz_words = (g.data_size + 31) / 32;
   if (hipMalloc((void**)&m->d_occ_t, (size_t)g.stride * m->occ_wpc * sizeof(uint32_t)) != hipSuccess ||
       hipMalloc((void**)&m->d_nz, (size_t)m->nz_words * sizeof(uint32_t)) != hipSuccess) {
