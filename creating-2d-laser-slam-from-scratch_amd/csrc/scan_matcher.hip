@@ -865,6 +865,205 @@ k_reduce_coarse(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ la
 }
 
 // ------------------------------------------------------------------------------------------
+// k_reduce_coarse_lds: k_reduce_coarse<true> restructured for throughput (same results bit for bit;
+// used when all penalised responses fit LDS and the tie mask has <= 256 words).  Differences:
+//  * the two penalty factors depend on the lattice cell only (distance) and on the angle only, so
+//    they are tabulated once (121 + 21 entries here) and a candidate costs one exact fp64 division
+//    and two multiplications -- r *= (dp * ap), the reference's own grouping (Mapper.cpp:399-414);
+//  * candidate indices advance incrementally (no integer divisions in the loops);
+//  * the search-space-probability merge is a max (order-independent): 64-bit LDS atomicMax on the
+//    bit patterns of non-negative doubles instead of a 121-step serial loop;
+//  * the tie average visits only the non-zero mask words (wave ballots), still in lattice order on
+//    one thread; the ordered covariance sums stay on one thread, with their LDS reads batched.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ lat,
+                    const int32_t* __restrict__ resp, size_t resp_stride, CoarseOut* __restrict__ out,
+                    int use_expansion, int pass_index) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double sh[256];
+  __shared__ double s_ap[kMaxAngles];
+  __shared__ unsigned long long s_nz[4];
+  __shared__ double s_avg[3];
+  __shared__ int s_status, s_bad;
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const Lattice& L = lat[s];
+  if (!L.active) return;
+  if (L.status != 0) {
+    if (tid == 0) { out[s].status = L.status; out[s].expand = 0; out[s].best = 0.0; }
+    return;
+  }
+  const int ncand = pc.nx * pc.ny;
+  const int total = ncand * pc.na;
+  const int words = (total + 31) / 32;  // <= 256 (host)
+  double* presp = (double*)smem;
+  double* latmax = presp + total;
+  double* probs = latmax + ncand;
+  double* terms = probs + g.probs_side * g.probs_side;  // 4 per lattice cell
+  uint32_t* mask = (uint32_t*)(terms + 4 * ncand);
+  int* cell = (int*)(mask + words);
+  double* dpen = terms;  // distance penalty per lattice cell; dead before `terms` is written
+  const int32_t* r = resp + (size_t)s * resp_stride;
+  const double center[3] = {L.center[0], L.center[1], L.center[2]};
+
+  // per-cell and per-angle penalty factors (Mapper.cpp:399-414) + search-space cell of every lattice
+  // position (offset = searchCenter - searchSpaceOffset, :332-333; WorldToGrid of the position, :440)
+  const double p_off_x = center[0] - pc.off_x, p_off_y = center[1] - pc.off_y;
+  if (tid == 0) s_bad = 0;
+  for (int c = tid; c < ncand; c += 256) {
+    const int xi = c % pc.nx, yi = c / pc.nx;
+    const double x = -pc.off_x + (uint32_t)xi * pc.res_x;  // Mapper.cpp:342-345
+    const double y = -pc.off_y + (uint32_t)yi * pc.res_y;  // :353-356
+    const double sd = ksq(x) + ksq(y);
+    double dp = 1.0 - (kDistPenaltyGain * sd / sc.dvp);
+    dpen[c] = dp > sc.min_dp ? dp : sc.min_dp;
+    const double wx = center[0] + x, wy = center[1] + y;
+    const int gx = world_to_grid(wx, p_off_x, g.scale), gy = world_to_grid(wy, p_off_y, g.scale);
+    cell[c] = (gx < 0 || gx >= g.probs_side || gy < 0 || gy >= g.probs_side) ? -1 : gy * g.probs_side + gx;
+  }
+  for (int a = tid; a < pc.na; a += 256) {
+    const double angle = (center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;  // :390-393
+    const double sad = ksq(angle - center[2]);
+    double ap = 1.0 - (kAnglePenaltyGain * sad / sc.avp);
+    s_ap[a] = ap > sc.min_ap ? ap : sc.min_ap;
+  }
+  for (int wd = tid; wd < words; wd += 256) mask[wd] = 0u;
+  for (int c = tid; c < g.probs_side * g.probs_side; c += 256) probs[c] = 0.0;  // Clear (:329)
+  __syncthreads();
+
+  // penalised responses, storage order (angle-major, coalesced) -> candidate order k = c*nA + a in LDS
+  const double denom = (double)((uint32_t)g.n_beams * (uint32_t)kOccupied);
+  double lm = -1.0;  // bestResponse starts at -1 (Mapper.cpp:431)
+  {
+    int a = tid / ncand, c = tid - a * ncand;
+    for (int t = tid; t < total; t += 256) {
+      double v = (double)r[t] / denom;  // GetResponse normalisation (:852)
+      if (sc.do_penalize && !double_equal(v, 0.0)) v *= (dpen[c] * s_ap[a]);
+      presp[c * pc.na + a] = v;
+      lm = lm > v ? lm : v;
+      c += 256;
+      while (c >= ncand) { c -= ncand; a++; }
+    }
+  }
+  const double best = block_max(lm, sh, tid, 256);  // contains the barriers that publish presp
+
+  // best response per lattice cell over all angles, max-merged into the search-space probabilities
+  // (Mapper.cpp:437-450); responses are >= +0, so the unsigned order of the bit patterns is the fp order
+  for (int c = tid; c < ncand; c += 256) {
+    double m = -1.0;
+    const double* pr = presp + c * pc.na;
+    for (int a = 0; a < pc.na; a++) m = m > pr[a] ? m : pr[a];
+    latmax[c] = m;
+    if (cell[c] < 0) s_bad = 1;
+    else atomicMax((unsigned long long*)&probs[cell[c]], (unsigned long long)__double_as_longlong(m < 0.0 ? 0.0 : m));
+  }
+  for (int k = tid; k < total; k += 256)
+    if (double_equal(presp[k], best)) atomicOr(&mask[k >> 5], 1u << (k & 31));
+  __syncthreads();
+  {  // which mask words are non-zero (words <= 256 = one per thread)
+    const unsigned long long nz = __ballot(tid < words && mask[tid] != 0u);
+    if ((tid & 63) == 0) s_nz[tid >> 6] = nz;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int st = s_bad ? LSLAM_ERR_PROBABILITY_SEARCH : 0;
+    double avg[3] = {0, 0, 0};
+    if (st == 0) {  // tie average in lattice order (Mapper.cpp:456-483), only over the words that hold ties
+      double ax = 0, ay = 0, tx = 0, ty = 0;
+      int cnt = 0;
+      for (int wv = 0; wv < 4; wv++) {
+        unsigned long long nzw = s_nz[wv];
+        while (nzw) {
+          const int wd = wv * 64 + (__ffsll((long long)nzw) - 1);
+          nzw &= nzw - 1;
+          uint32_t m = mask[wd];
+          while (m) {
+            const int bit = __ffs(m) - 1;
+            m &= m - 1;
+            const Cand cd = cand_of(wd * 32 + bit, pc, center);
+            const double h = normalize_angle(cd.angle);  // stored heading (:417-418)
+            ax += center[0] + cd.x;
+            ay += center[1] + cd.y;
+            tx += cos(h);
+            ty += sin(h);
+            cnt++;
+          }
+        }
+      }
+      if (cnt == 0) {
+        st = LSLAM_ERR_NO_BEST_POSE;
+      } else {
+        ax /= cnt; ay /= cnt; tx /= cnt; ty /= cnt;
+        avg[0] = ax; avg[1] = ay; avg[2] = atan2(ty, tx);
+      }
+    }
+    s_avg[0] = avg[0]; s_avg[1] = avg[1]; s_avg[2] = avg[2];
+    s_status = st;
+  }
+  __syncthreads();
+  // ComputePositionalCovariance terms (Mapper.cpp:573-594), one lattice cell per thread
+  const double dx = s_avg[0] - center[0], dy = s_avg[1] - center[1];
+  for (int c = tid; c < ncand; c += 256) {
+    const int xi = c % pc.nx, yi = c / pc.nx;
+    const double x = -pc.off_x + (uint32_t)xi * pc.res_x;
+    const double y = -pc.off_y + (uint32_t)yi * pc.res_y;
+    const double rr = cell[c] >= 0 ? probs[cell[c]] : 0.0;
+    terms[4 * c + 0] = rr;
+    terms[4 * c + 1] = (ksq(x - dx) * rr);
+    terms[4 * c + 2] = ((x - dx) * (y - dy) * rr);
+    terms[4 * c + 3] = (ksq(y - dy) * rr);
+  }
+  __syncthreads();
+  if (tid != 0) return;
+
+  CoarseOut o;
+  o.status = s_status;
+  o.flags = pass_index > 0 ? 1 : 0;
+  o.pad = 0;
+  const double avg[3] = {s_avg[0], s_avg[1], s_avg[2]};
+  double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (o.status == 0) {
+    if (best < kTol) {
+      cov[0] = kMaxVariance; cov[4] = kMaxVariance; cov[8] = 4 * ksq(pc.ang_res);
+    } else {
+      double axx = 0, axy = 0, ayy = 0, norm = 0;
+      const double thr = best - 0.1;
+      int c = 0;
+      for (; c + 4 <= ncand; c += 4) {  // y outer, x inner = candidate-cell order; reads batched, adds in order
+        double q[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) q[i] = terms[4 * c + i];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (q[4 * i] >= thr) { norm += q[4 * i]; axx += q[4 * i + 1]; axy += q[4 * i + 2]; ayy += q[4 * i + 3]; }
+      }
+      for (; c < ncand; c++) {
+        const double rr = terms[4 * c];
+        if (rr >= thr) { norm += rr; axx += terms[4 * c + 1]; axy += terms[4 * c + 2]; ayy += terms[4 * c + 3]; }
+      }
+      if (norm > kTol) {
+        double vxx = axx / norm, vxy = axy / norm, vyy = ayy / norm;
+        double vthth = 4 * ksq(pc.ang_res);
+        double min_xx = 0.1 * ksq(pc.res_x), min_yy = 0.1 * ksq(pc.res_y);
+        vxx = vxx > min_xx ? vxx : min_xx;
+        vyy = vyy > min_yy ? vyy : min_yy;
+        double mult = 1.0 / best;
+        cov[0] = vxx * mult; cov[1] = vxy * mult; cov[3] = vxy * mult; cov[4] = vyy * mult;
+        cov[8] = vthth;
+      }
+      if (double_equal(cov[0], 0.0)) cov[0] = kMaxVariance;
+      if (double_equal(cov[4], 0.0)) cov[4] = kMaxVariance;
+    }
+  }
+  o.mean[0] = avg[0]; o.mean[1] = avg[1]; o.mean[2] = avg[2];
+  for (int i = 0; i < 9; i++) o.cov[i] = cov[i];
+  o.best = best > 1.0 ? 1.0 : best;  // :514-517
+  // Mapper.cpp:242-244,259: expand (again) while the best response is still zero
+  o.expand = (use_expansion && o.status == 0 && pass_index < 3 && double_equal(o.best, 0.0)) ? 1 : 0;
+  out[s] = o;
+}
+
+// ------------------------------------------------------------------------------------------
 // Large lattices (the loop-closure matcher: search space 8-15 m -> 81..151 positions per side x 21
 // angles = 140-480 k candidates per match, Mapper.cpp:862-871, 976-1051).  Here the candidate
 // window of a beam is hundreds of cells wide and the windows of ALL candidates overlap almost
@@ -1712,7 +1911,11 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       LSLAM_HIP(ctx, hipMemcpyAsync(dbg_coarse_sums, m->d_resp.p, (size_t)p.nx * p.ny * p.na * sizeof(int32_t),
                                     hipMemcpyDeviceToDevice, ctx->stream));
     const bool cache = reduce_lds(p, true) <= 60 * 1024;
-    if (cache)
+    if (cache && ((size_t)p.nx * p.ny * p.na + 31) / 32 <= 256)
+      launch(ctx, "reduce_coarse", k_reduce_coarse_lds, dim3(S), dim3(256), reduce_lds(p, true), g, p, sc,
+             (const Lattice*)m->d_lat.p, (const int32_t*)m->d_resp.p, resp_stride, m->d_coarse.p,
+             (int)m->cfg.use_response_expansion, pass_index);
+    else if (cache)
       launch(ctx, "reduce_coarse", k_reduce_coarse<true>, dim3(S), dim3(256), reduce_lds(p, true), g, p, sc,
              (const Lattice*)m->d_lat.p, (const int32_t*)m->d_resp.p, resp_stride, m->d_coarse.p,
              (int)m->cfg.use_response_expansion, pass_index);
