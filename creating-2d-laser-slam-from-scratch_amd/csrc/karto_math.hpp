@@ -115,8 +115,15 @@ LSLAM_HD SensorXform sensor_xform(double px, double py, double ph) {
 LSLAM_HD void beam_world_point(double sx, double sy, double sh, double min_angle, double ang_res,
                                uint32_t beam, double r, double& px, double& py) {
   double angle = sh + min_angle + beam * ang_res;
+#if defined(__HIP_DEVICE_COMPILE__)
+  double sn, cs;  // one shared argument reduction; ocml's sincos returns the same values as sin and cos
+  sincos(angle, &sn, &cs);
+  px = sx + (r * cs);
+  py = sy + (r * sn);
+#else
   px = sx + (r * cos(angle));
   py = sy + (r * sin(angle));
+#endif
 }
 
 // One lookup-table entry of GridIndexLookup::ComputeOffsets (Karto.h:6486-6496): local point

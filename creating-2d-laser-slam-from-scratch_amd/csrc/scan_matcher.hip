@@ -86,8 +86,18 @@ k_scan_prep(const RT* __restrict__ ranges, int stride, const double* __restrict_
             double2* __restrict__ local, double2* __restrict__ world) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   int s = blockIdx.y;
-  if (b >= g.n_beams) return;
   double sx = poses[3 * s], sy = poses[3 * s + 1], sh = poses[3 * s + 2];
+  // the scan's own transform (two rotation matrices, one normalised heading) is the same for all of
+  // its beams: one thread of the block evaluates it
+  __shared__ SensorXform s_t;
+  __shared__ double s_h;
+  if (local && threadIdx.x == 0) {
+    s_t = sensor_xform(sx, sy, sh);
+    // rSourcePose - m_Transform (Pose2 operator-, Karto.h:2138-2141), heading = normalize(0 - th)
+    s_h = normalize_angle(0.0 - s_t.th);
+  }
+  __syncthreads();
+  if (b >= g.n_beams) return;
   double r = (double)ranges[(size_t)s * stride + b];
   double px, py;
   beam_world_point(sx, sy, sh, g.min_angle, g.ang_res, (uint32_t)b, r, px, py);
@@ -98,10 +108,7 @@ k_scan_prep(const RT* __restrict__ ranges, int stride, const double* __restrict_
     if (isnan(r) || isinf(r)) {
       lx = ly = __builtin_nan("");
     } else {
-      SensorXform t = sensor_xform(sx, sy, sh);
-      // rSourcePose - m_Transform (Pose2 operator-, Karto.h:2138-2141), heading = normalize(0 - th)
-      double h = normalize_angle(0.0 - t.th);
-      rot_apply(t.inv, px - t.tx, py - t.ty, h, lx, ly);
+      rot_apply(s_t.inv, px - s_t.tx, py - s_t.ty, s_h, lx, ly);
     }
     local[o] = make_double2(lx, ly);
   }
