@@ -53,6 +53,8 @@ struct SearchCfg {
   int do_penalize;
 };
 
+constexpr int kTilePad = 128;  // zero bytes in front of the tiled parity planes (dead rows read offset 0)
+constexpr int kTileYOff = 32;  // tiled planes: class rows start at grid row y = -kTileYOff (>= 2*16 - 1 + 1)
 constexpr int kRowZero = 64;  // k_resp_rows: row-load offset 0 = 64 zero guard bytes in front of plane 0
 constexpr int kMaxBeamsPerLane = 32;  // k_resp_rows: 8 lanes x 32 beams x 255 < 2^16 (packed DPP reduce)
 constexpr int kTileMinWaves = 2048;  // below this the fine pass stays on k_resp_rows (beam slices fill the chip)
@@ -208,6 +210,40 @@ k_deinterleave(const uint8_t* __restrict__ grid, uint8_t* __restrict__ f0, uint8
 }
 
 // ------------------------------------------------------------------------------------------
+// k_tile_planes: the parity planes again, TILED for the gather unit.  A vector-memory instruction
+// costs about one cycle per distinct 128-byte line its lanes touch (tools/micro/ta_rate.hip), and in
+// the linear planes the 64 beams of a row load sit on ~40 different lines: neighbouring beams of a
+// wall that is not parallel to x fall into different grid rows.  Here a line is a 2-D patch --
+// 4 lattice-consecutive rows (grid rows 2 apart: the planes are split by row parity as well) x 32
+// bytes -- and patches step 16 bytes in x, so every dword-aligned 16-byte row segment lies inside
+// one patch (2x the plane bytes).  Defined on the FLAT plane index like the planes themselves:
+//   T[q][ry][ty][tx][r][c] = F_q[((2*(4 ty + r) + ry) - kTileYOff) * widthStep/2 + 16 tx + c],
+// zero outside [0, dataSize/2); c in [0,32) may run past the row end = the next row (flat wrap).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_tile_planes(const uint8_t* __restrict__ grid, int stride, int data_size, uint32_t* __restrict__ tiles,
+              int tile_tx, int tile_ty) {
+  const size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // output dword
+  const size_t per_class = (size_t)tile_ty * tile_tx * 32;
+  if (d >= 4 * per_class) return;
+  const int cls = (int)(d / per_class);  // q * 2 + ry
+  const size_t rem = d - (size_t)cls * per_class;
+  const int c4 = (int)(rem & 7), r = (int)((rem >> 3) & 3);
+  const size_t t = rem >> 5;
+  const int tx = (int)(t % tile_tx), ty = (int)(t / tile_tx);
+  const int q = cls >> 1, ry = cls & 1;
+  const long long y = (long long)(2 * (4 * ty + r) + ry) - kTileYOff;
+  const long long m = y * (stride / 2) + 16 * tx + 4 * c4;
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const long long idx = 2 * (m + k) + q;
+    if (m + k >= 0 && idx < data_size) v |= (uint32_t)grid[idx] << (8 * k);
+  }
+  tiles[kTilePad / 4 + d] = v;
+}
+
+// ------------------------------------------------------------------------------------------
 // k_row_occupancy: exact skip mask for the row loads of k_resp_rows.  Only ~0.4 % of the grid is
 // non-zero, so most candidate rows of most beams sum zeros.  bit(x, y) = any G_flat[f .. f+kOccWin-1]
 // != 0 for f = x + y*widthStep (flat index, out-of-range bytes count as zero, y from -1).
@@ -292,12 +328,12 @@ k_row_occupancy(const uint32_t* __restrict__ nz, int n_words, int stride, int he
 // Block -> (scan, angle) mapping keeps all angles of a scan on one XCD (block b runs on XCD b%8),
 // so a scan's 17 KB of scan-frame points is fetched into ONE L2 instead of eight.
 // ------------------------------------------------------------------------------------------
-template <int NXD, int NYC>
+template <int NXD, int NYC, bool TILED>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))  // <= 128 VGPRs
 k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int step, int limit, Geom g,
             PassCfg pc, const Lattice* __restrict__ lat, const double2* __restrict__ cossin,
             const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int beam_slices,
-            int S, const uint32_t* __restrict__ occ_t, int occ_wpc) {
+            int S, const uint32_t* __restrict__ occ_t, int occ_wpc, int tile_tx, uint32_t tile_class_bytes) {
   constexpr int NW = NXD * NYC * 2;
   constexpr int kQueue = 128;
   static_assert(NYC <= 16 && 2 * (NYC - 1) < 32, "row mask / occupancy window width");
@@ -322,8 +358,10 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
   const int shift = step == 2 ? 1 : 0;
   const int bstride = 64 * beam_slices;
   // row loads address zbase + 32-bit offset: offset 0 is the zero guard band in front of plane 0
-  const uint8_t* zbase = src0 - kRowZero;
-  const uint32_t plane_delta = (uint32_t)(src1 - src0);
+  // (TILED: src0 is the tiled-plane buffer itself, whose first kTilePad bytes are zero)
+  const uint8_t* zbase = TILED ? src0 : src0 - kRowZero;
+  const uint32_t plane_delta = TILED ? 0u : (uint32_t)(src1 - src0);
+  const uint32_t tile_row_bytes = (uint32_t)tile_tx * 128u;  // one row of tiles
   const int occ_wph = occ_wpc >> 1;  // words per (column, row parity)
 
   for (int j0 = 0; j0 < pc.ny; j0 += NYC) {
@@ -339,18 +377,35 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       // dword-ALIGNED loads of NXD+1 words covering the row, realigned in registers: the planes and
       // widthStep are multiples of 4, so every row of a beam has the same byte phase
       const uint32_t sh = (uint32_t)e.x & 3u;
-      uint32_t cur = ((uint32_t)e.x & ~3u) + (uint32_t)kRowZero + (e.y < 0 ? plane_delta : 0u);
       // v_perm_b32 selectors: bytes sh+0 / sh+2 (even candidates) and sh+1 / sh+3 (odd) of the word pair,
       // each zero-extended into a 16-bit field (0x0C selects the constant 0)
       const uint32_t sel_e = 0x0C020C00u + sh * 0x00010001u;
       const uint32_t sel_o = 0x0C030C01u + sh * 0x00010001u;
       uint32_t wv[NYC][NXD + 1];
+      if constexpr (TILED) {
+        // e.x = X' | parity << 15 | (y + kTileYOff) << 16 (k_tile_planes): lattice row j is class row
+        // (yy >> 1) + j of class yy & 1; tile = 4 class rows x 32 bytes, tiles step 16 bytes in x
+        const uint32_t xa = (uint32_t)e.x & 0x7FFCu, yy = (uint32_t)e.x >> 16;
+        const uint32_t base_off = (uint32_t)kTilePad + (((uint32_t)e.x >> 15) & 1u) * 2u * tile_class_bytes +
+                                  (yy & 1u) * tile_class_bytes + (xa >> 4) * 128u + (xa & 15u);
+        const uint32_t z = (yy >> 1) << 5;  // class row * 32
 #pragma unroll
-      for (int j = 0; j < NYC; j++) {
-        // a masked row reads the zeros at offset 0 instead: straight-line loads beat exec-masked ones
-        const uint32_t off = cur & (uint32_t)__builtin_amdgcn_sbfe(e.y, j, 1);
-        __builtin_memcpy(wv[j], __builtin_assume_aligned(zbase + off, 4), 4 * (NXD + 1));
-        cur += (uint32_t)g.stride;
+        for (int j = 0; j < NYC; j++) {
+          const uint32_t zj = z + 32u * j;
+          uint32_t off = __umul24(zj >> 7, tile_row_bytes) + base_off;
+          off |= zj & 96u;  // row inside the tile; those two bits of base_off are clear
+          off &= (uint32_t)__builtin_amdgcn_sbfe(e.y, j, 1);  // a dead row reads the zero pad at offset 0
+          __builtin_memcpy(wv[j], __builtin_assume_aligned(zbase + off, 4), 4 * (NXD + 1));
+        }
+      } else {
+        uint32_t cur = ((uint32_t)e.x & ~3u) + (uint32_t)kRowZero + (e.y < 0 ? plane_delta : 0u);
+#pragma unroll
+        for (int j = 0; j < NYC; j++) {
+          // a masked row reads the zeros at offset 0 instead: straight-line loads beat exec-masked ones
+          const uint32_t off = cur & (uint32_t)__builtin_amdgcn_sbfe(e.y, j, 1);
+          __builtin_memcpy(wv[j], __builtin_assume_aligned(zbase + off, 4), 4 * (NXD + 1));
+          cur += (uint32_t)g.stride;
+        }
       }
 #pragma unroll
       for (int j = 0; j < NYC; j++)
@@ -399,20 +454,23 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
               if (rs >= -(4 * NXD) && rs < limit) mask |= 1u << j;
             }
           }
-          if (occ_t) {  // exact row occupancy (step 2): lattice rows are consecutive bits of one parity
-            int x = X0 + gx, y1 = Yb1 + gy;
+          int x = X0 + gx, y1 = Yb1 + gy;
+          if (occ_t || TILED) {
             if ((uint32_t)x >= (uint32_t)g.stride) {  // flat index wrapped into a neighbouring row
               const int y = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
               x = base - y * g.stride;
               y1 = y + 1;
             }
+          }
+          if (occ_t) {  // exact row occupancy (step 2): lattice rows are consecutive bits of one parity
             if ((uint32_t)y1 <= (uint32_t)y1_max) {
               have_occ = true;
               col = (uint32_t)__mul24(2 * x + (y1 & 1), occ_wph) + ((uint32_t)y1 >> 6);
               osh = ((uint32_t)y1 >> 1) & 31u;
             }
           }
-          m0i = m0;
+          // a live row has y + 2j >= -1, so y >= -(2 NYC - 1) > -kTileYOff whenever the mask is not empty
+          m0i = TILED ? (int)(((uint32_t)x >> 1) | (par << 15) | ((uint32_t)(y1 + kTileYOff - 1) << 16)) : m0;
         } else {
           const int t = gx + gy * g.stride;  // int32 like the reference
           const long long base = (long long)B0 + t;
@@ -422,7 +480,13 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
             long long rs = m0 + (long long)j * g.stride;
             if (rs >= -(long long)(4 * NXD) && rs < (long long)limit) mask |= 1u << j;
           }
-          m0i = (int)m0;  // no occupancy pruning on this path
+          if constexpr (TILED) {
+            const long long yl = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
+            const long long xl = base - yl * g.stride;
+            m0i = mask ? (int)(((uint32_t)xl >> 1) | (par << 15) | ((uint32_t)(yl + kTileYOff) << 16)) : 0;
+          } else {
+            m0i = (int)m0;
+          }  // no occupancy pruning on this path
         }
       }
       if (occ_t) {
@@ -1702,6 +1766,9 @@ struct lslam_matcher {
   int occ_win = 21;                 // grid bytes summarised per bit = row span of the coarse lattice
   uint32_t* d_nz = nullptr;         // flat non-zero bitmap, one bit per grid byte (k_nonzero_bits)
   int nz_words = 0;
+  uint8_t* d_ptiles = nullptr;      // tiled parity planes (k_tile_planes), allocated on first batch use
+  int ptile_tx = 0, ptile_ty = 0;
+  bool ptile_dirty = true, ptile_failed = false;
   uint4* d_tiles = nullptr;         // overlapping 4x4 cell blocks (k_tile4), allocated on first batch use
   int tile_cols = 0, tile_rows = 0;
   bool tile_dirty = true, tile_failed = false;
@@ -1853,15 +1920,43 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       const int limit = step == 2 ? g.data_size / 2 : g.data_size;
       // the bitmap covers row spans of kOccWin grid bytes: step*(nX-1)+1 must fit
       const uint32_t* occ = (m->use_row_occupancy && step == 2 && step * (p.nx - 1) + 1 <= m->occ_win) ? m->d_occ_t : (const uint32_t*)nullptr;
+      // coarse pass of a batch that fills the chip on its own: gather from the TILED parity planes
+      bool ptiled = step == 2 && slices == 1 && waves >= kTileMinWaves && !m->ptile_failed;
+      if (ptiled && !m->d_ptiles) {
+        m->ptile_tx = (g.stride / 2 + 15) / 16;
+        m->ptile_ty = ((g.height - 1 + kTileYOff) / 2) / 4 + 1;
+        const size_t bytes = (size_t)kTilePad + 4 * (size_t)m->ptile_ty * m->ptile_tx * 128;
+        if (bytes >= (1ull << 32) || hipMalloc((void**)&m->d_ptiles, bytes) != hipSuccess) {
+          (void)hipGetLastError();
+          m->d_ptiles = nullptr;
+          m->ptile_failed = true;  // keep to the linear planes
+          ptiled = false;
+        } else {
+          LSLAM_HIP(ctx, hipMemsetAsync(m->d_ptiles, 0, kTilePad, ctx->stream));
+        }
+      }
+      const uint32_t class_bytes = (uint32_t)((size_t)m->ptile_ty * m->ptile_tx * 128);
+      if (ptiled && m->ptile_dirty) {
+        const size_t dwords = (size_t)class_bytes;  // 4 classes x class_bytes / 4
+        launch(ctx, "tile_planes", k_tile_planes, dim3((unsigned)((dwords + 255) / 256)), dim3(256), 0,
+               (const uint8_t*)m->d_grid, g.stride, g.data_size, (uint32_t*)m->d_ptiles, m->ptile_tx, m->ptile_ty);
+        m->ptile_dirty = false;
+      }
+#define LSLAM_ROWS_ARGS(SRC0, SRC1)                                                                              \
+  grid, dim3(64), 0, SRC0, SRC1, step, limit, g, p, (const Lattice*)m->d_lat.p, (const double2*)m->d_cossin.p, \
+      (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc, m->ptile_tx, class_bytes
+      const uint8_t* pt = m->d_ptiles;
       if (variant == 1)
-        launch(ctx, name, k_resp_rows<1, 4>, grid, dim3(64), 0, s0, s1, step, limit, g, p, (const Lattice*)m->d_lat.p,
-               (const double2*)m->d_cossin.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc);
+        launch(ctx, name, k_resp_rows<1, 4, false>, LSLAM_ROWS_ARGS(s0, s1));
+      else if (variant == 2 && ptiled)
+        launch(ctx, name, k_resp_rows<3, 11, true>, LSLAM_ROWS_ARGS(pt, pt));
       else if (variant == 2)
-        launch(ctx, name, k_resp_rows<3, 11>, grid, dim3(64), 0, s0, s1, step, limit, g, p, (const Lattice*)m->d_lat.p,
-               (const double2*)m->d_cossin.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc);
+        launch(ctx, name, k_resp_rows<3, 11, false>, LSLAM_ROWS_ARGS(s0, s1));
+      else if (ptiled)
+        launch(ctx, name, k_resp_rows<4, 8, true>, LSLAM_ROWS_ARGS(pt, pt));
       else
-        launch(ctx, name, k_resp_rows<4, 8>, grid, dim3(64), 0, s0, s1, step, limit, g, p, (const Lattice*)m->d_lat.p,
-               (const double2*)m->d_cossin.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc);
+        launch(ctx, name, k_resp_rows<4, 8, false>, LSLAM_ROWS_ARGS(s0, s1));
+#undef LSLAM_ROWS_ARGS
       // scans whose lattice is not uniform (a coordinate rounds on a cell boundary) take the generic kernel
       launch(ctx, "resp_generic_fallback", k_resp_generic, dim3(128), dim3(64), 0, (const uint8_t*)m->d_grid, g, p,
              (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S,
@@ -1959,7 +2054,7 @@ int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, i
   g.off_x = center[0] - (0.5 * (g.roi_w - 1) * (1.0 / g.scale));
   g.off_y = center[1] - (0.5 * (g.roi_h - 1) * (1.0 / g.scale));
   LSLAM_HIP(ctx, hipMemsetAsync(m->d_grid, 0, (size_t)g.data_size, ctx->stream));  // Grid::Clear (Mapper.cpp:701)
-  m->sub_dirty = m->tile_dirty = true;
+  m->sub_dirty = m->tile_dirty = m->ptile_dirty = true;
   const int n = g.n_beams;
   if (B <= 0 || n <= 0) return LSLAM_OK;
   LSLAM_HIP(ctx, m->d_valid.reserve((size_t)B * n));
@@ -2141,6 +2236,7 @@ void lslam_matcher_destroy(lslam_matcher* m) {
   (void)hipFree(m->d_occ_t);
   (void)hipFree(m->d_nz);
   (void)hipFree(m->d_tiles);
+  (void)hipFree(m->d_ptiles);
   m->d_ranges64.release(); m->d_poses.release(); m->d_local.release(); m->d_world.release();
   m->d_valid.release(); m->d_fv_scratch.release(); m->d_lat.release(); m->d_cossin.release(); m->d_coarse.release(); m->d_resp.release();
   m->d_slow.release(); m->d_tbl.release(); m->d_big.release(); m->d_results.release(); m->d_dbg.release();
@@ -2181,7 +2277,7 @@ int lslam_matcher_set_grid_u8(lslam_matcher* m, const uint8_t* grid, const doubl
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   m->g.off_x = offset_xy[0];
   m->g.off_y = offset_xy[1];
-  m->sub_dirty = m->tile_dirty = true;
+  m->sub_dirty = m->tile_dirty = m->ptile_dirty = true;
   return LSLAM_OK;
 }
 
@@ -2192,7 +2288,7 @@ int lslam_matcher_set_grid_u8_dev(lslam_matcher* m, const uint8_t* grid_dev, con
     LSLAM_HIP(ctx, hipMemcpyAsync(m->d_grid, grid_dev, (size_t)m->g.data_size, hipMemcpyDeviceToDevice, ctx->stream));
   m->g.off_x = offset_xy[0];
   m->g.off_y = offset_xy[1];
-  m->sub_dirty = m->tile_dirty = true;
+  m->sub_dirty = m->tile_dirty = m->ptile_dirty = true;
   return LSLAM_OK;
 }
 
