@@ -308,6 +308,20 @@ k_row_occupancy(const uint32_t* __restrict__ nz, int n_words, int stride, int he
   occ_t[(size_t)x * (2 * words_per_half) + wq] = bits;
 }
 
+// pass C: the same bits regrouped for the gather unit: P[E][w][x] = words (w, w+1) of column x's
+// parity-E bitmap as one 64-bit value.  Column-major words put the 64 beams of a wave on 64 different
+// 128-byte lines (one line = 1024 rows of ONE column); x-major pairs put neighbouring beams --
+// neighbouring columns -- on the same line, and the (w, w+1) overlap keeps it one 8-byte load.
+__global__ void __launch_bounds__(256)
+k_occ_pairs(const uint32_t* __restrict__ occ_t, int stride, int words_per_half, uint2* __restrict__ pairs) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ew = blockIdx.y;  // E * words_per_half + w
+  if (x >= stride) return;
+  const int w = ew % words_per_half;
+  const uint32_t* col = occ_t + (size_t)x * (2 * words_per_half) + ew;
+  pairs[(size_t)ew * stride + x] = make_uint2(col[0], w + 1 < words_per_half ? col[1] : 0u);
+}
+
 // ------------------------------------------------------------------------------------------
 // k_resp_rows -- THE HOT KERNEL.
 // Exact response numerators (Mapper.cpp:819-856) of every candidate position of a uniform
@@ -333,7 +347,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int step, int limit, Geom g,
             PassCfg pc, const Lattice* __restrict__ lat, const double2* __restrict__ cossin,
             const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int beam_slices,
-            int S, const uint32_t* __restrict__ occ_t, int occ_wpc, int tile_tx, uint32_t tile_class_bytes) {
+            int S, const uint2* __restrict__ occ_t, int occ_wpc, int tile_tx, uint32_t tile_class_bytes) {
   constexpr int NW = NXD * NYC * 2;
   constexpr int kQueue = 128;
   static_assert(NYC <= 16 && 2 * (NYC - 1) < 32, "row mask / occupancy window width");
@@ -465,7 +479,7 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
           if (occ_t) {  // exact row occupancy (step 2): lattice rows are consecutive bits of one parity
             if ((uint32_t)y1 <= (uint32_t)y1_max) {
               have_occ = true;
-              col = (uint32_t)__mul24(2 * x + (y1 & 1), occ_wph) + ((uint32_t)y1 >> 6);
+              col = (uint32_t)__mul24(__mul24(y1 & 1, occ_wph) + (y1 >> 6), g.stride) + (uint32_t)x;
               osh = ((uint32_t)y1 >> 1) & 31u;
             }
           }
@@ -490,8 +504,8 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
         }
       }
       if (occ_t) {
-        const uint32_t lo = occ_t[col], hi = occ_t[(size_t)col + 1];
-        const uint32_t keep = __builtin_amdgcn_alignbit(hi, lo, osh);  // bit j <-> lattice row j0 + j
+        const uint2 ow = occ_t[col];  // x-major: neighbouring beams read neighbouring words (k_occ_pairs)
+        const uint32_t keep = __builtin_amdgcn_alignbit(ow.y, ow.x, osh);  // bit j <-> lattice row j0 + j
         mask &= have_occ ? keep : 0xFFFFFFFFu;
       }
       const unsigned long long votes = __ballot(mask != 0);
@@ -1762,6 +1776,7 @@ struct lslam_matcher {
   bool sub_dirty = true;            // the planes lag behind d_grid
   bool use_row_occupancy = true;
   uint32_t* d_occ_t = nullptr;      // transposed row-occupancy bitmap (k_row_occupancy)
+  uint2* d_occ_x = nullptr;         // the same bits as x-major 64-bit word pairs (k_occ_pairs): what k_resp_rows reads
   int occ_wpc = 0;
   int occ_win = 21;                 // grid bytes summarised per bit = row span of the coarse lattice
   uint32_t* d_nz = nullptr;         // flat non-zero bitmap, one bit per grid byte (k_nonzero_bits)
@@ -1866,6 +1881,8 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
            (const uint8_t*)m->d_grid, g.data_size, m->d_nz, m->nz_words);
     launch(ctx, "row_occupancy", k_row_occupancy, dim3((g.stride + 255) / 256, m->occ_wpc), dim3(256), 0,
            (const uint32_t*)m->d_nz, m->nz_words, g.stride, g.height, m->occ_win, m->d_occ_t, m->occ_wpc / 2);
+    launch(ctx, "occ_pairs", k_occ_pairs, dim3((g.stride + 255) / 256, m->occ_wpc), dim3(256), 0,
+           (const uint32_t*)m->d_occ_t, g.stride, m->occ_wpc / 2, m->d_occ_x);
     m->sub_dirty = false;
   }
   auto reduce_lds = [&](const PassCfg& p, bool cache) -> size_t {
@@ -1919,7 +1936,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       const uint8_t* s1 = step == 2 ? m->d_sub[1] : m->d_grid;
       const int limit = step == 2 ? g.data_size / 2 : g.data_size;
       // the bitmap covers row spans of kOccWin grid bytes: step*(nX-1)+1 must fit
-      const uint32_t* occ = (m->use_row_occupancy && step == 2 && step * (p.nx - 1) + 1 <= m->occ_win) ? m->d_occ_t : (const uint32_t*)nullptr;
+      const uint2* occ = (m->use_row_occupancy && step == 2 && step * (p.nx - 1) + 1 <= m->occ_win) ? m->d_occ_x : (const uint2*)nullptr;
       // coarse pass of a batch that fills the chip on its own: gather from the TILED parity planes
       bool ptiled = step == 2 && slices == 1 && waves >= kTileMinWaves && !m->ptile_failed;
       if (ptiled && !m->d_ptiles) {
@@ -2209,10 +2226,14 @@ int lslam_matcher_create(lslam_context* ctx, const lslam_matcher_config* cfg, co
   m->occ_wpc = 2 * (((g.height + 2) / 2 + 1 + 31) / 32 + 1);  // two row-parity bitmaps per column, +1 word each for the 64-bit read
   m->nz_words = (g.data_size + 31) / 32;
   if (hipMalloc((void**)&m->d_occ_t, (size_t)g.stride * m->occ_wpc * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc((void**)&m->d_occ_x, (size_t)g.stride * m->occ_wpc * sizeof(uint2)) != hipSuccess ||
       hipMalloc((void**)&m->d_nz, (size_t)m->nz_words * sizeof(uint32_t)) != hipSuccess) {
     (void)hipFree(m->d_grid_alloc);
     (void)hipFree(m->d_kernel);
     (void)hipFree(m->d_sub_alloc);
+    (void)hipFree(m->d_occ_t);
+    (void)hipFree(m->d_occ_x);
+    (void)hipFree(m->d_nz);
     delete m;
     return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the row-occupancy bitmap in HBM");
   }
@@ -2234,6 +2255,7 @@ void lslam_matcher_destroy(lslam_matcher* m) {
   (void)hipFree(m->d_kernel);
   (void)hipFree(m->d_sub_alloc);
   (void)hipFree(m->d_occ_t);
+  (void)hipFree(m->d_occ_x);
   (void)hipFree(m->d_nz);
   (void)hipFree(m->d_tiles);
   (void)hipFree(m->d_ptiles);
