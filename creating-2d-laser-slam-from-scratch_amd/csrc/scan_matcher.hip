@@ -576,6 +576,11 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
 // replaces three row loads.  Blocks are defined on the FLAT index, like the reference's 1-D bounds
 // rule (Mapper.cpp:841-845): an x that runs past widthStep continues in the next row.
 // ------------------------------------------------------------------------------------------
+// Block (ux, uy) -> slot: a 128-byte line holds 4 x 2 blocks = 8 x 4 cells (+ the blocks' own overlap), so
+// neighbouring beams share lines whichever way the wall runs (gathers cost ~1 cycle per distinct line).
+__host__ __device__ __forceinline__ size_t tile4_slot(int ux, int uy, int cols4) {
+  return ((size_t)((uy >> 1) * cols4 + (ux >> 2)) << 3) | (size_t)(((uy & 1) << 2) | (ux & 3));
+}
 constexpr int kTileYPad = 4;  // blocks start at Y = -4: flat indices of row y = -3 can wrap into row 0
 
 __global__ void __launch_bounds__(256)
@@ -593,7 +598,7 @@ k_tile4(const uint8_t* __restrict__ grid, int stride, int data_size, uint4* __re
     if (i + 2 >= 0 && i + 2 < data_size) hi = *reinterpret_cast<const uint16_t*>(grid + i + 2);
     w[r] = lo | (hi << 16);
   }
-  tiles[(size_t)uy * tile_cols + ux] = make_uint4(w[0], w[1], w[2], w[3]);
+  tiles[tile4_slot(ux, uy, (tile_cols + 3) / 4)] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -620,6 +625,7 @@ k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc,
   const double cosine = cs.x, sine = cs.y;
   const int X0 = L.gx[0], Y0 = L.gy[0];
   const int B0 = X0 + Y0 * g.stride;
+  const int cols4 = (tile_cols + 3) / 4;
   const double2* lp = local + (size_t)s * g.n_beams;
   // packed 16-bit fields: e[j] = candidates (0,j) | (2,j) << 16; o01 = (1,0) | (1,1) << 16; o2 = (1,2)
   uint32_t e0 = 0, e1 = 0, e2 = 0, o01 = 0, o2 = 0;
@@ -647,7 +653,7 @@ k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc,
         x = ok ? (int)(base - yl * g.stride) : 0;
       }
       if (ok) {
-        const uint4 t = tiles[(size_t)((y + kTileYPad) >> 1) * tile_cols + (x >> 1)];
+        const uint4 t = tiles[tile4_slot(x >> 1, (y + kTileYPad) >> 1, cols4)];
         const uint32_t dx = (uint32_t)x & 1u;
         const bool dy = (y & 1) != 0;
         const uint32_t r0 = dy ? t.y : t.x, r1 = dy ? t.z : t.y, r2 = dy ? t.w : t.z;
@@ -1906,7 +1912,8 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     if (tiled && !m->d_tiles) {
       m->tile_cols = g.stride / 2;
       m->tile_rows = (g.height + 1) / 2 + kTileYPad / 2 + 1;
-      if (hipMalloc((void**)&m->d_tiles, (size_t)m->tile_cols * m->tile_rows * sizeof(uint4)) != hipSuccess) {
+      m->tile_rows += m->tile_rows & 1;  // lines hold block rows in pairs
+      if (hipMalloc((void**)&m->d_tiles, (size_t)((m->tile_cols + 3) / 4) * 4 * m->tile_rows * sizeof(uint4)) != hipSuccess) {
         (void)hipGetLastError();
         m->d_tiles = nullptr;
         m->tile_failed = true;  // not enough HBM for the 4x copy: keep to the row kernel
