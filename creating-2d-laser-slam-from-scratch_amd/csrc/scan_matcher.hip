@@ -601,10 +601,15 @@ k_tile4(const uint8_t* __restrict__ grid, int stride, int data_size, uint4* __re
   tiles[tile4_slot(ux, uy, (tile_cols + 3) / 4)] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// wave64 sum, uniform result: four DPP adds give every lane its row-of-16 total, the four row totals
+// are read back as scalars
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v += (uint32_t)__shfl_xor((int)v, m);
-  return v;
+  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true);  // row_mirror
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+         (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 
 // One wave64 per (scan, angle); lanes stride over the beams.  Same exact numerators as
