@@ -1494,20 +1494,35 @@ k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc
   const int total = ncand * pc.na;
   const int32_t* r = resp + (size_t)s * resp_stride;
   const double center[3] = {L.center[0], L.center[1], L.center[2]};
+  // every thread keeps its candidates' penalised responses (the usual fine lattice has 99 of them:
+  // one per thread) instead of evaluating the division and the penalty twice
+  constexpr int kKeep = 4;
+  double mine[kKeep];
   auto value = [&](int k) -> double {
     const int a = k % pc.na, c = k / pc.na;
     return penalized(r[a * ncand + c], cand_of(k, pc, center), center, g.n_beams, sc);
   };
   double lm = -1.0;
-  for (int k = tid; k < total; k += 256) {
-    double v = value(k);
+#pragma unroll
+  for (int i = 0; i < kKeep; i++) {
+    const int k = tid + 256 * i;
+    mine[i] = k < total ? value(k) : -1.0;
+    lm = lm > mine[i] ? lm : mine[i];
+  }
+  for (int k = tid + 256 * kKeep; k < total; k += 256) {
+    const double v = value(k);
     lm = lm > v ? lm : v;
   }
   const int words = (total + 31) / 32;
   for (int wd = tid; wd < words; wd += 256) mask[wd] = 0u;
   if (tid < kMaxAngles) asum[tid] = 0;
   const double best = block_max(lm, sh, tid, 256);
-  for (int k = tid; k < total; k += 256)
+#pragma unroll
+  for (int i = 0; i < kKeep; i++) {
+    const int k = tid + 256 * i;
+    if (k < total && double_equal(mine[i], best)) atomicOr(&mask[k >> 5], 1u << (k & 31));
+  }
+  for (int k = tid + 256 * kKeep; k < total; k += 256)
     if (double_equal(value(k), best)) atomicOr(&mask[k >> 5], 1u << (k & 31));
   __syncthreads();
   if (tid == 0) {
@@ -1531,8 +1546,11 @@ k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc
     // GetResponse(angleIndex, gridIndex) for every fine angle at the best cell (:663-666).
     // Usually that cell is one of the fine lattice cells whose numerators are already there.
     int hit = -1;
-    for (int c = 0; c < ncand; c++)
-      if (L.gx[c % pc.nx] + L.gy[c / pc.nx] * g.stride == s_pos) hit = c;
+    for (int yi = 0, c = 0; yi < pc.ny; yi++) {
+      const int row = L.gy[yi] * g.stride;
+      for (int xi = 0; xi < pc.nx; xi++, c++)
+        if (L.gx[xi] + row == s_pos) hit = c;
+    }
     if (hit >= 0) {
       if (tid < pc.na) asum[tid] = r[tid * ncand + hit];
     } else {
