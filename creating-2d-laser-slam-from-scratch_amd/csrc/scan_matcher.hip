@@ -7,7 +7,7 @@
 //
 // Device pipeline of one batch of S independent scans against the resident correlation grid:
 //   k_scan_prep      S*N threads   ranges -> scan-frame points (Karto.h:5384-5388, 6423-6434)
-//   k_pass_setup     S threads     lattice cell coordinates of the pass (Mapper.cpp:339-386)
+//   k_pass_setup     wave per scan  lattice cell coordinates + cos/sin of the pass's angles (Mapper.cpp:339-393)
 //   k_resp_rows      S*nA waves    ** hot kernel ** all nX*nY response sums of one (scan, angle)
 //                                  for a uniform lattice (Mapper.cpp:373-424, 819-856)
 //   k_resp_generic   work list     same sums for arbitrary lattices (fine pass, fall-back)
@@ -123,8 +123,7 @@ k_scan_prep(const RT* __restrict__ ranges, int stride, const double* __restrict_
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
 k_pass_setup(int S, Geom g, PassCfg pc, const double* __restrict__ poses, const CoarseOut* __restrict__ coarse,
-             Lattice* __restrict__ lat, double2* __restrict__ cossin, int* __restrict__ slow_list,
-             int* __restrict__ slow_count, int want_step) {
+             Lattice* __restrict__ lat, double2* __restrict__ cossin, int want_step) {
   // one wave per scan: lane i owns lattice coordinates i, i+64 and candidate angles i, i+64
   const int s = blockIdx.x, lane = threadIdx.x;
   if (s >= S) return;
@@ -183,11 +182,6 @@ k_pass_setup(int S, Geom g, PassCfg pc, const double* __restrict__ poses, const 
     L.step_y = sty;
     L.status = status;
     L.active = active;
-    // scans the fast lattice kernel cannot take go to the generic kernel's work list
-    if (slow_list && active && status == 0 && !(stx == want_step && sty == want_step)) {
-      int k = atomicAdd(slow_count, 1);
-      slow_list[k] = s;
-    }
   }
 }
 
@@ -691,53 +685,69 @@ k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc,
 // Mapper.cpp:841-845.  `list` (optional) restricts the scans to a device-built work list.
 // ------------------------------------------------------------------------------------------
 constexpr int kPosChunk = 16;
-__global__ void __launch_bounds__(64)
-k_resp_generic(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, const Lattice* __restrict__ lat,
-               const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride,
-               int S, const int* __restrict__ list, const int* __restrict__ list_count) {
-  const int lane = threadIdx.x;
+// one work item = (angle a, chunk c of 16 lattice positions) of one scan, done by one wave
+__device__ __forceinline__ void generic_item(const uint8_t* __restrict__ grid, const Geom& g, const PassCfg& pc,
+                                             const Lattice& L, const double2* __restrict__ lp, int32_t* r, int a,
+                                             int c, int lane) {
   const int np = pc.nx * pc.ny;
-  const int chunks = (np + kPosChunk - 1) / kPosChunk;
-  const int per_scan = pc.na * chunks;
-  const long long n_scans = list ? *list_count : S;
-  const long long total = n_scans * per_scan;
-  for (long long w = blockIdx.x; w < total; w += gridDim.x) {
-    int s = (int)(w / per_scan);
-    if (list) s = list[s];
-    int rem = (int)(w % per_scan);
-    const int a = rem / chunks, c = rem % chunks;
-    const Lattice& L = lat[s];
-    if (!L.active || L.status != 0) continue;
-    const double angle = (L.center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;
-    const double cosine = cos(angle), sine = sin(angle);
-    int pos[kPosChunk];
+  const double angle = (L.center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;
+  const double cosine = cos(angle), sine = sin(angle);
+  int pos[kPosChunk];
+#pragma unroll
+  for (int q = 0; q < kPosChunk; q++) {
+    int f = c * kPosChunk + q;
+    pos[q] = f < np ? L.gx[f % pc.nx] + L.gy[f / pc.nx] * g.stride : -1;
+  }
+  int32_t acc[kPosChunk];
+#pragma unroll
+  for (int q = 0; q < kPosChunk; q++) acc[q] = 0;
+  for (int b = lane; b < g.n_beams; b += 64) {
+    double2 p = lp[b];
+    if (isnan(p.x)) continue;
+    int t = lookup_offset(p.x, p.y, cosine, sine, g.off_x, g.off_y, g.scale, g.stride);
 #pragma unroll
     for (int q = 0; q < kPosChunk; q++) {
-      int f = c * kPosChunk + q;
-      pos[q] = f < np ? L.gx[f % pc.nx] + L.gy[f / pc.nx] * g.stride : -1;
-    }
-    int32_t acc[kPosChunk];
-#pragma unroll
-    for (int q = 0; q < kPosChunk; q++) acc[q] = 0;
-    const double2* lp = local + (size_t)s * g.n_beams;
-    for (int b = lane; b < g.n_beams; b += 64) {
-      double2 p = lp[b];
-      if (isnan(p.x)) continue;
-      int t = lookup_offset(p.x, p.y, cosine, sine, g.off_x, g.off_y, g.scale, g.stride);
-#pragma unroll
-      for (int q = 0; q < kPosChunk; q++) {
-        long long idx = (long long)pos[q] + t;
-        if (pos[q] >= 0 && idx >= 0 && idx < g.data_size) acc[q] += grid[idx];
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < kPosChunk; q++) {
-      int v = acc[q];
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-      int f = c * kPosChunk + q;
-      if (lane == 0 && f < np) resp[(size_t)s * resp_stride + (size_t)a * np + f] = v;
+      long long idx = (long long)pos[q] + t;
+      if (pos[q] >= 0 && idx >= 0 && idx < g.data_size) acc[q] += grid[idx];
     }
   }
+#pragma unroll
+  for (int q = 0; q < kPosChunk; q++) {
+    int v = acc[q];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    int f = c * kPosChunk + q;
+    if (lane == 0 && f < np) r[(size_t)a * np + f] = v;
+  }
+}
+
+__global__ void __launch_bounds__(64)
+k_resp_generic(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, const Lattice* __restrict__ lat,
+               const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int S) {
+  const int chunks = (pc.nx * pc.ny + kPosChunk - 1) / kPosChunk;
+  const int per_scan = pc.na * chunks;
+  const long long total = (long long)S * per_scan;
+  for (long long w = blockIdx.x; w < total; w += gridDim.x) {
+    const int s = (int)(w / per_scan), rem = (int)(w % per_scan);
+    const Lattice& L = lat[s];
+    if (!L.active || L.status != 0) continue;
+    generic_item(grid, g, pc, L, local + (size_t)s * g.n_beams, resp + (size_t)s * resp_stride, rem / chunks,
+                 rem % chunks, threadIdx.x);
+  }
+}
+
+// The packed kernels (k_resp_rows, k_resp_tile3, k_resp_dense) skip a scan whose lattice is not
+// uniform -- a lattice coordinate that rounds on a cell boundary (k_pass_setup) -- and the scan's own
+// reduce block computes its numerators here before it reduces them: no work list, no extra launch.
+// `fb_step` is the lattice step the packed kernel required, or 0 when the generic kernel did the pass.
+__device__ __forceinline__ void block_generic_fallback(const uint8_t* __restrict__ grid, const Geom& g,
+                                                       const PassCfg& pc, const Lattice& L,
+                                                       const double2* __restrict__ lp, int32_t* r, int fb_step,
+                                                       int tid, int nthreads) {
+  if (fb_step == 0 || (L.step_x == fb_step && L.step_y == fb_step)) return;  // block-uniform
+  const int chunks = (pc.nx * pc.ny + kPosChunk - 1) / kPosChunk;
+  const int per_scan = pc.na * chunks;
+  for (int w = tid >> 6; w < per_scan; w += nthreads >> 6) generic_item(grid, g, pc, L, lp, r, w / chunks, w % chunks, tid & 63);
+  __syncthreads();  // the block reads these sums next
 }
 
 // ------------------------------------------------------------------------------------------
@@ -823,8 +833,9 @@ __device__ int tie_average(const uint32_t* mask, int total, const PassCfg& pc, c
 template <bool CACHE>
 __global__ void __launch_bounds__(256)
 k_reduce_coarse(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ lat,
-                const int32_t* __restrict__ resp, size_t resp_stride, CoarseOut* __restrict__ out,
-                int use_expansion, int pass_index) {
+                int32_t* resp, size_t resp_stride, CoarseOut* __restrict__ out,
+                int use_expansion, int pass_index, const uint8_t* __restrict__ grid,
+                const double2* __restrict__ local, int fb_step) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double sh[256];
   const int s = blockIdx.x, tid = threadIdx.x;
@@ -834,6 +845,7 @@ k_reduce_coarse(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ la
     if (tid == 0) { out[s].status = L.status; out[s].expand = 0; out[s].best = 0.0; }
     return;
   }
+  block_generic_fallback(grid, g, pc, L, local + (size_t)s * g.n_beams, resp + (size_t)s * resp_stride, fb_step, tid, 256);
   const int ncand = pc.nx * pc.ny;
   const int total = ncand * pc.na;
   const int words = (total + 31) / 32;
@@ -974,8 +986,9 @@ k_reduce_coarse(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ la
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ lat,
-                    const int32_t* __restrict__ resp, size_t resp_stride, CoarseOut* __restrict__ out,
-                    int use_expansion, int pass_index) {
+                    int32_t* resp, size_t resp_stride, CoarseOut* __restrict__ out,
+                    int use_expansion, int pass_index, const uint8_t* __restrict__ grid,
+                const double2* __restrict__ local, int fb_step) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double sh[256];
   __shared__ double s_ap[kMaxAngles];
@@ -989,6 +1002,7 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
     if (tid == 0) { out[s].status = L.status; out[s].expand = 0; out[s].best = 0.0; }
     return;
   }
+  block_generic_fallback(grid, g, pc, L, local + (size_t)s * g.n_beams, resp + (size_t)s * resp_stride, fb_step, tid, 256);
   const int ncand = pc.nx * pc.ny;
   const int total = ncand * pc.na;
   const int words = (total + 31) / 32;  // <= 256 (host)
@@ -1277,8 +1291,9 @@ k_resp_dense(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1,
 // responses are >= 0, so unsigned integer max == double max) | terms[4*ncand] | mask words
 __global__ void __launch_bounds__(256)
 k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ lat,
-                    const int32_t* __restrict__ resp, size_t resp_stride, CoarseOut* __restrict__ out,
-                    int use_expansion, int pass_index, double* __restrict__ scratch, size_t scratch_stride) {
+                    int32_t* resp, size_t resp_stride, CoarseOut* __restrict__ out,
+                    int use_expansion, int pass_index, double* __restrict__ scratch, size_t scratch_stride,
+                    const uint8_t* __restrict__ grid, const double2* __restrict__ local, int fb_step) {
   constexpr int kList = 2048;
   __shared__ double sh[256];
   __shared__ double chunk[4 * 256];
@@ -1292,6 +1307,7 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
     if (tid == 0) { out[s].status = L.status; out[s].expand = 0; out[s].best = 0.0; }
     return;
   }
+  block_generic_fallback(grid, g, pc, L, local + (size_t)s * g.n_beams, resp + (size_t)s * resp_stride, fb_step, tid, 256);
   const int ncand = pc.nx * pc.ny, total = ncand * pc.na, words = (total + 31) / 32;
   const int side2 = g.probs_side * g.probs_side;
   double* latmax = scratch + (size_t)s * scratch_stride;
@@ -1455,9 +1471,9 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc,
-              const Lattice* __restrict__ lat, const int32_t* __restrict__ resp, size_t resp_stride,
+              const Lattice* __restrict__ lat, int32_t* resp, size_t resp_stride,
               const double2* __restrict__ local, const CoarseOut* __restrict__ coarse,
-              lslam_match_result* __restrict__ out, int do_refine) {
+              lslam_match_result* __restrict__ out, int do_refine, int fb_step) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double sh[256];
   __shared__ int32_t asum[kMaxAngles];
@@ -1490,6 +1506,7 @@ k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc
     }
     return;
   }
+  block_generic_fallback(grid, g, pc, L, local + (size_t)s * g.n_beams, resp + (size_t)s * resp_stride, fb_step, tid, 256);
   const int ncand = pc.nx * pc.ny;
   const int total = ncand * pc.na;
   const int32_t* r = resp + (size_t)s * resp_stride;
@@ -1826,7 +1843,6 @@ struct lslam_matcher {
   DevBuf<double2> d_cossin;  // [S][kMaxAngles] cos/sin of the pass's candidate angles (k_pass_setup)
   DevBuf<CoarseOut> d_coarse;
   DevBuf<int32_t> d_resp;
-  DevBuf<int> d_slow;  // [0] = count, [1..] = list
   DevBuf<int32_t> d_tbl;     // large lattices: materialised lookup tables [S][nA][N]
   DevBuf<double> d_big;      // large lattices: reduce scratch
   DevBuf<lslam_match_result> d_results;
@@ -1895,7 +1911,6 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   LSLAM_HIP(ctx, m->d_cossin.reserve((size_t)S * kMaxAngles));
   LSLAM_HIP(ctx, m->d_coarse.reserve(S));
   LSLAM_HIP(ctx, m->d_resp.reserve((size_t)S * resp_stride));
-  LSLAM_HIP(ctx, m->d_slow.reserve((size_t)S + 1));
 
   SearchCfg sc{m->cfg.distance_variance_penalty, m->cfg.angle_variance_penalty,
                m->cfg.minimum_distance_penalty, m->cfg.minimum_angle_penalty, do_penalize};
@@ -1921,13 +1936,14 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   };
   // response numerators of one pass: packed row kernel for uniform lattices (step 2 on the parity
   // planes, step 1 on the grid), generic kernel for everything else
+  // lattice step the packed kernel of the last pass required (0 = the generic kernel did the pass):
+  // the reduce kernels compute the numerators of scans with a different (non-uniform) lattice themselves
+  int fb_step = 0;
   auto run_responses = [&](const PassCfg& p, int step, const char* name) -> int {
     const int variant = force_generic ? 0 : (p.nx <= 4 && p.ny <= 4) ? 1 : (p.nx <= 12) ? 2 : (p.nx <= 16) ? 3 : 0;
-    LSLAM_HIP(ctx, hipMemsetAsync(m->d_slow.p, 0, sizeof(int), ctx->stream));
-    int* slow_cnt = m->d_slow.p;
-    int* slow_list = m->d_slow.p + 1;
+    fb_step = variant ? step : 0;
     launch(ctx, "pass_setup", k_pass_setup, dim3(S), dim3(64), 0, S, g, p, d_poses,
-           (const CoarseOut*)m->d_coarse.p, m->d_lat.p, m->d_cossin.p, variant ? slow_list : (int*)nullptr, slow_cnt, step);
+           (const CoarseOut*)m->d_coarse.p, m->d_lat.p, m->d_cossin.p, step);
     const long long waves = (long long)((S + 7) / 8) * 8 * p.na;
     // fine pass of a batch big enough to fill the chip: one 16-byte load per beam from the 4x4 blocks
     bool tiled = variant == 1 && step == 1 && p.nx == 3 && p.ny == 3 && waves >= kTileMinWaves &&
@@ -1951,9 +1967,6 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       }
       launch(ctx, "resp_tile_fine", k_resp_tile3, dim3((unsigned)waves), dim3(64), 0, (const uint4*)m->d_tiles, m->tile_cols, g, p,
              (const Lattice*)m->d_lat.p, (const double2*)m->d_cossin.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S);
-      launch(ctx, "resp_generic_fallback", k_resp_generic, dim3(128), dim3(64), 0, (const uint8_t*)m->d_grid, g, p,
-             (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S,
-             (const int*)slow_list, (const int*)slow_cnt);
     } else if (variant) {
       // small batches: split the beams of one (scan, angle) over several waves to fill the chip
       int slices = 1;
@@ -2004,26 +2017,20 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       else
         launch(ctx, name, k_resp_rows<4, 8, false>, LSLAM_ROWS_ARGS(s0, s1));
 #undef LSLAM_ROWS_ARGS
-      // scans whose lattice is not uniform (a coordinate rounds on a cell boundary) take the generic kernel
-      launch(ctx, "resp_generic_fallback", k_resp_generic, dim3(128), dim3(64), 0, (const uint8_t*)m->d_grid, g, p,
-             (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S,
-             (const int*)slow_list, (const int*)slow_cnt);
     } else {
       int chunks = (p.nx * p.ny + kPosChunk - 1) / kPosChunk;
       long long items = (long long)S * p.na * chunks;
       launch(ctx, "resp_generic", k_resp_generic, dim3((unsigned)std::min<long long>(items, 1 << 20)), dim3(64), 0,
              (const uint8_t*)m->d_grid, g, p, (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p,
-             m->d_resp.p, resp_stride, S, (const int*)nullptr, (const int*)nullptr);
+             m->d_resp.p, resp_stride, S);
     }
     return LSLAM_OK;
   };
   auto run_coarse_big = [&](const PassCfg& p, int pass_index) -> int {
     // dense kernel for uniform lattices; scans with a non-uniform lattice fall to the generic kernel
-    LSLAM_HIP(ctx, hipMemsetAsync(m->d_slow.p, 0, sizeof(int), ctx->stream));
-    int* slow_cnt = m->d_slow.p;
-    int* slow_list = m->d_slow.p + 1;
+    fb_step = 2;
     launch(ctx, "pass_setup", k_pass_setup, dim3(S), dim3(64), 0, S, g, p, d_poses,
-           (const CoarseOut*)m->d_coarse.p, m->d_lat.p, m->d_cossin.p, slow_list, slow_cnt, 2);
+           (const CoarseOut*)m->d_coarse.p, m->d_lat.p, m->d_cossin.p, 2);
     LSLAM_HIP(ctx, m->d_tbl.reserve((size_t)S * p.na * g.n_beams));
     launch(ctx, "table_big", k_table_big, dim3((g.n_beams + 255) / 256, p.na, S), dim3(256), 0, S, g, p,
            (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_tbl.p);
@@ -2036,18 +2043,15 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     launch(ctx, "resp_dense", k_resp_dense, dim3((unsigned)((long long)S * p.na * n_tiles * slices)), dim3(64), 0,
            (const uint8_t*)m->d_sub[0], (const uint8_t*)m->d_sub[1], g.data_size / 2, g, p, (const Lattice*)m->d_lat.p,
            (const int32_t*)m->d_tbl.p, m->d_resp.p, resp_stride, n_tiles, slices);
-    launch(ctx, "resp_generic_fallback", k_resp_generic, dim3(256), dim3(64), 0, (const uint8_t*)m->d_grid, g, p,
-           (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S,
-           (const int*)slow_list, (const int*)slow_cnt);
-    if (dbg_coarse_sums && pass_index == 0)
-      LSLAM_HIP(ctx, hipMemcpyAsync(dbg_coarse_sums, m->d_resp.p, (size_t)p.nx * p.ny * p.na * sizeof(int32_t),
-                                    hipMemcpyDeviceToDevice, ctx->stream));
     const size_t ncand = (size_t)p.nx * p.ny, total = ncand * p.na;
     const size_t stride = ncand + (size_t)g.probs_side * g.probs_side + 4 * ncand + (total + 63) / 64 + 8;  // doubles
     LSLAM_HIP(ctx, m->d_big.reserve((size_t)S * stride));
     launch(ctx, "reduce_coarse_big", k_reduce_coarse_big, dim3(S), dim3(256), 0, g, p, sc, (const Lattice*)m->d_lat.p,
-           (const int32_t*)m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
-           m->d_big.p, stride);
+           m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
+           m->d_big.p, stride, (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step);
+    if (dbg_coarse_sums && pass_index == 0)  // after the reduce: it fills in scans the packed kernel skipped
+      LSLAM_HIP(ctx, hipMemcpyAsync(dbg_coarse_sums, m->d_resp.p, (size_t)p.nx * p.ny * p.na * sizeof(int32_t),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
     return LSLAM_OK;
   };
   auto run_coarse = [&](const PassCfg& p, int pass_index) -> int {
@@ -2056,22 +2060,21 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       return ctx->fail(LSLAM_ERR_UNSUPPORTED, "lattice %dx%d is outside the built kernels", p.nx, p.ny);
     int rc = run_responses(p, 2, "resp_rows_coarse");
     if (rc) return rc;
-    if (dbg_coarse_sums && pass_index == 0)
+    const bool cache = reduce_lds(p, true) <= 60 * 1024;
+#define LSLAM_REDUCE_ARGS                                                                                     \
+  g, p, sc, (const Lattice*)m->d_lat.p, m->d_resp.p, resp_stride, m->d_coarse.p,                              \
+      (int)m->cfg.use_response_expansion, pass_index, (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, \
+      fb_step
+    if (cache && ((size_t)p.nx * p.ny * p.na + 31) / 32 <= 256)
+      launch(ctx, "reduce_coarse", k_reduce_coarse_lds, dim3(S), dim3(256), reduce_lds(p, true), LSLAM_REDUCE_ARGS);
+    else if (cache)
+      launch(ctx, "reduce_coarse", k_reduce_coarse<true>, dim3(S), dim3(256), reduce_lds(p, true), LSLAM_REDUCE_ARGS);
+    else
+      launch(ctx, "reduce_coarse", k_reduce_coarse<false>, dim3(S), dim3(256), reduce_lds(p, false), LSLAM_REDUCE_ARGS);
+#undef LSLAM_REDUCE_ARGS
+    if (dbg_coarse_sums && pass_index == 0)  // after the reduce: it fills in scans the packed kernel skipped
       LSLAM_HIP(ctx, hipMemcpyAsync(dbg_coarse_sums, m->d_resp.p, (size_t)p.nx * p.ny * p.na * sizeof(int32_t),
                                     hipMemcpyDeviceToDevice, ctx->stream));
-    const bool cache = reduce_lds(p, true) <= 60 * 1024;
-    if (cache && ((size_t)p.nx * p.ny * p.na + 31) / 32 <= 256)
-      launch(ctx, "reduce_coarse", k_reduce_coarse_lds, dim3(S), dim3(256), reduce_lds(p, true), g, p, sc,
-             (const Lattice*)m->d_lat.p, (const int32_t*)m->d_resp.p, resp_stride, m->d_coarse.p,
-             (int)m->cfg.use_response_expansion, pass_index);
-    else if (cache)
-      launch(ctx, "reduce_coarse", k_reduce_coarse<true>, dim3(S), dim3(256), reduce_lds(p, true), g, p, sc,
-             (const Lattice*)m->d_lat.p, (const int32_t*)m->d_resp.p, resp_stride, m->d_coarse.p,
-             (int)m->cfg.use_response_expansion, pass_index);
-    else
-      launch(ctx, "reduce_coarse", k_reduce_coarse<false>, dim3(S), dim3(256), reduce_lds(p, false), g, p, sc,
-             (const Lattice*)m->d_lat.p, (const int32_t*)m->d_resp.p, resp_stride, m->d_coarse.p,
-             (int)m->cfg.use_response_expansion, pass_index);
     return LSLAM_OK;
   };
 
@@ -2086,8 +2089,8 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     if (rc) return rc;
   }
   launch(ctx, "reduce_fine", k_reduce_fine, dim3(S), dim3(256), (size_t)(((size_t)pf.nx * pf.ny * pf.na + 31) / 32) * 4 + 16,
-         (const uint8_t*)m->d_grid, g, pf, sc, (const Lattice*)m->d_lat.p, (const int32_t*)m->d_resp.p, resp_stride,
-         (const double2*)m->d_local.p, (const CoarseOut*)m->d_coarse.p, d_out, do_refine);
+         (const uint8_t*)m->d_grid, g, pf, sc, (const Lattice*)m->d_lat.p, m->d_resp.p, resp_stride,
+         (const double2*)m->d_local.p, (const CoarseOut*)m->d_coarse.p, d_out, do_refine, do_refine ? fb_step : 0);
   LSLAM_HIP(ctx, hipGetLastError());
   return LSLAM_OK;
 }
@@ -2291,7 +2294,7 @@ void lslam_matcher_destroy(lslam_matcher* m) {
   (void)hipFree(m->d_ptiles);
   m->d_ranges64.release(); m->d_poses.release(); m->d_local.release(); m->d_world.release();
   m->d_valid.release(); m->d_fv_scratch.release(); m->d_lat.release(); m->d_cossin.release(); m->d_coarse.release(); m->d_resp.release();
-  m->d_slow.release(); m->d_tbl.release(); m->d_big.release(); m->d_results.release(); m->d_dbg.release();
+  m->d_tbl.release(); m->d_big.release(); m->d_results.release(); m->d_dbg.release();
   delete m;
 }
 

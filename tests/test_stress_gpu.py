@@ -62,3 +62,54 @@ def test_random_sweep(ctx, oracle_lib, n_ranges, inc_deg, seed):
     ctx.profile(False)
     assert "resp_tile_fine" in prof and "resp_rows_fine" not in prof
     assert big.tobytes() == np.tile(res, 8).tobytes()
+
+
+def _kround(v):
+    return math.floor(v + 0.5) if v >= 0.0 else math.ceil(v - 0.5)
+
+
+def test_non_uniform_lattices(ctx, oracle_lib):
+    """Search centres whose lattice coordinates sit on cell boundaries: (centre + x_i - offset) * scale
+    lands on k + 0.5 up to rounding noise, so neighbouring lattice coordinates round differently and the
+    lattice is NOT uniform.  The packed kernels skip such scans and the scan's reduce block computes
+    the numerators itself (block_generic_fallback); results must still equal the oracle's."""
+    laser = synth.Laser()
+    thr = 12.0
+    port = oracle_lib.PortKarto(oracle_lib.default_cfg(), oracle_lib.laser_struct(laser, thr))
+    gm = api.ScanMatcher(ctx, api.baseline_config(range_threshold=thr), api.laser_params(laser, thr))
+    wl = synth.make_match_workload(n_base=20, n_query=24, seed=11, laser=laser)
+    port.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    off = gm.grid_info()["offset"]
+    res, scale = 0.05, 1.0 / 0.05
+    ranges, poses = wl.query_ranges.copy(), wl.query_poses.copy()
+    n_uneven = 0
+    for q in range(len(poses)):
+        # put x (even q) or y (odd q) of the centre half a cell off the grid raster
+        ax = q & 1
+        k = _kround((poses[q, ax] - off[ax]) * scale)
+        poses[q, ax] = off[ax] + (k + 0.5) * res
+        # the coarse lattice of this centre, with the device's own arithmetic (k_pass_setup)
+        nx = int(_kround(0.5 * 2.0 / (2 * res)) + 1)
+        cells = [_kround(((poses[q, ax] + (-0.5 + i * (2 * res))) - off[ax]) * scale) for i in range(nx)]
+        steps = {b - a for a, b in zip(cells, cells[1:])}
+        n_uneven += steps != {2}
+    assert n_uneven >= 4, "the construction should produce non-uniform lattices"
+    exp = [port.match(ranges[q], poses[q]) for q in range(len(ranges))]
+
+    def check(res_):
+        for q, (mean, cov, resp) in enumerate(exp):
+            assert res_["status"][q] == 0
+            assert np.abs(res_["pose"][q][:2] - mean[:2]).max() <= 1e-9
+            assert abs(math.remainder(res_["pose"][q][2] - mean[2], 2 * math.pi)) <= 1e-9
+            assert abs(res_["response"][q] - resp) <= 1e-12
+            assert np.abs(res_["covariance"][q] - cov).max() <= 1e-9 * max(1.0, np.abs(cov).max())
+
+    small = gm.match_batch(ranges, poses)  # row kernels with beam slices
+    check(small)
+    big = gm.match_batch(np.tile(ranges, (9, 1)), np.tile(poses, (9, 1)))  # tiled coarse + 4x4-block fine kernels
+    assert big.tobytes() == np.tile(small, 9).tobytes()
+    for q in range(4):  # integer numerators of non-uniform lattices, through the debug hook
+        p = poses[q]
+        _, _, _, st, sums = port.correlate_scan(ranges[q], p, p, 0.5, 0.1, 0.349, 0.0349, True, False, want_sums=True)
+        assert st == 0 and np.array_equal(gm.coarse_sums(ranges[q], p), sums)
