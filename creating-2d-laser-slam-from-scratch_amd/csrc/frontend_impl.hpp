@@ -140,7 +140,7 @@ int lslam_frontend_process(lslam_frontend* f, const double* ranges, int n_ranges
     LSLAM_HIP(ctx, hipMemcpyAsync(f->d_q.p + n, sp, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((n + 255) / 256, 1), dim3(256), 0,
            (const double*)f->d_q.p, n, (const double*)(f->d_q.p + n), m->g, (double2*)nullptr,
-           f->d_world.p + (size_t)slot * n);
+           f->d_world.p + (size_t)slot * n, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0);
     LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // d_q is reused by the next call
   }
   for (int i = 0; i < 3; i++) f->robot[(size_t)slot * 3 + i] = corrected[i];

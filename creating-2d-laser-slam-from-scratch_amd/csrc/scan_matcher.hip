@@ -82,10 +82,15 @@ struct CoarseOut {
 // the scan frame (Transform::InverseTransformPose, Karto.h:6426-6434).  lx = NaN marks INVALID_SCAN
 // (reading NaN/Inf, Karto.h:6478-6483).  One thread per (scan, beam); coalesced.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pass_setup_wave(int s, int lane, const Geom& g, const PassCfg& pc,
+                                                const double* center, int active, Lattice* lat,
+                                                double2* cossin, int want_step);  // below
+
 template <typename RT>
 __global__ void __launch_bounds__(256)
 k_scan_prep(const RT* __restrict__ ranges, int stride, const double* __restrict__ poses, Geom g,
-            double2* __restrict__ local, double2* __restrict__ world) {
+            double2* __restrict__ local, double2* __restrict__ world, PassCfg setup_pc, Lattice* setup_lat,
+            double2* setup_cossin, int setup_step) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   int s = blockIdx.y;
   double sx = poses[3 * s], sy = poses[3 * s + 1], sh = poses[3 * s + 2];
@@ -99,6 +104,11 @@ k_scan_prep(const RT* __restrict__ ranges, int stride, const double* __restrict_
     s_h = normalize_angle(0.0 - s_t.th);
   }
   __syncthreads();
+  // the first wave of the scan's first block also lays out the coarse search lattice (k_pass_setup, mode 0)
+  if (setup_lat && blockIdx.x == 0 && threadIdx.x < 64) {
+    const double center[3] = {sx, sy, sh};
+    pass_setup_wave(s, threadIdx.x, g, setup_pc, center, 1, setup_lat, setup_cossin, setup_step);
+  }
   if (b >= g.n_beams) return;
   double r = (double)ranges[(size_t)s * stride + b];
   double px, py;
@@ -121,23 +131,10 @@ k_scan_prep(const RT* __restrict__ ranges, int stride, const double* __restrict_
 // (Mapper.cpp:339-386): each lattice coordinate is rounded on its own, exactly like the reference
 // (the fine pass is centred on a possibly off-lattice tie average).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
-k_pass_setup(int S, Geom g, PassCfg pc, const double* __restrict__ poses, const CoarseOut* __restrict__ coarse,
-             Lattice* __restrict__ lat, double2* __restrict__ cossin, int want_step) {
-  // one wave per scan: lane i owns lattice coordinates i, i+64 and candidate angles i, i+64
-  const int s = blockIdx.x, lane = threadIdx.x;
-  if (s >= S) return;
-  double center[3];
-  int active = 1;
-  if (pc.mode == 0) {
-    center[0] = poses[3 * s]; center[1] = poses[3 * s + 1]; center[2] = poses[3 * s + 2];
-  } else if (pc.mode == 1) {
-    center[0] = poses[3 * s]; center[1] = poses[3 * s + 1]; center[2] = poses[3 * s + 2];
-    active = coarse[s].expand && coarse[s].status == 0;
-  } else {
-    center[0] = coarse[s].mean[0]; center[1] = coarse[s].mean[1]; center[2] = coarse[s].mean[2];
-    active = coarse[s].status == 0;
-  }
+// one wave (64 lanes) sets up scan s: lane i owns lattice coordinates i, i+64 and candidate angles i, i+64
+__device__ __forceinline__ void pass_setup_wave(int s, int lane, const Geom& g, const PassCfg& pc,
+                                                const double* center, int active, Lattice* lat,
+                                                double2* cossin, int want_step) {
   const double start_x = -pc.off_x, start_y = -pc.off_y;
   auto cell_x = [&](int i) {
     double x = start_x + (uint32_t)i * pc.res_x;
@@ -183,6 +180,25 @@ k_pass_setup(int S, Geom g, PassCfg pc, const double* __restrict__ poses, const 
     L.status = status;
     L.active = active;
   }
+}
+
+__global__ void __launch_bounds__(64)
+k_pass_setup(int S, Geom g, PassCfg pc, const double* __restrict__ poses, const CoarseOut* __restrict__ coarse,
+             Lattice* __restrict__ lat, double2* __restrict__ cossin, int want_step) {
+  const int s = blockIdx.x;
+  if (s >= S) return;
+  double center[3];
+  int active = 1;
+  if (pc.mode == 0) {
+    center[0] = poses[3 * s]; center[1] = poses[3 * s + 1]; center[2] = poses[3 * s + 2];
+  } else if (pc.mode == 1) {
+    center[0] = poses[3 * s]; center[1] = poses[3 * s + 1]; center[2] = poses[3 * s + 2];
+    active = coarse[s].expand && coarse[s].status == 0;
+  } else {
+    center[0] = coarse[s].mean[0]; center[1] = coarse[s].mean[1]; center[2] = coarse[s].mean[2];
+    active = coarse[s].status == 0;
+  }
+  pass_setup_wave(s, threadIdx.x, g, pc, center, active, lat, cossin, want_step);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -985,10 +1001,11 @@ k_reduce_coarse(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ la
 //    one thread; the ordered covariance sums stay on one thread, with their LDS reads batched.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ lat,
+k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
                     int32_t* resp, size_t resp_stride, CoarseOut* __restrict__ out,
                     int use_expansion, int pass_index, const uint8_t* __restrict__ grid,
-                const double2* __restrict__ local, int fb_step) {
+                const double2* __restrict__ local, int fb_step, PassCfg fine_pc,
+                    double2* fine_cossin, int fine_step) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double sh[256];
   __shared__ double s_ap[kMaxAngles];
@@ -1124,53 +1141,65 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
     terms[4 * c + 3] = (ksq(y - dy) * rr);
   }
   __syncthreads();
-  if (tid != 0) return;
-
-  CoarseOut o;
-  o.status = s_status;
-  o.flags = pass_index > 0 ? 1 : 0;
-  o.pad = 0;
-  const double avg[3] = {s_avg[0], s_avg[1], s_avg[2]};
-  double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  if (o.status == 0) {
-    if (best < kTol) {
-      cov[0] = kMaxVariance; cov[4] = kMaxVariance; cov[8] = 4 * ksq(pc.ang_res);
-    } else {
-      double axx = 0, axy = 0, ayy = 0, norm = 0;
-      const double thr = best - 0.1;
-      int c = 0;
-      for (; c + 4 <= ncand; c += 4) {  // y outer, x inner = candidate-cell order; reads batched, adds in order
-        double q[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) q[i] = terms[4 * c + i];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-          if (q[4 * i] >= thr) { norm += q[4 * i]; axx += q[4 * i + 1]; axy += q[4 * i + 2]; ayy += q[4 * i + 3]; }
+  __shared__ double s_mean[3];
+  __shared__ int s_ok;
+  if (tid == 0) {
+    CoarseOut o;
+    o.status = s_status;
+    o.flags = pass_index > 0 ? 1 : 0;
+    o.pad = 0;
+    const double avg[3] = {s_avg[0], s_avg[1], s_avg[2]};
+    double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (o.status == 0) {
+      if (best < kTol) {
+        cov[0] = kMaxVariance; cov[4] = kMaxVariance; cov[8] = 4 * ksq(pc.ang_res);
+      } else {
+        double axx = 0, axy = 0, ayy = 0, norm = 0;
+        const double thr = best - 0.1;
+        int c = 0;
+        for (; c + 4 <= ncand; c += 4) {  // y outer, x inner = candidate-cell order; reads batched, adds in order
+          double q[16];
+  #pragma unroll
+          for (int i = 0; i < 16; i++) q[i] = terms[4 * c + i];
+  #pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (q[4 * i] >= thr) { norm += q[4 * i]; axx += q[4 * i + 1]; axy += q[4 * i + 2]; ayy += q[4 * i + 3]; }
+        }
+        for (; c < ncand; c++) {
+          const double rr = terms[4 * c];
+          if (rr >= thr) { norm += rr; axx += terms[4 * c + 1]; axy += terms[4 * c + 2]; ayy += terms[4 * c + 3]; }
+        }
+        if (norm > kTol) {
+          double vxx = axx / norm, vxy = axy / norm, vyy = ayy / norm;
+          double vthth = 4 * ksq(pc.ang_res);
+          double min_xx = 0.1 * ksq(pc.res_x), min_yy = 0.1 * ksq(pc.res_y);
+          vxx = vxx > min_xx ? vxx : min_xx;
+          vyy = vyy > min_yy ? vyy : min_yy;
+          double mult = 1.0 / best;
+          cov[0] = vxx * mult; cov[1] = vxy * mult; cov[3] = vxy * mult; cov[4] = vyy * mult;
+          cov[8] = vthth;
+        }
+        if (double_equal(cov[0], 0.0)) cov[0] = kMaxVariance;
+        if (double_equal(cov[4], 0.0)) cov[4] = kMaxVariance;
       }
-      for (; c < ncand; c++) {
-        const double rr = terms[4 * c];
-        if (rr >= thr) { norm += rr; axx += terms[4 * c + 1]; axy += terms[4 * c + 2]; ayy += terms[4 * c + 3]; }
-      }
-      if (norm > kTol) {
-        double vxx = axx / norm, vxy = axy / norm, vyy = ayy / norm;
-        double vthth = 4 * ksq(pc.ang_res);
-        double min_xx = 0.1 * ksq(pc.res_x), min_yy = 0.1 * ksq(pc.res_y);
-        vxx = vxx > min_xx ? vxx : min_xx;
-        vyy = vyy > min_yy ? vyy : min_yy;
-        double mult = 1.0 / best;
-        cov[0] = vxx * mult; cov[1] = vxy * mult; cov[3] = vxy * mult; cov[4] = vyy * mult;
-        cov[8] = vthth;
-      }
-      if (double_equal(cov[0], 0.0)) cov[0] = kMaxVariance;
-      if (double_equal(cov[4], 0.0)) cov[4] = kMaxVariance;
     }
+    o.mean[0] = avg[0]; o.mean[1] = avg[1]; o.mean[2] = avg[2];
+    for (int i = 0; i < 9; i++) o.cov[i] = cov[i];
+    o.best = best > 1.0 ? 1.0 : best;  // :514-517
+    // Mapper.cpp:242-244,259: expand (again) while the best response is still zero
+    o.expand = (use_expansion && o.status == 0 && pass_index < 3 && double_equal(o.best, 0.0)) ? 1 : 0;
+    out[s] = o;
+    s_mean[0] = o.mean[0]; s_mean[1] = o.mean[1]; s_mean[2] = o.mean[2];
+    s_ok = o.status == 0;
   }
-  o.mean[0] = avg[0]; o.mean[1] = avg[1]; o.mean[2] = avg[2];
-  for (int i = 0; i < 9; i++) o.cov[i] = cov[i];
-  o.best = best > 1.0 ? 1.0 : best;  // :514-517
-  // Mapper.cpp:242-244,259: expand (again) while the best response is still zero
-  o.expand = (use_expansion && o.status == 0 && pass_index < 3 && double_equal(o.best, 0.0)) ? 1 : 0;
-  out[s] = o;
+  if (fine_cossin == nullptr) return;
+  // no expansion passes follow: this block's first wave lays out the scan's fine lattice around the
+  // mean it has just written (k_pass_setup, mode 2) -- one launch fewer
+  __syncthreads();
+  if (tid < 64) {
+    const double center2[3] = {s_mean[0], s_mean[1], s_mean[2]};
+    pass_setup_wave(s, tid, g, fine_pc, center2, s_ok, lat, fine_cossin, fine_step);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1915,8 +1944,11 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   SearchCfg sc{m->cfg.distance_variance_penalty, m->cfg.angle_variance_penalty,
                m->cfg.minimum_distance_penalty, m->cfg.minimum_angle_penalty, do_penalize};
 
+  // scan_prep also lays out the coarse lattice of pass 0 (mode 0 needs only the pose): one launch fewer
   launch(ctx, "scan_prep", k_scan_prep<RT>, dim3((g.n_beams + 255) / 256, S), dim3(256), 0, d_ranges,
-         stride, d_poses, g, m->d_local.p, (double2*)nullptr);
+         stride, d_poses, g, m->d_local.p, (double2*)nullptr, pc, m->d_lat.p, m->d_cossin.p, 2);
+  bool setup_done = true;  // consumed by the first pass
+
 
   if (m->sub_dirty) {  // refresh the parity planes of the grid (coarse pass source)
     launch(ctx, "deinterleave", k_deinterleave, dim3((g.data_size / 8 + 255) / 256), dim3(256), 0,
@@ -1942,8 +1974,10 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   auto run_responses = [&](const PassCfg& p, int step, const char* name) -> int {
     const int variant = force_generic ? 0 : (p.nx <= 4 && p.ny <= 4) ? 1 : (p.nx <= 12) ? 2 : (p.nx <= 16) ? 3 : 0;
     fb_step = variant ? step : 0;
-    launch(ctx, "pass_setup", k_pass_setup, dim3(S), dim3(64), 0, S, g, p, d_poses,
-           (const CoarseOut*)m->d_coarse.p, m->d_lat.p, m->d_cossin.p, step);
+    if (!setup_done)
+      launch(ctx, "pass_setup", k_pass_setup, dim3(S), dim3(64), 0, S, g, p, d_poses,
+             (const CoarseOut*)m->d_coarse.p, m->d_lat.p, m->d_cossin.p, step);
+    setup_done = false;
     const long long waves = (long long)((S + 7) / 8) * 8 * p.na;
     // fine pass of a batch big enough to fill the chip: one 16-byte load per beam from the 4x4 blocks
     bool tiled = variant == 1 && step == 1 && p.nx == 3 && p.ny == 3 && waves >= kTileMinWaves &&
@@ -2029,8 +2063,10 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   auto run_coarse_big = [&](const PassCfg& p, int pass_index) -> int {
     // dense kernel for uniform lattices; scans with a non-uniform lattice fall to the generic kernel
     fb_step = 2;
-    launch(ctx, "pass_setup", k_pass_setup, dim3(S), dim3(64), 0, S, g, p, d_poses,
-           (const CoarseOut*)m->d_coarse.p, m->d_lat.p, m->d_cossin.p, 2);
+    if (!setup_done)
+      launch(ctx, "pass_setup", k_pass_setup, dim3(S), dim3(64), 0, S, g, p, d_poses,
+             (const CoarseOut*)m->d_coarse.p, m->d_lat.p, m->d_cossin.p, 2);
+    setup_done = false;
     LSLAM_HIP(ctx, m->d_tbl.reserve((size_t)S * p.na * g.n_beams));
     launch(ctx, "table_big", k_table_big, dim3((g.n_beams + 255) / 256, p.na, S), dim3(256), 0, S, g, p,
            (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_tbl.p);
@@ -2065,8 +2101,14 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   g, p, sc, (const Lattice*)m->d_lat.p, m->d_resp.p, resp_stride, m->d_coarse.p,                              \
       (int)m->cfg.use_response_expansion, pass_index, (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, \
       fb_step
-    if (cache && ((size_t)p.nx * p.ny * p.na + 31) / 32 <= 256)
-      launch(ctx, "reduce_coarse", k_reduce_coarse_lds, dim3(S), dim3(256), reduce_lds(p, true), LSLAM_REDUCE_ARGS);
+    if (cache && ((size_t)p.nx * p.ny * p.na + 31) / 32 <= 256) {
+      const bool fuse_fine = n_exp == 0 && do_refine;  // nothing between this pass and the fine pass
+      launch(ctx, "reduce_coarse", k_reduce_coarse_lds, dim3(S), dim3(256), reduce_lds(p, true), g, p, sc,
+             m->d_lat.p, m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
+             (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step, pf,
+             fuse_fine ? m->d_cossin.p : (double2*)nullptr, 1);
+      setup_done = fuse_fine;
+    }
     else if (cache)
       launch(ctx, "reduce_coarse", k_reduce_coarse<true>, dim3(S), dim3(256), reduce_lds(p, true), LSLAM_REDUCE_ARGS);
     else
@@ -2361,7 +2403,7 @@ int lslam_matcher_set_base_scans(lslam_matcher* m, int B, const double* ranges, 
     if (rc) return rc;
     LSLAM_HIP(ctx, m->d_world.reserve((size_t)B * n));
     launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((n + 255) / 256, B), dim3(256), 0,
-           (const double*)m->d_ranges64.p, n, (const double*)m->d_poses.p, g, (double2*)nullptr, m->d_world.p);
+           (const double*)m->d_ranges64.p, n, (const double*)m->d_poses.p, g, (double2*)nullptr, m->d_world.p, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0);
   }
   int rc = rebuild_grid_dev(m, m->d_world.p, 0, B, B > 0 ? B : 1, center);
   if (rc) return rc;
@@ -2428,7 +2470,7 @@ int lslam_matcher_debug_lookup_table(lslam_matcher* m, const double* ranges, con
   LSLAM_HIP(ctx, m->d_local.reserve((size_t)g.n_beams));
   LSLAM_HIP(ctx, m->d_dbg.reserve((size_t)na * g.n_beams));
   launch(ctx, "scan_prep", k_scan_prep<double>, dim3((g.n_beams + 255) / 256, 1), dim3(256), 0,
-         (const double*)m->d_ranges64.p, g.n_beams, (const double*)m->d_poses.p, g, m->d_local.p, (double2*)nullptr);
+         (const double*)m->d_ranges64.p, g.n_beams, (const double*)m->d_poses.p, g, m->d_local.p, (double2*)nullptr, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0);
   launch(ctx, "debug_table", k_debug_table, dim3((g.n_beams + 255) / 256, na), dim3(256), 0, g,
          (const double2*)m->d_local.p, angle_center, angle_offset, angle_res, na, m->d_dbg.p);
   LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_dbg.p, (size_t)na * g.n_beams * sizeof(int32_t), hipMemcpyDeviceToHost,
@@ -2478,7 +2520,7 @@ int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges, const
   LSLAM_HIP(ctx, m->d_world.reserve((size_t)g.n_beams));
   LSLAM_HIP(ctx, m->d_valid.reserve((size_t)g.n_beams));
   launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((g.n_beams + 255) / 256, 1), dim3(256), 0,
-         (const double*)m->d_ranges64.p, g.n_beams, (const double*)m->d_poses.p, g, (double2*)nullptr, m->d_world.p);
+         (const double*)m->d_ranges64.p, g.n_beams, (const double*)m->d_poses.p, g, (double2*)nullptr, m->d_world.p, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0);
   {
     const size_t lds = (size_t)g.n_beams * (sizeof(double2) + 9) + 16;
     const int use_lds = lds <= 60 * 1024;
