@@ -5,14 +5,21 @@
 // karto::GridIndexLookup (Karto.h:6359-6555).  See DESIGN.md for the data layout and the
 // roofline of each kernel.
 //
-// Device pipeline of one batch of S independent scans against the resident correlation grid:
-//   k_scan_prep      S*N threads   ranges -> scan-frame points (Karto.h:5384-5388, 6423-6434)
-//   k_pass_setup     wave per scan  lattice cell coordinates + cos/sin of the pass's angles (Mapper.cpp:339-393)
-//   k_resp_rows      S*nA waves    ** hot kernel ** all nX*nY response sums of one (scan, angle)
-//                                  for a uniform lattice (Mapper.cpp:373-424, 819-856)
-//   k_resp_generic   work list     same sums for arbitrary lattices (fine pass, fall-back)
-//   k_reduce_coarse  S blocks      penalties, max, tie average, positional covariance
-//   k_reduce_fine    S blocks      same + angular covariance (Mapper.cpp:431-506, 535-692)
+// Device pipeline of one batch of S independent scans against the resident correlation grid
+// (five launches; response-expansion passes add k_pass_setup + k_resp_rows + k_reduce_coarse each):
+//   k_scan_prep      S*N threads   ranges -> scan-frame points (Karto.h:5384-5388, 6423-6434); its first
+//                                  wave per scan lays out the coarse lattice + cos/sin of the angles
+//                                  (pass_setup_wave, Mapper.cpp:339-393)
+//   k_resp_rows      S*nA waves    ** hot kernel ** all nX*nY response sums of one (scan, angle) for a
+//                                  uniform lattice (Mapper.cpp:373-424, 819-856); big batches gather from
+//                                  the 2-D tiled parity planes (k_tile_planes)
+//   k_reduce_coarse  S blocks      penalties, max, tie average, positional covariance; then the fine
+//                                  lattice of the scan
+//   k_resp_tile3     S*nA waves    fine pass: one 16-byte load per beam from overlapping 4x4 blocks
+//                                  (k_tile4); k_resp_rows<1,4> for small batches
+//   k_reduce_fine    S blocks      same reductions + angular covariance (Mapper.cpp:431-506, 535-692)
+//   k_resp_generic                 the same sums for arbitrary lattices; as block_generic_fallback it
+//                                  runs inside the reduce kernels for scans with a non-uniform lattice
 // Response numerators stay integers end to end (sum of uint8 <= 255*N); the fp64 part follows
 // the reference's expression order (built with -ffp-contract=off).
 #include <algorithm>
