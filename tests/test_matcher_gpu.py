@@ -305,6 +305,10 @@ def test_reference_indoor_default_config(ctx, oracle_lib):
         _assert_result(res[q], mean, cov, resp)
         good += resp > 0.3
     assert good >= 3
+    # the same scans 20x: enough waves for the tiled parity planes (<4,8,true>, two 8-row passes) and the
+    # 4x4-block fine kernel, with the expansion passes in between -- byte-identical to the small batch
+    big = gm.match_batch(np.tile(wl.query_ranges, (20, 1)), np.tile(wl.query_poses, (20, 1)))
+    assert big.tobytes() == np.tile(res, 20).tobytes()
     # full MatchScan too (grid rebuilt with the 13x13 smear around the query)
     mean, cov, resp = port.match_scan(wl.base_ranges, wl.base_poses, wl.query_ranges[1], wl.query_poses[1])
     r, m, c = gm.MatchScan(wl.query_ranges[1], wl.query_poses[1], wl.base_ranges, wl.base_poses)
