@@ -458,9 +458,11 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
     const int Yb1 = Y0 + j0 * step + 1;
     const int m0_max = limit - ((rows_here - 1) * g.stride + 4 * NXD);  // whole neighbourhood in range
     const int y1_max = g.height + 1 - step * (NYC - 1);                 // y+1 range of the occupancy window
+    double2 p_next = lp[min(64 * slice + lane, g.n_beams - 1)];
     for (int b0 = 64 * slice; b0 < g.n_beams; b0 += bstride) {
       const int b = b0 + lane;
-      const double2 p = lp[min(b, g.n_beams - 1)];
+      const double2 p = p_next;  // fetched one block ahead: its latency hides behind this block's arithmetic
+      p_next = lp[min(b + bstride, g.n_beams - 1)];
       uint32_t mask = 0u, par = 0u, col = 0u, osh = 0u;
       int m0i = 0;
       bool have_occ = false;
