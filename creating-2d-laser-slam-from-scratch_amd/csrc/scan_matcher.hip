@@ -1684,8 +1684,10 @@ __global__ void k_result_no_readings(int S, const double* poses, double coarse_a
 // lagging iterator, which always ends up at the new anchor; the run [old anchor, new anchor) is kept
 // iff the side test ss >= 0 (the very first run starts at index 0).  So:
 //   (1) every thread finds the successor next[i] of "its" point as if it were an anchor,
-//   (2) one thread follows the anchor chain through next[] (a few hundred LDS reads),
-//   (3) every chain link evaluates its side test and marks its run -- in parallel.
+//   (2) the anchors = the points reachable from the first valid point through next[]: pointer
+//       doubling marks them in ceil(log2 n) rounds (LDS path; the global-scratch path for very long
+//       scans walks the chain on one thread),
+//   (3) every anchor evaluates its side test and marks its run [anchor, next[anchor]) -- in parallel.
 // Every fp64 expression is the reference's.
 __global__ void __launch_bounds__(256)
 k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, double vx, double vy,
@@ -1697,13 +1699,16 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
   uint8_t* gv = valid + (size_t)b * n;
   const double2* p = gp;
   uint8_t* v = gv;
-  int *next, *chain;
+  int *next, *chain, *jump2 = nullptr;
+  uint8_t* reach = nullptr;
   if (use_lds) {
     double2* lp = (double2*)smem;
     next = (int*)(lp + n);
-    chain = next + n;
-    uint8_t* lv = (uint8_t*)(chain + n);
-    for (int i = tid; i < n; i += 256) { lp[i] = gp[i]; lv[i] = 0; }
+    chain = next + n;   // jump table A
+    jump2 = chain + n;  // jump table B
+    uint8_t* lv = (uint8_t*)(jump2 + n);
+    reach = lv + n;
+    for (int i = tid; i < n; i += 256) { lp[i] = gp[i]; lv[i] = 0; reach[i] = 0; }
     p = lp;
     v = lv;
   } else {
@@ -1723,24 +1728,45 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
       if (ksq(dx) + ksq(dy) > min_sq) break;  // :780-781
     }
     next[i] = j;
+    if (use_lds) chain[i] = j;
   }
   __syncthreads();
-  if (tid == 0) {
-    int len = 0;
-    for (int a = s_first; a < n; a = next[a]) chain[len++] = a;
-    s_len = len;
-  }
-  __syncthreads();
-  const int len = s_len;
-  for (int k = tid; k + 1 < len; k += 256) {
-    const int a = chain[k], f = chain[k + 1];
+  // the side test of anchor a against its successor f, and the run it keeps (:788-806)
+  auto keep_run = [&](int a, int f, bool first) {
     const double fx = p[a].x, fy = p[a].y, cx = p[f].x, cy = p[f].y;
-    const double aa = vy - fy;  // :788-791
+    const double aa = vy - fy;
     const double bb = fx - vx;
     const double cc = fy * vx - fx * vy;
     const double ss = cx * aa + cy * bb + cc;
-    if (!(ss < 0.0))            // :796-806
-      for (int t = (k == 0 ? 0 : a); t < f; t++) v[t] = 1;
+    if (!(ss < 0.0))
+      for (int t = (first ? 0 : a); t < f; t++) v[t] = 1;
+  };
+  if (use_lds) {
+    const int first = s_first;
+    if (tid == 0 && first < n) reach[first] = 1;
+    __syncthreads();
+    int* ja = chain;
+    int* jb = jump2;
+    for (int span = 1; span < n; span <<= 1) {  // ja = next^span; marks chain distances [span, 2 span)
+      for (int i = tid; i < n; i += 256) {
+        const int j = ja[i];
+        if (reach[i] && j < n) reach[j] = 1;
+        jb[i] = j < n ? ja[j] : n;
+      }
+      __syncthreads();
+      int* t = ja; ja = jb; jb = t;
+    }
+    for (int a = tid; a < n; a += 256)
+      if (reach[a] && next[a] < n) keep_run(a, next[a], a == first);
+  } else {
+    if (tid == 0) {
+      int len = 0;
+      for (int a = s_first; a < n; a = next[a]) chain[len++] = a;
+      s_len = len;
+    }
+    __syncthreads();
+    const int len = s_len;
+    for (int k = tid; k + 1 < len; k += 256) keep_run(chain[k], chain[k + 1], k == 0);
   }
   __syncthreads();
   if (use_lds)
@@ -2159,7 +2185,7 @@ int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, i
   const int n = g.n_beams;
   if (B <= 0 || n <= 0) return LSLAM_OK;
   LSLAM_HIP(ctx, m->d_valid.reserve((size_t)B * n));
-  const size_t lds = (size_t)n * (sizeof(double2) + 9) + 16;
+  const size_t lds = (size_t)n * (sizeof(double2) + 14) + 16;  // points, next, two jump tables, valid, reach
   const int use_lds = lds <= 60 * 1024;
   if (!use_lds) LSLAM_HIP(ctx, m->d_fv_scratch.reserve((size_t)B * 2 * n));
   launch(ctx, "find_valid", k_find_valid, dim3(B), dim3(256), use_lds ? lds : 0, n, d_world, ring_start, cap,
@@ -2531,7 +2557,7 @@ int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges, const
   launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((g.n_beams + 255) / 256, 1), dim3(256), 0,
          (const double*)m->d_ranges64.p, g.n_beams, (const double*)m->d_poses.p, g, (double2*)nullptr, m->d_world.p, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0);
   {
-    const size_t lds = (size_t)g.n_beams * (sizeof(double2) + 9) + 16;
+    const size_t lds = (size_t)g.n_beams * (sizeof(double2) + 14) + 16;
     const int use_lds = lds <= 60 * 1024;
     if (!use_lds) LSLAM_HIP(ctx, m->d_fv_scratch.reserve((size_t)2 * g.n_beams));
     launch(ctx, "find_valid", k_find_valid, dim3(1), dim3(256), use_lds ? lds : 0, g.n_beams,
