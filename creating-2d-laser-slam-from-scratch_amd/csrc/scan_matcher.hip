@@ -64,6 +64,7 @@ constexpr int kTilePad = 128;  // zero bytes in front of the tiled parity planes
 constexpr int kTileYOff = 32;  // tiled planes: class rows start at grid row y = -kTileYOff (>= 2*16 - 1 + 1)
 constexpr int kRowZero = 64;  // k_resp_rows: row-load offset 0 = 64 zero guard bytes in front of plane 0
 constexpr int kMaxBeamsPerLane = 32;  // k_resp_rows: 8 lanes x 32 beams x 255 < 2^16 (packed DPP reduce)
+constexpr int kOccMinScans = 8;      // smaller batches do not rebuild the row-occupancy bitmap for themselves
 constexpr int kTileMinWaves = 2048;  // below this the fine pass stays on k_resp_rows (beam slices fill the chip)
 constexpr int kMaxGridSide = 32768;  // widthStep and height: dataSize <= 2^30, flat indices stay int32
 
@@ -1884,6 +1885,7 @@ struct lslam_matcher {
   uint8_t* d_sub_alloc = nullptr;   // two parity planes F_0, F_1, each kGuard + data_size/2 + kGuard
   uint8_t* d_sub[2] = {nullptr, nullptr};
   bool sub_dirty = true;            // the planes lag behind d_grid
+  bool occ_dirty = true;            // so does the row-occupancy bitmap (built on demand: not for tiny batches)
   bool use_row_occupancy = true;
   uint32_t* d_occ_t = nullptr;      // transposed row-occupancy bitmap (k_row_occupancy)
   uint2* d_occ_x = nullptr;         // the same bits as x-major 64-bit word pairs (k_occ_pairs): what k_resp_rows reads
@@ -1988,13 +1990,20 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   if (m->sub_dirty) {  // refresh the parity planes of the grid (coarse pass source)
     launch(ctx, "deinterleave", k_deinterleave, dim3((g.data_size / 8 + 255) / 256), dim3(256), 0,
            (const uint8_t*)m->d_grid, m->d_sub[0], m->d_sub[1], g.data_size / 8);
+    m->sub_dirty = false;
+  }
+  // The exact row-occupancy bitmap costs ~30 us to rebuild; a handful of scans (the streaming front-end
+  // matches ONE scan per grid) does not earn that back, so tiny batches match without it unless it is
+  // already up to date.  Results do not depend on it either way.
+  const bool want_occ = m->use_row_occupancy && (S >= kOccMinScans || !m->occ_dirty);
+  if (want_occ && m->occ_dirty) {
     launch(ctx, "nonzero_bits", k_nonzero_bits, dim3((m->nz_words + 255) / 256), dim3(256), 0,
            (const uint8_t*)m->d_grid, g.data_size, m->d_nz, m->nz_words);
     launch(ctx, "row_occupancy", k_row_occupancy, dim3((g.stride + 255) / 256, m->occ_wpc), dim3(256), 0,
            (const uint32_t*)m->d_nz, m->nz_words, g.stride, g.height, m->occ_win, m->d_occ_t, m->occ_wpc / 2);
     launch(ctx, "occ_pairs", k_occ_pairs, dim3((g.stride + 255) / 256, m->occ_wpc), dim3(256), 0,
            (const uint32_t*)m->d_occ_t, g.stride, m->occ_wpc / 2, m->d_occ_x);
-    m->sub_dirty = false;
+    m->occ_dirty = false;
   }
   auto reduce_lds = [&](const PassCfg& p, bool cache) -> size_t {
     size_t total = (size_t)p.nx * p.ny * p.na;
@@ -2048,7 +2057,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       const uint8_t* s1 = step == 2 ? m->d_sub[1] : m->d_grid;
       const int limit = step == 2 ? g.data_size / 2 : g.data_size;
       // the bitmap covers row spans of kOccWin grid bytes: step*(nX-1)+1 must fit
-      const uint2* occ = (m->use_row_occupancy && step == 2 && step * (p.nx - 1) + 1 <= m->occ_win) ? m->d_occ_x : (const uint2*)nullptr;
+      const uint2* occ = (want_occ && step == 2 && step * (p.nx - 1) + 1 <= m->occ_win) ? m->d_occ_x : (const uint2*)nullptr;
       // coarse pass of a batch that fills the chip on its own: gather from the TILED parity planes
       bool ptiled = step == 2 && slices == 1 && waves >= kTileMinWaves && !m->ptile_failed;
       if (ptiled && !m->d_ptiles) {
@@ -2181,7 +2190,7 @@ int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, i
   g.off_x = center[0] - (0.5 * (g.roi_w - 1) * (1.0 / g.scale));
   g.off_y = center[1] - (0.5 * (g.roi_h - 1) * (1.0 / g.scale));
   LSLAM_HIP(ctx, hipMemsetAsync(m->d_grid, 0, (size_t)g.data_size, ctx->stream));  // Grid::Clear (Mapper.cpp:701)
-  m->sub_dirty = m->tile_dirty = m->ptile_dirty = true;
+  m->sub_dirty = m->occ_dirty = m->tile_dirty = m->ptile_dirty = true;
   const int n = g.n_beams;
   if (B <= 0 || n <= 0) return LSLAM_OK;
   LSLAM_HIP(ctx, m->d_valid.reserve((size_t)B * n));
@@ -2409,7 +2418,7 @@ int lslam_matcher_set_grid_u8(lslam_matcher* m, const uint8_t* grid, const doubl
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   m->g.off_x = offset_xy[0];
   m->g.off_y = offset_xy[1];
-  m->sub_dirty = m->tile_dirty = m->ptile_dirty = true;
+  m->sub_dirty = m->occ_dirty = m->tile_dirty = m->ptile_dirty = true;
   return LSLAM_OK;
 }
 
@@ -2420,7 +2429,7 @@ int lslam_matcher_set_grid_u8_dev(lslam_matcher* m, const uint8_t* grid_dev, con
     LSLAM_HIP(ctx, hipMemcpyAsync(m->d_grid, grid_dev, (size_t)m->g.data_size, hipMemcpyDeviceToDevice, ctx->stream));
   m->g.off_x = offset_xy[0];
   m->g.off_y = offset_xy[1];
-  m->sub_dirty = m->tile_dirty = m->ptile_dirty = true;
+  m->sub_dirty = m->occ_dirty = m->tile_dirty = m->ptile_dirty = true;
   return LSLAM_OK;
 }
 
