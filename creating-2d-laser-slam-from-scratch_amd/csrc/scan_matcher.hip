@@ -1801,29 +1801,72 @@ __device__ __forceinline__ void atomic_max_u8(uint8_t* base, size_t idx, uint32_
 }
 
 // AddScan (Mapper.cpp:716-748) for every valid point of every base scan in parallel: the thread
-// that turns a cell into 100 ("not already occupied", :734-740) smears it (SmearPoint,
-// Mapper.h:971-1005) as a max-merge scatter.  Order-independent because the kernel's only 100 is
+// that turns a cell into 100 ("not already occupied", :734-740) lists it, and k_smear_list smears
+// every listed cell (SmearPoint, Mapper.h:971-1005) as a max-merge scatter.  Order-independent because the kernel's only 100 is
 // its centre (checked at create time; otherwise k_add_scans_serial runs).
 __global__ void __launch_bounds__(256)
-k_mark_smear(int B, int n, const double2* __restrict__ world, int ring_start, int cap,
-             const uint8_t* __restrict__ valid, Geom g, const uint8_t* __restrict__ kernel,
-             uint8_t* __restrict__ grid) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int b = blockIdx.y;
-  if (i >= n || !valid[(size_t)b * n + i]) return;
-  double2 p = world[(size_t)((ring_start + b) % cap) * n + i];
-  int gx = world_to_grid(p.x, g.off_x, g.scale);
-  int gy = world_to_grid(p.y, g.off_y, g.scale);
-  if (gx < 0 || gx >= g.roi_w || gy < 0 || gy >= g.roi_h) return;  // IsUpTo on the ROI (:724-729)
-  size_t idx = (size_t)(gx + g.border) + (size_t)(gy + g.border) * g.stride;
-  if (!atomic_set_u8(grid, idx, (uint32_t)kOccupied)) return;  // value already set (:734-738)
-  const int hk = g.kernel_size / 2;
-  for (int j = -hk; j <= hk; j++) {
-    size_t row = (size_t)(gx + g.border) + (size_t)(gy + j + g.border) * g.stride;
-    for (int k = -hk; k <= hk; k++) {
-      uint32_t kv = kernel[(k + hk) + g.kernel_size * (j + hk)];
-      if (kv && (j || k)) atomic_max_u8(grid, row + k, kv);
+k_mark_centres(int B, int n, const double2* __restrict__ world, int ring_start, int cap,
+               const uint8_t* __restrict__ valid, Geom g, uint8_t* __restrict__ grid,
+               uint32_t* __restrict__ list, int* __restrict__ count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  uint32_t idx = 0xFFFFFFFFu;  // no cell
+  if (i < n && valid[(size_t)b * n + i]) {
+    const double2 p = world[(size_t)((ring_start + b) % cap) * n + i];
+    const int gx = world_to_grid(p.x, g.off_x, g.scale);
+    const int gy = world_to_grid(p.y, g.off_y, g.scale);
+    if (gx >= 0 && gx < g.roi_w && gy >= 0 && gy < g.roi_h)  // IsUpTo on the ROI (:724-729)
+      idx = (uint32_t)((gx + g.border) + (gy + g.border) * g.stride);
+  }
+  // neighbouring beams mostly hit the same cell: only the first lane of such a run goes for the CAS
+  const uint32_t left = (uint32_t)__shfl_up((int)idx, 1);
+  const bool contender = idx != 0xFFFFFFFFu && ((threadIdx.x & 63) == 0 || left != idx);
+  // "value already set -> skip" (:734-738): exactly one thread per cell wins and its point smears
+  const bool winner = contender && atomic_set_u8(grid, idx, (uint32_t)kOccupied);
+  const unsigned long long won = __ballot(winner);
+  if (won) {  // one counter update per wave
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)won) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(count, __popcll(won));
+    base = __shfl(base, leader);
+    if (winner) list[base + __popcll(won & ((1ull << lane) - 1ull))] = idx;
+  }
+}
+
+// SmearPoint of every listed centre, one thread per (centre, kernel row, aligned word of that row):
+// byte-wise max of up to four kernel values into the word by CAS.  All of a centre's words are in
+// flight together instead of one thread walking its 49 cells.
+__global__ void __launch_bounds__(256)
+k_smear_list(const uint32_t* __restrict__ list, const int* __restrict__ count, Geom g,
+             const uint8_t* __restrict__ kernel, uint8_t* __restrict__ grid, int words_per_row) {
+  const int ks = g.kernel_size, hk = ks / 2;
+  const int items = ks * words_per_row;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long c = t / items;
+  if (c >= *count) return;
+  const int item = (int)(t - c * items), j = item / words_per_row - hk, w = item % words_per_row;
+  const long long centre = (long long)list[c] + (long long)j * g.stride;  // this row's centre byte
+  const long long word0 = ((centre - hk) & ~3ll) + 4ll * w;               // aligned word of the row
+  uint32_t want = 0;
+#pragma unroll
+  for (int bb = 0; bb < 4; bb++) {
+    const long long k = word0 + bb - centre;
+    if (k >= -hk && k <= hk) want |= (uint32_t)kernel[(int)(k + hk) + ks * (j + hk)] << (8 * bb);
+  }
+  if (!want) return;
+  uint32_t* wp = (uint32_t*)(grid + word0);
+  uint32_t old = *wp;
+  for (;;) {
+    uint32_t mx = 0;
+#pragma unroll
+    for (int bb = 0; bb < 4; bb++) {
+      const uint32_t o = (old >> (8 * bb)) & 0xFFu, v = (want >> (8 * bb)) & 0xFFu;
+      mx |= (o > v ? o : v) << (8 * bb);
     }
+    if (mx == old) break;
+    const uint32_t prev = atomicCAS(wp, old, mx);
+    if (prev == old) break;
+    old = prev;
   }
 }
 
@@ -1905,6 +1948,7 @@ struct lslam_matcher {
   DevBuf<double2> d_local, d_world;
   DevBuf<uint8_t> d_valid;
   DevBuf<int> d_fv_scratch;
+  DevBuf<uint32_t> d_centres;  // [0] = count, [1..] = flat grid index of every newly occupied cell (AddScans)
   DevBuf<Lattice> d_lat;
   DevBuf<double2> d_cossin;  // [S][kMaxAngles] cos/sin of the pass's candidate angles (k_pass_setup)
   DevBuf<CoarseOut> d_coarse;
@@ -2199,10 +2243,19 @@ int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, i
   if (!use_lds) LSLAM_HIP(ctx, m->d_fv_scratch.reserve((size_t)B * 2 * n));
   launch(ctx, "find_valid", k_find_valid, dim3(B), dim3(256), use_lds ? lds : 0, n, d_world, ring_start, cap,
          center[0], center[1], m->d_valid.p, use_lds, m->d_fv_scratch.p);
-  if (m->kernel_center_only)
-    launch(ctx, "mark_smear", k_mark_smear, dim3((n + 255) / 256, B), dim3(256), 0, B, n, d_world, ring_start, cap,
-           (const uint8_t*)m->d_valid.p, g, (const uint8_t*)m->d_kernel, m->d_grid);
-  else
+  if (m->kernel_center_only) {
+    // (1) centres: the first point to reach a cell sets it to 100 and is listed; (2) every listed centre
+    // smears, one thread per aligned word of its footprint
+    LSLAM_HIP(ctx, m->d_centres.reserve((size_t)B * n + 1));
+    LSLAM_HIP(ctx, hipMemsetAsync(m->d_centres.p, 0, sizeof(uint32_t), ctx->stream));
+    launch(ctx, "mark_centres", k_mark_centres, dim3((n + 255) / 256, B), dim3(256), 0, B, n, d_world, ring_start, cap,
+           (const uint8_t*)m->d_valid.p, g, m->d_grid, m->d_centres.p + 1, (int*)m->d_centres.p);
+    const int wpr = (g.kernel_size + 3) / 4 + 1;
+    const long long threads = (long long)B * n * g.kernel_size * wpr;
+    launch(ctx, "smear", k_smear_list, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+           (const uint32_t*)(m->d_centres.p + 1), (const int*)m->d_centres.p, g, (const uint8_t*)m->d_kernel, m->d_grid,
+           wpr);
+  } else
     launch(ctx, "add_scans_serial", k_add_scans_serial, dim3(1), dim3(64), 0, B, n, d_world, ring_start, cap,
            (const uint8_t*)m->d_valid.p, g, (const uint8_t*)m->d_kernel, m->d_grid);
   LSLAM_HIP(ctx, hipGetLastError());
@@ -2379,7 +2432,7 @@ void lslam_matcher_destroy(lslam_matcher* m) {
   (void)hipFree(m->d_tiles);
   (void)hipFree(m->d_ptiles);
   m->d_ranges64.release(); m->d_poses.release(); m->d_local.release(); m->d_world.release();
-  m->d_valid.release(); m->d_fv_scratch.release(); m->d_lat.release(); m->d_cossin.release(); m->d_coarse.release(); m->d_resp.release();
+  m->d_valid.release(); m->d_fv_scratch.release(); m->d_centres.release(); m->d_lat.release(); m->d_cossin.release(); m->d_coarse.release(); m->d_resp.release();
   m->d_tbl.release(); m->d_big.release(); m->d_results.release(); m->d_dbg.release();
   delete m;
 }
