@@ -189,11 +189,13 @@ def main():
         avg_ms = total_ms / max(launches, 1)
         per_launch_bytes = (coarse_bytes if dom_name == "resp_rows_coarse" else match_bytes) * B
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = ROOT / "profiles" / "traffic.json"  # PMC HBM bytes per launch of the same command (see profiles/README.md)
+        traffic, limiter = None, None
+        tfile = ROOT / "profiles" / "traffic.json"  # PMC figures per launch of the same command (see profiles/README.md)
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get(dom_name, {}).get("hbm_bytes_per_launch")
+                rec = json.loads(tfile.read_text()).get(dom_name, {})
+                traffic = rec.get("hbm_bytes_per_launch")
+                limiter = rec.get("limiter")  # what the counters say actually bounds the kernel
             except Exception:
                 traffic = None
         roofline = {
@@ -203,6 +205,8 @@ def main():
             "whole_match_algorithmic_GBs": round(value / world * match_bytes / 1e9, 2),
             "whole_match_frac": round(value / world * match_bytes / 1e9 / HBM_PEAK_GBS, 5),
         }
+        if limiter:
+            roofline["limiter_pmc"] = limiter
 
     # ---- CPU baseline on this box's host cores (rank 0, N=1 only) ----
     cpu_baseline = None
