@@ -60,7 +60,7 @@ struct SearchCfg {
   int do_penalize;
 };
 
-constexpr int kTilePad = 128;  // zero bytes in front of the tiled parity planes (dead rows read offset 0)
+constexpr int kTilePad = 512;  // zero bytes in front of the tiled parity planes (a dead row j reads offset 32 j)
 constexpr int kTileYOff = 32;  // tiled planes: class rows start at grid row y = -kTileYOff (>= 2*16 - 1 + 1)
 constexpr int kRowZero = 64;  // k_resp_rows: row-load offset 0 = 64 zero guard bytes in front of plane 0
 constexpr int kMaxBeamsPerLane = 32;  // k_resp_rows: 8 lanes x 32 beams x 255 < 2^16 (packed DPP reduce)
@@ -228,29 +228,31 @@ k_deinterleave(const uint8_t* __restrict__ grid, uint8_t* __restrict__ f0, uint8
 }
 
 // ------------------------------------------------------------------------------------------
-// k_tile_planes: the parity planes again, TILED for the gather unit.  A vector-memory instruction
+// k_tile_planes: the parity planes again, laid out for the gather unit.  A vector-memory instruction
 // costs about one cycle per distinct 128-byte line its lanes touch (tools/micro/ta_rate.hip), and in
 // the linear planes the 64 beams of a row load sit on ~40 different lines: neighbouring beams of a
-// wall that is not parallel to x fall into different grid rows.  Here a line is a 2-D patch --
-// 4 lattice-consecutive rows (grid rows 2 apart: the planes are split by row parity as well) x 32
-// bytes -- and patches step 16 bytes in x, so every dword-aligned 16-byte row segment lies inside
-// one patch (2x the plane bytes).  Defined on the FLAT plane index like the planes themselves:
-//   T[q][ry][ty][tx][r][c] = F_q[((2*(4 ty + r) + ry) - kTileYOff) * widthStep/2 + 16 tx + c],
-// zero outside [0, dataSize/2); c in [0,32) may run past the row end = the next row (flat wrap).
+// wall that is not parallel to x fall into different grid rows.  Here the planes are split by row
+// parity as well (lattice rows are 2 grid rows apart) and cut into vertical STRIPS 32 bytes wide that
+// step 16 bytes in x, each strip stored row after row: a 128-byte line is a 2-D patch of 4
+// lattice-consecutive rows x 32 bytes, every dword-aligned 16-byte row segment lies inside one
+// strip (2x the plane bytes), and the rows of one beam are 32 bytes apart -- an immediate offset.
+// Defined on the FLAT plane index like the planes themselves:
+//   T[q][ry][tx][Y'][c] = F_q[((2 Y' + ry) - kTileYOff) * widthStep/2 + 16 tx + c],   c in [0, 32),
+// zero outside [0, dataSize/2); c may run past the row end = the next row (flat wrap).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_tile_planes(const uint8_t* __restrict__ grid, int stride, int data_size, uint32_t* __restrict__ tiles,
-              int tile_tx, int tile_ty) {
+              int tile_tx, int tile_rows) {
   const size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // output dword
-  const size_t per_class = (size_t)tile_ty * tile_tx * 32;
+  const size_t per_class = (size_t)tile_tx * tile_rows * 8;
   if (d >= 4 * per_class) return;
   const int cls = (int)(d / per_class);  // q * 2 + ry
   const size_t rem = d - (size_t)cls * per_class;
-  const int c4 = (int)(rem & 7), r = (int)((rem >> 3) & 3);
-  const size_t t = rem >> 5;
-  const int tx = (int)(t % tile_tx), ty = (int)(t / tile_tx);
+  const int c4 = (int)(rem & 7);
+  const size_t t = rem >> 3;
+  const int row = (int)(t % tile_rows), tx = (int)(t / tile_rows);
   const int q = cls >> 1, ry = cls & 1;
-  const long long y = (long long)(2 * (4 * ty + r) + ry) - kTileYOff;
+  const long long y = (long long)(2 * row + ry) - kTileYOff;
   const long long m = y * (stride / 2) + 16 * tx + 4 * c4;
   uint32_t v = 0;
 #pragma unroll
@@ -365,7 +367,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int step, int limit, Geom g,
             PassCfg pc, const Lattice* __restrict__ lat, const double2* __restrict__ cossin,
             const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int beam_slices,
-            int S, const uint2* __restrict__ occ_t, int occ_wpc, int tile_tx, uint32_t tile_class_bytes) {
+            int S, const uint2* __restrict__ occ_t, int occ_wpc, int tile_rows, uint32_t tile_class_bytes) {
   constexpr int NW = NXD * NYC * 2;
   constexpr int kQueue = 128;
   static_assert(NYC <= 16 && 2 * (NYC - 1) < 32, "row mask / occupancy window width");
@@ -393,7 +395,7 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
   // (TILED: src0 is the tiled-plane buffer itself, whose first kTilePad bytes are zero)
   const uint8_t* zbase = TILED ? src0 : src0 - kRowZero;
   const uint32_t plane_delta = TILED ? 0u : (uint32_t)(src1 - src0);
-  const uint32_t tile_row_bytes = (uint32_t)tile_tx * 128u;  // one row of tiles
+  const uint32_t strip_bytes = (uint32_t)tile_rows * 32u;  // one 32-byte-wide strip, all class rows
   const int occ_wph = occ_wpc >> 1;  // words per (column, row parity)
 
   for (int j0 = 0; j0 < pc.ny; j0 += NYC) {
@@ -416,18 +418,16 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       uint32_t wv[NYC][NXD + 1];
       if constexpr (TILED) {
         // e.x = X' | parity << 15 | (y + kTileYOff) << 16 (k_tile_planes): lattice row j is class row
-        // (yy >> 1) + j of class yy & 1; tile = 4 class rows x 32 bytes, tiles step 16 bytes in x
+        // (yy >> 1) + j of class yy & 1, 32 bytes after row j - 1 in the beam's strip
         const uint32_t xa = (uint32_t)e.x & 0x7FFCu, yy = (uint32_t)e.x >> 16;
         const uint32_t base_off = (uint32_t)kTilePad + (((uint32_t)e.x >> 15) & 1u) * 2u * tile_class_bytes +
-                                  (yy & 1u) * tile_class_bytes + (xa >> 4) * 128u + (xa & 15u);
-        const uint32_t z = (yy >> 1) << 5;  // class row * 32
+                                  (yy & 1u) * tile_class_bytes + (xa >> 4) * strip_bytes + (yy >> 1) * 32u +
+                                  (xa & 15u);
 #pragma unroll
         for (int j = 0; j < NYC; j++) {
-          const uint32_t zj = z + 32u * j;
-          uint32_t off = __umul24(zj >> 7, tile_row_bytes) + base_off;
-          off |= zj & 96u;  // row inside the tile; those two bits of base_off are clear
-          off &= (uint32_t)__builtin_amdgcn_sbfe(e.y, j, 1);  // a dead row reads the zero pad at offset 0
-          __builtin_memcpy(wv[j], __builtin_assume_aligned(zbase + off, 4), 4 * (NXD + 1));
+          // a dead row reads the zero pad (offset 32 j < kTilePad); the row step is an immediate offset
+          const uint32_t off = base_off & (uint32_t)__builtin_amdgcn_sbfe(e.y, j, 1);
+          __builtin_memcpy(wv[j], __builtin_assume_aligned(zbase + (size_t)off + 32 * j, 4), 4 * (NXD + 1));
         }
       } else {
         uint32_t cur = ((uint32_t)e.x & ~3u) + (uint32_t)kRowZero + (e.y < 0 ? plane_delta : 0u);
@@ -1937,7 +1937,7 @@ struct lslam_matcher {
   uint32_t* d_nz = nullptr;         // flat non-zero bitmap, one bit per grid byte (k_nonzero_bits)
   int nz_words = 0;
   uint8_t* d_ptiles = nullptr;      // tiled parity planes (k_tile_planes), allocated on first batch use
-  int ptile_tx = 0, ptile_ty = 0;
+  int ptile_tx = 0, ptile_rows = 0;
   bool ptile_dirty = true, ptile_failed = false;
   uint4* d_tiles = nullptr;         // overlapping 4x4 cell blocks (k_tile4), allocated on first batch use
   int tile_cols = 0, tile_rows = 0;
@@ -2106,8 +2106,8 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       bool ptiled = step == 2 && slices == 1 && waves >= kTileMinWaves && !m->ptile_failed;
       if (ptiled && !m->d_ptiles) {
         m->ptile_tx = (g.stride / 2 + 15) / 16;
-        m->ptile_ty = ((g.height - 1 + kTileYOff) / 2) / 4 + 1;
-        const size_t bytes = (size_t)kTilePad + 4 * (size_t)m->ptile_ty * m->ptile_tx * 128;
+        m->ptile_rows = (((g.height - 1 + kTileYOff) / 2 + 1) + 3) & ~3;  // class rows, whole 4-row lines
+        const size_t bytes = (size_t)kTilePad + 4 * (size_t)m->ptile_rows * m->ptile_tx * 32;
         if (bytes >= (1ull << 32) || hipMalloc((void**)&m->d_ptiles, bytes) != hipSuccess) {
           (void)hipGetLastError();
           m->d_ptiles = nullptr;
@@ -2117,16 +2117,16 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
           LSLAM_HIP(ctx, hipMemsetAsync(m->d_ptiles, 0, kTilePad, ctx->stream));
         }
       }
-      const uint32_t class_bytes = (uint32_t)((size_t)m->ptile_ty * m->ptile_tx * 128);
+      const uint32_t class_bytes = (uint32_t)((size_t)m->ptile_rows * m->ptile_tx * 32);
       if (ptiled && m->ptile_dirty) {
         const size_t dwords = (size_t)class_bytes;  // 4 classes x class_bytes / 4
         launch(ctx, "tile_planes", k_tile_planes, dim3((unsigned)((dwords + 255) / 256)), dim3(256), 0,
-               (const uint8_t*)m->d_grid, g.stride, g.data_size, (uint32_t*)m->d_ptiles, m->ptile_tx, m->ptile_ty);
+               (const uint8_t*)m->d_grid, g.stride, g.data_size, (uint32_t*)m->d_ptiles, m->ptile_tx, m->ptile_rows);
         m->ptile_dirty = false;
       }
 #define LSLAM_ROWS_ARGS(SRC0, SRC1)                                                                              \
   grid, dim3(64), 0, SRC0, SRC1, step, limit, g, p, (const Lattice*)m->d_lat.p, (const double2*)m->d_cossin.p, \
-      (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc, m->ptile_tx, class_bytes
+      (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc, m->ptile_rows, class_bytes
       const uint8_t* pt = m->d_ptiles;
       if (variant == 1)
         launch(ctx, name, k_resp_rows<1, 4, false>, LSLAM_ROWS_ARGS(s0, s1));
