@@ -113,3 +113,33 @@ def test_non_uniform_lattices(ctx, oracle_lib):
         p = poses[q]
         _, _, _, st, sums = port.correlate_scan(ranges[q], p, p, 0.5, 0.1, 0.349, 0.0349, True, False, want_sums=True)
         assert st == 0 and np.array_equal(gm.coarse_sums(ranges[q], p), sums)
+
+
+def test_many_beam_laser(ctx, oracle_lib):
+    """A 0.125-degree laser (2881 beams): more than kMaxBeamsPerLane * 64 beams per (scan, angle), so even
+    a chip-filling batch splits the beams of a wave (beam slices + integer atomics) to keep the packed
+    16-bit partial sums exact; the fine pass packs up to 256 beams per lane."""
+    n = 2881
+    laser = synth.Laser(n_ranges=n, angle_min=math.radians(-180.0), angle_increment=math.radians(0.125),
+                        range_max=30.0)
+    thr = 20.0
+    port = oracle_lib.PortKarto(oracle_lib.default_cfg(), oracle_lib.laser_struct(laser, thr))
+    gm = api.ScanMatcher(ctx, api.baseline_config(range_threshold=thr), api.laser_params(laser, thr))
+    world = synth.arena(size=40.0, n_axis=12, n_rot=4, seed=21)
+    wl = synth.make_match_workload(n_base=10, n_query=12, seed=21, laser=laser, world=world, query_spread=2.0)
+    port.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    assert np.array_equal(gm.GetCorrelationGrid(), port.grid())
+    p0 = wl.query_poses[0]
+    _, _, _, st, sums = port.correlate_scan(wl.query_ranges[0], p0, p0, 0.5, 0.1, 0.349, 0.0349, True, False,
+                                            want_sums=True)
+    assert st == 0 and np.array_equal(gm.coarse_sums(wl.query_ranges[0], p0), sums)
+    small = gm.match_batch(wl.query_ranges, wl.query_poses)
+    for q in range(len(small)):
+        mean, cov, resp = port.match(wl.query_ranges[q], wl.query_poses[q])
+        assert small["status"][q] == 0
+        assert np.abs(small["pose"][q][:2] - mean[:2]).max() <= 1e-9
+        assert abs(math.remainder(small["pose"][q][2] - mean[2], 2 * math.pi)) <= 1e-9
+        assert abs(small["response"][q] - resp) <= 1e-12
+    big = gm.match_batch(np.tile(wl.query_ranges, (17, 1)), np.tile(wl.query_poses, (17, 1)))  # 204 scans
+    assert big.tobytes() == np.tile(small, 17).tobytes()
