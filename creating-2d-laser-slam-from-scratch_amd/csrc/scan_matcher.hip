@@ -1073,14 +1073,25 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
   double lm = -1.0;  // bestResponse starts at -1 (Mapper.cpp:431)
   {
     int a = tid / ncand, c = tid - a * ncand;
-    for (int t = tid; t < total; t += 256) {
-      double v = (double)r[t] / denom;  // GetResponse normalisation (:852)
+    auto one = [&](int32_t sum) {
+      double v = (double)sum / denom;  // GetResponse normalisation (:852)
       if (sc.do_penalize && !double_equal(v, 0.0)) v *= (dpen[c] * s_ap[a]);
       presp[c * pc.na + a] = v;
       lm = lm > v ? lm : v;
       c += 256;
       while (c >= ncand) { c -= ncand; a++; }
+    };
+    // the numerators of a thread are fetched together (independent loads in flight), 8 at a time
+    constexpr int kBatch = 8;
+    int t = tid;
+    for (; t + 256 * (kBatch - 1) < total; t += 256 * kBatch) {
+      int32_t rv[kBatch];
+#pragma unroll
+      for (int i = 0; i < kBatch; i++) rv[i] = r[t + 256 * i];
+#pragma unroll
+      for (int i = 0; i < kBatch; i++) one(rv[i]);
     }
+    for (; t < total; t += 256) one(r[t]);
   }
   const double best = block_max(lm, sh, tid, 256);  // contains the barriers that publish presp
 
