@@ -1149,6 +1149,13 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
     s_status = st;
   }
   __syncthreads();
+  // No expansion passes follow: the block's LAST wave lays out the scan's fine lattice around the mean
+  // just found (k_pass_setup, mode 2; one launch fewer) while the other waves go on to the covariance.
+  // The lattice record of this pass is not read again below (centre and flags are in registers).
+  if (fine_cossin != nullptr && tid >= 192) {
+    const double center2[3] = {s_avg[0], s_avg[1], s_avg[2]};
+    pass_setup_wave(s, tid - 192, g, fine_pc, center2, s_status == 0, lat, fine_cossin, fine_step);
+  }
   // ComputePositionalCovariance terms (Mapper.cpp:573-594), one lattice cell per thread
   const double dx = s_avg[0] - center[0], dy = s_avg[1] - center[1];
   for (int c = tid; c < ncand; c += 256) {
@@ -1162,8 +1169,6 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
     terms[4 * c + 3] = (ksq(y - dy) * rr);
   }
   __syncthreads();
-  __shared__ double s_mean[3];
-  __shared__ int s_ok;
   if (tid == 0) {
     CoarseOut o;
     o.status = s_status;
@@ -1210,16 +1215,6 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
     // Mapper.cpp:242-244,259: expand (again) while the best response is still zero
     o.expand = (use_expansion && o.status == 0 && pass_index < 3 && double_equal(o.best, 0.0)) ? 1 : 0;
     out[s] = o;
-    s_mean[0] = o.mean[0]; s_mean[1] = o.mean[1]; s_mean[2] = o.mean[2];
-    s_ok = o.status == 0;
-  }
-  if (fine_cossin == nullptr) return;
-  // no expansion passes follow: this block's first wave lays out the scan's fine lattice around the
-  // mean it has just written (k_pass_setup, mode 2) -- one launch fewer
-  __syncthreads();
-  if (tid < 64) {
-    const double center2[3] = {s_mean[0], s_mean[1], s_mean[2]};
-    pass_setup_wave(s, tid, g, fine_pc, center2, s_ok, lat, fine_cossin, fine_step);
   }
 }
 
