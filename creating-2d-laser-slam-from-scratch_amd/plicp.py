@@ -1,0 +1,199 @@
+"""lesson3 PL-ICP frame-to-frame match (BASELINE config 1): CPU plumbing, no GPU.
+
+Mirrors the reference's wrapper around Censi's C Scan Matcher:
+  * `PlicpParams`        -- the sm_params the node fills in (lesson3/src/scan_match_plicp.cc:38-157),
+  * `laser_scan_to_ldp`  -- LaserScanToLDP (scan_match_plicp.cc:220-261): a reading is valid iff
+                            range_min < r < range_max, theta[i] = angle_min + i * angle_increment,
+  * `scan_match_with_plicp` -- ScanMatchWithPLICP (scan_match_plicp.cc:266-300): reference scan at
+                            [0,0,0], zero first guess, result = pose of the new scan in the old one.
+
+PARITY UNPINNED: the arithmetic of the reference lives in the third-party library `csm` (`sm_icp`,
+apt `ros-kinetic-csm`, no version pinned, not vendored under /root/reference).  `sm_icp`
+below restates the PUBLISHED algorithm (A. Censi, "An ICP variant using a point-to-line metric",
+ICRA 2008) with exhaustive correspondence search -- csm's "correspondence tricks" only accelerate the
+same search -- trimmed / adaptive / duplicate outlier rejection, and the closed-form point-to-line
+minimiser (Lagrange multiplier on c^2 + s^2 = 1).  It is anchored by a known-answer test on a synthetic
+scan pair (tests/test_plicp.py), not by the reference's numbers.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+
+import numpy as np
+
+
+@dataclasses.dataclass
+class PlicpParams:
+    """Defaults of ScanMatchPLICP::InitParams (scan_match_plicp.cc:43-156)."""
+
+    max_angular_correction_deg: float = 45.0
+    max_linear_correction: float = 1.0
+    max_iterations: int = 10
+    epsilon_xy: float = 0.000001
+    epsilon_theta: float = 0.000001
+    max_correspondence_dist: float = 1.0
+    sigma: float = 0.010
+    use_corr_tricks: int = 1
+    restart: int = 0
+    restart_threshold_mean_error: float = 0.01
+    restart_dt: float = 1.0
+    restart_dtheta: float = 0.1
+    clustering_threshold: float = 0.25
+    orientation_neighbourhood: int = 20
+    use_point_to_line_distance: int = 1
+    do_alpha_test: int = 0
+    do_alpha_test_thresholdDeg: float = 20.0
+    outliers_maxPerc: float = 0.90
+    outliers_adaptive_order: float = 0.7
+    outliers_adaptive_mult: float = 2.0
+    do_visibility_test: int = 0
+    outliers_remove_doubles: int = 1
+    do_compute_covariance: int = 0
+    debug_verify_tricks: int = 0
+    use_ml_weights: int = 0
+    use_sigma_weights: int = 0
+
+
+@dataclasses.dataclass
+class Ldp:
+    """The fields of csm's laser_data the wrapper fills (scan_match_plicp.cc:222-260)."""
+
+    valid: np.ndarray  # int8 [n]
+    readings: np.ndarray  # float64 [n], -1 for an invalid range
+    theta: np.ndarray  # float64 [n]
+    min_theta: float
+    max_theta: float
+
+    def points(self) -> np.ndarray:
+        return np.stack([self.readings * np.cos(self.theta), self.readings * np.sin(self.theta)], axis=1)
+
+
+def laser_scan_to_ldp(ranges, angle_min: float, angle_increment: float, range_min: float, range_max: float) -> Ldp:
+    r = np.asarray(ranges, dtype=np.float64)
+    n = len(r)
+    with np.errstate(invalid="ignore"):
+        valid = (r > range_min) & (r < range_max)  # :231 (NaN compares false)
+    theta = angle_min + np.arange(n, dtype=np.float64) * angle_increment  # :244
+    return Ldp(valid.astype(np.int8), np.where(valid, r, -1.0), theta, float(theta[0]), float(theta[-1]))
+
+
+def _solve_point_to_line(p: np.ndarray, q: np.ndarray, nrm: np.ndarray):
+    """min over (t, theta) of sum_k (n_k . (R(theta) p_k + t - q_k))^2, closed form.
+
+    With x = [tx, ty, c, s] and rows a_k = [nx, ny, n.p, n.(-py, px)] the cost is |A x - b|^2 subject to
+    c^2 + s^2 = 1.  Eliminating t leaves a 2x2 problem u^T S u + h^T u with |u| = 1, solved through the
+    Lagrange condition (2S + 2 lambda I) u = -h: a quartic in lambda in S's eigenbasis.
+    """
+    a = np.stack([nrm[:, 0], nrm[:, 1], nrm[:, 0] * p[:, 0] + nrm[:, 1] * p[:, 1],
+                  -nrm[:, 0] * p[:, 1] + nrm[:, 1] * p[:, 0]], axis=1)
+    b = nrm[:, 0] * q[:, 0] + nrm[:, 1] * q[:, 1]
+    m = a.T @ a
+    g = -2.0 * (a.T @ b)
+    aa, bb, dd = m[:2, :2], m[:2, 2:], m[2:, 2:]
+    if abs(np.linalg.det(aa)) < 1e-12:
+        return None
+    ainv = np.linalg.inv(aa)
+    s2 = dd - bb.T @ ainv @ bb
+    h = g[2:] - bb.T @ ainv @ g[:2]
+    e, v = np.linalg.eigh(s2)
+    hp = v.T @ h
+    # hp0^2 (2 e1 + 2 L)^2 + hp1^2 (2 e0 + 2 L)^2 = (2 e0 + 2 L)^2 (2 e1 + 2 L)^2
+    p0 = np.poly1d([2.0, 2.0 * e[0]])
+    p1 = np.poly1d([2.0, 2.0 * e[1]])
+    poly = p0 * p0 * p1 * p1 - hp[0] ** 2 * p1 * p1 - hp[1] ** 2 * p0 * p0
+    best = None
+    for lam in np.roots(poly.coeffs):
+        if abs(lam.imag) > 1e-9 * max(1.0, abs(lam.real)):
+            continue
+        den = 2.0 * e + 2.0 * lam.real
+        if np.any(np.abs(den) < 1e-15):
+            continue
+        u = v @ (-hp / den)
+        nu = np.linalg.norm(u)
+        if nu < 1e-12:
+            continue
+        u = u / nu
+        cost = u @ s2 @ u + h @ u
+        if best is None or cost < best[0]:
+            best = (cost, u)
+    if best is None:
+        return None
+    u = best[1]
+    t = -ainv @ (bb @ u + 0.5 * g[:2])
+    return np.array([t[0], t[1], math.atan2(u[1], u[0])])
+
+
+def sm_icp(params: PlicpParams, laser_ref: Ldp, laser_sens: Ldp, first_guess=(0.0, 0.0, 0.0)) -> dict:
+    """Restated PL-ICP.  Returns csm's sm_result fields the node reads: valid, x[3], iterations, nvalid, error."""
+    ref_ok = np.flatnonzero(laser_ref.valid)
+    sens_ok = np.flatnonzero(laser_sens.valid)
+    out = {"valid": 0, "x": np.zeros(3), "iterations": 0, "nvalid": 0, "error": float("inf")}
+    if len(ref_ok) < 3 or len(sens_ok) < 3:
+        return out
+    q_all = laser_ref.points()
+    p_all = laser_sens.points()
+    x = np.array(first_guess, dtype=np.float64)
+    max_d2 = params.max_correspondence_dist ** 2
+    err = float("inf")
+    nvalid = 0
+    it = 0
+    for it in range(1, params.max_iterations + 1):
+        c, s = math.cos(x[2]), math.sin(x[2])
+        pw = p_all[sens_ok] @ np.array([[c, s], [-s, c]]) + x[:2]
+        d2 = ((pw[:, None, :] - q_all[ref_ok][None, :, :]) ** 2).sum(axis=2)
+        j1k = d2.argmin(axis=1)
+        j1 = ref_ok[j1k]
+        dmin = d2[np.arange(len(sens_ok)), j1k]
+        # second point of the segment: the valid index neighbour of j1 that is closer
+        n = len(laser_ref.valid)
+        lo, hi = np.clip(j1 - 1, 0, n - 1), np.clip(j1 + 1, 0, n - 1)
+        d_lo = np.where((laser_ref.valid[lo] == 1) & (lo != j1), ((pw - q_all[lo]) ** 2).sum(axis=1), np.inf)
+        d_hi = np.where((laser_ref.valid[hi] == 1) & (hi != j1), ((pw - q_all[hi]) ** 2).sum(axis=1), np.inf)
+        j2 = np.where(d_lo <= d_hi, lo, hi)
+        ok = (dmin <= max_d2) & np.isfinite(np.minimum(d_lo, d_hi))
+        seg = q_all[j2] - q_all[j1]
+        seg_len = np.linalg.norm(seg, axis=1)
+        ok &= seg_len > 1e-12
+        nrm = np.zeros_like(seg)
+        nrm[ok] = np.stack([-seg[ok, 1], seg[ok, 0]], axis=1) / seg_len[ok, None]
+        dist = np.abs(((pw - q_all[j1]) * nrm).sum(axis=1)) if params.use_point_to_line_distance else np.sqrt(dmin)
+        # outliers: no two sens points on the same j1 (keep the closest), trimmed, adaptive
+        if params.outliers_remove_doubles:
+            order = np.lexsort((dist, j1))
+            first = np.ones(len(order), dtype=bool)
+            first[1:] = j1[order][1:] != j1[order][:-1]
+            keep = np.zeros(len(order), dtype=bool)
+            keep[order[first]] = True
+            ok &= keep
+        idx = np.flatnonzero(ok)
+        if len(idx) < 3:
+            return out
+        srt = idx[np.argsort(dist[idx])]
+        srt = srt[: max(3, int(math.floor(params.outliers_maxPerc * len(srt))))]
+        ref_err = dist[srt[min(len(srt) - 1, int(math.floor(params.outliers_adaptive_order * len(srt))))]]
+        srt = srt[dist[srt] <= params.outliers_adaptive_mult * ref_err + 1e-12]
+        if len(srt) < 3:
+            return out
+        sol = _solve_point_to_line(p_all[sens_ok][srt], q_all[j1[srt]], nrm[srt])
+        if sol is None:
+            return out
+        nvalid = len(srt)
+        cs, sn = math.cos(sol[2]), math.sin(sol[2])
+        res = ((p_all[sens_ok][srt] @ np.array([[cs, sn], [-sn, cs]]) + sol[:2] - q_all[j1[srt]]) * nrm[srt]).sum(axis=1)
+        err = float((res ** 2).sum())
+        delta = sol - x
+        delta[2] = math.remainder(delta[2], 2.0 * math.pi)
+        x = sol
+        if math.hypot(delta[0], delta[1]) < params.epsilon_xy and abs(delta[2]) < params.epsilon_theta:
+            break
+    out.update(iterations=it, nvalid=int(nvalid), error=err, x=x)
+    within = (math.hypot(x[0] - first_guess[0], x[1] - first_guess[1]) <= params.max_linear_correction and
+              abs(math.remainder(x[2] - first_guess[2], 2.0 * math.pi)) <= math.radians(params.max_angular_correction_deg))
+    out["valid"] = int(within and nvalid >= 3)
+    return out
+
+
+def scan_match_with_plicp(params: PlicpParams, prev_ldp: Ldp, curr_ldp: Ldp) -> dict:
+    """ScanMatchWithPLICP (:266-300): laser_ref = previous scan at [0,0,0], first_guess = 0."""
+    return sm_icp(params, prev_ldp, curr_ldp, (0.0, 0.0, 0.0))
