@@ -1696,12 +1696,12 @@ __global__ void k_result_no_readings(int S, const double* poses, double coarse_a
 //       scans walks the chain on one thread),
 //   (3) every anchor evaluates its side test and marks its run [anchor, next[anchor]) -- in parallel.
 // Every fp64 expression is the reference's.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, double vx, double vy,
              uint8_t* __restrict__ valid, int use_lds, int* __restrict__ scratch) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int s_first, s_len;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const double2* gp = world + (size_t)((ring_start + b) % cap) * n;
   uint8_t* gv = valid + (size_t)b * n;
   const double2* p = gp;
@@ -1715,18 +1715,18 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
     jump2 = chain + n;  // jump table B
     uint8_t* lv = (uint8_t*)(jump2 + n);
     reach = lv + n;
-    for (int i = tid; i < n; i += 256) { lp[i] = gp[i]; lv[i] = 0; reach[i] = 0; }
+    for (int i = tid; i < n; i += nt) { lp[i] = gp[i]; lv[i] = 0; reach[i] = 0; }
     p = lp;
     v = lv;
   } else {
     next = scratch + (size_t)b * 2 * n;
     chain = next + n;
-    for (int i = tid; i < n; i += 256) gv[i] = 0;
+    for (int i = tid; i < n; i += nt) gv[i] = 0;
   }
   if (tid == 0) { s_first = n; s_len = 0; }
   __syncthreads();
   const double min_sq = ksq(0.1);
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += nt) {
     const double fx = p[i].x, fy = p[i].y;
     if (!isnan(fx) && !isnan(fy)) atomicMin(&s_first, i);  // first anchor (Mapper.cpp:774-778)
     int j = i + 1;
@@ -1755,7 +1755,7 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
     int* ja = chain;
     int* jb = jump2;
     for (int span = 1; span < n; span <<= 1) {  // ja = next^span; marks chain distances [span, 2 span)
-      for (int i = tid; i < n; i += 256) {
+      for (int i = tid; i < n; i += nt) {
         const int j = ja[i];
         if (reach[i] && j < n) reach[j] = 1;
         jb[i] = j < n ? ja[j] : n;
@@ -1763,7 +1763,7 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
       __syncthreads();
       int* t = ja; ja = jb; jb = t;
     }
-    for (int a = tid; a < n; a += 256)
+    for (int a = tid; a < n; a += nt)
       if (reach[a] && next[a] < n) keep_run(a, next[a], a == first);
   } else {
     if (tid == 0) {
@@ -1773,11 +1773,11 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
     }
     __syncthreads();
     const int len = s_len;
-    for (int k = tid; k + 1 < len; k += 256) keep_run(chain[k], chain[k + 1], k == 0);
+    for (int k = tid; k + 1 < len; k += nt) keep_run(chain[k], chain[k + 1], k == 0);
   }
   __syncthreads();
   if (use_lds)
-    for (int i = tid; i < n; i += 256) gv[i] = v[i];
+    for (int i = tid; i < n; i += nt) gv[i] = v[i];
 }
 
 // returns true iff THIS thread changed byte idx to v (CAS on the containing aligned word)
@@ -2247,7 +2247,7 @@ int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, i
   const size_t lds = (size_t)n * (sizeof(double2) + 14) + 16;  // points, next, two jump tables, valid, reach
   const int use_lds = lds <= 60 * 1024;
   if (!use_lds) LSLAM_HIP(ctx, m->d_fv_scratch.reserve((size_t)B * 2 * n));
-  launch(ctx, "find_valid", k_find_valid, dim3(B), dim3(256), use_lds ? lds : 0, n, d_world, ring_start, cap,
+  launch(ctx, "find_valid", k_find_valid, dim3(B), dim3(n > 512 ? 1024 : 256), use_lds ? lds : 0, n, d_world, ring_start, cap,
          center[0], center[1], m->d_valid.p, use_lds, m->d_fv_scratch.p);
   if (m->kernel_center_only) {
     // (1) centres: the first point to reach a cell sets it to 100 and is listed; (2) every listed centre
@@ -2628,7 +2628,7 @@ int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges, const
     const size_t lds = (size_t)g.n_beams * (sizeof(double2) + 14) + 16;
     const int use_lds = lds <= 60 * 1024;
     if (!use_lds) LSLAM_HIP(ctx, m->d_fv_scratch.reserve((size_t)2 * g.n_beams));
-    launch(ctx, "find_valid", k_find_valid, dim3(1), dim3(256), use_lds ? lds : 0, g.n_beams,
+    launch(ctx, "find_valid", k_find_valid, dim3(1), dim3(g.n_beams > 512 ? 1024 : 256), use_lds ? lds : 0, g.n_beams,
            (const double2*)m->d_world.p, 0, 1, viewpoint[0], viewpoint[1], m->d_valid.p, use_lds, m->d_fv_scratch.p);
   }
   LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_valid.p, (size_t)g.n_beams, hipMemcpyDeviceToHost, ctx->stream));
