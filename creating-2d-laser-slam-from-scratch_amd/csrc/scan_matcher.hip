@@ -1828,7 +1828,14 @@ k_mark_centres(int B, int n, const double2* __restrict__ world, int ring_start, 
   const uint32_t left = (uint32_t)__shfl_up((int)idx, 1);
   const bool contender = idx != 0xFFFFFFFFu && ((threadIdx.x & 63) == 0 || left != idx);
   // "value already set -> skip" (:734-738): exactly one thread per cell wins and its point smears
-  const bool winner = contender && atomic_set_u8(grid, idx, (uint32_t)kOccupied);
+  // (the grid was cleared just before and nothing smears until the next kernel: every byte is 0 or 100,
+  // so one atomicOr of 100 both sets the cell and tells whether it was still free)
+  bool winner = false;
+  if (contender) {
+    const int sh = (int)(idx & 3u) * 8;
+    const uint32_t old = atomicOr((uint32_t*)(grid + (idx & ~3u)), (uint32_t)kOccupied << sh);
+    winner = ((old >> sh) & 0xFFu) == 0u;
+  }
   const unsigned long long won = __ballot(winner);
   if (won) {  // one counter update per wave
     const int lane = threadIdx.x & 63, leader = __ffsll((long long)won) - 1;
