@@ -468,7 +468,7 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       int m0i = 0;
       bool have_occ = false;
       // NaN = INVALID_SCAN (k_scan_prep writes both coordinates); testing both keeps the point ONE 16-byte load
-      if ((b < g.n_beams) & !isnan(p.x) & !isnan(p.y)) {
+      if ((int)(b < g.n_beams) & (int)!isnan(p.x) & (int)!isnan(p.y)) {
         // ComputeOffsets + WorldToGrid (Karto.h:6465-6494, 4237-4252): identical fp64 expression tree;
         // (int)math::Round(v) taken as trunc(copysign(|v| + 0.5, v))
         const double ox = cosine * p.x - sine * p.y, oy = sine * p.x + cosine * p.y;
@@ -708,7 +708,7 @@ k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc,
 // k_resp_generic: exact response numerators for arbitrary candidate positions (fine pass 3x3,
 // non-uniform lattices, anything the packed kernel does not cover).  Work item = (scan, angle,
 // chunk of 16 positions); lanes stride over beams; per-byte bounds check exactly as
-// Mapper.cpp:841-845.  `list` (optional) restricts the scans to a device-built work list.
+// Mapper.cpp:841-845.
 // ------------------------------------------------------------------------------------------
 constexpr int kPosChunk = 16;
 // one work item = (angle a, chunk c of 16 lattice positions) of one scan, done by one wave
@@ -1778,32 +1778,6 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
   __syncthreads();
   if (use_lds)
     for (int i = tid; i < n; i += nt) gv[i] = v[i];
-}
-
-// returns true iff THIS thread changed byte idx to v (CAS on the containing aligned word)
-__device__ __forceinline__ bool atomic_set_u8(uint8_t* base, size_t idx, uint32_t v) {
-  uint32_t* w = (uint32_t*)(base + (idx & ~(size_t)3));
-  const int sh = (int)(idx & 3) * 8;
-  uint32_t old = *w;
-  for (;;) {
-    if (((old >> sh) & 0xFFu) == v) return false;
-    uint32_t want = (old & ~(0xFFu << sh)) | (v << sh);
-    uint32_t prev = atomicCAS(w, old, want);
-    if (prev == old) return true;
-    old = prev;
-  }
-}
-
-__device__ __forceinline__ void atomic_max_u8(uint8_t* base, size_t idx, uint32_t v) {
-  uint32_t* w = (uint32_t*)(base + (idx & ~(size_t)3));
-  const int sh = (int)(idx & 3) * 8;
-  uint32_t old = *w;
-  while (((old >> sh) & 0xFFu) < v) {
-    uint32_t want = (old & ~(0xFFu << sh)) | (v << sh);
-    uint32_t prev = atomicCAS(w, old, want);
-    if (prev == old) break;
-    old = prev;
-  }
 }
 
 // AddScan (Mapper.cpp:716-748) for every valid point of every base scan in parallel: the thread
