@@ -273,6 +273,15 @@ def test_full_size_properties(ctx):
         assert full[i].tobytes() == full[i % len(wl.query_ranges)].tobytes()
     half = gm.match_batch(ranges[: S // 2][::-1], poses[: S // 2][::-1])[::-1]
     assert half.tobytes() == full[: S // 2].tobytes()
+    # the full BASELINE batch (4096 scans: tiled parity planes + 4x4-block fine kernel) equals the same
+    # scans matched 64 at a time (linear planes + row kernels): the layouts change nothing
+    idx4 = np.arange(4096) % len(wl.query_ranges)
+    pert = synth.perturb(wl.query_poses[idx4], 0.2, math.radians(6.0), 99)  # 4096 different search centres
+    big = gm.match_batch(wl.query_ranges[idx4], pert)
+    assert (big["status"] == 0).all()
+    for lo in (0, 1984, 4032):
+        small = gm.match_batch(wl.query_ranges[idx4][lo:lo + 64], pert[lo:lo + 64])
+        assert small.tobytes() == big[lo:lo + 64].tobytes()
     # self-match: the last base scan matched from its own pose stays within one fine cell
     own = gm.match_batch(wl.base_ranges[-1:], wl.base_poses[-1:])
     assert own["response"][0] > 0.5
