@@ -312,6 +312,14 @@ struct lslam_map {
   float lo_free = 0.f, lo_occ = 0.f;
   DevBuf<float> d_pts;
   DevBuf<int8_t> d_i8;
+  // host -> device staging of the per-scan points: a ring of pinned slots, so updateByScan only enqueues
+  // (copy + two kernels per level) and returns; a slot is reused when its copy has completed
+  static constexpr int kStageSlots = 8;
+  float* h_stage = nullptr;
+  size_t stage_cap = 0;  // floats per slot
+  hipEvent_t stage_ev[kStageSlots] = {};
+  bool stage_busy[kStageSlots] = {};
+  unsigned stage_next = 0;
 };
 
 namespace {
@@ -437,6 +445,9 @@ void lslam_map_destroy(lslam_map* map) {
   }
   map->d_pts.release();
   map->d_i8.release();
+  if (map->h_stage) (void)hipHostFree(map->h_stage);
+  for (auto e : map->stage_ev)
+    if (e) (void)hipEventDestroy(e);
   delete map;
 }
 
@@ -480,17 +491,48 @@ int lslam_map_update_by_scan_dev(lslam_map* map, const float* pts_dev, int n, co
   return update_impl(map, pts_dev, n, origo, pose, 0, 0.f, 0.f, 0.0);
 }
 
+namespace {
+// Copy the caller's points through a pinned ring slot to d_pts on the context stream.  The caller's
+// buffer is free again when this returns; the device copy is ordered before the kernels that follow.
+int stage_points(lslam_map* map, const float* pts, int n) {
+  lslam_context* ctx = map->ctx;
+  const size_t floats = (size_t)2 * (n > 0 ? n : 1);
+  LSLAM_HIP(ctx, map->d_pts.reserve(floats));
+  if (n <= 0) return LSLAM_OK;
+  if (floats > map->stage_cap) {  // (re)build the ring; drains whatever is in flight first
+    LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (map->h_stage) (void)hipHostFree(map->h_stage);
+    map->h_stage = nullptr;
+    map->stage_cap = 0;
+    const size_t cap = floats + floats / 4 + 64;
+    LSLAM_HIP(ctx, hipHostMalloc((void**)&map->h_stage, cap * lslam_map::kStageSlots * sizeof(float), hipHostMallocDefault));
+    map->stage_cap = cap;
+    for (int i = 0; i < lslam_map::kStageSlots; i++) {
+      if (!map->stage_ev[i]) LSLAM_HIP(ctx, hipEventCreateWithFlags(&map->stage_ev[i], hipEventDisableTiming));
+      map->stage_busy[i] = false;
+    }
+  }
+  const int slot = (int)(map->stage_next++ % lslam_map::kStageSlots);
+  if (map->stage_busy[slot]) LSLAM_HIP(ctx, hipEventSynchronize(map->stage_ev[slot]));
+  float* h = map->h_stage + (size_t)slot * map->stage_cap;
+  memcpy(h, pts, (size_t)2 * n * sizeof(float));
+  LSLAM_HIP(ctx, hipMemcpyAsync(map->d_pts.p, h, (size_t)2 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  LSLAM_HIP(ctx, hipEventRecord(map->stage_ev[slot], ctx->stream));
+  map->stage_busy[slot] = true;
+  return LSLAM_OK;
+}
+}  // namespace
+
+// Asynchronous like every device-side mutation of the map: the update is ENQUEUED on the context stream
+// when this returns (the caller's `pts` may be reused at once); the readers -- lslam_map_read_*,
+// lslam_map_match_data, lslam_synchronize -- are ordered after it.
 int lslam_map_update_by_scan(lslam_map* map, const float* pts, int n, const float origo[2], const float pose[3]) {
   if (!map || n < 0 || (n > 0 && !pts) || !origo || !pose) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_context* ctx = map->ctx;
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
-  LSLAM_HIP(ctx, map->d_pts.reserve((size_t)2 * (n > 0 ? n : 1)));
-  if (n > 0)
-    LSLAM_HIP(ctx, hipMemcpyAsync(map->d_pts.p, pts, (size_t)2 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  int rc = update_impl(map, map->d_pts.p, n, origo, pose, 0, 0.f, 0.f, 0.0);
+  int rc = stage_points(map, pts, n);
   if (rc) return rc;
-  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return LSLAM_OK;
+  return update_impl(map, map->d_pts.p, n, origo, pose, 0, 0.f, 0.f, 0.0);
 }
 
 int lslam_map_update_just_once(lslam_map* map, const float* pts, int n, const float origo[2], float begin_x,
@@ -498,14 +540,10 @@ int lslam_map_update_just_once(lslam_map* map, const float* pts, int n, const fl
   if (!map || n < 0 || (n > 0 && !pts) || !origo || !(metres_per_cell > 0)) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_context* ctx = map->ctx;
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
-  LSLAM_HIP(ctx, map->d_pts.reserve((size_t)2 * (n > 0 ? n : 1)));
-  if (n > 0)
-    LSLAM_HIP(ctx, hipMemcpyAsync(map->d_pts.p, pts, (size_t)2 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  const float pose[3] = {0.f, 0.f, 0.f};
-  int rc = update_impl(map, map->d_pts.p, n, origo, pose, 1, begin_x, begin_y, metres_per_cell);
+  int rc = stage_points(map, pts, n);
   if (rc) return rc;
-  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return LSLAM_OK;
+  const float pose[3] = {0.f, 0.f, 0.f};
+  return update_impl(map, map->d_pts.p, n, origo, pose, 1, begin_x, begin_y, metres_per_cell);
 }
 
 int lslam_map_match_data(lslam_map* map, const float* pts, int n, const float begin_world[3], float out_pose[3],

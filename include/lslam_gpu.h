@@ -253,7 +253,10 @@ float lslam_map_scale_to_map(const lslam_map* map, int level); /* getScaleToMap 
 /* OccGridMapBase::updateByScan (H/map/OccGridMapBase.h:118-168) on every pyramid level, level
  * i using points*(1/2^i) like DataPointContainer::setFrom (H/scan/DataPointContainer.h:46-58).
  * points_xy: n points in LEVEL-0 MAP-CELL units, robot frame (hector_slam.cc:320-362);
- * origo_xy: DataContainer origo; pose_world: (x[m], y[m], heading). */
+ * origo_xy: DataContainer origo; pose_world: (x[m], y[m], heading).
+ * ASYNCHRONOUS: the update is enqueued on the context stream when the call returns (points_xy has
+ * been copied and may be reused at once); lslam_map_read_*, lslam_map_match_data and
+ * lslam_synchronize are ordered after it. */
 int lslam_map_update_by_scan(lslam_map* map, const float* points_xy, int n,
                              const float origo_xy[2], const float pose_world[3]);
 int lslam_map_update_by_scan_dev(lslam_map* map, const float* points_xy_dev, int n,
