@@ -133,13 +133,32 @@ k_logodds_apply(LevelGeom g, const float* __restrict__ pts, int n, const uint32_
   const uint32_t me = kBeamMask - (uint32_t)i;
   const uint32_t ep = g.epoch;
   const Ray r = ray_of(l, g.sx);
-  // crossed cells: free once per scan unless some beam ends here (bresenhamCellFree, :302-313)
-  for (unsigned c = lane; c < r.abs_da; c += 64) {
-    const unsigned off = ray_cell(r, c);
-    uint32_t fk = free_key[off];
-    if ((fk & kBeamMask) != me) continue;             // not the first beam crossing this cell
-    if ((occ_key[off] >> kBeamBits) == ep) continue;  // a hit cell: handled by its occ owner
-    logodds[off] += g.lo_free;
+  // crossed cells: free once per scan unless some beam ends here (bresenhamCellFree, :302-313).
+  // Four cells per lane and pass, their three reads issued together: the kernel is a chain of dependent
+  // L2 round trips, not bandwidth, so the reads of non-owners are the cheaper evil.
+  constexpr int kIlp = 4;
+  for (unsigned c0 = lane; c0 < r.abs_da; c0 += 64 * kIlp) {
+    unsigned off[kIlp];
+    uint32_t fk[kIlp], ok[kIlp];
+    float lo[kIlp];
+#pragma unroll
+    for (int u = 0; u < kIlp; u++) {
+      const unsigned c = c0 + 64u * u;
+      off[u] = ray_cell(r, c < r.abs_da ? c : c0);
+    }
+#pragma unroll
+    for (int u = 0; u < kIlp; u++) {
+      fk[u] = free_key[off[u]];
+      ok[u] = occ_key[off[u]];
+      lo[u] = logodds[off[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < kIlp; u++) {
+      if (c0 + 64u * u >= r.abs_da) continue;
+      if ((fk[u] & kBeamMask) != me) continue;       // not the first beam crossing this cell
+      if ((ok[u] >> kBeamBits) == ep) continue;      // a hit cell: handled by its occ owner
+      logodds[off[u]] = lo[u] + g.lo_free;           // the owner is the only writer of this cell in this kernel
+    }
   }
   // end cell (bresenhamCellOcc, :316-330)
   if (lane == 0) {
