@@ -143,9 +143,18 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    barrier()
+    # one untimed step with HIP events around EVERY kernel: the per-kernel table and the dominant kernel's name
     ctx.profile(True)
+    ctx.profile_only(None)
     ctx.profile_reset()
+    step()
+    prof_all = ctx.profile_read()
+    dom_name = max(prof_all, key=lambda k: prof_all[k][1]) if prof_all else None
+    # the timed region keeps the events of the dominant kernel only (the roofline measurement): two events
+    # per launch cost ~3 us of stream time, ten of them per step would be 4 % of the step
+    ctx.profile_only(dom_name)
+    ctx.profile_reset()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -156,7 +165,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ctx.profile(False)
-    prof = ctx.profile_read()
+    prof = ctx.profile_read()  # the dominant kernel, timed live over the timed region
+    ctx.profile_only(None)
 
     # "poses out": gather every rank's result records (after the timed region; 112 B/scan)
     res_np = results.cpu().numpy().view(api.RESULT_DTYPE).reshape(-1)
@@ -182,9 +192,8 @@ def main():
     na_c = int(np.floor(cfg.coarse_search_angle_offset * 2.0 / cfg.coarse_angle_resolution + 0.5) + 1)
     na_f = int(np.floor(0.5 * cfg.coarse_angle_resolution * 2.0 / cfg.fine_search_angle_offset + 0.5) + 1)
     coarse_bytes, match_bytes = algorithmic_bytes(nx, ny, na_c, 3, 3, na_f, N_BEAMS)
-    dom_name = max(prof, key=lambda k: prof[k][1]) if prof else None
     roofline = None
-    if dom_name:
+    if dom_name and dom_name in prof:
         launches, total_ms = prof[dom_name]
         avg_ms = total_ms / max(launches, 1)
         per_launch_bytes = (coarse_bytes if dom_name == "resp_rows_coarse" else match_bytes) * B
@@ -273,7 +282,9 @@ def main():
             "no data-path collective; all_gather of 112-B results after the timed region",
         },
         "results_ok": n_ok_all,
-        "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())},
+        # every kernel of one (untimed) profiled step; the dominant kernel's figure in `roofline` is the
+        # live average over the timed region
+        "kernel_ms_per_step": {k: round(v[1], 4) for k, v in sorted(prof_all.items())},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
     }

@@ -150,6 +150,7 @@ def lib() -> C.CDLL:
     L.lslam_dev_upload.argtypes = [vp, vp, vp, C.c_size_t]
     L.lslam_dev_download.argtypes = [vp, vp, vp, C.c_size_t]
     L.lslam_profile_enable.argtypes = [vp, i32]
+    L.lslam_profile_only.argtypes = [vp, C.c_char_p]
     L.lslam_profile_reset.argtypes = [vp]
     L.lslam_profile_read.argtypes = [vp, vp, i32]
     L.lslam_matcher_config_defaults.argtypes = [C.POINTER(MatcherConfig)]
@@ -275,6 +276,10 @@ class Context:
 
     def profile(self, on: bool):
         self.check(self.L.lslam_profile_enable(self.h, int(on)))
+
+    def profile_only(self, kernel_name: str | None):
+        """Time only the kernels launched under this name (None = all): fewer events in the stream."""
+        self.check(self.L.lslam_profile_only(self.h, kernel_name.encode() if kernel_name else None))
 
     def profile_reset(self):
         self.check(self.L.lslam_profile_reset(self.h))

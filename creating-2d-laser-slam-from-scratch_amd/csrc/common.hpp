@@ -24,6 +24,7 @@ struct KernelTimer {
     hipEvent_t e0, e1;
   };
   bool enabled = false;
+  std::string only;  // empty = time every kernel, else only launches under this name
   std::vector<Rec> pending;
   std::vector<hipEvent_t> pool;
   std::map<std::string, std::pair<int64_t, double>> totals;  // name -> (launches, ms)
@@ -118,7 +119,7 @@ struct DevBuf {
 template <typename K, typename... Args>
 inline void launch(lslam_context* ctx, const char* name, K kernel, dim3 grid, dim3 block,
                    size_t shmem, Args... args) {
-  if (ctx->timer.enabled) {
+  if (ctx->timer.enabled && (ctx->timer.only.empty() || ctx->timer.only == name)) {
     hipEvent_t e0 = ctx->timer.get(), e1 = ctx->timer.get();
     (void)hipEventRecord(e0, ctx->stream);
     hipLaunchKernelGGL(kernel, grid, block, shmem, ctx->stream, args...);

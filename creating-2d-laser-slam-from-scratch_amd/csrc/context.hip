@@ -86,6 +86,11 @@ int lslam_profile_enable(lslam_context* ctx, int on) {
   ctx->timer.enabled = on != 0;
   return LSLAM_OK;
 }
+int lslam_profile_only(lslam_context* ctx, const char* kernel_name) {
+  if (!ctx) return LSLAM_ERR_INVALID_ARGUMENT;
+  ctx->timer.only = kernel_name ? kernel_name : "";
+  return LSLAM_OK;
+}
 int lslam_profile_reset(lslam_context* ctx) {
   if (!ctx) return LSLAM_ERR_INVALID_ARGUMENT;
   (void)hipStreamSynchronize(ctx->stream);

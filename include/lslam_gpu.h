@@ -76,6 +76,9 @@ typedef struct lslam_kernel_time {
   double total_ms;
 } lslam_kernel_time;
 int lslam_profile_enable(lslam_context* ctx, int on);
+/* restrict the timing to kernels launched under this name (NULL or "" = every kernel): two events per
+ * launch cost ~3 us of stream time, which matters when a batch is five kernels */
+int lslam_profile_only(lslam_context* ctx, const char* kernel_name);
 int lslam_profile_reset(lslam_context* ctx);
 int lslam_profile_read(lslam_context* ctx, lslam_kernel_time* out, int capacity);
 
