@@ -809,14 +809,18 @@ __device__ __forceinline__ double penalized(int32_t sum, const Cand& cd, const d
   return r;
 }
 
+// max over the block: butterfly inside each wave, then the (<= 16) wave maxima through LDS.  Two barriers;
+// the first also publishes whatever the callers wrote to LDS before the call.
 __device__ __forceinline__ double block_max(double v, double* sh, int tid, int nthreads) {
-  sh[tid] = v;
-  __syncthreads();
-  for (int o = nthreads / 2; o > 0; o >>= 1) {
-    if (tid < o) sh[tid] = sh[tid] > sh[tid + o] ? sh[tid] : sh[tid + o];
-    __syncthreads();
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const double o = __shfl_xor(v, m);
+    v = v > o ? v : o;
   }
+  if ((tid & 63) == 0) sh[tid >> 6] = v;
+  __syncthreads();
   double r = sh[0];
+  for (int w = 1; w < (nthreads >> 6); w++) r = r > sh[w] ? r : sh[w];
   __syncthreads();
   return r;
 }
