@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="scans per GPU per step")
     ap.add_argument("--n-base", type=int, default=70, help="running-window scans rasterised into the grid")
-    ap.add_argument("--cpu-sample", type=int, default=3000, help="scan-matches timed on the host for cpu_baseline")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="scan-matches timed on the host for cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-cores", type=int, default=0, help="also time the reference on this many host cores (0 = min(nproc, 64))")
     ap.add_argument("--broadcast-grid", action="store_true", help="build the grid on rank 0 and RCCL-broadcast it")
