@@ -54,12 +54,11 @@ def _cpu_worker(args):
     return sec * len(q_r), len(q_r)
 
 
-def cpu_multicore(wl, n_unique, per_core, cores):
+def cpu_multicore(wl, q_r, q_p, cores):
     """Embarrassingly parallel CPU number (SURVEY.md §8(d) ii): one independent matcher per process."""
     import multiprocessing as mp
 
-    idx = np.arange(per_core) % n_unique
-    job = (wl.base_ranges, wl.base_poses, wl.center_pose, wl.query_ranges[idx], wl.query_poses[idx], wl.laser)
+    job = (wl.base_ranges, wl.base_poses, wl.center_pose, q_r, q_p, wl.laser)
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
@@ -116,7 +115,6 @@ def main():
     # ---- synthetic workload (SURVEY.md §8(d) cfg 4): same grid on every rank, own scans per rank ----
     n_unique = 64  # distinct query scans, tiled to --batch (numpy ray casting of 4096 scans would take minutes)
     wl = synth.make_match_workload(n_base=args.n_base, n_query=n_unique, seed=5, query_spread=3.0)
-    wl.query_poses = synth.perturb(wl.truth_poses, 0.3, np.deg2rad(10.0), 77 + rank)  # own odometry error per rank
     gm = api.ScanMatcher(ctx, cfg, api.laser_params(wl.laser))
     assert gm.num_beams == N_BEAMS
     if args.broadcast_grid and distributed:
@@ -127,8 +125,11 @@ def main():
         gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)  # redundant build: cheaper than the broadcast
     B = args.batch
     idx = np.arange(B) % n_unique
+    # every batch element is its own problem: the 64 ray-cast scans are reused, but each element gets its own
+    # odometry error (own search centre, own lattice, own cells), different on every rank
+    batch_poses = synth.perturb(wl.truth_poses[idx], 0.3, np.deg2rad(10.0), 77 + rank)
     ranges32 = torch.from_numpy(wl.query_ranges[idx].astype(np.float32)).to(dev)
-    poses = torch.from_numpy(np.ascontiguousarray(wl.query_poses[idx])).to(dev)
+    poses = torch.from_numpy(np.ascontiguousarray(batch_poses)).to(dev)
     results = torch.zeros((B, 112), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
@@ -223,8 +224,7 @@ def main():
         from oracle import pyoracle as po
 
         sample = max(8, min(args.cpu_sample, B))
-        sidx = np.arange(sample) % n_unique
-        q_r, q_p = wl.query_ranges[sidx], wl.query_poses[sidx]
+        q_r, q_p = wl.query_ranges[idx[:sample]], batch_poses[:sample]
         if po.have_ref():
             ref = po.RefKarto(po.default_cfg(), po.laser_struct(wl.laser))
             ref.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
@@ -255,7 +255,7 @@ def main():
         if kind == "reference":
             try:  # all-core figure beside the single-core one; never the headline baseline
                 cores = args.cpu_cores or min(os.cpu_count() or 1, 64)
-                rate, busy, wall = cpu_multicore(wl, n_unique, 200, cores)
+                rate, busy, wall = cpu_multicore(wl, q_r[:200], q_p[:200], cores)
                 cpu_baseline["multicore"] = {"value": round(rate, 1), "unit": "scan-matches/s", "cores": cores,
                                              "sample": f"200 scan-matches per process, slowest process {busy:.2f} s"}
             except Exception as e:  # pragma: no cover
