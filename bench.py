@@ -70,6 +70,12 @@ def cpu_multicore(wl, q_r, q_p, cores):
 
 
 def main():
+    # stdout carries the ONE JSON line and nothing else: the reference library behind the CPU baseline
+    # (oracle/_ref) chats on std::cout ("Registering sensor ...", also at exit), so fd 1 is pointed at stderr
+    # for everything but the final print
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -288,7 +294,8 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
     }
-    print(json.dumps(line))
+    json_out.write(json.dumps(line) + "\n")
+    json_out.flush()
     if distributed:
         dist.destroy_process_group()
 
