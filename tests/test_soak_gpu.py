@@ -1,0 +1,50 @@
+"""Soak: random worlds, window sizes, odometry errors and invalid readings; 256-scan batches (large enough
+for the tiled coarse planes and the 4x4-block fine kernel) compared with the reference itself where
+oracle/_ref is available (else with the pinned restatement).  Responses must be exact, poses and
+covariances equal to rounding."""
+import math
+
+import numpy as np
+import pytest
+
+from lslam_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_world_batches_vs_reference(ctx, oracle_lib, seed):
+    po = oracle_lib
+    rng = np.random.default_rng(100 + seed)
+    laser = synth.Laser()
+    world = synth.arena(size=rng.uniform(30, 90), n_axis=int(rng.integers(6, 30)), n_rot=int(rng.integers(2, 10)),
+                        seed=200 + seed)
+    wl = synth.make_match_workload(n_base=int(rng.integers(10, 70)), n_query=32, seed=300 + seed, laser=laser,
+                                   world=world, query_spread=rng.uniform(0.5, 4.0))
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    B = 256
+    idx = np.arange(B) % 32
+    poses = synth.perturb(wl.truth_poses[idx], rng.uniform(0.05, 0.45), math.radians(rng.uniform(2, 18)), 400 + seed)
+    ranges = wl.query_ranges[idx].copy()
+    ranges[rng.random(ranges.shape) < 0.01] = np.inf
+    res = gm.match_batch(ranges, poses)
+    if po.have_ref():
+        ref = po.RefKarto(po.default_cfg(), po.laser_struct(laser))
+        ref.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
+        _, c_poses, c_covs, c_resp = ref.match_fixed_grid(ranges, poses)
+        c_covs = np.asarray(c_covs).reshape(B, 9)
+    else:
+        port = po.PortKarto(po.default_cfg(), po.laser_struct(laser))
+        port.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
+        c_poses, c_resp, c_covs = np.zeros((B, 3)), np.zeros(B), np.zeros((B, 9))
+        for i in range(B):
+            m, c, r = port.match(ranges[i], poses[i])
+            c_poses[i], c_resp[i], c_covs[i] = m, r, np.asarray(c).reshape(-1)
+    assert (res["status"] == 0).all()
+    d = res["pose"] - c_poses
+    d[:, 2] = np.arctan2(np.sin(d[:, 2]), np.cos(d[:, 2]))
+    assert np.abs(d).max() <= 1e-12
+    assert np.abs(res["response"] - c_resp).max() == 0.0
+    assert np.abs(res["covariance"].reshape(B, 9) - c_covs).max() <= 1e-12
+    assert res["response"].mean() > 0.3  # the matches are real ones

@@ -2,7 +2,9 @@
 """Secondary measurements for the BASELINE configs that are parity cases rather than the headline
 bench line (bench.py): config 2 (log-odds update), config 3 (single-scan MatchScan), config 5
 (streaming match + map update).  Each prints one JSON line with the GPU number and the CPU oracle
-timed beside it on the same inputs.  Usage: python tools/bench_extra.py [--scans N]"""
+timed beside it on the same inputs -- the oracle is used exactly as in bench.py's cpu_baseline leg: as the timed
+CPU baseline and as the checker of the GPU results, never as a producer of them.
+Usage: python tools/bench_extra.py [--scans N]"""
 import argparse
 import json
 import math
