@@ -213,12 +213,12 @@ __device__ __forceinline__ float gn_cof3(const float* m, int i, int j) {
   return m[3 * i1 + j1] * m[3 * i2 + j2] - m[3 * i1 + j2] * m[3 * i2 + j1];
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_gn_match(GnLevels lv, const float* __restrict__ pts, int n, float bx, float by, float bth,
            float* __restrict__ out /* pose[3] + H[9] */) {
   extern __shared__ float terms[];  // [n][9]
-  __shared__ float s_est[3];
-  const int tid = threadIdx.x;
+  __shared__ float s_est[3], s_sum[9];
+  const int tid = threadIdx.x, nt = blockDim.x;
   float tmp0 = bx, tmp1 = by, tmp2 = bth;
   float Hlast[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int L = lv.n_levels - 1; L >= 0; --L) {
@@ -238,7 +238,7 @@ k_gn_match(GnLevels lv, const float* __restrict__ pts, int n, float bx, float by
       const float e0 = s_est[0], e1 = s_est[1], e2 = s_est[2];
       const float c = (float)cos((double)e2), s = (float)sin((double)e2);  // Rotation2Df + sinRot/cosRot (:85-88)
       const float lim_x = (float)sx - 2.0f, lim_y = (float)sy - 2.0f;     // MapDimensionProperties.h:66-70
-      for (int i = tid; i < n; i += 256) {
+      for (int i = tid; i < n; i += nt) {
         const float px = pts[2 * i] * factor, py = pts[2 * i + 1] * factor;
         const float cx = (c * px + (-s) * py) + e0;
         const float cy = (s * px + c * py) + e1;
@@ -263,13 +263,18 @@ k_gn_match(GnLevels lv, const float* __restrict__ pts, int n, float bx, float by
         t[6] = gxv * gyv; t[7] = gxv * rotDeriv; t[8] = gyv * rotDeriv;
       }
       __syncthreads();
+      // sequential fp32 accumulation in point order (:94-126): the nine sums are independent chains, so
+      // nine lanes walk the points, one chain each -- same order, same roundings, a ninth of the latency
+      if (tid < 9) {
+        float acc = 0.0f;
+#pragma unroll 8
+        for (int i = 0; i < n; i++) acc += terms[9 * i + tid];
+        s_sum[tid] = acc;
+      }
+      __syncthreads();
       if (tid == 0) {
-        float d0 = 0, d1 = 0, d2 = 0, h00 = 0, h11 = 0, h22 = 0, h01 = 0, h02 = 0, h12 = 0;
-        for (int i = 0; i < n; i++) {  // sequential fp32 accumulation, point order (:94-126)
-          const float* t = terms + 9 * i;
-          d0 += t[0]; d1 += t[1]; d2 += t[2];
-          h00 += t[3]; h11 += t[4]; h22 += t[5]; h01 += t[6]; h02 += t[7]; h12 += t[8];
-        }
+        const float d0 = s_sum[0], d1 = s_sum[1], d2 = s_sum[2], h00 = s_sum[3], h11 = s_sum[4], h22 = s_sum[5],
+                    h01 = s_sum[6], h02 = s_sum[7], h12 = s_sum[8];
         float H[9] = {h00, h01, h02, h01, h11, h12, h02, h12, h22};
         for (int q = 0; q < 9; q++) Hlast[q] = H[q];
         if (h00 != 0.0f && h11 != 0.0f) {  // estimateTransformationLogLh (ScanMatcher.h:113-133)
@@ -588,7 +593,7 @@ int lslam_map_match_data(lslam_map* map, const float* pts, int n, const float be
   const size_t lds = (size_t)std::max(n, 1) * 9 * sizeof(float);
   if (lds > 64 * 1024)
     LSLAM_HIP(ctx, hipFuncSetAttribute((const void*)k_gn_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  launch(ctx, "gn_match", k_gn_match, dim3(1), dim3(256), lds, lv, (const float*)map->d_pts.p, n, begin_world[0],
+  launch(ctx, "gn_match", k_gn_match, dim3(1), dim3(n > 512 ? 1024 : 256), lds, lv, (const float*)map->d_pts.p, n, begin_world[0],
          begin_world[1], begin_world[2], d_out);
   float host[12];
   LSLAM_HIP(ctx, hipMemcpyAsync(host, d_out, sizeof host, hipMemcpyDeviceToHost, ctx->stream));

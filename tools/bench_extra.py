@@ -155,6 +155,46 @@ def cfg5_streaming(ctx, n_scans):
     return res
 
 
+def hector_front_end(ctx, n_scans):
+    """Next-row #2: lesson4's loop matchData -> updateByScan (Gauss-Newton on a 3-level 1024^2 pyramid)."""
+    laser = synth.Laser()
+    n, cell, levels = 1024, 0.05, 3
+    off = (n * cell * 0.5, n * cell * 0.5)
+    world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=3)
+    path = synth.trajectory(world, n_scans, step=0.05, seed=3, bounds=6.0)
+    rng = np.random.default_rng(1)
+    pts_all = [synth.hector_points(synth.cast_scan(world, t, laser, 0.01, 0.0, rng), laser, 1.0 / cell, use_max=20.0)
+               for t in path]
+    hints = [(t + np.array([0.05, -0.04, 0.02])).astype(np.float32) for t in path]
+
+    def run(match, update):
+        t0 = time.perf_counter()
+        poses = []
+        for k, (pts, hint) in enumerate(zip(pts_all, hints)):
+            pose = path[0].astype(np.float32) if k == 0 else match(pts, hint)
+            update(pts, pose)
+            poses.append(pose)
+        return time.perf_counter() - t0, np.array(poses)
+
+    gpu = api.OccGridMap(ctx, n, n, cell, off, levels=levels)
+    gpu.setUpdateOccupiedFactor(0.9)
+    g_s, g_poses = run(lambda pts, h: gpu.matchData(h, pts)[0], lambda pts, pose: gpu.updateByScan(pts, (0.0, 0.0), pose))
+    ctx.synchronize()
+    cpus = [po.PortHector(n >> i, n >> i, cell * 2 ** i, off) for i in range(levels)]
+    for c in cpus:
+        c.setUpdateOccupiedFactor(0.9)
+
+    def cpu_update(pts, pose):
+        for i, c in enumerate(cpus):
+            c.updateByScan(pts if i == 0 else pts * np.float32(po.PortHector.level_factor(i)), (0.0, 0.0), pose)
+
+    c_s, c_poses = run(lambda pts, h: po.PortHector.match_data(cpus, pts, h)[0], cpu_update)
+    return {"config": "lesson4 front-end loop: matchData (Gauss-Newton, 3-level 1024^2 pyramid) + updateByScan per scan",
+            "scans": n_scans, "gpu_scans_per_s": round(n_scans / g_s, 1), "cpu_port_scans_per_s": round(n_scans / c_s, 1),
+            "cpu_cores": 1, "max_pose_diff_vs_port": float(np.abs(g_poses - c_poses).max()),
+            "max_pose_err_vs_truth_xy": float(np.hypot(*(g_poses[:, :2] - path[:, :2]).T).max())}
+
+
 def loop_closure(ctx, n_queries):
     """Next-row #3: loop-closure matcher instance, 10 m search space @0.05 m -> 101x101x21 candidates,
     coarse pass only, no penalty (TryCloseLoop, Mapper.cpp:991)."""
@@ -193,6 +233,7 @@ def main():
     ap.add_argument("--single", type=int, default=200)
     ap.add_argument("--stream", type=int, default=1000)
     ap.add_argument("--loop", type=int, default=64)
+    ap.add_argument("--hector", type=int, default=300)
     args = ap.parse_args()
     po.build("restate")
     ctx = api.Context(0)
@@ -200,6 +241,7 @@ def main():
     print(json.dumps(cfg3_single_scan(ctx, args.single)))
     print(json.dumps(cfg5_streaming(ctx, args.stream)))
     print(json.dumps(loop_closure(ctx, args.loop)))
+    print(json.dumps(hector_front_end(ctx, args.hector)))
 
 
 if __name__ == "__main__":
