@@ -195,6 +195,32 @@ def hector_front_end(ctx, n_scans):
             "max_pose_err_vs_truth_xy": float(np.hypot(*(g_poses[:, :2] - path[:, :2]).T).max())}
 
 
+def occgrid_from_scans(ctx, n_scans):
+    """Next-row #1: lesson6's published map, OccupancyGrid::CreateFromScans over all scans (karto_slam.cc:507-512)."""
+    laser = synth.Laser()
+    world = synth.arena(size=60.0, n_axis=18, n_rot=6, seed=9)
+    path = synth.trajectory(world, n_scans, step=0.2, seed=9, bounds=20.0)
+    rng = np.random.default_rng(9)
+    ranges = np.stack([synth.ranges_to_f64(synth.cast_scan(world, t, laser, 0.01, 0.01, rng)) for t in path])
+    thr = 20.0
+    lp = api.laser_params(laser, thr)
+    g = api.OccupancyGrid.CreateFromScans(ctx, lp, ranges[:8], path[:8], 0.05)  # warm-up
+    t0 = time.perf_counter()
+    g = api.OccupancyGrid.CreateFromScans(ctx, lp, ranges, path, 0.05)
+    got = g.data()
+    gpu_s = time.perf_counter() - t0
+    res = {"config": "Karto OccupancyGrid::CreateFromScans (hit/pass counters, TraceLine) over a whole trajectory, host API "
+                     "incl. upload of the ranges and download of the grid", "scans": n_scans,
+           "grid": list(got.shape), "gpu_ms": round(gpu_s * 1e3, 2)}
+    if po.have_ref():
+        ref = po.RefKarto(po.default_cfg(), po.laser_struct(laser, thr))
+        t0 = time.perf_counter()
+        exp, _ = ref.occgrid_from_scans(ranges, path, 0.05)
+        res["cpu_reference_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+        res["cells_equal"] = bool(np.array_equal(got, exp))
+    return res
+
+
 def loop_closure(ctx, n_queries):
     """Next-row #3: loop-closure matcher instance, 10 m search space @0.05 m -> 101x101x21 candidates,
     coarse pass only, no penalty (TryCloseLoop, Mapper.cpp:991)."""
@@ -234,6 +260,7 @@ def main():
     ap.add_argument("--stream", type=int, default=1000)
     ap.add_argument("--loop", type=int, default=64)
     ap.add_argument("--hector", type=int, default=300)
+    ap.add_argument("--occgrid", type=int, default=500)
     args = ap.parse_args()
     po.build("restate")
     ctx = api.Context(0)
@@ -242,6 +269,7 @@ def main():
     print(json.dumps(cfg5_streaming(ctx, args.stream)))
     print(json.dumps(loop_closure(ctx, args.loop)))
     print(json.dumps(hector_front_end(ctx, args.hector)))
+    print(json.dumps(occgrid_from_scans(ctx, args.occgrid)))
 
 
 if __name__ == "__main__":
