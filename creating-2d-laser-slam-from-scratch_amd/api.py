@@ -204,7 +204,8 @@ def lib() -> C.CDLL:
     L.lslam_map_update_by_scan.argtypes = [vp, vp, i32, vp, vp]
     L.lslam_map_update_by_scan_dev.argtypes = [vp, vp, i32, vp, vp]
     L.lslam_map_update_just_once.argtypes = [vp, vp, i32, vp, C.c_float, C.c_float, dbl]
-    L.lslam_map_match_data.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.lslam_map_match_data.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    L.lslam_map_cached_points.argtypes = [vp]
     L.lslam_map_read_logodds.argtypes = [vp, i32, vp]
     L.lslam_map_read_occupancy_i8.argtypes = [vp, i32, vp]
     L.lslam_map_cells_dev_ptr.restype = vp
@@ -589,14 +590,20 @@ class OccGridMap:
         self.ctx.check(self.L.lslam_map_update_just_once(self.h, p.ctypes.data, p.shape[0], o.ctypes.data,
                                                          begin[0], begin[1], metres_per_cell))
 
-    def matchData(self, begin_estimate_world, points_xy):
-        """MapRepMultiMap::matchData -> (pose[3] float32, covMatrix 3x3 float32)."""
+    def matchData(self, begin_estimate_world, points_xy, origo_xy=(0.0, 0.0)):
+        """MapRepMultiMap::matchData -> (pose[3] float32, covMatrix 3x3 float32).  Like the reference
+        (MapRepMultiMap.h:161) the container is cached: the NEXT updateByScan feeds the levels above 0
+        from it, whatever container that call is handed."""
         p = np.ascontiguousarray(points_xy, dtype=np.float32).reshape(-1, 2)
+        o = np.ascontiguousarray(origo_xy, dtype=np.float32)
         b = np.ascontiguousarray(begin_estimate_world, dtype=np.float32)
         pose, cov = np.zeros(3, dtype=np.float32), np.zeros(9, dtype=np.float32)
-        self.ctx.check(self.L.lslam_map_match_data(self.h, p.ctypes.data, p.shape[0], b.ctypes.data, pose.ctypes.data,
-                                                   cov.ctypes.data))
+        self.ctx.check(self.L.lslam_map_match_data(self.h, p.ctypes.data, p.shape[0], o.ctypes.data, b.ctypes.data,
+                                                   pose.ctypes.data, cov.ctypes.data))
         return pose, cov.reshape(3, 3)
+
+    def cached_points(self) -> int:
+        return self.L.lslam_map_cached_points(self.h)
 
     def logodds(self, level: int = 0) -> np.ndarray:
         sx, sy = self.size(level)

@@ -14,7 +14,7 @@
 // Device formulation (one WAVE per beam, closed-form Bresenham cells, two kernels, no atomics on
 // the float plane):
 //   k_logodds_mark   walks the Bresenham line; atomicMax(free_key[cell]) along the ray and
-//                    atomicMax(occ_key[end]) where key = epoch<<12 | (4095-beam): for the current
+//                    atomicMax(occ_key[end]) where key = epoch<<16 | (65535-beam): for the current
 //                    epoch the max key is the SMALLEST beam index that touched the cell.
 //   k_logodds_apply  walks again; the owner of a cell (min beam ending in it, else min beam crossing
 //                    it) applies exactly the float operations the sequential reference applies.
@@ -30,7 +30,7 @@ using namespace lslam;
 
 namespace {
 
-constexpr int kBeamBits = 12;
+constexpr int kBeamBits = 16;  // 65536 points per container; the epoch keeps 16 bits (marks cleared every 65535 scans)
 constexpr int kMaxBeams = 1 << kBeamBits;
 constexpr uint32_t kBeamMask = kMaxBeams - 1;
 constexpr uint32_t kMaxEpoch = (1u << (32 - kBeamBits)) - 1;
@@ -57,11 +57,16 @@ struct Line {
 __device__ __forceinline__ Line beam_line(const LevelGeom& g, const float* __restrict__ pts, int i) {
   Line l;
   l.x0 = g.bx; l.y0 = g.by;
+  bool representable;
   float px = pts[2 * i], py = pts[2 * i + 1];
   if (g.just_once) {
     // scanBeginMapi + (int)round(p / 0.05) with p in metres (:202-203); float / double -> double
-    l.x1 = g.bx + (int)round((double)px / g.metres_per_cell);
-    l.y1 = g.by + (int)round((double)py / g.metres_per_cell);
+    const double rx = round((double)px / g.metres_per_cell), ry = round((double)py / g.metres_per_cell);
+    // x86 cvttsd2si yields INT_MIN for NaN / Inf / out-of-range and the in-map test then drops the beam; the
+    // gfx950 conversion saturates instead (NaN -> 0), so reject those end points explicitly
+    representable = fabs(rx) < 2147483648.0 && fabs(ry) < 2147483648.0;
+    l.x1 = g.bx + (int)rx;
+    l.y1 = g.by + (int)ry;
   } else {
     px = px * g.factor;  // setFrom (H/scan/DataPointContainer.h:54-57); factor 1 on level 0 is exact
     py = py * g.factor;
@@ -69,10 +74,11 @@ __device__ __forceinline__ Line beam_line(const LevelGeom& g, const float* __res
     float ey = (g.s * px + g.c * py) + g.ty;
     ex += 0.5f;
     ey += 0.5f;
+    representable = fabsf(ex) < 2147483648.0f && fabsf(ey) < 2147483648.0f;  // false for NaN / Inf too
     l.x1 = (int)ex;
     l.y1 = (int)ey;
   }
-  l.valid = !(l.x0 == l.x1 && l.y0 == l.y1) && l.x0 >= 0 && l.x0 < g.sx && l.y0 >= 0 && l.y0 < g.sy &&
+  l.valid = representable && !(l.x0 == l.x1 && l.y0 == l.y1) && l.x0 >= 0 && l.x0 < g.sx && l.y0 >= 0 && l.y0 < g.sy &&
             l.x1 >= 0 && l.x1 < g.sx && l.y1 >= 0 && l.y1 < g.sy;
   return l;
 }
@@ -285,7 +291,8 @@ k_gn_match(GnLevels lv, const float* __restrict__ pts, int n, float bx, float by
                                gn_cof3(H, 0, 1) * invdet, gn_cof3(H, 1, 1) * invdet, gn_cof3(H, 2, 1) * invdet,
                                gn_cof3(H, 0, 2) * invdet, gn_cof3(H, 1, 2) * invdet, gn_cof3(H, 2, 2) * invdet};
           float sd[3];
-          for (int r = 0; r < 3; r++) sd[r] = (Hi[3 * r] * d0 + Hi[3 * r + 1] * d1) + Hi[3 * r + 2] * d2;
+          // H.inverse() * dTr: Eigen's coefficient-based product sums a 3-term row as a0 + (a1 + a2) (Core/Redux.h)
+          for (int r = 0; r < 3; r++) sd[r] = Hi[3 * r] * d0 + (Hi[3 * r + 1] * d1 + Hi[3 * r + 2] * d2);
           if (sd[2] > 0.2f) sd[2] = 0.2f; else if (sd[2] < -0.2f) sd[2] = -0.2f;
           s_est[0] += sd[0]; s_est[1] += sd[1]; s_est[2] += sd[2];
         }
@@ -335,6 +342,12 @@ struct lslam_map {
   float off_x = 0.f, off_y = 0.f;
   float lo_free = 0.f, lo_occ = 0.f;
   DevBuf<float> d_pts;
+  // MapRepMultiMap::dataContainers (H/slam_main/MapRepMultiMap.h:161,186,220): the points + origo of the LAST
+  // matchData call; updateByScan feeds the levels above 0 from these, whatever container it is handed
+  DevBuf<float> d_cached;
+  int n_cached = 0;
+  float cached_origo[2] = {0.f, 0.f};
+  DevBuf<float> d_gn_out;
   DevBuf<int8_t> d_i8;
   // host -> device staging of the per-scan points: a ring of pinned slots, so updateByScan only enqueues
   // (copy + two kernels per level) and returns; a slot is reused when its copy has completed
@@ -357,15 +370,23 @@ int clear_marks(lslam_map* map, Level& L) {
   return LSLAM_OK;
 }
 
-int update_impl(lslam_map* map, const float* d_pts, int n, const float origo[2], const float pose[3],
+int update_impl(lslam_map* map, const float* d_pts, int n, const float* origo, const float pose[3],
                 int just_once, float begin_x, float begin_y, double metres_per_cell) {
   lslam_context* ctx = map->ctx;
-  if (n > kMaxBeams)
+  if (n > kMaxBeams || (!just_once && map->levels.size() > 1 && map->n_cached > kMaxBeams))
     return ctx->fail(LSLAM_ERR_UNSUPPORTED, "at most %d points per scan are supported (got %d)", kMaxBeams, n);
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
   const int n_levels = just_once ? 1 : (int)map->levels.size();
+  const float* const d_pts0 = d_pts;
+  const int n0 = n;
+  const float origo0[2] = {origo[0], origo[1]};
   for (int li = 0; li < n_levels; li++) {
     Level& L = map->levels[li];
+    // level 0 takes the container it is handed, level i > 0 takes dataContainers[i-1] = what the last matchData
+    // cached (H/slam_main/MapRepMultiMap.h:174-191) -- empty until the first matchData
+    d_pts = li == 0 ? d_pts0 : map->d_cached.p;
+    n = li == 0 ? n0 : map->n_cached;
+    origo = li == 0 ? origo0 : map->cached_origo;
     if (L.epoch >= kMaxEpoch) {
       int rc = clear_marks(map, L);
       if (rc) return rc;
@@ -468,6 +489,8 @@ void lslam_map_destroy(lslam_map* map) {
     if (L.d_occ) (void)hipFree(L.d_occ);
   }
   map->d_pts.release();
+  map->d_cached.release();
+  map->d_gn_out.release();
   map->d_i8.release();
   if (map->h_stage) (void)hipHostFree(map->h_stage);
   for (auto e : map->stage_ev)
@@ -570,8 +593,8 @@ int lslam_map_update_just_once(lslam_map* map, const float* pts, int n, const fl
   return update_impl(map, map->d_pts.p, n, origo, pose, 1, begin_x, begin_y, metres_per_cell);
 }
 
-int lslam_map_match_data(lslam_map* map, const float* pts, int n, const float begin_world[3], float out_pose[3],
-                         float out_cov[9]) {
+int lslam_map_match_data(lslam_map* map, const float* pts, int n, const float origo[2], const float begin_world[3],
+                         float out_pose[3], float out_cov[9]) {
   if (!map || n < 0 || (n > 0 && !pts) || !begin_world || !out_pose) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_context* ctx = map->ctx;
   if ((int)map->levels.size() > kGnMaxLevels)
@@ -579,10 +602,18 @@ int lslam_map_match_data(lslam_map* map, const float* pts, int n, const float be
   if ((size_t)n * 9 * sizeof(float) > 150 * 1024)
     return ctx->fail(LSLAM_ERR_UNSUPPORTED, "at most %d points per scan in matchData", (int)(150 * 1024 / 36));
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
-  LSLAM_HIP(ctx, map->d_pts.reserve((size_t)2 * (n > 0 ? n : 1) + 16));
-  float* d_out = map->d_pts.p + (size_t)2 * (n > 0 ? n : 1);
+  LSLAM_HIP(ctx, map->d_cached.reserve((size_t)2 * (n > 0 ? n : 1)));
+  LSLAM_HIP(ctx, map->d_gn_out.reserve(16));
+  float* d_out = map->d_gn_out.p;
+  // dataContainers[index-1].setFrom(dataContainer, ...) (MapRepMultiMap.h:161): the container is cached for the
+  // next updateByScan -- also when it is empty
   if (n > 0)
-    LSLAM_HIP(ctx, hipMemcpyAsync(map->d_pts.p, pts, (size_t)2 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    LSLAM_HIP(ctx, hipMemcpyAsync(map->d_cached.p, pts, (size_t)2 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  if (map->levels.size() > 1) {
+    map->n_cached = n;
+    map->cached_origo[0] = origo ? origo[0] : 0.f;
+    map->cached_origo[1] = origo ? origo[1] : 0.f;
+  }
   GnLevels lv;
   lv.n_levels = (int)map->levels.size();
   for (int i = 0; i < lv.n_levels; i++) {
@@ -593,8 +624,8 @@ int lslam_map_match_data(lslam_map* map, const float* pts, int n, const float be
   const size_t lds = (size_t)std::max(n, 1) * 9 * sizeof(float);
   if (lds > 64 * 1024)
     LSLAM_HIP(ctx, hipFuncSetAttribute((const void*)k_gn_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  launch(ctx, "gn_match", k_gn_match, dim3(1), dim3(n > 512 ? 1024 : 256), lds, lv, (const float*)map->d_pts.p, n, begin_world[0],
-         begin_world[1], begin_world[2], d_out);
+  launch(ctx, "gn_match", k_gn_match, dim3(1), dim3(n > 512 ? 1024 : 256), lds, lv, (const float*)map->d_cached.p, n,
+         begin_world[0], begin_world[1], begin_world[2], d_out);
   float host[12];
   LSLAM_HIP(ctx, hipMemcpyAsync(host, d_out, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -602,6 +633,8 @@ int lslam_map_match_data(lslam_map* map, const float* pts, int n, const float be
   if (out_cov) for (int i = 0; i < 9; i++) out_cov[i] = host[3 + i];
   return LSLAM_OK;
 }
+
+int lslam_map_cached_points(const lslam_map* map) { return map ? map->n_cached : LSLAM_ERR_INVALID_ARGUMENT; }
 
 int lslam_map_read_logodds(lslam_map* map, int level, float* out) {
   if (!map || !out || level < 0 || level >= (int)map->levels.size()) return LSLAM_ERR_INVALID_ARGUMENT;

@@ -211,8 +211,10 @@ class MapRepGpu {
     if (rc != LSLAM_OK) throw std::runtime_error(lslam_last_error(ctx_));
   }
   // Eigen::Vector3f matchData(beginEstimateWorld, dataContainer, covMatrix)
-  void matchData(const float beginEstimateWorld[3], const float* pointsXY, int n, float outPose[3], float outCov[9]) {
-    int rc = lslam_map_match_data(h_, pointsXY, n, beginEstimateWorld, outPose, outCov);
+  // (the container is cached for the levels above 0 of the next updateByScan, like MapRepMultiMap.h:161)
+  void matchData(const float beginEstimateWorld[3], const float* pointsXY, int n, const float origo[2], float outPose[3],
+                 float outCov[9]) {
+    int rc = lslam_map_match_data(h_, pointsXY, n, origo, beginEstimateWorld, outPose, outCov);
     if (rc != LSLAM_OK) throw std::runtime_error(lslam_last_error(ctx_));
   }
   // getGridMap(level) contents: log-odds plane / the int8 data of nav_msgs::OccupancyGrid

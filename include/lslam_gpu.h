@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LSLAM_ABI_VERSION 1
+#define LSLAM_ABI_VERSION 2
 
 typedef enum lslam_status {
   LSLAM_OK = 0,
@@ -253,10 +253,18 @@ int lslam_map_set_update_factor_occupied(lslam_map* map, float p); /* :108-111 *
 int lslam_map_levels(const lslam_map* map);
 int lslam_map_size(const lslam_map* map, int level, int* size_x, int* size_y);
 float lslam_map_scale_to_map(const lslam_map* map, int level); /* getScaleToMap (:292-295) */
-/* OccGridMapBase::updateByScan (H/map/OccGridMapBase.h:118-168) on every pyramid level, level
- * i using points*(1/2^i) like DataPointContainer::setFrom (H/scan/DataPointContainer.h:46-58).
+/* MapRepMultiMap::updateByScan (H/slam_main/MapRepMultiMap.h:174-191): OccGridMapBase::updateByScan
+ * (H/map/OccGridMapBase.h:118-168) on every pyramid level.  Level 0 takes (points_xy, origo_xy); level
+ * i > 0 takes -- exactly like the reference's dataContainers[i-1] -- the container CACHED BY THE LAST
+ * lslam_map_match_data CALL, scaled by 1/2^i (DataPointContainer::setFrom, H/scan/DataPointContainer.h:
+ * 46-58): empty until the first matchData, stale if the caller updates with a different scan than it
+ * matched.  HectorSlamProcessor::update always matches first (HectorSlamProcessor.h:84-110), so in the
+ * reference's own flow all levels see the same scan.  A single-level map has no such coupling.
  * points_xy: n points in LEVEL-0 MAP-CELL units, robot frame (hector_slam.cc:320-362);
  * origo_xy: DataContainer origo; pose_world: (x[m], y[m], heading).
+ * Points whose end cell is not representable (NaN/Inf or beyond the int32 range) are dropped, as on
+ * the reference's x86 build, where the float->int cast yields INT_MIN and the in-map test rejects it.
+ * At most 65536 points per container (LSLAM_ERR_UNSUPPORTED beyond; the reference has no limit).
  * ASYNCHRONOUS: the update is enqueued on the context stream when the call returns (points_xy has
  * been copied and may be reused at once); lslam_map_read_*, lslam_map_match_data and
  * lslam_synchronize are ordered after it. */
@@ -272,11 +280,14 @@ int lslam_map_update_just_once(lslam_map* map, const float* points_xy, int n,
                                double metres_per_cell);
 /* MapRepresentationInterface::matchData (H/slam_main/MapRepresentationInterface.h:58-60) =
  * MapRepMultiMap::matchData (H/slam_main/MapRepMultiMap.h:144-167): coarse-to-fine Gauss-Newton
- * scan-to-map matching on the pyramid.  points_xy as for updateByScan (level-0 map-cell units);
- * begin_world = beginEstimateWorld; out_cov = covMatrix (the last Hessian, ScanMatcher.h:82-86).
- * n = 0 returns begin_world unchanged (ScanMatcher.h:96). */
-int lslam_map_match_data(lslam_map* map, const float* points_xy, int n, const float begin_world[3],
-                         float out_pose[3], float out_cov[9]);
+ * scan-to-map matching on the pyramid.  points_xy / origo_xy = the DataContainer (level-0 map-cell
+ * units; origo_xy may be NULL = (0,0); the matcher itself never reads the origo, but the container is
+ * cached for the next updateByScan, see above); begin_world = beginEstimateWorld; out_cov = covMatrix
+ * (the last Hessian, ScanMatcher.h:82-86).  n = 0 returns begin_world unchanged (ScanMatcher.h:96). */
+int lslam_map_match_data(lslam_map* map, const float* points_xy, int n, const float origo_xy[2],
+                         const float begin_world[3], float out_pose[3], float out_cov[9]);
+/* size of the cached containers (dataContainers[i].getSize()); 0 before the first matchData */
+int lslam_map_cached_points(const lslam_map* map);
 /* LogOddsCell::logOddsVal of every cell, row-major y*size_x+x (H/map/GridMapLogOdds.h:85) */
 int lslam_map_read_logodds(lslam_map* map, int level, float* out_host);
 /* nav_msgs/OccupancyGrid data as hector_slam.cc:287-304 / hector_mapping.cc:186-200 publish

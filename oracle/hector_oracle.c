@@ -221,37 +221,52 @@ static void hessian_derivs(const hor_map* m, const float pose[3], const float* p
   H[3] = H[1]; H[6] = H[2]; H[7] = H[5];
 }
 
+/* ScanMatcher::matchData on ONE level (H/matcher/ScanMatcher.h:60-99): pts are scaled by `factor` first
+ * (DataPointContainer::setFrom); 1 + max_iter Gauss-Newton steps; n == 0 returns begin_world and leaves out_cov. */
+void hor_match_level(const hor_map* m, const float* pts, int n, float factor, const float begin_world[3], int max_iter,
+                     float out_pose[3], float out_cov[9]) {
+  if (n == 0) { /* matchData returns beginEstimateWorld (ScanMatcher.h:96) */
+    out_pose[0] = begin_world[0]; out_pose[1] = begin_world[1]; out_pose[2] = begin_world[2];
+    return;
+  }
+  /* getMapCoordsPose */
+  float sc = m->scale_to_map;
+  float est[3] = {(sc * begin_world[0] + 0.0f * begin_world[1]) + m->t_x,
+                  (0.0f * begin_world[0] + sc * begin_world[1]) + m->t_y, begin_world[2]};
+  float H[9], dTr[3];
+  for (int it = 0; it < 1 + max_iter; it++) { /* ScanMatcher.h:73-80 */
+    hessian_derivs(m, est, pts, factor, n, H, dTr);
+    if (H[0] != 0.0f && H[4] != 0.0f) {
+      float Hi[9], sd[3];
+      inverse3(H, Hi);
+      /* H.inverse() * dTr: coefficient-based product, inner sum by Eigen's redux_novec_unroller: a0 + (a1 + a2) */
+      for (int r = 0; r < 3; r++) sd[r] = Hi[3 * r] * dTr[0] + (Hi[3 * r + 1] * dTr[1] + Hi[3 * r + 2] * dTr[2]);
+      if (sd[2] > 0.2f) sd[2] = 0.2f; else if (sd[2] < -0.2f) sd[2] = -0.2f;
+      est[0] += sd[0]; est[1] += sd[1]; est[2] += sd[2];
+    }
+  }
+  est[2] = normalize_angle_f(est[2]);
+  memcpy(out_cov, H, sizeof H);
+  /* getWorldCoordsPose: worldTmap = mapTworld.inverse() (H/map/GridMapBase.h:285) */
+  float invdet = 1.0f / (sc * sc - 0.0f * 0.0f);
+  float l00 = sc * invdet, l01 = -0.0f * invdet, l10 = -0.0f * invdet, l11 = sc * invdet;
+  float wt0 = -(l00 * m->t_x + l01 * m->t_y), wt1 = -(l10 * m->t_x + l11 * m->t_y);
+  out_pose[0] = (l00 * est[0] + l01 * est[1]) + wt0;
+  out_pose[1] = (l10 * est[0] + l11 * est[1]) + wt1;
+  out_pose[2] = est[2];
+}
+
+void hor_hessian_derivs(const hor_map* m, const float* pts, int n, const float pose_map[3], float H[9], float dTr[3]) {
+  hessian_derivs(m, pose_map, pts, 1.0f, n, H, dTr);
+}
+
 void hor_match_data(hor_map* const* levels, int n_levels, const float* pts, int n, const float begin_world[3],
                     float out_pose[3], float out_cov[9]) {
   float tmp[3] = {begin_world[0], begin_world[1], begin_world[2]};
   for (int lv = n_levels - 1; lv >= 0; --lv) { /* MapRepMultiMap.h:151-165 */
-    const hor_map* m = levels[lv];
-    float factor = lv == 0 ? 1.0f : hor_level_factor(lv);
-    int max_iter = lv == 0 ? 5 : 3;
-    if (n == 0) continue; /* matchData returns beginEstimateWorld (ScanMatcher.h:96) */
-    /* getMapCoordsPose */
-    float sc = m->scale_to_map;
-    float est[3] = {(sc * tmp[0] + 0.0f * tmp[1]) + m->t_x, (0.0f * tmp[0] + sc * tmp[1]) + m->t_y, tmp[2]};
-    float H[9], dTr[3];
-    for (int it = 0; it < 1 + max_iter; it++) { /* ScanMatcher.h:73-80 */
-      hessian_derivs(m, est, pts, factor, n, H, dTr);
-      if (H[0] != 0.0f && H[4] != 0.0f) {
-        float Hi[9], sd[3];
-        inverse3(H, Hi);
-        for (int r = 0; r < 3; r++) sd[r] = (Hi[3 * r] * dTr[0] + Hi[3 * r + 1] * dTr[1]) + Hi[3 * r + 2] * dTr[2];
-        if (sd[2] > 0.2f) sd[2] = 0.2f; else if (sd[2] < -0.2f) sd[2] = -0.2f;
-        est[0] += sd[0]; est[1] += sd[1]; est[2] += sd[2];
-      }
-    }
-    est[2] = normalize_angle_f(est[2]);
-    memcpy(out_cov, H, sizeof H);
-    /* getWorldCoordsPose: worldTmap = mapTworld.inverse() (H/map/GridMapBase.h:285) */
-    float invdet = 1.0f / (sc * sc - 0.0f * 0.0f);
-    float l00 = sc * invdet, l01 = -0.0f * invdet, l10 = -0.0f * invdet, l11 = sc * invdet;
-    float wt0 = -(l00 * m->t_x + l01 * m->t_y), wt1 = -(l10 * m->t_x + l11 * m->t_y);
-    tmp[0] = (l00 * est[0] + l01 * est[1]) + wt0;
-    tmp[1] = (l10 * est[0] + l11 * est[1]) + wt1;
-    tmp[2] = est[2];
+    float next[3];
+    hor_match_level(levels[lv], pts, n, lv == 0 ? 1.0f : hor_level_factor(lv), tmp, lv == 0 ? 5 : 3, next, out_cov);
+    tmp[0] = next[0]; tmp[1] = next[1]; tmp[2] = next[2];
   }
   out_pose[0] = tmp[0]; out_pose[1] = tmp[1]; out_pose[2] = tmp[2];
 }

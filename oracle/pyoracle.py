@@ -577,6 +577,8 @@ class PortHector:
             L.hor_match_data.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp]
             L.hor_level_factor.restype = C.c_float
             L.hor_level_factor.argtypes = [C.c_int]
+            L.hor_match_level.argtypes = [vp, vp, C.c_int, C.c_float, vp, C.c_int, vp, vp]
+            L.hor_hessian_derivs.argtypes = [vp, vp, C.c_int, vp, vp, vp]
             cls._L = L
         return cls._L
 
@@ -647,3 +649,345 @@ class PortHector:
     @classmethod
     def level_factor(cls, level: int) -> float:
         return cls.lib().hor_level_factor(level)
+
+    def update_index(self):
+        out = np.zeros((self.sy, self.sx), dtype=np.int32)
+        self.L.hor_read_update_index(self.h, out.ctypes.data)
+        return out
+
+    def match_level(self, points_xy, begin_world, max_iterations, factor=1.0):
+        p = np.ascontiguousarray(points_xy, dtype=np.float32).reshape(-1, 2)
+        b = np.ascontiguousarray(begin_world, dtype=np.float32)
+        pose, cov = np.zeros(3, dtype=np.float32), np.zeros(9, dtype=np.float32)
+        self.L.hor_match_level(self.h, p.ctypes.data, p.shape[0], factor, b.ctypes.data, max_iterations,
+                               pose.ctypes.data, cov.ctypes.data)
+        return pose, cov.reshape(3, 3)
+
+    def hessian_derivs(self, points_xy, pose_map):
+        p = np.ascontiguousarray(points_xy, dtype=np.float32).reshape(-1, 2)
+        q = np.ascontiguousarray(pose_map, dtype=np.float32)
+        H, d = np.zeros(9, np.float32), np.zeros(3, np.float32)
+        self.L.hor_hessian_derivs(self.h, p.ctypes.data, p.shape[0], q.ctypes.data, H.ctypes.data, d.ctypes.data)
+        return H.reshape(3, 3), d
+
+
+class PortHectorRep:
+    """MapRepMultiMap (H/slam_main/MapRepMultiMap.h) over PortHector levels: constructor geometry (:57-93),
+    matchData coarse-to-fine with the per-level containers it caches (:144-167), updateByScan feeding the levels
+    above 0 from those cached containers (:174-191) -- also when they are stale or still empty."""
+
+    def __init__(self, map_resolution, size_x, size_y, levels, start=(0.5, 0.5)):
+        f32 = np.float32
+        res = f32(map_resolution)
+        off = (res * f32(size_x) * f32(start[0]), res * f32(size_y) * f32(start[1]))
+        self.maps = []
+        sx, sy = size_x, size_y
+        for _ in range(levels):
+            self.maps.append(PortHector(sx, sy, float(res), (float(off[0]), float(off[1]))))
+            sx //= 2
+            sy //= 2
+            res = f32(res * f32(2.0))
+        self.levels = levels
+        self.cached = [(np.zeros((0, 2), np.float32), np.zeros(2, np.float32)) for _ in range(levels - 1)]
+
+    def setUpdateFactorFree(self, p):
+        for m in self.maps:
+            m.setUpdateFreeFactor(p)
+
+    def setUpdateFactorOccupied(self, p):
+        for m in self.maps:
+            m.setUpdateOccupiedFactor(p)
+
+    def reset(self):
+        for m in self.maps:
+            m.reset()
+
+    def matchData(self, points_xy, begin_world, origo_xy=(0.0, 0.0)):
+        p = np.ascontiguousarray(points_xy, dtype=np.float32).reshape(-1, 2)
+        o = np.ascontiguousarray(origo_xy, dtype=np.float32)
+        for lv in range(1, self.levels):  # setFrom: origo * factor, points * factor
+            f = np.float32(PortHector.level_factor(lv))
+            self.cached[lv - 1] = (p * f, o * f)
+        return PortHector.match_data(self.maps, p, begin_world)
+
+    def updateByScan(self, points_xy, origo_xy, pose_world):
+        self.maps[0].updateByScan(points_xy, origo_xy, pose_world)
+        for lv in range(1, self.levels):
+            pts, org = self.cached[lv - 1]
+            self.maps[lv].updateByScan(pts, org, pose_world)
+
+    def cached_points(self, level):
+        return len(self.cached[level - 1][0])
+
+    def logodds(self, level=0):
+        return self.maps[level].logodds()
+
+    def occupancy_i8(self, level=0):
+        return self.maps[level].occupancy_i8()
+
+
+def have_ref_hector() -> bool:
+    return (HERE / "_ref" / "libhector_ref.so").exists()
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a.reshape(shape) if shape is not None else a
+
+
+class _HrefLib:
+    """oracle/_ref/libhector_ref.so: lesson4's UNMODIFIED hector_mapping headers behind
+    oracle/hector_ref_driver.cpp (compiled against oracle/shim/Eigen; exists only where
+    `make -C oracle ref_hector` ran with /root/reference present -- travels to the GPU box)."""
+
+    _L = None
+
+    @classmethod
+    def lib(cls):
+        if cls._L is None:
+            path = HERE / "_ref" / "libhector_ref.so"
+            if not path.exists():
+                build("ref_hector")
+            L = C.CDLL(str(path))
+            vp, i, f = C.c_void_p, C.c_int, C.c_float
+            sig = {
+                "href_map_create": (vp, [i, i, f, f, f]),
+                "href_map_destroy": (None, [vp]),
+                "href_map_reset": (None, [vp]),
+                "href_map_set_update_free_factor": (None, [vp, f]),
+                "href_map_set_update_occupied_factor": (None, [vp, f]),
+                "href_map_scale_to_map": (f, [vp]),
+                "href_map_obstacle_threshold": (f, [vp]),
+                "href_map_update_index": (i, [vp]),
+                "href_map_update_by_scan": (None, [vp, vp, i, vp, vp]),
+                "href_map_update_just_once": (None, [vp, vp, i, vp]),
+                "href_map_read_logodds": (None, [vp, vp]),
+                "href_map_read_update_index": (None, [vp, vp]),
+                "href_map_read_occupancy_i8": (None, [vp, vp]),
+                "href_map_match_data": (None, [vp, vp, i, vp, vp, i, vp, vp]),
+                "href_map_hessian_derivs": (None, [vp, vp, i, vp, vp, vp]),
+                "href_map_world_to_map_pose": (None, [vp, vp, vp]),
+                "href_map_map_to_world_pose": (None, [vp, vp, vp]),
+                "href_rep_create": (vp, [f, i, i, C.c_uint, f, f]),
+                "href_rep_destroy": (None, [vp]),
+                "href_rep_reset": (None, [vp]),
+                "href_rep_levels": (i, [vp]),
+                "href_rep_level_info": (None, [vp, i, vp, vp, vp]),
+                "href_rep_set_update_factor_free": (None, [vp, f]),
+                "href_rep_set_update_factor_occupied": (None, [vp, f]),
+                "href_rep_scale_to_map": (f, [vp]),
+                "href_rep_match_data": (None, [vp, vp, i, vp, vp, vp, vp]),
+                "href_rep_update_by_scan": (None, [vp, vp, i, vp, vp]),
+                "href_rep_on_map_updated": (None, [vp]),
+                "href_rep_cached_points": (i, [vp, i]),
+                "href_rep_read_logodds": (None, [vp, i, vp]),
+                "href_rep_read_update_index": (None, [vp, i, vp]),
+                "href_rep_read_occupancy_i8": (None, [vp, i, vp]),
+                "href_proc_create": (vp, [f, i, i, f, f, i]),
+                "href_proc_destroy": (None, [vp]),
+                "href_proc_set_factors": (None, [vp, f, f]),
+                "href_proc_set_update_thresholds": (None, [vp, f, f]),
+                "href_proc_update": (i, [vp, vp, i, vp, vp, i]),
+                "href_proc_last_pose": (None, [vp, vp, vp]),
+                "href_proc_levels": (i, [vp]),
+                "href_proc_level_dims": (None, [vp, i, vp]),
+                "href_proc_read_logodds": (None, [vp, i, vp]),
+                "href_proc_read_occupancy_i8": (None, [vp, i, vp]),
+                "href_pose_difference_larger_than": (i, [vp, vp, f, f]),
+                "href_normalize_angle": (f, [f]),
+                "href_sizeof_cell": (i, []),
+            }
+            for name, (res, args) in sig.items():
+                fn = getattr(L, name)
+                fn.restype, fn.argtypes = res, args
+            cls._L = L
+        return cls._L
+
+
+class RefHector:
+    """One hectorslam::GridMap level of the reference (same surface as PortHector)."""
+
+    def __init__(self, size_x, size_y, cell_length, offset=(0.0, 0.0)):
+        self.L = _HrefLib.lib()
+        self.sx, self.sy = size_x, size_y
+        self.h = self.L.href_map_create(size_x, size_y, cell_length, offset[0], offset[1])
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.href_map_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.L.href_map_reset(self.h)
+
+    def setUpdateFreeFactor(self, p):
+        self.L.href_map_set_update_free_factor(self.h, p)
+
+    def setUpdateOccupiedFactor(self, p):
+        self.L.href_map_set_update_occupied_factor(self.h, p)
+
+    def getScaleToMap(self):
+        return self.L.href_map_scale_to_map(self.h)
+
+    def updateByScan(self, points_xy, origo_xy, pose_world):
+        p, o, w = _f32(points_xy, (-1, 2)), _f32(origo_xy), _f32(pose_world)
+        self.L.href_map_update_by_scan(self.h, p.ctypes.data, p.shape[0], o.ctypes.data, w.ctypes.data)
+
+    def updateByScanJustOnce(self, points_xy_m, origo_xy=(0.0, 0.0)):
+        """The literal demo variant: begin (800,800) and 0.05 m cells are hard-coded by the reference."""
+        p, o = _f32(points_xy_m, (-1, 2)), _f32(origo_xy)
+        self.L.href_map_update_just_once(self.h, p.ctypes.data, p.shape[0], o.ctypes.data)
+
+    def logodds(self):
+        out = np.zeros((self.sy, self.sx), dtype=np.float32)
+        self.L.href_map_read_logodds(self.h, out.ctypes.data)
+        return out
+
+    def update_index(self):
+        out = np.zeros((self.sy, self.sx), dtype=np.int32)
+        self.L.href_map_read_update_index(self.h, out.ctypes.data)
+        return out
+
+    def occupancy_i8(self):
+        out = np.zeros((self.sy, self.sx), dtype=np.int8)
+        self.L.href_map_read_occupancy_i8(self.h, out.ctypes.data)
+        return out
+
+    def match_level(self, points_xy, begin_world, max_iterations, origo_xy=(0.0, 0.0)):
+        p, o, b = _f32(points_xy, (-1, 2)), _f32(origo_xy), _f32(begin_world)
+        pose, cov = np.zeros(3, np.float32), np.zeros(9, np.float32)
+        self.L.href_map_match_data(self.h, p.ctypes.data, p.shape[0], o.ctypes.data, b.ctypes.data, max_iterations,
+                                   pose.ctypes.data, cov.ctypes.data)
+        return pose, cov.reshape(3, 3)
+
+    def hessian_derivs(self, points_xy, pose_map):
+        p, q = _f32(points_xy, (-1, 2)), _f32(pose_map)
+        H, d = np.zeros(9, np.float32), np.zeros(3, np.float32)
+        self.L.href_map_hessian_derivs(self.h, p.ctypes.data, p.shape[0], q.ctypes.data, H.ctypes.data, d.ctypes.data)
+        return H.reshape(3, 3), d
+
+    def world_to_map_pose(self, w):
+        out, w32 = np.zeros(3, np.float32), _f32(w)
+        self.L.href_map_world_to_map_pose(self.h, w32.ctypes.data, out.ctypes.data)
+        return out
+
+    def map_to_world_pose(self, p):
+        out, p32 = np.zeros(3, np.float32), _f32(p)
+        self.L.href_map_map_to_world_pose(self.h, p32.ctypes.data, out.ctypes.data)
+        return out
+
+
+class RefHectorRep:
+    """hectorslam::MapRepMultiMap of the reference (H/slam_main/MapRepMultiMap.h)."""
+
+    def __init__(self, map_resolution, size_x, size_y, levels, start=(0.5, 0.5)):
+        self.L = _HrefLib.lib()
+        self.h = self.L.href_rep_create(map_resolution, size_x, size_y, levels, start[0], start[1])
+        self.levels = self.L.href_rep_levels(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.href_rep_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def level_info(self, level):
+        dims, cell, off = np.zeros(2, np.int32), C.c_float(), np.zeros(2, np.float32)
+        self.L.href_rep_level_info(self.h, level, dims.ctypes.data, C.addressof(cell), off.ctypes.data)
+        return int(dims[0]), int(dims[1]), float(cell.value), (float(off[0]), float(off[1]))
+
+    def setUpdateFactorFree(self, p):
+        self.L.href_rep_set_update_factor_free(self.h, p)
+
+    def setUpdateFactorOccupied(self, p):
+        self.L.href_rep_set_update_factor_occupied(self.h, p)
+
+    def getScaleToMap(self):
+        return self.L.href_rep_scale_to_map(self.h)
+
+    def reset(self):
+        self.L.href_rep_reset(self.h)
+
+    def matchData(self, points_xy, begin_world, origo_xy=(0.0, 0.0)):
+        p, o, b = _f32(points_xy, (-1, 2)), _f32(origo_xy), _f32(begin_world)
+        pose, cov = np.zeros(3, np.float32), np.zeros(9, np.float32)
+        self.L.href_rep_match_data(self.h, p.ctypes.data, p.shape[0], o.ctypes.data, b.ctypes.data, pose.ctypes.data,
+                                   cov.ctypes.data)
+        return pose, cov.reshape(3, 3)
+
+    def updateByScan(self, points_xy, origo_xy, pose_world):
+        p, o, w = _f32(points_xy, (-1, 2)), _f32(origo_xy), _f32(pose_world)
+        self.L.href_rep_update_by_scan(self.h, p.ctypes.data, p.shape[0], o.ctypes.data, w.ctypes.data)
+
+    def onMapUpdated(self):
+        self.L.href_rep_on_map_updated(self.h)
+
+    def cached_points(self, level):
+        return self.L.href_rep_cached_points(self.h, level)
+
+    def logodds(self, level=0):
+        sx, sy, _, _ = self.level_info(level)
+        out = np.zeros((sy, sx), dtype=np.float32)
+        self.L.href_rep_read_logodds(self.h, level, out.ctypes.data)
+        return out
+
+    def occupancy_i8(self, level=0):
+        sx, sy, _, _ = self.level_info(level)
+        out = np.zeros((sy, sx), dtype=np.int8)
+        self.L.href_rep_read_occupancy_i8(self.h, level, out.ctypes.data)
+        return out
+
+
+class RefHectorProcessor:
+    """hectorslam::HectorSlamProcessor of the reference (H/slam_main/HectorSlamProcessor.h)."""
+
+    def __init__(self, map_resolution, size_x, size_y, start=(0.5, 0.5), levels=3, p_free=None, p_occ=None):
+        self.L = _HrefLib.lib()
+        self.h = self.L.href_proc_create(map_resolution, size_x, size_y, start[0], start[1], levels)
+        if p_free is not None:
+            self.L.href_proc_set_factors(self.h, p_free, p_occ)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.href_proc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update(self, points_xy, pose_hint, origo_xy=(0.0, 0.0), map_without_matching=False) -> bool:
+        p, o, b = _f32(points_xy, (-1, 2)), _f32(origo_xy), _f32(pose_hint)
+        return bool(self.L.href_proc_update(self.h, p.ctypes.data, p.shape[0], o.ctypes.data, b.ctypes.data,
+                                            int(map_without_matching)))
+
+    def last_pose(self):
+        pose, cov = np.zeros(3, np.float32), np.zeros(9, np.float32)
+        self.L.href_proc_last_pose(self.h, pose.ctypes.data, cov.ctypes.data)
+        return pose, cov.reshape(3, 3)
+
+    def logodds(self, level=0):
+        d = np.zeros(2, np.int32)
+        self.L.href_proc_level_dims(self.h, level, d.ctypes.data)
+        out = np.zeros((int(d[1]), int(d[0])), dtype=np.float32)
+        self.L.href_proc_read_logodds(self.h, level, out.ctypes.data)
+        return out
+
+
+def href_pose_difference_larger_than(a, b, dist, ang) -> bool:
+    L = _HrefLib.lib()
+    a32, b32 = _f32(a), _f32(b)  # keep the temporaries alive across the call
+    return bool(L.href_pose_difference_larger_than(a32.ctypes.data, b32.ctypes.data, dist, ang))

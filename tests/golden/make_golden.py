@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/*.npz from the REFERENCE ITSELF (oracle/_ref = the reference's open_karto
-compiled unmodified from /root/reference; only possible in the build container).
+"""Generates tests/golden/*.npz from the REFERENCE ITSELF (oracle/_ref = the reference's open_karto and
+lesson4 hector_mapping headers compiled unmodified from /root/reference; only possible in the build container).
 
     python tests/golden/make_golden.py
 
@@ -9,8 +9,10 @@ karto_match_golden.npz : seeded base window + queries (float32 ranges as a Laser
     CorrelateScan results, the shared correlation grid (sparse), coarse lookup-table and
     search-space-probability digests.
 karto_frontend_golden.npz : a 30-scan trajectory through karto::Mapper::Process (corrected poses).
-hector_golden.npz : log-odds map of 4 scans from oracle/hector_oracle.c -- NOT from the reference
-    (lesson4 needs Eigen/ROS, absent here): a regression pin of the restatement, parity unpinned.
+hector_golden.npz : from the reference's own lesson4 hector_mapping headers, compiled unmodified as
+    oracle/_ref/libhector_ref.so (Eigen from oracle/shim/Eigen): the log-odds map of 4 scans through
+    OccGridMapBase::updateByScan, and a 40-scan run of HectorSlamProcessor::update on a 3-level pyramid
+    (start estimates, matched poses, Hessians, which scans updated the map, per-level map digests).
 """
 import hashlib
 import math
@@ -72,10 +74,11 @@ def main():
         ranges.append(r); processed.append(ok); poses.append(pose)
     np.savez_compressed(OUT / "karto_frontend_golden.npz", ranges=np.stack(ranges), odom=odom,
                         processed=np.array(processed), corrected=np.stack(poses))
-    # hector (restatement only)
+    # hector: from the reference's own hector_mapping headers (oracle/_ref/libhector_ref.so)
+    assert po.have_ref_hector(), "needs /root/reference to build oracle/_ref/libhector_ref.so"
     n, cell = 600, 0.05
     off = (n * cell * 0.5, n * cell * 0.5)
-    hm = po.PortHector(n, n, cell, off)
+    hm = po.RefHector(n, n, cell, off)
     hm.setUpdateOccupiedFactor(0.9)
     hworld = synth.arena(size=28.0, n_axis=6, n_rot=3, seed=17)
     hpath = synth.trajectory(hworld, 4, step=0.5, seed=17, bounds=4.0)
@@ -84,9 +87,30 @@ def main():
         hm.updateByScan(synth.hector_points(r, laser, 1.0 / cell, use_max=14.0), (0.0, 0.0), p.astype(np.float32))
     lo = hm.logodds()
     hnz = np.flatnonzero(lo.reshape(-1)).astype(np.int32)
+    # lesson4 loop through HectorSlamProcessor::update: 3-level 1024^2 pyramid, 40 scans
+    pn, LV = 1024, 3
+    proc = po.RefHectorProcessor(cell, pn, pn, (0.5, 0.5), LV, p_free=0.4, p_occ=0.9)
+    est = np.zeros(3, np.float32)
+    p_ranges, p_start, p_pose, p_cov, p_upd = [], [], [], [], []
+    pworld = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=5)
+    for k in range(40):
+        truth = (0.04 * k, 0.015 * k, 0.004 * k)
+        r = synth.cast_scan(pworld, truth, laser)
+        pts = synth.hector_points(r, laser, 1.0 / cell, use_max=20.0)
+        p_start.append(est.copy())
+        p_upd.append(proc.update(pts, est))
+        est, cov = proc.last_pose()
+        p_ranges.append(r); p_pose.append(est.copy()); p_cov.append(cov.copy())
+    plo = [proc.logodds(lv) for lv in range(LV)]
     np.savez_compressed(OUT / "hector_golden.npz", ranges=hr, poses=hpath.astype(np.float32), size=np.array([n, n]),
                         cell=np.float32(cell), offset=np.array(off, dtype=np.float32), use_max=np.float32(14.0),
-                        nz_index=hnz, nz_value=lo.reshape(-1)[hnz], occupancy_sha256=np.array(sha(hm.occupancy_i8())))
+                        nz_index=hnz, nz_value=lo.reshape(-1)[hnz], occupancy_sha256=np.array(sha(hm.occupancy_i8())),
+                        proc_size=np.array([pn, LV]), proc_use_max=np.float32(20.0), proc_ranges=np.stack(p_ranges),
+                        proc_start=np.stack(p_start), proc_pose=np.stack(p_pose), proc_cov=np.stack(p_cov),
+                        proc_updated=np.array(p_upd), proc_logodds_sha256=np.array([sha(a) for a in plo]),
+                        proc_nonzero=np.array([np.count_nonzero(a) for a in plo]),
+                        proc_truth_last=np.array(truth, np.float32))
+    assert np.abs(est - np.array(truth)).max() < 0.05, (est, truth)
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size, "bytes")
 

@@ -60,11 +60,12 @@ def test_port_reproduces_reference_frontend_vectors(oracle_lib):
         assert np.array_equal(pose2, pose)
 
 
-def test_hector_restatement_regression(oracle_lib):
+def _replay_hector_golden(make_map, make_rep, laser):
+    """Shared by the CPU (restatement) and GPU (HIP) checks of tests/golden/hector_golden.npz, which was produced by
+    the reference's own hector_mapping headers (tests/golden/make_golden.py)."""
     d = np.load(G / "hector_golden.npz")
-    laser = synth.Laser()
     n = int(d["size"][0])
-    hm = oracle_lib.PortHector(n, n, float(d["cell"]), tuple(d["offset"]))
+    hm = make_map(n, n, float(d["cell"]), tuple(float(v) for v in d["offset"]))
     hm.setUpdateOccupiedFactor(0.9)
     for r, p in zip(d["ranges"], d["poses"]):
         hm.updateByScan(synth.hector_points(r, laser, 1.0 / float(d["cell"]), use_max=float(d["use_max"])), (0.0, 0.0), p)
@@ -73,6 +74,29 @@ def test_hector_restatement_regression(oracle_lib):
     exp[d["nz_index"]] = d["nz_value"]
     assert lo.tobytes() == exp.tobytes()
     assert sha(hm.occupancy_i8()) == str(d["occupancy_sha256"])
+    # the lesson4 loop: HectorSlamProcessor::update, replayed from the reference's own pose chain
+    pn, LV = (int(v) for v in d["proc_size"])
+    rep = make_rep(float(d["cell"]), pn, pn, LV)
+    rep.setUpdateFactorFree(0.4)
+    rep.setUpdateFactorOccupied(0.9)
+    worst = 0.0
+    for k in range(len(d["proc_ranges"])):
+        pts = synth.hector_points(d["proc_ranges"][k], laser, 1.0 / float(d["cell"]), use_max=float(d["proc_use_max"]))
+        pose, cov = rep.matchData(pts, d["proc_start"][k])
+        worst = max(worst, float(np.abs(pose - d["proc_pose"][k]).max()))
+        assert np.abs(cov - d["proc_cov"][k]).max() <= 1e-3 * max(1.0, float(np.abs(d["proc_cov"][k]).max()))
+        if d["proc_updated"][k]:
+            rep.updateByScan(pts, (0.0, 0.0), d["proc_pose"][k])  # the reference's pose: maps stay comparable
+    for lv in range(LV):
+        assert sha(rep.logodds(lv)) == str(d["proc_logodds_sha256"][lv]), lv
+        assert np.count_nonzero(rep.logodds(lv)) == int(d["proc_nonzero"][lv])
+    return worst
+
+
+def test_hector_restatement_equals_reference_vectors(oracle_lib):
+    """oracle/hector_oracle.c reproduces the reference-generated vectors bit for bit (poses included)."""
+    worst = _replay_hector_golden(lambda *a: oracle_lib.PortHector(*a), oracle_lib.PortHectorRep, synth.Laser())
+    assert worst == 0.0
 
 
 @pytest.mark.gpu
@@ -100,15 +124,28 @@ def test_hip_reproduces_reference_match_vectors(ctx, gm_data):
 
 @pytest.mark.gpu
 def test_hip_reproduces_hector_vectors(ctx):
-    d = np.load(G / "hector_golden.npz")
-    laser = synth.Laser()
-    n = int(d["size"][0])
-    hm = api.OccGridMap(ctx, n, n, float(d["cell"]), tuple(float(v) for v in d["offset"]))
-    hm.setUpdateOccupiedFactor(0.9)
-    for r, p in zip(d["ranges"], d["poses"]):
-        hm.updateByScan(synth.hector_points(r, laser, 1.0 / float(d["cell"]), use_max=float(d["use_max"])), (0.0, 0.0), p)
-    lo = hm.logodds().reshape(-1)
-    exp = np.zeros_like(lo)
-    exp[d["nz_index"]] = d["nz_value"]
-    assert lo.tobytes() == exp.tobytes()
-    assert sha(hm.occupancy_i8()) == str(d["occupancy_sha256"])
+    """HIP log-odds update: map bytes equal to the reference's; Gauss-Newton matchData poses within the fp32
+    tolerance (1e-4 m / rad; the device libm differs from glibc in the last ulp of exp/sin/cos)."""
+
+    class GpuRep:
+        def __init__(self, cell, sx, sy, levels):
+            self.m = api.OccGridMap(ctx, sx, sy, cell, (np.float32(cell) * sx * np.float32(0.5),) * 2, levels=levels)
+
+        def setUpdateFactorFree(self, p):
+            self.m.setUpdateFreeFactor(p)
+
+        def setUpdateFactorOccupied(self, p):
+            self.m.setUpdateOccupiedFactor(p)
+
+        def matchData(self, pts, begin):
+            return self.m.matchData(begin, pts)
+
+        def updateByScan(self, pts, origo, pose):
+            self.m.updateByScan(pts, origo, pose)
+
+        def logodds(self, lv):
+            return self.m.logodds(lv)
+
+    worst = _replay_hector_golden(lambda sx, sy, cell, off: api.OccGridMap(ctx, sx, sy, cell, off), GpuRep, synth.Laser())
+    assert worst <= 1e-4
+    print("max |pose_hip - pose_reference| over the golden lesson4 loop =", worst)

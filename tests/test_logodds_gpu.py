@@ -81,25 +81,75 @@ def test_free_then_occupied_same_scan(ctx, oracle_lib):
 
 
 def test_pyramid_levels(ctx, oracle_lib):
-    """MapRepMultiMap: level i = size>>i, cell*2^i, points*(1/2^i) (MapRepMultiMap.h:57-93,174-191)."""
+    """MapRepMultiMap: level i = size>>i, cell*2^i, points*(1/2^i) from the container CACHED BY matchData
+    (MapRepMultiMap.h:57-93,144-191) -- compared with the reference's own MapRepMultiMap where its build is present
+    and with the restatement (pinned to it in tests/test_oracle_vs_ref.py) always."""
     n, cell, levels = 512, 0.05, 3
-    off = (n * cell * 0.5, n * cell * 0.5)
-    gpu = api.OccGridMap(ctx, n, n, cell, off, levels=levels)
-    cpus = [oracle_lib.PortHector(n >> i, n >> i, cell * 2 ** i, off) for i in range(levels)]
+    gpu = api.OccGridMap(ctx, n, n, cell, (n * cell * 0.5, n * cell * 0.5), levels=levels)
+    reps = [oracle_lib.PortHectorRep(cell, n, n, levels)]
+    if oracle_lib.have_ref_hector():
+        reps.append(oracle_lib.RefHectorRep(cell, n, n, levels))
     assert gpu.levels == levels
-    for pts, pose in scans_for_map(3, seed=9, map_cells=n):
+    scans = scans_for_map(4, seed=9, map_cells=n)
+    # the reference's quirk first: updateByScan before any matchData leaves the levels above 0 untouched
+    pts0, pose0 = scans[0]
+    pts0 = pts0[(np.abs(pts0) < 200).all(axis=1)]
+    pose0 = (pose0 * np.float32(0.2)).astype(np.float32)
+    for m in reps + [gpu]:
+        m.updateByScan(pts0, (1.5, -0.5), pose0)
+    assert gpu.cached_points() == 0
+    assert np.count_nonzero(gpu.logodds(0)) > 0 and np.count_nonzero(gpu.logodds(1)) == 0
+    for k, (pts, pose) in enumerate(scans[1:]):
         pts = pts[(np.abs(pts) < 200).all(axis=1)]
         pose = (pose * np.float32(0.2)).astype(np.float32)
-        gpu.updateByScan(pts, (1.5, -0.5), pose)
-        for i, c in enumerate(cpus):
-            f = np.float32(oracle_lib.PortHector.level_factor(i))
-            if i == 0:
-                c.updateByScan(pts, (1.5, -0.5), pose)
-            else:
-                c.updateByScan(pts * f, np.array([1.5, -0.5], dtype=np.float32) * f, pose)
-    for i, c in enumerate(cpus):
+        for r in reps:
+            r.matchData(pts, pose, (1.5, -0.5))
+        gpu.matchData(pose, pts, (1.5, -0.5))
+        assert gpu.cached_points() == len(pts)
+        # stale container on purpose in the last round: level 0 gets HALF the scan, the upper levels the cached one
+        upd = pts if k < 2 else pts[: len(pts) // 2]
+        for m in reps + [gpu]:
+            m.updateByScan(upd, (1.5, -0.5), pose)
+    for i in range(levels):
         assert gpu.size(i) == (n >> i, n >> i)
-        assert c.logodds().tobytes() == gpu.logodds(i).tobytes()
+        for r in reps:
+            assert r.logodds(i).tobytes() == gpu.logodds(i).tobytes(), i
+
+
+def test_non_finite_and_huge_points_are_dropped(ctx, oracle_lib):
+    """The reference only ever sees finite points, but its x86 float->int cast turns NaN / Inf / out-of-range into
+    INT_MIN, which the in-map test of updateLineBresenhami rejects (OccGridMapBase.h:226-238): the beam is skipped."""
+    n, cell = 200, 0.05
+    cpu = oracle_lib.PortHector(n, n, cell, (5.0, 5.0))
+    gpu = api.OccGridMap(ctx, n, n, cell, (5.0, 5.0))
+    nan, inf = np.float32("nan"), np.float32("inf")
+    pts = np.array([[40, 0], [nan, 3], [3, nan], [inf, 0], [0, -inf], [3e9, 0], [-3e9, 1], [1e20, 1e20], [0, 30],
+                    [nan, nan]], dtype=np.float32)
+    pose = np.array([0.0, 0.0, 0.2], dtype=np.float32)
+    cpu.updateByScan(pts, (0.0, 0.0), pose)
+    gpu.updateByScan(pts, (0.0, 0.0), pose)
+    a = cpu.logodds()
+    assert (a > 0).sum() == 2  # only the two finite in-map beams end in a cell
+    assert a.tobytes() == gpu.logodds().tobytes()
+    assert gpu.logodds()[100, 100] < 0 and gpu.logodds()[0, 0] == 0  # nothing was traced to cell (0,0)
+
+
+def test_more_than_4096_points(ctx, oracle_lib):
+    """The per-cell key carries the beam index in 16 bits: containers of up to 65536 points."""
+    n, cell = 600, 0.05
+    cpu = oracle_lib.PortHector(n, n, cell, (15.0, 15.0))
+    gpu = api.OccGridMap(ctx, n, n, cell, (15.0, 15.0))
+    rng = np.random.default_rng(5)
+    ang = rng.uniform(-math.pi, math.pi, 9000)
+    rad = rng.uniform(20, 280, 9000)
+    pts = np.stack([rad * np.cos(ang), rad * np.sin(ang)], axis=1).astype(np.float32)
+    pose = np.array([0.3, -0.4, 0.7], dtype=np.float32)
+    for _ in range(2):
+        cpu.updateByScan(pts, (0.0, 0.0), pose)
+        gpu.updateByScan(pts, (0.0, 0.0), pose)
+    assert cpu.logodds().tobytes() == gpu.logodds().tobytes()
+    with pytest.raises(Exception):
+        gpu.updateByScan(np.zeros((70000, 2), np.float32), (0.0, 0.0), pose)
 
 
 def test_update_just_once_demo_variant(ctx, oracle_lib):
@@ -151,10 +201,11 @@ def test_gauss_newton_match_data(ctx, oracle_lib):
         pts = synth.hector_points(r, laser, 1.0 / cell, use_max=20.0)
         if k == 0:
             pose_c = pose_g = t.astype(np.float32)
+            gpu.matchData(pose_c, pts)  # like HectorSlamProcessor::update: match first (caches the containers)
         else:
             hint = (t + np.array([0.08, -0.06, 0.03])).astype(np.float32)
             pose_c, H_c = oracle_lib.PortHector.match_data(cpus, pts, hint)
-            pose_g, H_g = gpu.matchData(hint, pts)
+            pose_g, H_g = gpu.matchData(hint, pts)  # also caches pts for the update below
             d = float(np.abs(pose_c - pose_g).max())
             worst = max(worst, d)
             assert d <= 1e-4, (k, pose_c, pose_g)

@@ -176,3 +176,244 @@ def test_occupancy_grid_counters(po, workload):
         b, ob = port.occgrid_from_scans(wl.base_ranges, wl.base_poses, res)
         assert a.shape == b.shape and np.array_equal(oa, ob)
         assert (a == 100).sum() > 100 and np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# lesson4 (Hector): oracle/hector_oracle.c against the reference's own hector_mapping headers, compiled
+# unmodified as oracle/_ref/libhector_ref.so (oracle/hector_ref_driver.cpp; Eigen from oracle/shim/Eigen).
+# Everything is compared BIT FOR BIT (float32 bytes).
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def hpo(oracle_lib):
+    if not oracle_lib.have_ref_hector():
+        pytest.skip("oracle/_ref/libhector_ref.so not built (needs /root/reference)")
+    return oracle_lib
+
+
+def _hector_scans(n_scans, seed, size=40.0, spread=3.0, use_max=20.0, cell=0.05):
+    laser = synth.Laser()
+    world = synth.arena(size=size, n_axis=10, n_rot=4, seed=5)
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_scans):
+        pose = np.array([rng.uniform(-spread, spread), rng.uniform(-spread, spread), rng.uniform(-math.pi, math.pi)], np.float32)
+        r = synth.cast_scan(world, tuple(float(v) for v in pose), laser, 0.01, 0.01, rng)
+        out.append((synth.hector_points(r, laser, 1.0 / cell, use_max=use_max), pose, r))
+    return out
+
+
+@pytest.mark.parametrize("p_occ,n,cell", [(0.9, 1000, 0.05), (0.6, 640, 0.1)])
+def test_hector_update_by_scan_vs_reference(hpo, p_occ, n, cell):
+    """OccGridMapBase::updateByScan (H/map/OccGridMapBase.h:118-168) incl. beams leaving the map (640x0.1 m map is
+    smaller than the 20 m the scans reach), the once-per-scan rule and the occupied clamp over repeated scans."""
+    off = (n * cell * 0.5, n * cell * 0.5)
+    ref, port = hpo.RefHector(n, n, cell, off), hpo.PortHector(n, n, cell, off)
+    assert hpo._HrefLib.lib().href_sizeof_cell() == 8  # LogOddsCell {float, int} (SURVEY §8 sizes)
+    for m in (ref, port):
+        m.setUpdateFreeFactor(0.4)
+        m.setUpdateOccupiedFactor(p_occ)
+    assert ref.getScaleToMap() == port.getScaleToMap()
+    scans = _hector_scans(12, seed=3, cell=cell)
+    for k, (pts, pose, _) in enumerate(scans + scans[:3] * 4):  # the repeats drive cells towards the clamp
+        origo = (0.0, 0.0) if k % 3 else (1.5, -0.5)            # a laser mounted off the base centre
+        ref.updateByScan(pts, origo, pose)
+        port.updateByScan(pts, origo, pose)
+    a, b = ref.logodds(), port.logodds()
+    assert np.count_nonzero(a) > 50000
+    assert a.tobytes() == b.tobytes()
+    assert np.array_equal(ref.update_index(), port.update_index())
+    assert np.array_equal(ref.occupancy_i8(), port.occupancy_i8())
+
+
+def test_hector_clamp_is_reached(hpo):
+    """updateSetOccupied adds only below 50 (H/map/GridMapLogOdds.h:108-114): hammer one wall until it saturates."""
+    n, cell = 400, 0.05
+    off = (n * cell * 0.5, n * cell * 0.5)
+    ref, port = hpo.RefHector(n, n, cell, off), hpo.PortHector(n, n, cell, off)
+    for m in (ref, port):
+        m.setUpdateOccupiedFactor(0.9)
+    pts, pose, _ = _hector_scans(1, seed=9, size=16.0, spread=0.5, use_max=9.0)[0]
+    for _ in range(40):
+        ref.updateByScan(pts, (0.0, 0.0), pose)
+        port.updateByScan(pts, (0.0, 0.0), pose)
+    a = ref.logodds()
+    assert a.max() > 50.0 and a.max() < 50.0 + 2.2  # crossed the clamp once, then stopped
+    assert a.tobytes() == port.logodds().tobytes()
+
+
+def test_hector_just_once_vs_reference(hpo):
+    """updateByScanJustOnce (H/map/OccGridMapBase.h:175-217), the make_hector_map demo: 1600^2 map, points in metres,
+    begin cell (800,800) and 1/0.05 hard-coded by the reference."""
+    laser = synth.Laser()
+    ref, port = hpo.RefHector(1600, 1600, 0.05, (40.0, 40.0)), hpo.PortHector(1600, 1600, 0.05, (40.0, 40.0))
+    world = synth.arena(size=60.0, n_axis=10, n_rot=4, seed=8)
+    for k in range(3):
+        r = synth.cast_scan(world, (0.3 * k, -0.2 * k, 0.1 * k), laser)
+        pm = synth.hector_points_metres(r, laser)
+        ref.updateByScanJustOnce(pm)
+        port.updateByScanJustOnce(pm)
+    assert np.count_nonzero(ref.logodds()) > 100000
+    assert ref.logodds().tobytes() == port.logodds().tobytes()
+
+
+def test_hector_hessian_and_level_match_vs_reference(hpo):
+    """getCompleteHessianDerivs / interpMapValueWithDerivatives (H/map/OccGridMapUtil.h:77-228) and
+    ScanMatcher::matchData on one level (H/matcher/ScanMatcher.h:60-139), incl. starts far enough off that the
+    0.2 rad clamp of the search direction fires and points fall outside the map."""
+    n, cell = 512, 0.1
+    off = (n * cell * 0.5, n * cell * 0.5)
+    ref, port = hpo.RefHector(n, n, cell, off), hpo.PortHector(n, n, cell, off)
+    for m in (ref, port):
+        m.setUpdateOccupiedFactor(0.9)
+    scans = _hector_scans(10, seed=11, spread=1.5, cell=cell)
+    for pts, pose, _ in scans:
+        ref.updateByScan(pts, (0.0, 0.0), pose)
+        port.updateByScan(pts, (0.0, 0.0), pose)
+    rng = np.random.default_rng(12)
+    for pts, pose, _ in scans:
+        for scale in (0.02, 0.3, 3.0):
+            start = (pose + rng.uniform(-1, 1, 3) * np.array([scale, scale, 0.3 * scale])).astype(np.float32)
+            pm = ref.world_to_map_pose(start)
+            Hr, dr = ref.hessian_derivs(pts, pm)
+            Hp, dp = port.hessian_derivs(pts, pm)
+            assert Hr.tobytes() == Hp.tobytes() and dr.tobytes() == dp.tobytes()
+            for iters in (0, 3, 5):
+                pr, cr = ref.match_level(pts, start, iters)
+                pp, cp = port.match_level(pts, start, iters)
+                assert pr.tobytes() == pp.tobytes(), (start, iters, pr, pp)
+                assert cr.tobytes() == cp.tobytes()
+    # empty container: begin estimate comes straight back (ScanMatcher.h:96)
+    pr, _ = ref.match_level(np.zeros((0, 2), np.float32), (1.0, 2.0, 0.3), 5)
+    pp, _ = port.match_level(np.zeros((0, 2), np.float32), (1.0, 2.0, 0.3), 5)
+    assert pr.tolist() == pp.tolist() == [1.0, 2.0, np.float32(0.3)]
+
+
+def test_hector_pyramid_match_and_update_vs_reference(hpo):
+    """MapRepMultiMap (H/slam_main/MapRepMultiMap.h): constructor geometry per level, matchData coarse-to-fine,
+    updateByScan on every level from the containers cached by matchData -- and the reference's quirk that
+    updateByScan WITHOUT a preceding matchData leaves the levels above 0 on stale (initially empty) containers."""
+    laser = synth.Laser()
+    n, cell, LV = 1024, 0.05, 3
+    rep = hpo.RefHectorRep(cell, n, n, LV, (0.5, 0.5))
+    rep.setUpdateFactorFree(0.4)
+    rep.setUpdateFactorOccupied(0.9)
+    ports = []
+    for lv in range(LV):
+        sx, sy, c, off = rep.level_info(lv)
+        assert (sx, sy) == (n >> lv, n >> lv) and c == np.float32(cell) * np.float32(2 ** lv)
+        assert off == (np.float32(cell) * n * np.float32(0.5),) * 2
+        p = hpo.PortHector(sx, sy, c, off)
+        p.setUpdateFreeFactor(0.4)
+        p.setUpdateOccupiedFactor(0.9)
+        ports.append(p)
+    world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=5)
+    scan0 = synth.hector_points(synth.cast_scan(world, (0.3, -0.2, 0.1), laser), laser, 1.0 / cell)
+    # the quirk: no matchData yet -> dataContainers[] are empty -> only level 0 is updated
+    rep.updateByScan(scan0, (0.0, 0.0), (0.3, -0.2, 0.1))
+    assert rep.cached_points(1) == 0 and np.count_nonzero(rep.logodds(0)) > 0
+    assert np.count_nonzero(rep.logodds(1)) == 0 and np.count_nonzero(rep.logodds(2)) == 0
+    rep.reset()
+    est = np.array([0.3, -0.2, 0.1], np.float32)
+    for k in range(25):
+        truth = (0.3 + 0.05 * k, -0.2 + 0.02 * k, 0.1 + 0.01 * k)
+        pts = synth.hector_points(synth.cast_scan(world, truth, laser), laser, 1.0 / cell)
+        guess = est if k else np.array(truth, np.float32)
+        e_ref, H_ref = rep.matchData(pts, guess)
+        e_port, H_port = hpo.PortHector.match_data(ports, pts, guess)
+        assert e_ref.tobytes() == e_port.tobytes(), (k, e_ref, e_port)
+        assert H_ref.tobytes() == H_port.tobytes()
+        assert rep.cached_points(1) == len(pts) == rep.cached_points(2)
+        est = e_ref
+        rep.updateByScan(pts, (0.0, 0.0), est)
+        rep.onMapUpdated()
+        for lv, p in enumerate(ports):
+            f = np.float32(hpo.PortHector.level_factor(lv)) if lv else np.float32(1)
+            p.updateByScan(pts.astype(np.float32) * f, (0.0, 0.0), est)
+    assert np.abs(est - np.array(truth)).max() < 0.05
+    for lv in range(LV):
+        assert rep.logodds(lv).tobytes() == ports[lv].logodds().tobytes()
+        assert np.array_equal(rep.occupancy_i8(lv), ports[lv].occupancy_i8())
+
+
+def test_hector_processor_loop_vs_restatement(hpo):
+    """HectorSlamProcessor::update (H/slam_main/HectorSlamProcessor.h:84-110) over a trajectory: pose chain fed back as
+    the next start estimate (hector_slam.cc:200-204), map updated only when poseDifferenceLargerThan says so.  The
+    predicate is the reference's own (its unqualified abs(float) resolves to abs(int) with this toolchain:
+    H/util/UtilFunctions.h:88, so sub-radian heading changes alone never trigger an update)."""
+    laser = synth.Laser()
+    n, cell, LV = 1024, 0.05, 3
+    proc = hpo.RefHectorProcessor(cell, n, n, (0.5, 0.5), LV, p_free=0.4, p_occ=0.9)
+    assert hpo.href_pose_difference_larger_than([0, 0, 0.5], [0, 0, 0], 10.0, 0.13) is False  # abs(int)
+    assert hpo.href_pose_difference_larger_than([0, 0, 1.5], [0, 0, 0], 10.0, 0.13) is True
+    ports = []
+    for lv in range(LV):
+        c = np.float32(cell) * np.float32(2 ** lv)
+        p = hpo.PortHector(n >> lv, n >> lv, c, (np.float32(cell) * n * np.float32(0.5),) * 2)
+        p.setUpdateFreeFactor(0.4)
+        p.setUpdateOccupiedFactor(0.9)
+        ports.append(p)
+    world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=5)
+    est = np.zeros(3, np.float32)
+    last_update = np.full(3, np.finfo(np.float32).max, np.float32)
+    updates = 0
+    for k in range(60):
+        truth = (0.04 * k, 0.015 * k, 0.004 * k)
+        pts = synth.hector_points(synth.cast_scan(world, truth, laser), laser, 1.0 / cell)
+        did = proc.update(pts, est)
+        new_ref, cov_ref = proc.last_pose()
+        new_port, cov_port = hpo.PortHector.match_data(ports, pts, est)
+        assert new_ref.tobytes() == new_port.tobytes(), k
+        assert cov_ref.tobytes() == cov_port.tobytes()
+        if hpo.href_pose_difference_larger_than(new_port, last_update, 0.4, 0.13):
+            for lv, p in enumerate(ports):
+                f = np.float32(hpo.PortHector.level_factor(lv)) if lv else np.float32(1)
+                p.updateByScan(pts.astype(np.float32) * f, (0.0, 0.0), new_port)
+            last_update = new_port.copy()
+            updates += 1
+            assert did
+        else:
+            assert not did
+        est = new_ref
+    assert 4 <= updates <= 10
+    assert np.abs(est - np.array(truth)).max() < 0.05
+    for lv in range(LV):
+        assert proc.logodds(lv).tobytes() == ports[lv].logodds().tobytes()
+
+
+def test_hector_non_finite_points_vs_reference(hpo):
+    """NaN / Inf / out-of-int-range points: the x86 float->int cast gives INT_MIN, the in-map test drops the beam
+    (H/map/OccGridMapBase.h:226-238) -- the behaviour the HIP kernel reproduces explicitly."""
+    n, cell = 200, 0.05
+    ref, port = hpo.RefHector(n, n, cell, (5.0, 5.0)), hpo.PortHector(n, n, cell, (5.0, 5.0))
+    nan, inf = np.float32("nan"), np.float32("inf")
+    pts = np.array([[40, 0], [nan, 3], [3, nan], [inf, 0], [0, -inf], [3e9, 0], [-3e9, 1], [1e20, 1e20], [0, 30],
+                    [nan, nan]], dtype=np.float32)
+    for m in (ref, port):
+        m.updateByScan(pts, (0.0, 0.0), (0.0, 0.0, 0.2))
+    a = ref.logodds()
+    assert (a > 0).sum() == 2 and a[0, 0] == 0
+    assert a.tobytes() == port.logodds().tobytes()
+
+
+def test_hector_rep_restatement_vs_reference(hpo):
+    """PortHectorRep (the restated MapRepMultiMap incl. its cached containers) against the reference's, with a stale
+    container on purpose."""
+    laser = synth.Laser()
+    n, cell, LV = 512, 0.05, 3
+    ref, port = hpo.RefHectorRep(cell, n, n, LV), hpo.PortHectorRep(cell, n, n, LV)
+    for m in (ref, port):
+        m.setUpdateFactorFree(0.4)
+        m.setUpdateFactorOccupied(0.9)
+    world = synth.arena(size=20.0, n_axis=4, n_rot=2, seed=2)
+    for k in range(6):
+        truth = (3.0 + 0.05 * k, 3.0, 0.02 * k)
+        pts = synth.hector_points(synth.cast_scan(world, truth, laser), laser, 1.0 / cell, use_max=12.0)
+        if k != 3:  # scan 3 is integrated without matching it first -> levels > 0 reuse scan 2's container
+            a, b = ref.matchData(pts, truth, (0.5, 0.25)), port.matchData(pts, truth, (0.5, 0.25))
+            assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+        ref.updateByScan(pts, (0.5, 0.25), truth)
+        ref.onMapUpdated()
+        port.updateByScan(pts, (0.5, 0.25), truth)
+    for lv in range(LV):
+        assert np.count_nonzero(ref.logodds(lv)) > 100
+        assert ref.logodds(lv).tobytes() == port.logodds(lv).tobytes()

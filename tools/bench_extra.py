@@ -171,7 +171,9 @@ def hector_front_end(ctx, n_scans):
         t0 = time.perf_counter()
         poses = []
         for k, (pts, hint) in enumerate(zip(pts_all, hints)):
-            pose = path[0].astype(np.float32) if k == 0 else match(pts, hint)
+            # like HectorSlamProcessor::update (HectorSlamProcessor.h:84-110): always match first -- on the empty map
+            # of scan 0 that returns the start estimate unchanged, and it caches the containers of the levels above 0
+            pose = match(pts, path[0].astype(np.float32) if k == 0 else hint)
             update(pts, pose)
             poses.append(pose)
         return time.perf_counter() - t0, np.array(poses)
@@ -180,15 +182,9 @@ def hector_front_end(ctx, n_scans):
     gpu.setUpdateOccupiedFactor(0.9)
     g_s, g_poses = run(lambda pts, h: gpu.matchData(h, pts)[0], lambda pts, pose: gpu.updateByScan(pts, (0.0, 0.0), pose))
     ctx.synchronize()
-    cpus = [po.PortHector(n >> i, n >> i, cell * 2 ** i, off) for i in range(levels)]
-    for c in cpus:
-        c.setUpdateOccupiedFactor(0.9)
-
-    def cpu_update(pts, pose):
-        for i, c in enumerate(cpus):
-            c.updateByScan(pts if i == 0 else pts * np.float32(po.PortHector.level_factor(i)), (0.0, 0.0), pose)
-
-    c_s, c_poses = run(lambda pts, h: po.PortHector.match_data(cpus, pts, h)[0], cpu_update)
+    cpu = po.PortHectorRep(cell, n, n, levels)
+    cpu.setUpdateFactorOccupied(0.9)
+    c_s, c_poses = run(lambda pts, h: cpu.matchData(pts, h)[0], lambda pts, pose: cpu.updateByScan(pts, (0.0, 0.0), pose))
     return {"config": "lesson4 front-end loop: matchData (Gauss-Newton, 3-level 1024^2 pyramid) + updateByScan per scan",
             "scans": n_scans, "gpu_scans_per_s": round(n_scans / g_s, 1), "cpu_port_scans_per_s": round(n_scans / c_s, 1),
             "cpu_cores": 1, "max_pose_diff_vs_port": float(np.abs(g_poses - c_poses).max()),
