@@ -210,6 +210,8 @@ def lib() -> C.CDLL:
     L.lslam_map_read_occupancy_i8.argtypes = [vp, i32, vp]
     L.lslam_map_cells_dev_ptr.restype = vp
     L.lslam_map_cells_dev_ptr.argtypes = [vp, i32]
+    L.lslam_matcher_set_option.argtypes = [vp, i32, i32]
+    L.lslam_matcher_read_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     _LIB = L
     return L
 
@@ -363,6 +365,16 @@ class ScanMatcher:
         self.ctx.check(self.L.lslam_matcher_set_grid_u8_dev(self.h, ptr, o.ctypes.data))
 
     @property
+    def set_option(self, name: str, value: int):
+        opt = {"row_occupancy": 1, "collect_stats": 2}[name]
+        self.ctx.check(self.L.lslam_matcher_set_option(self.h, opt, int(value)))
+
+    def read_stats(self) -> dict:
+        out = (C.c_uint64 * 4)()
+        self.ctx.check(self.L.lslam_matcher_read_stats(self.h, out))
+        return {"rows_in_range": int(out[0]), "rows_live": int(out[1]), "beam_angles": int(out[2]),
+                "beam_angles_queued": int(out[3])}
+
     def grid_dev_ptr(self) -> int:
         return self.L.lslam_matcher_grid_dev_ptr(self.h)
 

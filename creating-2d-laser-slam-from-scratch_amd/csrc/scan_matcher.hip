@@ -342,6 +342,17 @@ k_occ_pairs(const uint32_t* __restrict__ occ_t, int stride, int words_per_half, 
   pairs[(size_t)ew * stride + x] = make_uint2(col[0], w + 1 < words_per_half ? col[1] : 0u);
 }
 
+// wave64 sum, uniform result: four DPP adds give every lane its row-of-16 total, the four row totals
+// are read back as scalars
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true);  // row_mirror
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+         (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
 // ------------------------------------------------------------------------------------------
 // k_resp_rows -- THE HOT KERNEL.
 // Exact response numerators (Mapper.cpp:819-856) of every candidate position of a uniform
@@ -362,12 +373,16 @@ k_occ_pairs(const uint32_t* __restrict__ occ_t, int stride, int words_per_half, 
 // Block -> (scan, angle) mapping keeps all angles of a scan on one XCD (block b runs on XCD b%8),
 // so a scan's 17 KB of scan-frame points is fetched into ONE L2 instead of eight.
 // ------------------------------------------------------------------------------------------
-template <int NXD, int NYC, bool TILED>
+// STATS = true is the instrumented twin used for ONE untimed launch by lslam_matcher_read_stats (bench.py's
+// pruned_row_fraction): it counts, per launch, the lattice rows inside the reference's index range, the rows
+// still live after the exact row-occupancy pruning, the readable beams and the beams queued for phase B.
+template <int NXD, int NYC, bool TILED, bool STATS = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))  // <= 128 VGPRs
 k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int step, int limit, Geom g,
             PassCfg pc, const Lattice* __restrict__ lat, const double2* __restrict__ cossin,
             const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int beam_slices,
-            int S, const uint2* __restrict__ occ_t, int occ_wpc, int tile_rows, uint32_t tile_class_bytes) {
+            int S, const uint2* __restrict__ occ_t, int occ_wpc, int tile_rows, uint32_t tile_class_bytes,
+            unsigned long long* __restrict__ stats) {
   constexpr int NW = NXD * NYC * 2;
   constexpr int kQueue = 128;
   static_assert(NYC <= 16 && 2 * (NYC - 1) < 32, "row mask / occupancy window width");
@@ -453,6 +468,7 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
     // table cell is within +-2^15 cells every index below is exact in int32 (24-bit multiplies, unsigned
     // range compares); any other beam takes the 64-bit path.
     int qcount = 0, qhead = 0;
+    uint32_t st_rows = 0, st_live = 0, st_beams = 0, st_queued = 0;  // STATS only
     const int rows_here = min(NYC, pc.ny - j0);
     const uint32_t all_rows = (1u << rows_here) - 1u;
     const int B0 = X0 + Y0 * g.stride + j0 * step * g.stride;
@@ -523,10 +539,18 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
           }  // no occupancy pruning on this path
         }
       }
+      if constexpr (STATS) {
+        st_rows += (uint32_t)__popc(mask);
+        st_beams += (uint32_t)((int)(b < g.n_beams) & (int)!isnan(p.x) & (int)!isnan(p.y));
+      }
       if (occ_t) {
         const uint2 ow = occ_t[col];  // x-major: neighbouring beams read neighbouring words (k_occ_pairs)
         const uint32_t keep = __builtin_amdgcn_alignbit(ow.y, ow.x, osh);  // bit j <-> lattice row j0 + j
         mask &= have_occ ? keep : 0xFFFFFFFFu;
+      }
+      if constexpr (STATS) {
+        st_live += (uint32_t)__popc(mask);
+        st_queued += mask ? 1u : 0u;
       }
       const unsigned long long votes = __ballot(mask != 0);
       if (mask) {
@@ -543,6 +567,15 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
     }
     if (qcount > 0) drain(qhead, qcount);
     __syncthreads();
+    if constexpr (STATS) {
+      const uint32_t t0 = wave_sum(st_rows), t1 = wave_sum(st_live), t2 = wave_sum(st_beams), t3 = wave_sum(st_queued);
+      if (lane == 0 && stats) {
+        atomicAdd(&stats[0], (unsigned long long)t0);
+        atomicAdd(&stats[1], (unsigned long long)t1);
+        atomicAdd(&stats[2], (unsigned long long)t2);
+        atomicAdd(&stats[3], (unsigned long long)t3);
+      }
+    }
 
     // Reduce over the wave.  A lane saw at most kMaxBeamsPerLane beams (the host slices longer scans),
     // so three packed DPP adds -- lanes xor 1, xor 2, then the mirrored quad -- leave every group of 8
@@ -619,17 +652,6 @@ k_tile4(const uint8_t* __restrict__ grid, int stride, int data_size, uint4* __re
     w[r] = lo | (hi << 16);
   }
   tiles[tile4_slot(ux, uy, (tile_cols + 3) / 4)] = make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-// wave64 sum, uniform result: four DPP adds give every lane its row-of-16 total, the four row totals
-// are read back as scalars
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
-  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true);  // row_mirror
-  return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
-         (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 
 // One wave64 per (scan, angle); lanes stride over the beams.  Same exact numerators as
@@ -1920,7 +1942,9 @@ struct lslam_matcher {
   uint8_t* d_sub[2] = {nullptr, nullptr};
   bool sub_dirty = true;            // the planes lag behind d_grid
   bool occ_dirty = true;            // so does the row-occupancy bitmap (built on demand: not for tiny batches)
-  bool use_row_occupancy = true;
+  bool use_row_occupancy = true;    // lslam_matcher_set_option(LSLAM_OPT_ROW_OCCUPANCY)
+  bool collect_stats = false;       // lslam_matcher_set_option(LSLAM_OPT_COLLECT_STATS): instrumented coarse kernel
+  DevBuf<unsigned long long> d_stats;
   uint32_t* d_occ_t = nullptr;      // transposed row-occupancy bitmap (k_row_occupancy)
   uint2* d_occ_x = nullptr;         // the same bits as x-major 64-bit word pairs (k_occ_pairs): what k_resp_rows reads
   int occ_wpc = 0;
@@ -2117,9 +2141,15 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       }
 #define LSLAM_ROWS_ARGS(SRC0, SRC1)                                                                              \
   grid, dim3(64), 0, SRC0, SRC1, step, limit, g, p, (const Lattice*)m->d_lat.p, (const double2*)m->d_cossin.p, \
-      (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc, m->ptile_rows, class_bytes
+      (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc, m->ptile_rows, class_bytes, \
+      (unsigned long long*)(m->collect_stats ? m->d_stats.p : nullptr)
       const uint8_t* pt = m->d_ptiles;
-      if (variant == 1)
+      if (m->collect_stats && variant == 2 && step == 2) {  // instrumented twin (untimed diagnostics only)
+        if (ptiled)
+          launch(ctx, name, k_resp_rows<3, 11, true, true>, LSLAM_ROWS_ARGS(pt, pt));
+        else
+          launch(ctx, name, k_resp_rows<3, 11, false, true>, LSLAM_ROWS_ARGS(s0, s1));
+      } else if (variant == 1)
         launch(ctx, name, k_resp_rows<1, 4, false>, LSLAM_ROWS_ARGS(s0, s1));
       else if (variant == 2 && ptiled)
         launch(ctx, name, k_resp_rows<3, 11, true>, LSLAM_ROWS_ARGS(pt, pt));
@@ -2478,6 +2508,38 @@ int lslam_matcher_set_grid_u8_dev(lslam_matcher* m, const uint8_t* grid_dev, con
 }
 
 void* lslam_matcher_grid_dev_ptr(lslam_matcher* m) { return m ? (void*)m->d_grid : nullptr; }
+
+int lslam_matcher_set_option(lslam_matcher* m, int option, int value) {
+  if (!m) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = m->ctx;
+  switch (option) {
+    case LSLAM_OPT_ROW_OCCUPANCY:
+      m->use_row_occupancy = value != 0;
+      return LSLAM_OK;
+    case LSLAM_OPT_COLLECT_STATS:
+      if (value) {
+        LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+        LSLAM_HIP(ctx, m->d_stats.reserve(8));
+        LSLAM_HIP(ctx, hipMemsetAsync(m->d_stats.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+      }
+      m->collect_stats = value != 0;
+      return LSLAM_OK;
+    default:
+      return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "unknown matcher option %d", option);
+  }
+}
+
+int lslam_matcher_read_stats(lslam_matcher* m, uint64_t out[4]) {
+  if (!m || !out) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = m->ctx;
+  if (!m->d_stats.p) return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "LSLAM_OPT_COLLECT_STATS was never enabled");
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  unsigned long long host[4];
+  LSLAM_HIP(ctx, hipMemcpyAsync(host, m->d_stats.p, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 4; i++) out[i] = host[i];
+  return LSLAM_OK;
+}
 
 int lslam_matcher_set_base_scans(lslam_matcher* m, int B, const double* ranges, int stride,
                                  const double* sensor_poses, const double center[3]) {

@@ -145,6 +145,17 @@ int lslam_matcher_set_grid_u8_dev(lslam_matcher* m, const uint8_t* grid_dev, con
 /* device address of the grid bytes (height*widthStep), e.g. as an RCCL broadcast buffer */
 void* lslam_matcher_grid_dev_ptr(lslam_matcher* m);
 
+/* Tuning / diagnostics switches; none of them changes a result.
+ *  LSLAM_OPT_ROW_OCCUPANCY (default 1): exact zero-row pruning of the coarse pass.  0 = every in-range lattice row
+ *    of every beam is gathered -- the worst case over world sparsity (bench.py reports both step times).
+ *  LSLAM_OPT_COLLECT_STATS (default 0): 1 clears the counters and routes coarse passes through an instrumented twin of
+ *    the hot kernel (slower: for an untimed diagnostic launch); lslam_matcher_read_stats then returns, summed over
+ *    the passes since: [0] lattice rows inside the reference's index range (Mapper.cpp:841-845), [1] rows still live
+ *    after pruning, [2] readable beam x angle pairs, [3] those with at least one live row. */
+enum { LSLAM_OPT_ROW_OCCUPANCY = 1, LSLAM_OPT_COLLECT_STATS = 2 };
+int lslam_matcher_set_option(lslam_matcher* m, int option, int value);
+int lslam_matcher_read_stats(lslam_matcher* m, uint64_t out[4]);
+
 /* LocalizedRangeScan::GetSensorAt / SetSensorPose (Karto.h:5280-5313), host-side, double */
 void lslam_sensor_pose_from_robot(const lslam_laser* laser, const double robot[3], double sensor[3]);
 void lslam_robot_pose_from_sensor(const lslam_laser* laser, const double sensor[3], double robot[3]);

@@ -1,0 +1,54 @@
+"""`python bench.py --gpus N` really starts N ranks, shards SURVEY §8(e)'s [r*B/W,(r+1)*B/W) partition over them and
+gathers byte-identical results.  On the 1-GPU test box the two ranks talk gloo and share GPU 0
+(LSLAM_BENCH_BACKEND=gloo); on an 8-GPU node the same command line runs RCCL over xGMI."""
+import json
+import os
+import pathlib
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def run_bench(tmp_path, gpus, extra=(), backend=None):
+    out = tmp_path / f"res_{gpus}.npy"
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    if backend:
+        env["LSLAM_BENCH_BACKEND"] = backend
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "1", "--no-cpu",
+           "--no-diagnostics", "--batch", "1024", "--dump-results", str(out), *extra]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout  # ONE JSON line, from rank 0 only
+    return json.loads(lines[0]), np.load(out)
+
+
+def test_two_ranks_equal_one_rank(tmp_path):
+    one, r1 = run_bench(tmp_path, 1)
+    two, r2 = run_bench(tmp_path, 2, backend="gloo")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["scaling"] == "strong" and two["config"]["scans_per_gpu_per_step"] == 512
+    assert one["results_ok"] == two["results_ok"] == 1024
+    assert r1.shape == r2.shape == (1024, 112)
+    assert r1.tobytes() == r2.tobytes()  # the gathered records of the sharded run are the single-rank ones
+    assert two["gather_ms"] is not None
+
+
+def test_weak_scaling_mode_and_gpu_count_check(tmp_path):
+    two, r2 = run_bench(tmp_path, 2, extra=("--scaling", "weak"), backend="gloo")
+    assert two["scaling"] == "weak" and two["config"]["scans_per_step"] == 2048 and r2.shape == (2048, 112)
+    # asking for more GPUs than the box has must fail loudly, not wrap local_rank around
+    import torch
+
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LSLAM_BENCH_BACKEND")}
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n + 1), "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "visible" in (p.stderr + p.stdout)
