@@ -364,7 +364,6 @@ class ScanMatcher:
         o = _f64(offset)
         self.ctx.check(self.L.lslam_matcher_set_grid_u8_dev(self.h, ptr, o.ctypes.data))
 
-    @property
     def set_option(self, name: str, value: int):
         opt = {"row_occupancy": 1, "collect_stats": 2}[name]
         self.ctx.check(self.L.lslam_matcher_set_option(self.h, opt, int(value)))
@@ -375,6 +374,7 @@ class ScanMatcher:
         return {"rows_in_range": int(out[0]), "rows_live": int(out[1]), "beam_angles": int(out[2]),
                 "beam_angles_queued": int(out[3])}
 
+    @property
     def grid_dev_ptr(self) -> int:
         return self.L.lslam_matcher_grid_dev_ptr(self.h)
 

@@ -1,6 +1,6 @@
 mkdir -p gpurun_out/pmc && cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-run() { n=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc/$n -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu > $R/gpurun_out/pmc/$n.log 2>&1; }
+run() { n=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc/$n -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu --no-diagnostics > $R/gpurun_out/pmc/$n.log 2>&1; }
 run sq SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU
 run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_FLAT_READ_WAVEFRONTS_sum TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE
 run fetch FETCH_SIZE TCC_HIT_sum
