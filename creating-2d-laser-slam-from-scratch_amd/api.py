@@ -210,6 +210,8 @@ def lib() -> C.CDLL:
     L.lslam_map_read_occupancy_i8.argtypes = [vp, i32, vp]
     L.lslam_map_cells_dev_ptr.restype = vp
     L.lslam_map_cells_dev_ptr.argtypes = [vp, i32]
+    L.lslam_map_update_batch.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.lslam_map_update_batch_dev.argtypes = [vp, i32, vp, vp, vp, vp]
     L.lslam_matcher_set_option.argtypes = [vp, i32, i32]
     L.lslam_matcher_read_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     _LIB = L
@@ -595,6 +597,25 @@ class OccGridMap:
         o = np.ascontiguousarray(origo_xy, dtype=np.float32)
         w = np.ascontiguousarray(robot_pose_world, dtype=np.float32)
         self.ctx.check(self.L.lslam_map_update_by_scan_dev(self.h, points_ptr, n, o.ctypes.data, w.ctypes.data))
+
+    def updateByScans(self, points_list, origos_xy, robot_poses_world):
+        """Batched update: exactly len(points_list) successive updateByScan calls (every level fed the same scan),
+        marked in parallel and applied in one pass over the map."""
+        counts = np.array([len(p) for p in points_list], dtype=np.int32)
+        pts = (np.concatenate([np.asarray(p, dtype=np.float32).reshape(-1, 2) for p in points_list])
+               if len(points_list) else np.zeros((0, 2), np.float32))
+        pts = np.ascontiguousarray(pts, dtype=np.float32)
+        o = np.ascontiguousarray(np.broadcast_to(np.asarray(origos_xy, dtype=np.float32), (len(counts), 2)))
+        w = np.ascontiguousarray(robot_poses_world, dtype=np.float32).reshape(len(counts), 3)
+        self.ctx.check(self.L.lslam_map_update_batch(self.h, len(counts), pts.ctypes.data, counts.ctypes.data,
+                                                     o.ctypes.data, w.ctypes.data))
+
+    def updateByScans_dev(self, points_ptr: int, counts, origos_xy, robot_poses_world):
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        o = np.ascontiguousarray(np.broadcast_to(np.asarray(origos_xy, dtype=np.float32), (len(counts), 2)))
+        w = np.ascontiguousarray(robot_poses_world, dtype=np.float32).reshape(len(counts), 3)
+        self.ctx.check(self.L.lslam_map_update_batch_dev(self.h, len(counts), points_ptr, counts.ctypes.data,
+                                                         o.ctypes.data, w.ctypes.data))
 
     def updateByScanJustOnce(self, points_xy_m, origo_xy=(0.0, 0.0), begin=(800.0, 800.0), metres_per_cell=0.05):
         p = np.ascontiguousarray(points_xy_m, dtype=np.float32).reshape(-1, 2)

@@ -183,6 +183,173 @@ k_logodds_apply(LevelGeom g, const float* __restrict__ pts, int n, const uint32_
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// BATCHED update: K scans, each with its own pose, applied to the map exactly as K successive
+// updateByScan calls would (the float operations of a cell are applied in scan order; cells are
+// independent of each other).  The single-scan path above is bound by two dependent ~10 us kernels
+// per scan; here the K scans are MARKED in parallel and APPLIED by one pass over the map:
+//   k_lo_batch_hits  thread per (scan, beam): end cell -> byte plane[s][cell] = HIT, and the cell is
+//                    entered in scan s's small hash with atomicMin(first beam ending there);
+//   k_lo_batch_rays  wave per (scan, beam), closed-form Bresenham cells: a crossed cell whose byte is not
+//                    HIT gets plane[s][cell] = CROSSED (plain byte store, every writer writes the same
+//                    value); a crossed HIT cell records atomicMin(first beam crossing it) in the hash;
+//   k_lo_batch_resolve thread per hash entry: a hit cell crossed by an earlier beam of its scan -> byte HIT_UNDO;
+//   k_lo_batch_apply thread per 4 cells: walks the K plane bytes of its cells in scan order and applies
+//                    +free / [(v+free)-free] +occ-if-<50, the float sequence of the sequential reference
+//                    (H/map/OccGridMapBase.h:302-330).
+// Plane bytes carry a 6-bit batch epoch so the planes are cleared once per 63 batches, not per batch.
+// HBM-bound byte work: per batch the apply pass streams K bytes + 8 B per cell (coalesced), the ray
+// pass touches one byte per traversed cell; no atomics on the traversal path.
+// ------------------------------------------------------------------------------------------
+struct ScanHdr {     // one scan of a batch on one pyramid level (host-computed like LevelGeom)
+  float c, s, tx, ty;
+  int bx, by;        // begin cell
+  int n, pts_off;    // points of this scan: pts[2*(pts_off + i)]
+};
+struct BatchGeom {
+  int sx, sy, K;
+  float factor, lo_free, lo_occ;
+  uint32_t tag;      // epoch << 2
+  uint32_t hash_mask;  // slots per scan - 1 (power of two >= 2 * max points per scan)
+};
+constexpr uint32_t kCodeCrossed = 1u, kCodeHit = 2u, kCodeHitUndo = 3u;
+constexpr uint32_t kHashEmpty = 0xFFFFFFFFu;
+
+__device__ __forceinline__ Line batch_line(const BatchGeom& g, const ScanHdr& h, const float* __restrict__ pts, int i) {
+  LevelGeom lg;
+  lg.sx = g.sx; lg.sy = g.sy; lg.c = h.c; lg.s = h.s; lg.tx = h.tx; lg.ty = h.ty; lg.factor = g.factor;
+  lg.just_once = 0; lg.bx = h.bx; lg.by = h.by; lg.metres_per_cell = 0.0;
+  return beam_line(lg, pts + 2 * (size_t)h.pts_off, i);
+}
+__device__ __forceinline__ uint32_t hash_slot0(uint32_t cell, uint32_t mask) { return (cell * 2654435761u) >> 7 & mask; }
+
+__global__ void __launch_bounds__(256)
+k_lo_batch_hits(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __restrict__ pts, uint8_t* __restrict__ planes,
+                uint32_t* __restrict__ hkey, uint32_t* __restrict__ hhit) {
+  const int sidx = blockIdx.y;
+  const ScanHdr h = hdr[sidx];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= h.n) return;
+  const Line l = batch_line(g, h, pts, i);
+  if (!l.valid) return;
+  const uint32_t cell = (uint32_t)(l.y1 * g.sx + l.x1);
+  planes[(size_t)sidx * g.sx * g.sy + cell] = (uint8_t)(g.tag | kCodeHit);
+  const size_t hb = (size_t)sidx * (g.hash_mask + 1);
+  uint32_t slot = hash_slot0(cell, g.hash_mask);
+  for (;;) {
+    const uint32_t old = atomicCAS(&hkey[hb + slot], kHashEmpty, cell);
+    if (old == kHashEmpty || old == cell) break;
+    slot = (slot + 1) & g.hash_mask;
+  }
+  atomicMin(&hhit[hb + slot], (uint32_t)i);
+}
+
+__global__ void __launch_bounds__(256)
+k_lo_batch_rays(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __restrict__ pts, uint8_t* __restrict__ planes,
+                const uint32_t* __restrict__ hkey, uint32_t* __restrict__ hcross, int n_max) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave index = scan * n_max + beam
+  const int sidx = w / n_max, i = w - sidx * n_max;
+  if (sidx >= g.K) return;
+  const ScanHdr h = hdr[sidx];
+  if (i >= h.n) return;
+  const Line l = batch_line(g, h, pts, i);
+  if (!l.valid) return;
+  const Ray r = ray_of(l, g.sx);
+  uint8_t* plane = planes + (size_t)sidx * g.sx * g.sy;
+  const uint32_t crossed = g.tag | kCodeCrossed, hit = g.tag | kCodeHit;
+  const size_t hb = (size_t)sidx * (g.hash_mask + 1);
+  for (unsigned c = lane; c < r.abs_da; c += 64) {
+    const unsigned cell = ray_cell(r, c);
+    const uint32_t b = plane[cell];
+    if (b == hit) {  // some beam of this scan ends here: remember the first beam that crosses it
+      uint32_t slot = hash_slot0(cell, g.hash_mask);
+      while (hkey[hb + slot] != cell) slot = (slot + 1) & g.hash_mask;  // entered by k_lo_batch_hits
+      atomicMin(&hcross[hb + slot], (uint32_t)i);
+    } else if (b != crossed) {
+      plane[cell] = (uint8_t)crossed;
+    }
+  }
+}
+
+// hash entry -> plane byte: a hit cell that an EARLIER beam of the same scan crossed becomes HIT_UNDO, so the apply
+// pass needs nothing but the plane bytes (per-cell hash look-ups there were serialised dependent loads on the
+// wall cells: 160 us per batch)
+__global__ void __launch_bounds__(256)
+k_lo_batch_resolve(BatchGeom g, const uint32_t* __restrict__ hkey, const uint32_t* __restrict__ hhit,
+                   const uint32_t* __restrict__ hcross, uint8_t* __restrict__ planes) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t slots = (size_t)g.hash_mask + 1;
+  if (idx >= slots * g.K) return;
+  const uint32_t cell = hkey[idx];
+  if (cell == kHashEmpty) return;
+  if (hcross[idx] < hhit[idx]) planes[(idx / slots) * (size_t)g.sx * g.sy + cell] = (uint8_t)(g.tag | kCodeHitUndo);
+}
+
+__global__ void __launch_bounds__(256)
+k_lo_batch_apply(BatchGeom g, const uint8_t* __restrict__ planes, float* __restrict__ logodds) {
+  const size_t cells = (size_t)g.sx * g.sy;
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 cells
+  if (q * 4 >= cells) return;
+  const uint32_t tag4 = g.tag * 0x01010101u;
+  const bool full = q * 4 + 4 <= cells;
+  float v[4];
+  if (full) {
+    const float4 f = *reinterpret_cast<const float4*>(logodds + q * 4);
+    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = q * 4 + k < cells ? logodds[q * 4 + k] : 0.f;
+  }
+  bool dirty = false;
+  // the K plane words of these 4 cells, kChunk at a time: all loads of a chunk are issued before the first is used
+  // (one dependent load per scan made this pass latency-bound: 64 round trips per thread)
+  constexpr int kChunk = 16;
+  const uint8_t* pq = planes + q * 4;
+  for (int s0 = 0; s0 < g.K; s0 += kChunk) {
+    uint32_t wv[kChunk];
+    if (full && s0 + kChunk <= g.K) {  // straight-line: 16 independent loads in flight
+#pragma unroll
+      for (int u = 0; u < kChunk; u++) wv[u] = *reinterpret_cast<const uint32_t*>(pq + (size_t)(s0 + u) * cells);
+    } else {
+#pragma unroll
+      for (int u = 0; u < kChunk; u++) {
+        wv[u] = 0u;  // epoch 0 never matches a live tag (tags start at 1 << 2)
+        if (s0 + u < g.K)
+          for (size_t k = q * 4; k < cells && k < q * 4 + 4; k++)
+            wv[u] |= (uint32_t)planes[(size_t)(s0 + u) * cells + k] << (8 * (k - q * 4));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk; u++) {
+      const uint32_t t = (wv[u] ^ tag4) & 0xFCFCFCFCu;             // a byte of t is 0 iff its epoch is current
+      if (((t - 0x01010101u) & ~t & 0x80808080u) == 0u) continue;  // no byte of this batch in the word
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t b = (wv[u] >> (8 * k)) & 0xFFu;
+        if ((b & 0xFCu) != g.tag) continue;
+        const uint32_t code = b & 3u;
+        if (code == kCodeCrossed) {
+          v[k] += g.lo_free;  // bresenhamCellFree, once per scan (:302-313)
+          dirty = true;
+        } else if (code != 0u) {  // bresenhamCellOcc (:316-330)
+          if (code == kCodeHitUndo) {  // crossed by an EARLIER beam: marked free, then un-marked
+            v[k] += g.lo_free;
+            v[k] -= g.lo_free;
+          }
+          if (v[k] < 50.0f) v[k] += g.lo_occ;  // updateSetOccupied (H/map/GridMapLogOdds.h:108-114)
+          dirty = true;
+        }
+      }
+    }
+  }
+  if (dirty) {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (q * 4 + k < cells) logodds[q * 4 + k] = v[k];
+  }
+}
+
 __global__ void k_occupancy_i8(const float* __restrict__ v, int8_t* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -332,6 +499,11 @@ struct Level {
   uint32_t* d_free = nullptr;
   uint32_t* d_occ = nullptr;
   uint32_t epoch = 0;
+  // batched update (k_lo_batch_*): one byte plane per scan slot, allocated on first use
+  uint8_t* d_planes = nullptr;
+  int plane_slots = 0;
+  size_t plane_stride = 0;  // bytes per plane = cells rounded up to 4
+  uint32_t batch_epoch = 0;
 };
 
 }  // namespace
@@ -348,6 +520,8 @@ struct lslam_map {
   int n_cached = 0;
   float cached_origo[2] = {0.f, 0.f};
   DevBuf<float> d_gn_out;
+  DevBuf<uint32_t> d_hash;      // [3][K][slots]: key, first hit beam, first crossing beam
+  DevBuf<ScanHdr> d_hdr;
   DevBuf<int8_t> d_i8;
   // host -> device staging of the per-scan points: a ring of pinned slots, so updateByScan only enqueues
   // (copy + two kernels per level) and returns; a slot is reused when its copy has completed
@@ -487,10 +661,13 @@ void lslam_map_destroy(lslam_map* map) {
     if (L.d_logodds) (void)hipFree(L.d_logodds);
     if (L.d_free) (void)hipFree(L.d_free);
     if (L.d_occ) (void)hipFree(L.d_occ);
+    if (L.d_planes) (void)hipFree(L.d_planes);
   }
   map->d_pts.release();
   map->d_cached.release();
   map->d_gn_out.release();
+  map->d_hash.release();
+  map->d_hdr.release();
   map->d_i8.release();
   if (map->h_stage) (void)hipHostFree(map->h_stage);
   for (auto e : map->stage_ev)
@@ -580,6 +757,143 @@ int lslam_map_update_by_scan(lslam_map* map, const float* pts, int n, const floa
   int rc = stage_points(map, pts, n);
   if (rc) return rc;
   return update_impl(map, map->d_pts.p, n, origo, pose, 0, 0.f, 0.f, 0.0);
+}
+
+namespace {
+constexpr int kBatchMaxScans = 64;
+
+// K successive MapRepMultiMap::updateByScan calls (every level fed the same scan, i.e. each scan matched first) in
+// four launches per level.  d_pts: the K containers back to back; counts / origos / poses are host arrays.
+int update_batch_impl(lslam_map* map, int K, const float* d_pts, const int32_t* counts, const float* origos,
+                      const float* poses) {
+  lslam_context* ctx = map->ctx;
+  int n_max = 0;
+  for (int k = 0; k < K; k++) {
+    if (counts[k] < 0 || counts[k] > kMaxBeams)
+      return ctx->fail(LSLAM_ERR_UNSUPPORTED, "at most %d points per scan are supported (got %d)", kMaxBeams, counts[k]);
+    n_max = std::max(n_max, counts[k]);
+  }
+  if (n_max == 0) return LSLAM_OK;
+  uint32_t slots = 64;
+  while (slots < 2u * (uint32_t)n_max) slots *= 2;
+  LSLAM_HIP(ctx, map->d_hash.reserve((size_t)3 * K * slots));
+  LSLAM_HIP(ctx, map->d_hdr.reserve((size_t)K * map->levels.size()));
+  std::vector<ScanHdr> hdr((size_t)K * map->levels.size());
+  std::vector<int> off(K + 1, 0);
+  for (int k = 0; k < K; k++) off[k + 1] = off[k] + counts[k];
+  for (size_t li = 0; li < map->levels.size(); li++) {
+    const Level& L = map->levels[li];
+    const float factor = li == 0 ? 1.0f : (float)(1.0 / pow(2.0, (double)li));
+    for (int k = 0; k < K; k++) {
+      ScanHdr& h = hdr[li * K + k];
+      const float* pose = poses + 3 * k;
+      const float ox = li == 0 ? origos[2 * k] : origos[2 * k] * factor;
+      const float oy = li == 0 ? origos[2 * k + 1] : origos[2 * k + 1] * factor;
+      const float sc = L.scale_to_map;
+      const float mx = (sc * pose[0] + 0.0f * pose[1]) + L.t_x;  // getMapCoordsPose (H/map/GridMapBase.h:238-242)
+      const float my = (0.0f * pose[0] + sc * pose[1]) + L.t_y;
+      h.c = cosf(pose[2]);
+      h.s = sinf(pose[2]);
+      h.tx = mx; h.ty = my;
+      const float bxf = (h.c * ox + (-h.s) * oy) + mx;  // H/map/OccGridMapBase.h:132
+      const float byf = (h.s * ox + h.c * oy) + my;
+      h.bx = (int)(bxf + 0.5f);                         // :135
+      h.by = (int)(byf + 0.5f);
+      h.n = counts[k];
+      h.pts_off = off[k];
+    }
+  }
+  LSLAM_HIP(ctx, hipMemcpyAsync(map->d_hdr.p, hdr.data(), hdr.size() * sizeof(ScanHdr), hipMemcpyHostToDevice, ctx->stream));
+  for (size_t li = 0; li < map->levels.size(); li++) {
+    Level& L = map->levels[li];
+    const size_t cells = (size_t)L.sx * L.sy;
+    if (L.plane_slots < K) {
+      LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (L.d_planes) (void)hipFree(L.d_planes);
+      L.d_planes = nullptr;
+      L.plane_slots = 0;
+      L.plane_stride = (cells + 3) & ~(size_t)3;
+      const int want = std::min(kBatchMaxScans, std::max(K, 8));
+      if (hipMalloc((void**)&L.d_planes, L.plane_stride * want) != hipSuccess)
+        return ctx->fail(LSLAM_ERR_HIP, "cannot allocate %d batch planes of %zu bytes", want, L.plane_stride);
+      L.plane_slots = want;
+      L.batch_epoch = 0;
+    }
+    if (L.batch_epoch == 0 || L.batch_epoch >= 63) {  // 6-bit epoch in the plane bytes
+      LSLAM_HIP(ctx, hipMemsetAsync(L.d_planes, 0, L.plane_stride * L.plane_slots, ctx->stream));
+      L.batch_epoch = 0;
+    }
+    L.batch_epoch++;
+    LSLAM_HIP(ctx, hipMemsetAsync(map->d_hash.p, 0xFF, (size_t)3 * K * slots * sizeof(uint32_t), ctx->stream));
+    BatchGeom g;
+    g.sx = L.sx; g.sy = L.sy; g.K = K;
+    g.factor = li == 0 ? 1.0f : (float)(1.0 / pow(2.0, (double)li));
+    g.lo_free = map->lo_free; g.lo_occ = map->lo_occ;
+    g.tag = L.batch_epoch << 2;
+    g.hash_mask = slots - 1;
+    // the planes are indexed [slot * cells]: plane_stride == cells whenever cells % 4 == 0; otherwise the kernels'
+    // (size_t)sidx * sx * sy would not match -- keep it simple and require the rounded size to be exact
+    if (L.plane_stride != cells) return ctx->fail(LSLAM_ERR_UNSUPPORTED, "batched update needs size_x*size_y %% 4 == 0");
+    uint32_t* hkey = map->d_hash.p;
+    uint32_t* hhit = hkey + (size_t)K * slots;
+    uint32_t* hcross = hhit + (size_t)K * slots;
+    const ScanHdr* d_h = map->d_hdr.p + li * K;
+    launch(ctx, "lo_batch_hits", k_lo_batch_hits, dim3((n_max + 255) / 256, K), dim3(256), 0, g, d_h, d_pts, L.d_planes, hkey, hhit);
+    const long long waves = (long long)K * n_max;
+    launch(ctx, "lo_batch_rays", k_lo_batch_rays, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, g, d_h, d_pts, L.d_planes,
+           (const uint32_t*)hkey, hcross, n_max);
+    launch(ctx, "lo_batch_resolve", k_lo_batch_resolve, dim3((unsigned)(((size_t)K * slots + 255) / 256)), dim3(256), 0, g,
+           (const uint32_t*)hkey, (const uint32_t*)hhit, (const uint32_t*)hcross, L.d_planes);
+    launch(ctx, "lo_batch_apply", k_lo_batch_apply, dim3((unsigned)((cells / 4 + 255) / 256 + 1)), dim3(256), 0, g,
+           (const uint8_t*)L.d_planes, L.d_logodds);
+  }
+  LSLAM_HIP(ctx, hipGetLastError());
+  return LSLAM_OK;
+}
+}  // namespace
+
+// n_scans containers back to back in points_xy; batches larger than 64 scans are cut into groups of 64
+int lslam_map_update_batch_dev(lslam_map* map, int n_scans, const float* points_xy_dev, const int32_t* n_points,
+                               const float* origos_xy, const float* poses_world) {
+  if (!map || n_scans < 0 || !n_points || !origos_xy || !poses_world) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = map->ctx;
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  size_t done_pts = 0;
+  for (int k0 = 0; k0 < n_scans; k0 += kBatchMaxScans) {
+    const int K = std::min(kBatchMaxScans, n_scans - k0);
+    int rc = update_batch_impl(map, K, points_xy_dev + 2 * done_pts, n_points + k0, origos_xy + 2 * k0, poses_world + 3 * k0);
+    if (rc) return rc;
+    for (int k = 0; k < K; k++) done_pts += (size_t)n_points[k0 + k];
+  }
+  if (n_scans > 0 && map->levels.size() > 1) {  // dataContainers now hold the last scan (as after its matchData)
+    const int last = n_scans - 1;
+    const int n = n_points[last];
+    LSLAM_HIP(ctx, map->d_cached.reserve((size_t)2 * (n > 0 ? n : 1)));
+    if (n > 0)
+      LSLAM_HIP(ctx, hipMemcpyAsync(map->d_cached.p, points_xy_dev + 2 * (done_pts - (size_t)n), (size_t)2 * n * sizeof(float),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+    map->n_cached = n;
+    map->cached_origo[0] = origos_xy[2 * last];
+    map->cached_origo[1] = origos_xy[2 * last + 1];
+  }
+  return LSLAM_OK;
+}
+
+int lslam_map_update_batch(lslam_map* map, int n_scans, const float* points_xy, const int32_t* n_points,
+                           const float* origos_xy, const float* poses_world) {
+  if (!map || n_scans < 0 || !n_points || !origos_xy || !poses_world) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = map->ctx;
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  size_t total = 0;
+  for (int k = 0; k < n_scans; k++) {
+    if (n_points[k] < 0) return LSLAM_ERR_INVALID_ARGUMENT;
+    total += (size_t)n_points[k];
+  }
+  if (total > 0 && !points_xy) return LSLAM_ERR_INVALID_ARGUMENT;
+  if (total > (size_t)INT32_MAX / 2) return ctx->fail(LSLAM_ERR_UNSUPPORTED, "batch too large");
+  int rc = stage_points(map, points_xy, (int)total);
+  if (rc) return rc;
+  return lslam_map_update_batch_dev(map, n_scans, map->d_pts.p, n_points, origos_xy, poses_world);
 }
 
 int lslam_map_update_just_once(lslam_map* map, const float* pts, int n, const float origo[2], float begin_x,

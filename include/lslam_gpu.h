@@ -283,6 +283,20 @@ int lslam_map_update_by_scan(lslam_map* map, const float* points_xy, int n,
                              const float origo_xy[2], const float pose_world[3]);
 int lslam_map_update_by_scan_dev(lslam_map* map, const float* points_xy_dev, int n,
                                  const float origo_xy[2], const float pose_world[3]);
+/* BATCHED update: n_scans containers, each with its own origo and robot pose, applied exactly as n_scans successive
+ * [matchData-cached] updateByScan calls in this order would (bit-identical log-odds planes: the float operations of
+ * every cell are applied in scan order), but marked in parallel and applied by one pass over the map -- three
+ * launches per pyramid level per 64 scans instead of two dependent launches per scan and level.  For callers that know
+ * several poses before the map is needed again: an offline map build from known poses, or a front-end whose matcher does
+ * not read this map (the Karto front-end of BASELINE config 5).
+ * points_xy: the containers back to back (sum of n_points[] points, level-0 map-cell units); n_points[n_scans];
+ * origos_xy[n_scans][2]; poses_world[n_scans][3].  Every level is fed the same scan (each scan counts as matched
+ * first); afterwards the cached container is the last scan's.  size_x*size_y must be a multiple of 4 on every level. */
+int lslam_map_update_batch(lslam_map* map, int n_scans, const float* points_xy, const int32_t* n_points,
+                           const float* origos_xy, const float* poses_world);
+/* same with the points already in HBM (n_points / origos / poses stay host arrays: a few bytes per scan) */
+int lslam_map_update_batch_dev(lslam_map* map, int n_scans, const float* points_xy_dev, const int32_t* n_points,
+                               const float* origos_xy, const float* poses_world);
 /* OccGridMapBase::updateByScanJustOnce (H/map/OccGridMapBase.h:175-217): the lesson4
  * make_hector_map demo variant -- points in METRES, begin cell and 1/0.05 scale hard-coded by
  * the reference (we take them as parameters; pass 800,800,0.05 for the literal behaviour). */

@@ -221,3 +221,62 @@ def test_gauss_newton_match_data(ctx, oracle_lib):
     # empty scan: beginEstimateWorld comes back unchanged
     p, _ = gpu.matchData(np.array([1.0, 2.0, 0.3], np.float32), np.zeros((0, 2), np.float32))
     assert np.array_equal(p, np.array([1.0, 2.0, 0.3], np.float32))
+
+
+def test_batched_update_equals_sequential(ctx, oracle_lib):
+    """lslam_map_update_batch: K scans marked in parallel + one apply pass == K successive updateByScan calls, bit for
+    bit, on every pyramid level -- including repeats that reach the occupied clamp, an empty scan, uneven point counts,
+    off-centre origos and more than 64 scans (two groups)."""
+    n, cell, levels = 512, 0.05, 3
+    gpu_b = api.OccGridMap(ctx, n, n, cell, (n * cell * 0.5, n * cell * 0.5), levels=levels)
+    gpu_s = api.OccGridMap(ctx, n, n, cell, (n * cell * 0.5, n * cell * 0.5), levels=levels)
+    cpu = oracle_lib.PortHectorRep(cell, n, n, levels)
+    for m in (gpu_b, gpu_s):
+        m.setUpdateOccupiedFactor(0.9)
+    cpu.setUpdateFactorOccupied(0.9)
+    scans = scans_for_map(9, seed=21, map_cells=n)
+    seq = []
+    for rep in range(9):  # 81 scans: the same walls over and over -> clamp at 50
+        for k, (pts, pose) in enumerate(scans):
+            pts = pts[(np.abs(pts) < 220).all(axis=1)]
+            if k == 4 and rep == 1:
+                pts = pts[:0]  # an empty container
+            elif k % 3 == 1:
+                pts = pts[: 200 + 37 * k]
+            pose = (pose * np.float32(0.25)).astype(np.float32)
+            seq.append((pts, np.array([0.4 * (k % 2), -0.2 * (k % 3)], np.float32), pose))
+    for pts, origo, pose in seq:
+        for m in (gpu_s, cpu):
+            m.matchData(pose if m is gpu_s else pts, pts if m is gpu_s else pose, origo)
+            m.updateByScan(pts, origo, pose)
+    gpu_b.updateByScans([s[0] for s in seq], np.stack([s[1] for s in seq]), np.stack([s[2] for s in seq]))
+    assert gpu_b.cached_points() == len(seq[-1][0])
+    for lv in range(levels):
+        a = gpu_s.logodds(lv)
+        assert np.count_nonzero(a) > 1000
+        assert a.tobytes() == cpu.logodds(lv).tobytes(), lv
+        assert a.tobytes() == gpu_b.logodds(lv).tobytes(), lv
+    # a second batch on top of the first (plane epochs advance), then a plain update in between
+    gpu_b.updateByScans([s[0] for s in seq[:5]], np.stack([s[1] for s in seq[:5]]), np.stack([s[2] for s in seq[:5]]))
+    for pts, origo, pose in seq[:5]:
+        gpu_s.matchData(pose, pts, origo)
+        gpu_s.updateByScan(pts, origo, pose)
+    assert gpu_s.logodds(0).tobytes() == gpu_b.logodds(0).tobytes()
+
+
+def test_batched_update_free_then_occupied_order(ctx, oracle_lib):
+    """The (v+free)-free rule depends on beam order inside a scan (OccGridMapBase.h:316-330): hand-made beams, both
+    orders, duplicates, through the batched path."""
+    n, cell = 200, 0.05
+    cpu = oracle_lib.PortHector(n, n, cell, (5.0, 5.0))
+    gpu = api.OccGridMap(ctx, n, n, cell, (5.0, 5.0))
+    pts = np.array([[40, 0], [20, 0], [10, 0], [30, 0], [30, 0], [0.2, 0.1], [-15, 25], [-15, 25], [-7.5, 12.5],
+                    [500, 0], [0, -60]], dtype=np.float32)
+    pose = np.zeros(3, np.float32)
+    batch = []
+    for k in range(6):
+        cpu.updateByScan(pts, (0.0, 0.0), pose)
+        batch.append(pts.copy())
+        pts = pts[::-1].copy()
+    gpu.updateByScans(batch, (0.0, 0.0), np.zeros((6, 3), np.float32))
+    assert cpu.logodds().tobytes() == gpu.logodds().tobytes()
