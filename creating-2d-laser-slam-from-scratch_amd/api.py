@@ -93,6 +93,41 @@ RESULT_DTYPE = np.dtype(
 assert RESULT_DTYPE.itemsize == 112 == C.sizeof(MatchResult)
 
 
+class FrontEndConfig(C.Structure):
+    """lslam_frontend_config: the Mapper parameters Mapper::Process / MapperGraph read (Mapper.cpp:1457-1604)."""
+
+    _fields_ = [
+        ("scan_buffer_size", C.c_int32),
+        ("use_scan_barycenter", C.c_int32),
+        ("do_loop_closing", C.c_int32),
+        ("loop_match_minimum_chain_size", C.c_int32),
+        ("scan_buffer_maximum_scan_distance", C.c_double),
+        ("minimum_travel_distance", C.c_double),
+        ("minimum_travel_heading", C.c_double),
+        ("minimum_time_interval", C.c_double),
+        ("link_match_minimum_response_fine", C.c_double),
+        ("link_scan_maximum_distance", C.c_double),
+        ("loop_search_maximum_distance", C.c_double),
+        ("loop_match_maximum_variance_coarse", C.c_double),
+        ("loop_match_minimum_response_coarse", C.c_double),
+        ("loop_match_minimum_response_fine", C.c_double),
+        ("loop_search_space_dimension", C.c_double),
+        ("loop_search_space_resolution", C.c_double),
+        ("loop_search_space_smear_deviation", C.c_double),
+    ]
+
+
+def frontend_config(**kw) -> FrontEndConfig:
+    """Library defaults (lslam_frontend_config_defaults) with keyword overrides."""
+    c = FrontEndConfig()
+    lib().lslam_frontend_config_defaults(C.byref(c))
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise AttributeError(k)
+        setattr(c, k, v)
+    return c
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("total_ms", C.c_double)]
 
@@ -185,6 +220,13 @@ def lib() -> C.CDLL:
     L.lslam_frontend_reset.argtypes = [vp]
     L.lslam_frontend_process.argtypes = [vp, vp, i32, vp, C.POINTER(i32), vp, vp, C.POINTER(dbl)]
     L.lslam_frontend_running_scans.argtypes = [vp]
+    L.lslam_frontend_config_defaults.argtypes = [C.POINTER(FrontEndConfig)]
+    L.lslam_frontend_config_defaults.restype = None
+    L.lslam_frontend_create_ex.argtypes = [vp, C.POINTER(FrontEndConfig), C.POINTER(vp)]
+    L.lslam_frontend_process_stamped.argtypes = [vp, vp, i32, vp, dbl, C.POINTER(i32), vp, vp, C.POINTER(dbl)]
+    L.lslam_frontend_num_scans.argtypes = [vp]
+    L.lslam_frontend_scan_pose.argtypes = [vp, i32, vp]
+    L.lslam_frontend_stats.argtypes = [vp, vp]
     L.lslam_occgrid_create_from_scans.argtypes = [vp, C.POINTER(LaserParams), i32, vp, i32, vp, dbl, C.POINTER(vp)]
     L.lslam_occgrid_destroy.argtypes = [vp]
     L.lslam_occgrid_destroy.restype = None
@@ -458,14 +500,19 @@ class ScanMatcher:
 
 
 class FrontEnd:
-    """Pose path of karto::Mapper::Process with a device-resident running-scan window."""
+    """karto::Mapper::Process with every processed scan resident in HBM: running-window match, AddEdges with
+    LinkNearChains, TryCloseLoop (config=frontend_config(...)); without `config` the round-1 four-parameter form
+    (library defaults for the graph side, loop closing off)."""
 
     def __init__(self, matcher: ScanMatcher, scan_buffer_size=70, scan_buffer_max_distance=20.0,
-                 min_travel_distance=0.2, min_travel_heading=math.radians(10.0)):
+                 min_travel_distance=0.2, min_travel_heading=math.radians(10.0), config: FrontEndConfig | None = None):
         self.m, self.ctx, self.L = matcher, matcher.ctx, matcher.L
         h = C.c_void_p()
-        self.ctx.check(self.L.lslam_frontend_create(matcher.h, scan_buffer_size, scan_buffer_max_distance,
-                                                    min_travel_distance, min_travel_heading, C.byref(h)))
+        if config is not None:
+            self.ctx.check(self.L.lslam_frontend_create_ex(matcher.h, C.byref(config), C.byref(h)))
+        else:
+            self.ctx.check(self.L.lslam_frontend_create(matcher.h, scan_buffer_size, scan_buffer_max_distance,
+                                                        min_travel_distance, min_travel_heading, C.byref(h)))
         self.h = h
         matcher._frontends.add(self)
 
@@ -480,14 +527,28 @@ class FrontEnd:
         except Exception:
             pass
 
-    def Process(self, ranges, odom_pose):
+    def Process(self, ranges, odom_pose, time_s: float = 0.0):
         """-> (processed, corrected robot pose, covariance 3x3, response)"""
         r, o = _f64(ranges), _f64(odom_pose)
         ok, resp = C.c_int(), C.c_double()
         pose, cov = np.zeros(3), np.zeros(9)
-        self.ctx.check(self.L.lslam_frontend_process(self.h, r.ctypes.data, r.shape[0], o.ctypes.data, C.byref(ok),
-                                                     pose.ctypes.data, cov.ctypes.data, C.byref(resp)))
+        self.ctx.check(self.L.lslam_frontend_process_stamped(self.h, r.ctypes.data, r.shape[0], o.ctypes.data, time_s,
+                                                             C.byref(ok), pose.ctypes.data, cov.ctypes.data, C.byref(resp)))
         return bool(ok.value), pose, cov.reshape(3, 3), resp.value
+
+    def num_scans(self) -> int:
+        return self.L.lslam_frontend_num_scans(self.h)
+
+    def scan_pose(self, scan_id: int) -> np.ndarray:
+        out = np.zeros(3)
+        self.ctx.check(self.L.lslam_frontend_scan_pose(self.h, scan_id, out.ctypes.data))
+        return out
+
+    def stats(self) -> dict:
+        out = np.zeros(6, dtype=np.int64)
+        self.ctx.check(self.L.lslam_frontend_stats(self.h, out.ctypes.data))
+        return dict(zip(("scans", "edges", "chain_matches", "loop_coarse_matches", "loop_fine_matches", "loops_closed"),
+                        (int(v) for v in out)))
 
     def running_scans(self) -> int:
         return self.L.lslam_frontend_running_scans(self.h)

@@ -1,66 +1,378 @@
-// Streaming front-end: the pose-relevant part of karto::Mapper::Process (Mapper.cpp:1999-2079)
-// with a DEVICE-RESIDENT running-scan window.  Included at the end of scan_matcher.hip (it drives
-// that file's kernels).
+// Streaming front-end: karto::Mapper::Process (Mapper.cpp:1999-2079) with every processed scan resident in
+// HBM.  Included at the end of scan_matcher.hip (it drives that file's kernels).
 //
-// Per processed scan (everything between the two host decisions stays on the GPU):
+// Per processed scan:
 //   host   lastTransform propagation (Mapper.cpp:2021-2025), HasMovedEnough (:2087-2120)
-//   device AddScans of the window around the query (find_valid, mark+smear; parity planes and
-//          row-occupancy refreshed), coarse+fine search of the query (MatchScan, :2040)
-//   host   SetSensorPose(bestPose) (:2044), AddEdges' closing SetSensorPose(ComputeWeightedMean)
-//          for the single-mean case (:957-972), AddRunningScan window policy (Mapper.h:1365-1386)
-//   device world points of the accepted scan into its ring slot (LocalizedRangeScan::Update,
-//          Karto.h:5362-5428) -- computed once per scan, reused by every later grid rebuild
-// The pose graph itself (vertices/edges, LinkNearChains, loop closure, solvers) is the reference's
-// back-end and stays on the host, out of scope.
+//   device MatchScan against the running scans (:2037-2045): AddScans of the window around the query
+//          (find_valid, mark + smear; parity planes refreshed), coarse + fine search
+//   host   MapperGraph::AddEdges (:901-973): LinkScans to the previous scan, LinkChainToScan to the running scans,
+//          LinkNearChains -- breadth-first FindNearLinkedScans over the pose graph, FindNearChains, one device
+//          MatchScan per near chain -- and the closing SetSensorPose(ComputeWeightedMean(means, covariances))
+//   device world points of the scan at its final pose (LocalizedRangeScan::Update, Karto.h:5362-5428) -- computed
+//          once, reused by every later grid rebuild (running window, near chains, loop-closure chains)
+//   host   AddRunningScan window policy (Mapper.h:1365-1386)
+//   both   MapperGraph::TryCloseLoop (:976-1051): FindPossibleLoopClosure on the host, coarse MatchScan of each
+//          candidate chain on the LOOP matcher (second lslam_matcher: 8 m search space -> 81 x 81 x 21 lattice),
+//          fine MatchScan on the sequential matcher, SetSensorPose + LinkChainToScan when both pass
+// What stays out: the ScanSolver behind CorrectPoses() (spa / g2o / ceres / gtsam are third-party back-ends; the
+// reference's own library ships none, Mapper.cpp:1392-1412).  Without a solver a closed loop re-poses the closing
+// scan and links it, exactly what karto::Mapper does when no optimizer is attached.
+//
+// Chains are always contiguous ranges of scan ids (running window, FindNearChains, FindPossibleLoopClosure all grow
+// them over consecutive state ids), so a chain is (first id, count) into the resident world-point array.
+//
+// Numerics: the graph decisions compare squared distances between scan barycentres with thresholds.  The barycentre
+// (mean of the filtered world points) is evaluated as sensor + R(heading) * mean(r_i (cos a_i, sin a_i)) instead of
+// summing the world points one by one; it differs from the reference's sum by ~1e-15 m, which can change a decision
+// only when a distance sits within that of a threshold.
 #pragma once
+
+#include <cfloat>
+#include <queue>
+
+struct lslam_frontend_scan {
+  double odom[3], robot[3], sensor[3];
+  double bary[2];           // GetBarycenterPose position, or the sensor position when the scan has no filtered reading
+  double blx = 0, bly = 0;  // sum of r_i (cos a_i, sin a_i) over the filtered readings (scan frame)
+  int nfilt = 0;
+  double time = 0;
+  std::vector<std::pair<int, int>> edges;  // Vertex::m_Edges: (source, target) in insertion order
+};
 
 struct lslam_frontend {
   lslam_matcher* m = nullptr;
-  int buf_size = 0;
-  double buf_dist = 0, min_travel = 0, min_heading = 0;
-  int cap = 0, start = 0, count = 0;  // ring of window scans
-  DevBuf<double2> d_world;             // [cap][n] world points of window scans
-  DevBuf<double> d_q;                  // query ranges (n) + pose (3)
+  lslam_matcher* loop_m = nullptr;  // MapperGraph::m_pLoopScanMatcher (owned)
+  lslam_frontend_config cfg;
+  std::vector<lslam_frontend_scan> scans;  // MapperSensorManager::GetScans, by state id
+  int run_start = 0, run_count = 0;        // running scans = ids [run_start, run_start + run_count)
+  int cap = 0;                             // scans the device arrays hold
+  double2* d_world = nullptr;              // [cap][n] world points at the scans' current poses
+  double* d_ranges = nullptr;              // [cap][n] readings (kept to re-pose a scan after a closed loop)
+  DevBuf<double> d_q;                      // query pose (3)
   DevBuf<lslam_match_result> d_res;
-  std::vector<double> robot;           // [cap][3] corrected robot poses, ring-indexed
+  std::vector<double> cos_a, sin_a;        // cos / sin of minimum_angle + i * angular_resolution
   bool have_last = false;
-  double last_odom[3] = {0, 0, 0}, last_corr[3] = {0, 0, 0};
+  int64_t n_chain_matches = 0, n_loop_coarse = 0, n_loop_fine = 0, n_loops_closed = 0, n_edges = 0;
 };
 
 namespace {
 
 inline double sq_dist2(const double* a, const double* b) { return ksq(a[0] - b[0]) + ksq(a[1] - b[1]); }
 
+int fe_grow(lslam_frontend* f, int need) {
+  if (need <= f->cap) return LSLAM_OK;
+  lslam_context* ctx = f->m->ctx;
+  const size_t n = (size_t)std::max(f->m->g.n_beams, 1);
+  int cap = std::max(256, f->cap);
+  while (cap < need) cap *= 2;
+  double2* w = nullptr;
+  double* r = nullptr;
+  if (hipMalloc((void**)&w, (size_t)cap * n * sizeof(double2)) != hipSuccess ||
+      hipMalloc((void**)&r, (size_t)cap * n * sizeof(double)) != hipSuccess) {
+    if (w) (void)hipFree(w);
+    return ctx->fail(LSLAM_ERR_HIP, "cannot keep %d scans resident in HBM", cap);
+  }
+  if (f->cap > 0) {
+    LSLAM_HIP(ctx, hipMemcpyAsync(w, f->d_world, (size_t)f->cap * n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
+    LSLAM_HIP(ctx, hipMemcpyAsync(r, f->d_ranges, (size_t)f->cap * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(f->d_world);
+    (void)hipFree(f->d_ranges);
+  }
+  f->d_world = w;
+  f->d_ranges = r;
+  f->cap = cap;
+  return LSLAM_OK;
+}
+
+// SetSensorPose (Karto.h:5297-5313) + the barycentre of the filtered readings at that pose (Karto.h:5362-5416)
+void fe_set_sensor_pose(const lslam_frontend* f, lslam_frontend_scan& s, const double sensor[3]) {
+  for (int i = 0; i < 3; i++) s.sensor[i] = sensor[i];
+  lslam_robot_pose_from_sensor(&f->m->laser, sensor, s.robot);
+  if (s.nfilt > 0) {
+    const double c = cos(sensor[2]), sn = sin(sensor[2]);
+    s.bary[0] = sensor[0] + (c * s.blx - sn * s.bly) / (double)s.nfilt;
+    s.bary[1] = sensor[1] + (sn * s.blx + c * s.bly) / (double)s.nfilt;
+  } else {
+    s.bary[0] = sensor[0];
+    s.bary[1] = sensor[1];
+  }
+}
+// GetReferencePose(m_pUseScanBarycenter) position
+inline const double* fe_ref(const lslam_frontend* f, const lslam_frontend_scan& s) {
+  return f->cfg.use_scan_barycenter ? s.bary : s.sensor;
+}
+
+// world points of scan `id` at its current sensor pose into its resident slot
+int fe_update_world(lslam_frontend* f, int id) {
+  lslam_matcher* m = f->m;
+  lslam_context* ctx = m->ctx;
+  const int n = m->g.n_beams;
+  if (n <= 0) return LSLAM_OK;
+  LSLAM_HIP(ctx, hipMemcpyAsync(f->d_q.p, f->scans[id].sensor, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((n + 255) / 256, 1), dim3(256), 0,
+         (const double*)(f->d_ranges + (size_t)id * n), n, (const double*)f->d_q.p, m->g, (double2*)nullptr,
+         f->d_world + (size_t)id * n, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0);
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // d_q and the host pose are reused by the next call
+  return LSLAM_OK;
+}
+
+// ScanMatcher::MatchScan(pScan, chain, mean, covariance, doPenalize, doRefineMatch) (Mapper.cpp:184-291) of resident
+// scan `id`, posed at `sensor`, against the resident scans [first, first + count)
+int fe_match(lslam_frontend* f, lslam_matcher* m, int id, const double sensor[3], int first, int count, int do_penalize,
+             int do_refine, lslam_match_result* out) {
+  lslam_context* ctx = m->ctx;
+  const int n = f->m->g.n_beams;
+  if (n <= 0) {  // scan without readings (Mapper.cpp:199-209): rMean = scanPose
+    memset(out, 0, sizeof *out);
+    for (int i = 0; i < 3; i++) out->pose[i] = sensor[i];
+    out->covariance[0] = out->covariance[4] = kMaxVariance;
+    out->covariance[8] = 4 * ksq(m->cfg.coarse_angle_resolution);
+    return LSLAM_OK;
+  }
+  LSLAM_HIP(ctx, hipMemcpyAsync(f->d_q.p, sensor, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  int rc = rebuild_grid_dev(m, f->d_world, first, count, f->cap, sensor);
+  if (rc) return rc;
+  rc = match_batch_impl<double>(m, 1, f->d_ranges + (size_t)id * n, n, f->d_q.p, do_penalize, do_refine, f->d_res.p, nullptr, 0);
+  if (rc) return rc;
+  LSLAM_HIP(ctx, hipMemcpyAsync(out, f->d_res.p, sizeof *out, hipMemcpyDeviceToHost, ctx->stream));
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (out->status != LSLAM_OK) return ctx->fail(out->status, "scan matcher: the reference throws here");
+  return LSLAM_OK;
+}
+
+// MapperGraph::AddEdge + LinkScans (Mapper.cpp:1072-1121): a new edge unless `from` already has one whose target is `to`
+void fe_link_scans(lslam_frontend* f, int from, int to) {
+  for (const auto& e : f->scans[from].edges)
+    if (e.second == to) return;
+  f->scans[from].edges.emplace_back(from, to);  // Edge ctor: source->AddEdge, target->AddEdge (Mapper.h:304-309)
+  f->scans[to].edges.emplace_back(from, to);
+  f->n_edges++;
+}
+
+// LinkChainToScan (Mapper.cpp:1152-1167) with GetClosestScanToPose (:1054-1070)
+void fe_link_chain_to_scan(lslam_frontend* f, int first, int count, int id) {
+  const double* pose = fe_ref(f, f->scans[id]);
+  int closest = -1;
+  double best = DBL_MAX;
+  for (int i = first; i < first + count; i++) {
+    const double d = sq_dist2(pose, fe_ref(f, f->scans[i]));
+    if (d < best) {
+      best = d;
+      closest = i;
+    }
+  }
+  if (closest < 0) return;
+  if (best < ksq(f->cfg.link_scan_maximum_distance) + kTol) fe_link_scans(f, closest, id);
+}
+
+// FindNearLinkedScans (Mapper.cpp:1277-1286): BreadthFirstTraversal + NearScanVisitor (Mapper.h:542-643)
+std::vector<int> fe_near_linked(const lslam_frontend* f, int id, double max_distance) {
+  const double* center = fe_ref(f, f->scans[id]);
+  const double max2 = ksq(max_distance);
+  std::queue<int> to_visit;
+  std::vector<char> seen(f->scans.size(), 0);
+  std::vector<int> valid;
+  to_visit.push(id);
+  seen[id] = 1;
+  do {
+    const int v = to_visit.front();
+    to_visit.pop();
+    if (sq_dist2(fe_ref(f, f->scans[v]), center) <= max2 - kTol) {
+      valid.push_back(v);
+      for (const auto& e : f->scans[v].edges) {  // GetAdjacentVertices (Mapper.h:251-272)
+        const int adj[2] = {e.first, e.second};
+        for (int k = 0; k < 2; k++)
+          if (adj[k] != v && !seen[adj[k]]) {
+            to_visit.push(adj[k]);
+            seen[adj[k]] = 1;
+          }
+      }
+    }
+  } while (!to_visit.empty());
+  return valid;
+}
+
+// FindNearChains (Mapper.cpp:1170-1274): (first id, count) of every valid chain
+std::vector<std::pair<int, int>> fe_near_chains(const lslam_frontend* f, int id) {
+  std::vector<std::pair<int, int>> chains;
+  const double* scan_pose = fe_ref(f, f->scans[id]);
+  const double lim = ksq(f->cfg.link_scan_maximum_distance) + kTol;
+  std::vector<char> processed(f->scans.size(), 0);
+  const std::vector<int> near = fe_near_linked(f, id, f->cfg.link_scan_maximum_distance);
+  const int end = (int)f->scans.size();
+  for (int near_id : near) {
+    if (near_id == id) continue;
+    if (processed[near_id]) continue;
+    processed[near_id] = 1;
+    bool valid = true;
+    int lo = near_id, hi = near_id;
+    for (int c = near_id - 1; c >= 0; c--) {
+      if (c == id) valid = false;
+      if (sq_dist2(scan_pose, fe_ref(f, f->scans[c])) < lim) {
+        lo = c;
+        processed[c] = 1;
+      } else {
+        break;
+      }
+    }
+    for (int c = near_id + 1; c < end; c++) {
+      if (c == id) valid = false;
+      if (sq_dist2(scan_pose, fe_ref(f, f->scans[c])) < lim) {
+        hi = c;
+        processed[c] = 1;
+      } else {
+        break;
+      }
+    }
+    if (valid) chains.emplace_back(lo, hi - lo + 1);
+  }
+  return chains;
+}
+
+// FindPossibleLoopClosure (Mapper.cpp:1332-1390); rStartNum advances across calls
+std::pair<int, int> fe_possible_loop_closure(const lslam_frontend* f, int id, const std::vector<char>& is_near_linked,
+                                             int& start_num) {
+  const double* pose = fe_ref(f, f->scans[id]);
+  const double lim = ksq(f->cfg.loop_search_maximum_distance) + kTol;
+  const int n_scans = (int)f->scans.size();
+  int first = 0, count = 0;
+  for (; start_num < n_scans; start_num++) {
+    const int c = start_num;
+    if (sq_dist2(fe_ref(f, f->scans[c]), pose) < lim) {
+      if (is_near_linked[c]) {
+        count = 0;  // chain.clear(): a linked scan cannot be in the chain
+      } else {
+        if (count == 0) first = c;
+        count++;
+      }
+    } else {
+      if (count >= f->cfg.loop_match_minimum_chain_size) return {first, count};
+      count = 0;
+    }
+  }
+  return {first, count};  // the reference returns whatever is left when the scans run out
+}
+
+// TryCloseLoop (Mapper.cpp:976-1051), one sensor
+int fe_try_close_loop(lslam_frontend* f, int id) {
+  int start_num = 0;
+  auto next_chain = [&]() {
+    // FindPossibleLoopClosure recomputes the near-linked set on every call (the graph may have gained an edge)
+    std::vector<char> linked(f->scans.size(), 0);
+    for (int v : fe_near_linked(f, id, f->cfg.loop_search_maximum_distance)) linked[v] = 1;
+    return fe_possible_loop_closure(f, id, linked, start_num);
+  };
+  std::pair<int, int> chain = next_chain();
+  while (chain.second > 0) {
+    lslam_match_result coarse;
+    int rc = fe_match(f, f->loop_m, id, f->scans[id].sensor, chain.first, chain.second, 0, 0, &coarse);
+    if (rc) return rc;
+    f->n_loop_coarse++;
+    if (coarse.response > f->cfg.loop_match_minimum_response_coarse &&
+        coarse.covariance[0] < f->cfg.loop_match_maximum_variance_coarse &&
+        coarse.covariance[4] < f->cfg.loop_match_maximum_variance_coarse) {
+      lslam_match_result fine;  // tmpScan.SetSensorPose(bestPose); MatchScan(&tmpScan, chain, ..., false)
+      rc = fe_match(f, f->m, id, coarse.pose, chain.first, chain.second, 0, 1, &fine);
+      if (rc) return rc;
+      f->n_loop_fine++;
+      if (!(fine.response < f->cfg.loop_match_minimum_response_fine)) {
+        fe_set_sensor_pose(f, f->scans[id], fine.pose);  // pScan->SetSensorPose(bestPose)
+        rc = fe_update_world(f, id);
+        if (rc) return rc;
+        fe_link_chain_to_scan(f, chain.first, chain.second, id);
+        f->n_loops_closed++;  // CorrectPoses(): no ScanSolver attached
+      }
+    }
+    chain = next_chain();
+  }
+  return LSLAM_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
-int lslam_frontend_create(lslam_matcher* m, int scan_buffer_size, double scan_buffer_max_distance,
-                          double min_travel_distance, double min_travel_heading, lslam_frontend** out) {
-  if (!m || !out || scan_buffer_size < 1) return LSLAM_ERR_INVALID_ARGUMENT;
+void lslam_frontend_config_defaults(lslam_frontend_config* c) {
+  if (!c) return;
+  memset(c, 0, sizeof *c);
+  c->scan_buffer_size = 70;                      // Mapper.cpp:1501-1515
+  c->scan_buffer_maximum_scan_distance = 20.0;
+  c->minimum_travel_distance = 0.2;              // :1480-1499
+  c->minimum_travel_heading = 10.0 * kPi180;
+  c->minimum_time_interval = 3600.0;             // :1468-1478
+  c->use_scan_barycenter = 1;                    // :1462-1466
+  c->link_match_minimum_response_fine = 0.8;     // :1517-1521
+  c->link_scan_maximum_distance = 10.0;          // :1523-1527
+  c->loop_search_maximum_distance = 4.0;         // :1529-1533
+  c->do_loop_closing = 1;                        // :1535-1538
+  c->loop_match_minimum_chain_size = 10;         // :1540-1545
+  c->loop_match_maximum_variance_coarse = 0.4 * 0.4;  // :1547-1552
+  c->loop_match_minimum_response_coarse = 0.8;   // :1554-1558
+  c->loop_match_minimum_response_fine = 0.8;     // :1560-1564
+  c->loop_search_space_dimension = 8.0;          // :1586-1589
+  c->loop_search_space_resolution = 0.05;        // :1591-1594
+  c->loop_search_space_smear_deviation = 0.03;   // :1596-1600
+}
+
+int lslam_frontend_create_ex(lslam_matcher* m, const lslam_frontend_config* cfg, lslam_frontend** out) {
+  if (!m || !cfg || !out || cfg->scan_buffer_size < 1) return LSLAM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
   lslam_context* ctx = m->ctx;
   lslam_frontend* f = new lslam_frontend();
   f->m = m;
-  f->buf_size = scan_buffer_size;
-  f->buf_dist = scan_buffer_max_distance;
-  f->min_travel = min_travel_distance;
-  f->min_heading = min_travel_heading;
-  f->cap = scan_buffer_size + 1;  // the new scan is pushed before the front is trimmed
-  const size_t n = (size_t)std::max(m->g.n_beams, 1);
-  if (f->d_world.reserve((size_t)f->cap * n) != hipSuccess || f->d_q.reserve(n + 3) != hipSuccess ||
-      f->d_res.reserve(1) != hipSuccess) {
-    delete f;
-    return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the running-scan window in HBM");
+  f->cfg = *cfg;
+  if (cfg->do_loop_closing) {  // MapperGraph ctor (Mapper.cpp:862-871): the loop matcher shares every other parameter
+    lslam_matcher_config lc = m->cfg;
+    lc.search_size = cfg->loop_search_space_dimension;
+    lc.resolution = cfg->loop_search_space_resolution;
+    lc.smear_deviation = cfg->loop_search_space_smear_deviation;
+    int rc = lslam_matcher_create(ctx, &lc, &m->laser, &f->loop_m);
+    if (rc) {
+      delete f;
+      return rc;
+    }
   }
-  f->robot.assign((size_t)f->cap * 3, 0.0);
+  if (f->d_q.reserve(4) != hipSuccess || f->d_res.reserve(1) != hipSuccess) {
+    lslam_frontend_destroy(f);
+    return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the front-end scratch in HBM");
+  }
+  int rc = fe_grow(f, 256);
+  if (rc) {
+    lslam_frontend_destroy(f);
+    return rc;
+  }
+  const int n = m->g.n_beams;
+  f->cos_a.resize(n);
+  f->sin_a.resize(n);
+  for (int i = 0; i < n; i++) {
+    const double a = m->laser.minimum_angle + (double)i * m->laser.angular_resolution;
+    f->cos_a[i] = cos(a);
+    f->sin_a[i] = sin(a);
+  }
   *out = f;
   return LSLAM_OK;
+}
+
+// The four-parameter form of round 1: library defaults for the pose-graph side, loop closing off
+int lslam_frontend_create(lslam_matcher* m, int scan_buffer_size, double scan_buffer_max_distance,
+                          double min_travel_distance, double min_travel_heading, lslam_frontend** out) {
+  lslam_frontend_config c;
+  lslam_frontend_config_defaults(&c);
+  c.scan_buffer_size = scan_buffer_size;
+  c.scan_buffer_maximum_scan_distance = scan_buffer_max_distance;
+  c.minimum_travel_distance = min_travel_distance;
+  c.minimum_travel_heading = min_travel_heading;
+  c.do_loop_closing = 0;
+  return lslam_frontend_create_ex(m, &c, out);
 }
 
 void lslam_frontend_destroy(lslam_frontend* f) {
   if (!f) return;
   (void)hipStreamSynchronize(f->m->ctx->stream);
-  f->d_world.release();
+  if (f->loop_m) lslam_matcher_destroy(f->loop_m);
+  if (f->d_world) (void)hipFree(f->d_world);
+  if (f->d_ranges) (void)hipFree(f->d_ranges);
   f->d_q.release();
   f->d_res.release();
   delete f;
@@ -68,20 +380,40 @@ void lslam_frontend_destroy(lslam_frontend* f) {
 
 int lslam_frontend_reset(lslam_frontend* f) {
   if (!f) return LSLAM_ERR_INVALID_ARGUMENT;
-  f->start = f->count = 0;
+  f->scans.clear();
+  f->run_start = f->run_count = 0;
   f->have_last = false;
+  f->n_chain_matches = f->n_loop_coarse = f->n_loop_fine = f->n_loops_closed = f->n_edges = 0;
   return LSLAM_OK;
 }
 
-int lslam_frontend_running_scans(const lslam_frontend* f) { return f ? f->count : LSLAM_ERR_INVALID_ARGUMENT; }
+int lslam_frontend_running_scans(const lslam_frontend* f) { return f ? f->run_count : LSLAM_ERR_INVALID_ARGUMENT; }
+int lslam_frontend_num_scans(const lslam_frontend* f) { return f ? (int)f->scans.size() : LSLAM_ERR_INVALID_ARGUMENT; }
 
-int lslam_frontend_process(lslam_frontend* f, const double* ranges, int n_ranges, const double odom_pose[3],
-                           int* processed, double corrected_pose[3], double covariance[9], double* response) {
+int lslam_frontend_scan_pose(const lslam_frontend* f, int scan_id, double robot_pose[3]) {
+  if (!f || !robot_pose || scan_id < 0 || scan_id >= (int)f->scans.size()) return LSLAM_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < 3; i++) robot_pose[i] = f->scans[scan_id].robot[i];
+  return LSLAM_OK;
+}
+
+int lslam_frontend_stats(const lslam_frontend* f, int64_t out[6]) {
+  if (!f || !out) return LSLAM_ERR_INVALID_ARGUMENT;
+  out[0] = (int64_t)f->scans.size();
+  out[1] = f->n_edges;
+  out[2] = f->n_chain_matches;
+  out[3] = f->n_loop_coarse;
+  out[4] = f->n_loop_fine;
+  out[5] = f->n_loops_closed;
+  return LSLAM_OK;
+}
+
+int lslam_frontend_process_stamped(lslam_frontend* f, const double* ranges, int n_ranges, const double odom_pose[3],
+                                   double time_s, int* processed, double corrected_pose[3], double covariance[9],
+                                   double* response) {
   if (!f || !ranges || !odom_pose || !processed || !corrected_pose) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_matcher* m = f->m;
   lslam_context* ctx = m->ctx;
-  const Geom g0 = m->g;
-  const int n = g0.n_beams;
+  const int n = m->g.n_beams;
   if (n_ranges < n) return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "n_ranges %d < num_beams %d", n_ranges, n);
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
   const lslam_laser* laser = &m->laser;
@@ -89,81 +421,107 @@ int lslam_frontend_process(lslam_frontend* f, const double* ranges, int n_ranges
   double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // Mapper.cpp:2033-2034
   double resp = 0.0;
   *processed = 0;
+  if (covariance) memcpy(covariance, cov, sizeof cov);  // also what a rejected scan reports
+  if (response) *response = 0.0;
   if (f->have_last) {
-    PoseXform t = pose_xform(f->last_odom, f->last_corr);  // :2021-2025
+    const lslam_frontend_scan& last = f->scans.back();
+    PoseXform t = pose_xform(last.odom, last.robot);  // :2021-2025
     pose_xform_apply(t, odom_pose, corrected);
-    double lsp[3], csp[3];  // HasMovedEnough on the ODOMETRIC sensor poses (:2087-2120)
-    lslam_sensor_pose_from_robot(laser, f->last_odom, lsp);
-    lslam_sensor_pose_from_robot(laser, odom_pose, csp);
-    double dh = normalize_angle(csp[2] - lsp[2]);
-    bool moved = fabs(dh) >= f->min_heading;
-    if (!moved) moved = sq_dist2(lsp, csp) >= ksq(f->min_travel) - kTol;
+    // HasMovedEnough (:2087-2120): time first, then the ODOMETRIC sensor poses
+    bool moved = (time_s - last.time) >= f->cfg.minimum_time_interval;
+    if (!moved) {
+      double lsp[3], csp[3];
+      lslam_sensor_pose_from_robot(laser, last.odom, lsp);
+      lslam_sensor_pose_from_robot(laser, odom_pose, csp);
+      const double dh = normalize_angle(csp[2] - lsp[2]);
+      moved = fabs(dh) >= f->cfg.minimum_travel_heading;
+      if (!moved) moved = sq_dist2(lsp, csp) >= ksq(f->cfg.minimum_travel_distance) - kTol;
+    }
     if (!moved) {
       for (int i = 0; i < 3; i++) corrected_pose[i] = corrected[i];
       return LSLAM_OK;
     }
-    // MatchScan(pScan, runningScans) (:2037-2045)
-    double qsp[3];
-    lslam_sensor_pose_from_robot(laser, corrected, qsp);
-    if (n > 0) {
-      LSLAM_HIP(ctx, hipMemcpyAsync(f->d_q.p, ranges, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-      LSLAM_HIP(ctx, hipMemcpyAsync(f->d_q.p + n, qsp, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-      int rc = rebuild_grid_dev(m, f->d_world.p, f->start, f->count, f->cap, qsp);
-      if (rc) return rc;
-      rc = match_batch_impl<double>(m, 1, f->d_q.p, n, f->d_q.p + n, 1, 1, f->d_res.p, nullptr, 0);
-      if (rc) return rc;
-      lslam_match_result r;
-      LSLAM_HIP(ctx, hipMemcpyAsync(&r, f->d_res.p, sizeof r, hipMemcpyDeviceToHost, ctx->stream));
-      LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if (r.status != LSLAM_OK) return ctx->fail(r.status, "scan matcher: the reference throws here");
-      resp = r.response;
-      for (int i = 0; i < 9; i++) cov[i] = r.covariance[i];
-      lslam_robot_pose_from_sensor(laser, r.pose, corrected);  // SetSensorPose(bestPose) (:2044)
-    } else {  // scan without readings (Mapper.cpp:199-209): rMean = scanPose
-      cov[0] = cov[4] = kMaxVariance;
-      cov[8] = 4 * ksq(m->cfg.coarse_angle_resolution);
-      lslam_robot_pose_from_sensor(laser, qsp, corrected);
+  }
+  const int id = (int)f->scans.size();
+  int rc = fe_grow(f, id + 1);
+  if (rc) return rc;
+  if (n > 0)
+    LSLAM_HIP(ctx, hipMemcpyAsync(f->d_ranges + (size_t)id * n, ranges, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  lslam_frontend_scan s;
+  for (int i = 0; i < 3; i++) s.odom[i] = odom_pose[i];
+  s.time = time_s;
+  for (int i = 0; i < n; i++) {  // the filtered readings (Karto.h:5381-5405): minimum range <= r <= range threshold
+    const double r = ranges[i];
+    if (r >= laser->minimum_range && r <= laser->range_threshold) {
+      s.blx += r * f->cos_a[i];
+      s.bly += r * f->sin_a[i];
+      s.nfilt++;
     }
-    // AddEdges (:957-972): means = {GetSensorPose()}, covariances = {covariance}
-    double sp[3], wm[3];
-    lslam_sensor_pose_from_robot(laser, corrected, sp);
-    weighted_mean_single(sp, cov, wm);
-    lslam_robot_pose_from_sensor(laser, wm, corrected);
   }
-  // AddRunningScan (Mapper.h:1365-1386): push, then trim the front
-  const int slot = (f->start + f->count) % f->cap;
-  if (n > 0) {
-    double sp[3];
-    lslam_sensor_pose_from_robot(laser, corrected, sp);
-    if (!f->have_last)  // first scan: its ranges were not uploaded yet
-      LSLAM_HIP(ctx, hipMemcpyAsync(f->d_q.p, ranges, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    LSLAM_HIP(ctx, hipMemcpyAsync(f->d_q.p + n, sp, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((n + 255) / 256, 1), dim3(256), 0,
-           (const double*)f->d_q.p, n, (const double*)(f->d_q.p + n), m->g, (double2*)nullptr,
-           f->d_world.p + (size_t)slot * n, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0);
-    LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // d_q is reused by the next call
+  double sp[3];
+  lslam_sensor_pose_from_robot(laser, corrected, sp);
+  if (f->have_last) {  // MatchScan(pScan, runningScans) + SetSensorPose(bestPose) (:2037-2045)
+    lslam_match_result r;
+    rc = fe_match(f, m, id, sp, f->run_start, f->run_count, 1, 1, &r);
+    if (rc) return rc;
+    resp = r.response;
+    for (int i = 0; i < 9; i++) cov[i] = r.covariance[i];
+    for (int i = 0; i < 3; i++) sp[i] = r.pose[i];
+  } else if (n > 0) {
+    LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's ranges are free again when we return
   }
-  for (int i = 0; i < 3; i++) f->robot[(size_t)slot * 3 + i] = corrected[i];
-  f->count++;
+  fe_set_sensor_pose(f, s, sp);
+  f->scans.push_back(s);  // AddScan + AddVertex (:2048-2054)
+  // ---- MapperGraph::AddEdges (:901-973) ----
+  if (f->have_last) {
+    fe_link_scans(f, id - 1, id);
+    std::vector<double> means(f->scans[id].sensor, f->scans[id].sensor + 3), covs(cov, cov + 9);
+    fe_link_chain_to_scan(f, f->run_start, f->run_count, id);
+    // LinkNearChains (:1124-1149)
+    for (const auto& chain : fe_near_chains(f, id)) {
+      if (chain.second < f->cfg.loop_match_minimum_chain_size) continue;
+      lslam_match_result r;
+      rc = fe_match(f, m, id, f->scans[id].sensor, chain.first, chain.second, 0, 1, &r);
+      if (rc) return rc;
+      f->n_chain_matches++;
+      if (r.response > f->cfg.link_match_minimum_response_fine - kTol) {
+        means.insert(means.end(), r.pose, r.pose + 3);
+        covs.insert(covs.end(), r.covariance, r.covariance + 9);
+        fe_link_chain_to_scan(f, chain.first, chain.second, id);
+      }
+    }
+    double wm[3];
+    weighted_mean((int)(means.size() / 3), means.data(), covs.data(), wm);
+    fe_set_sensor_pose(f, f->scans[id], wm);  // pScan->SetSensorPose(ComputeWeightedMean(means, covariances))
+  }
+  rc = fe_update_world(f, id);
+  if (rc) return rc;
+  // ---- AddRunningScan (Mapper.h:1365-1386): push, then trim the front ----
+  if (f->run_count == 0) f->run_start = id;
+  f->run_count++;
   for (;;) {
-    double fs[3], bs[3];
-    lslam_sensor_pose_from_robot(laser, &f->robot[(size_t)f->start * 3], fs);
-    lslam_sensor_pose_from_robot(laser, &f->robot[(size_t)((f->start + f->count - 1) % f->cap) * 3], bs);
-    double d2 = sq_dist2(fs, bs);
-    if (!((uint32_t)f->count > (uint32_t)f->buf_size || d2 > ksq(f->buf_dist) - kTol)) break;
-    f->start = (f->start + 1) % f->cap;
-    f->count--;
+    const double d2 = sq_dist2(f->scans[f->run_start].sensor, f->scans[f->run_start + f->run_count - 1].sensor);
+    if (!((uint32_t)f->run_count > (uint32_t)f->cfg.scan_buffer_size ||
+          d2 > ksq(f->cfg.scan_buffer_maximum_scan_distance) - kTol))
+      break;
+    f->run_start++;
+    f->run_count--;
   }
-  for (int i = 0; i < 3; i++) {
-    f->last_odom[i] = odom_pose[i];  // SetLastScan (:2074)
-    f->last_corr[i] = corrected[i];
-    corrected_pose[i] = corrected[i];
+  if (f->cfg.do_loop_closing && f->loop_m) {  // :2063-2070
+    rc = fe_try_close_loop(f, id);
+    if (rc) return rc;
   }
-  f->have_last = true;
+  f->have_last = true;  // SetLastScan (:2074)
+  for (int i = 0; i < 3; i++) corrected_pose[i] = f->scans[id].robot[i];
   if (covariance) memcpy(covariance, cov, sizeof cov);
   if (response) *response = resp;
   *processed = 1;
   return LSLAM_OK;
+}
+
+int lslam_frontend_process(lslam_frontend* f, const double* ranges, int n_ranges, const double odom_pose[3],
+                           int* processed, double corrected_pose[3], double covariance[9], double* response) {
+  return lslam_frontend_process_stamped(f, ranges, n_ranges, odom_pose, 0.0, processed, corrected_pose, covariance, response);
 }
 
 }  // extern "C"

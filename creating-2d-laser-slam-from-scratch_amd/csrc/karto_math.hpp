@@ -233,4 +233,33 @@ LSLAM_HD void weighted_mean_single(const double mean[3], const double cov[9], do
   out[2] = atan2(ty, tx);
 }
 
+// MapperGraph::ComputeWeightedMean for n (mean, covariance) pairs, same accumulation order (Mapper.cpp:1288-1330):
+// the running-scan match plus whatever LinkNearChains contributed.  means: n*3, covs: n*9.
+inline void weighted_mean(int n, const double* means, const double* covs, double out[3]) {
+  double sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double* inv = new double[(size_t)9 * n];
+  for (int i = 0; i < n; i++) {
+    mat3_inverse(covs + 9 * i, inv + 9 * i);  // Matrix3::Inverse, 1e-14 tolerance (release build: no assert)
+    for (int k = 0; k < 9; k++) sum[k] += inv[9 * i + k];
+  }
+  double ios[9];
+  mat3_inverse(sum, ios);
+  double ax = 0.0, ay = 0.0, tx = 0.0, ty = 0.0;
+  for (int i = 0; i < n; i++) {
+    const double* m = means + 3 * i;
+    tx += cos(m[2]);
+    ty += sin(m[2]);
+    double w[9];
+    mat3_mul(ios, inv + 9 * i, w);
+    ax += w[0] * m[0] + w[1] * m[1] + w[2] * m[2];  // Matrix3 * Pose2, Pose2 += (Karto.h:2574-2583, 2117-2121)
+    ay += w[3] * m[0] + w[4] * m[1] + w[5] * m[2];
+  }
+  delete[] inv;
+  tx /= n;
+  ty /= n;
+  out[0] = ax;
+  out[1] = ay;
+  out[2] = atan2(ty, tx);
+}
+
 }  // namespace lslam

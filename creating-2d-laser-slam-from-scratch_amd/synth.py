@@ -155,6 +155,44 @@ def trajectory(
     return np.asarray(poses, dtype=np.float64)
 
 
+def loop_trajectory(n: int, w: float = 10.0, h: float = 6.0, step: float = 0.25, origin=(-5.0, -3.0)) -> np.ndarray:
+    """n poses driving the perimeter of a w x h rectangle again and again (heading along the side): a trajectory that
+    REVISITS, so the pose graph links near chains and closes loops (SURVEY.md §8(d) cfg 5: closed loops)."""
+    per = 2.0 * (w + h)
+    out = np.empty((n, 3))
+    for i in range(n):
+        s = (i * step) % per
+        if s < w:
+            x, y, th = s, 0.0, 0.0
+        elif s < w + h:
+            x, y, th = w, s - w, math.pi / 2
+        elif s < 2 * w + h:
+            x, y, th = w - (s - w - h), h, math.pi
+        else:
+            x, y, th = 0.0, h - (s - 2 * w - h), -math.pi / 2
+        out[i] = (origin[0] + x, origin[1] + y, th)
+    return out
+
+
+def drifting_odometry(path: np.ndarray, scale: float = 1.02, sigma_xy: float = 0.005, sigma_th: float = 0.002,
+                      seed: int = 7) -> np.ndarray:
+    """Dead-reckoned odometry for `path`: every increment is re-expressed in the drifting frame, stretched by `scale`
+    and perturbed -- the error accumulates, which is what loop closure is for."""
+    rng = np.random.default_rng(seed)
+    odom = [np.array(path[0], dtype=np.float64)]
+    for i in range(1, len(path)):
+        d = path[i] - path[i - 1]
+        d[2] = math.atan2(math.sin(d[2]), math.cos(d[2]))
+        a = odom[-1][2] - path[i - 1][2]
+        c, s = math.cos(a), math.sin(a)
+        dx, dy = c * d[0] - s * d[1], s * d[0] + c * d[1]
+        nxt = odom[-1] + np.array([dx * scale + rng.normal(0, sigma_xy), dy * scale + rng.normal(0, sigma_xy),
+                                   d[2] + rng.normal(0, sigma_th)])
+        nxt[2] = math.atan2(math.sin(nxt[2]), math.cos(nxt[2]))
+        odom.append(nxt)
+    return np.array(odom)
+
+
 def perturb(poses: np.ndarray, max_xy: float, max_th: float, seed: int) -> np.ndarray:
     """Odometry error: uniform(+-max_xy, +-max_th) added to each truth pose."""
     rng = np.random.default_rng(seed)

@@ -211,23 +211,62 @@ int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges,
                                    uint8_t* out_host);
 
 /* ---------------------------------------------------------------------------------------- */
-/* Streaming front-end: the pose path of karto::Mapper::Process (Mapper.cpp:1999-2079) with a  */
-/* device-resident running-scan window (replaces Mapper::Process as karto_slam.cc:444 calls it, */
-/* minus the pose graph, which stays on the host)                                              */
+/* Streaming front-end: karto::Mapper::Process (Mapper.cpp:1999-2079) with every processed scan  */
+/* resident in HBM (replaces Mapper::Process as karto_slam.cc:444 calls it; the pose graph's    */
+/* matches run on the device, its bookkeeping on the host, the optional solver stays outside)   */
 /* ---------------------------------------------------------------------------------------- */
 typedef struct lslam_frontend lslam_frontend;
-/* scan_buffer_size / scan_buffer_max_distance: ScanBufferSize, ScanBufferMaximumScanDistance
- * (Mapper.cpp:1501-1515); min_travel_*: MinimumTravelDistance / MinimumTravelHeading (:1480-1499).
- * The matcher must outlive the front-end; its grid is rebuilt on every processed scan. */
+/* The Mapper parameters Mapper::Process and MapperGraph read (Mapper.cpp:1457-1604; defaults = the library's).
+ * Variances are VARIANCES (the node's setters square their inputs, Mapper.cpp:1919-1927, 1873-1876). */
+typedef struct lslam_frontend_config {
+  int32_t scan_buffer_size;                  /* ScanBufferSize */
+  int32_t use_scan_barycenter;               /* UseScanBarycenter: reference pose of a scan = barycentre of its readings */
+  int32_t do_loop_closing;                   /* DoLoopClosing: TryCloseLoop after every processed scan */
+  int32_t loop_match_minimum_chain_size;     /* LoopMatchMinimumChainSize (also the minimum near-chain size) */
+  double scan_buffer_maximum_scan_distance;  /* ScanBufferMaximumScanDistance */
+  double minimum_travel_distance;            /* MinimumTravelDistance */
+  double minimum_travel_heading;             /* MinimumTravelHeading [rad] */
+  double minimum_time_interval;              /* MinimumTimeInterval [s] */
+  double link_match_minimum_response_fine;   /* LinkMatchMinimumResponseFine */
+  double link_scan_maximum_distance;         /* LinkScanMaximumDistance */
+  double loop_search_maximum_distance;       /* LoopSearchMaximumDistance */
+  double loop_match_maximum_variance_coarse; /* LoopMatchMaximumVarianceCoarse */
+  double loop_match_minimum_response_coarse; /* LoopMatchMinimumResponseCoarse */
+  double loop_match_minimum_response_fine;   /* LoopMatchMinimumResponseFine */
+  double loop_search_space_dimension;        /* LoopSearchSpaceDimension: the loop matcher's search_size */
+  double loop_search_space_resolution;       /* LoopSearchSpaceResolution */
+  double loop_search_space_smear_deviation;  /* LoopSearchSpaceSmearDeviation */
+} lslam_frontend_config;
+void lslam_frontend_config_defaults(lslam_frontend_config* cfg);
+/* Mapper::Process with its pose graph (Mapper.cpp:1999-2079, 862-1390): every processed scan stays resident in HBM;
+ * AddEdges' LinkNearChains matches (Mapper.cpp:1124-1149) and TryCloseLoop's coarse (loop matcher, created here from
+ * the sequential matcher's parameters + the three loop_search_space_* values, Mapper.cpp:862-871) and fine matches
+ * (Mapper.cpp:976-1051) run on the device, the graph walk (breadth-first FindNearLinkedScans, FindNearChains,
+ * FindPossibleLoopClosure) on the host.  No ScanSolver: CorrectPoses() is a no-op exactly as in karto::Mapper without
+ * an optimizer (the solvers are third-party back-ends).  The matcher must outlive the front-end. */
+int lslam_frontend_create_ex(lslam_matcher* m, const lslam_frontend_config* cfg, lslam_frontend** out);
+/* round-1 spelling: library defaults for everything not named here, loop closing OFF.
+ * scan_buffer_size / scan_buffer_max_distance: ScanBufferSize, ScanBufferMaximumScanDistance
+ * (Mapper.cpp:1501-1515); min_travel_*: MinimumTravelDistance / MinimumTravelHeading (:1480-1499). */
 int lslam_frontend_create(lslam_matcher* m, int scan_buffer_size, double scan_buffer_max_distance,
                           double min_travel_distance, double min_travel_heading, lslam_frontend** out);
 void lslam_frontend_destroy(lslam_frontend* f);
 int lslam_frontend_reset(lslam_frontend* f);
 /* One LaserScan in (ranges widened to double, odometric ROBOT pose), corrected ROBOT pose out.
- * *processed = 0 when HasMovedEnough rejects the scan (Mapper.cpp:2028-2031).  covariance/response
- * may be NULL. */
+ * *processed = 0 when HasMovedEnough rejects the scan (Mapper.cpp:2028-2031): corrected_pose is then the odometric
+ * pose carried through the last correction, covariance the identity and response 0.  covariance/response may be NULL.
+ * lslam_frontend_process = time 0 (the MinimumTimeInterval test of HasMovedEnough never fires). */
 int lslam_frontend_process(lslam_frontend* f, const double* ranges, int n_ranges, const double odom_pose[3],
                            int* processed, double corrected_pose[3], double covariance[9], double* response);
+int lslam_frontend_process_stamped(lslam_frontend* f, const double* ranges, int n_ranges, const double odom_pose[3],
+                                   double time_s, int* processed, double corrected_pose[3], double covariance[9],
+                                   double* response);
+/* GetAllProcessedScans().size(); corrected ROBOT pose of processed scan `scan_id` as it stands now (a closed loop
+ * re-poses the closing scan); out[6] = scans, graph edges, near-chain matches, loop coarse matches, loop fine
+ * matches, loops closed */
+int lslam_frontend_num_scans(const lslam_frontend* f);
+int lslam_frontend_scan_pose(const lslam_frontend* f, int scan_id, double robot_pose[3]);
+int lslam_frontend_stats(const lslam_frontend* f, int64_t out[6]);
 int lslam_frontend_running_scans(const lslam_frontend* f); /* ScanManager::GetRunningScans().size() */
 
 /* ---------------------------------------------------------------------------------------- */

@@ -36,6 +36,20 @@ class KrefCfg(C.Structure):
         ("scan_buffer_max_scan_distance", C.c_double),
         ("minimum_travel_distance", C.c_double),
         ("minimum_travel_heading", C.c_double),
+        ("do_loop_closing", C.c_int),
+        ("loop_match_minimum_chain_size", C.c_int),
+        ("link_match_minimum_response_fine", C.c_double),
+        ("link_scan_maximum_distance", C.c_double),
+        ("loop_search_maximum_distance", C.c_double),
+        ("loop_match_maximum_variance_coarse", C.c_double),
+        ("loop_match_minimum_response_coarse", C.c_double),
+        ("loop_match_minimum_response_fine", C.c_double),
+        ("loop_search_space_dimension", C.c_double),
+        ("loop_search_space_resolution", C.c_double),
+        ("loop_search_space_smear_deviation", C.c_double),
+        ("minimum_time_interval", C.c_double),
+        ("use_scan_barycenter", C.c_int),
+        ("reserved", C.c_int),
     ]
 
 
@@ -71,6 +85,22 @@ def default_cfg(**kw) -> KrefCfg:
         scan_buffer_max_scan_distance=20.0,
         minimum_travel_distance=0.2,
         minimum_travel_heading=np.deg2rad(10.0),
+        # pose-graph side of Mapper::Process: library defaults (Mapper.cpp:1516-1604); loop closing is OFF unless asked
+        # for (LinkNearChains is unconditional in AddEdges either way)
+        do_loop_closing=0,
+        loop_match_minimum_chain_size=10,
+        link_match_minimum_response_fine=0.8,
+        link_scan_maximum_distance=10.0,
+        loop_search_maximum_distance=4.0,
+        loop_match_maximum_variance_coarse=0.4 * 0.4,
+        loop_match_minimum_response_coarse=0.8,
+        loop_match_minimum_response_fine=0.8,
+        loop_search_space_dimension=8.0,
+        loop_search_space_resolution=0.05,
+        loop_search_space_smear_deviation=0.03,
+        minimum_time_interval=3600.0,
+        use_scan_barycenter=1,
+        reserved=0,
     )
     d.update(kw)
     return KrefCfg(**d)
@@ -130,6 +160,9 @@ class RefKarto:
         L.kref_find_valid_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.kref_process.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.kref_running_scans.argtypes = [C.c_void_p]
+        L.kref_graph_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.kref_graph_stats.restype = None
+        L.kref_scan_pose.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.kref_occupancy_grid.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.kref_last_error.restype = C.c_char_p
         L.kref_last_error.argtypes = [C.c_void_p]
@@ -276,6 +309,18 @@ class RefKarto:
 
     def running_scans(self) -> int:
         return self.L.kref_running_scans(self.h)
+
+    def graph_stats(self):
+        """(vertices, edges) of the reference's pose graph."""
+        out = np.zeros(2, dtype=np.int32)
+        self.L.kref_graph_stats(self.h, out.ctypes.data)
+        return int(out[0]), int(out[1])
+
+    def scan_pose(self, scan_id: int) -> np.ndarray:
+        out = np.zeros(3)
+        if self.L.kref_scan_pose(self.h, scan_id, out.ctypes.data) != 0:
+            raise IndexError(scan_id)
+        return out
 
     def occupancy_grid(self, resolution: float):
         d = np.zeros(2, dtype=np.int32)

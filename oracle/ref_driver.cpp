@@ -70,6 +70,21 @@ struct kref_cfg {
   double scan_buffer_max_scan_distance;
   double minimum_travel_distance;
   double minimum_travel_heading;
+  // pose-graph side of Mapper::Process (AddEdges / LinkNearChains / TryCloseLoop); Mapper.cpp:1516-1604
+  int do_loop_closing;
+  int loop_match_minimum_chain_size;
+  double link_match_minimum_response_fine;
+  double link_scan_maximum_distance;
+  double loop_search_maximum_distance;
+  double loop_match_maximum_variance_coarse;  // a VARIANCE (the node's setter squares its input)
+  double loop_match_minimum_response_coarse;
+  double loop_match_minimum_response_fine;
+  double loop_search_space_dimension;
+  double loop_search_space_resolution;
+  double loop_search_space_smear_deviation;
+  double minimum_time_interval;
+  int use_scan_barycenter;
+  int reserved;
 };
 
 struct kref_laser {
@@ -113,7 +128,21 @@ void* kref_create(const kref_cfg* c, const kref_laser* l) {
     m->m_pScanBufferMaximumScanDistance->SetValue(c->scan_buffer_max_scan_distance);
     m->m_pMinimumTravelDistance->SetValue(c->minimum_travel_distance);
     m->m_pMinimumTravelHeading->SetValue(c->minimum_travel_heading);
-    m->m_pDoLoopClosing->SetValue(false);  // lesson6.1 front-end only; no solver (back-end out of scope)
+    // no ScanSolver is ever attached (spa / g2o / ceres / gtsam are third-party back-ends, out of scope), so a closed
+    // loop re-poses the closing scan and links it (Mapper.cpp:1029-1036) but CorrectPoses() has nothing to run
+    m->m_pDoLoopClosing->SetValue(c->do_loop_closing != 0);
+    m->m_pLoopMatchMinimumChainSize->SetValue((kt_int32u)c->loop_match_minimum_chain_size);
+    m->m_pLinkMatchMinimumResponseFine->SetValue(c->link_match_minimum_response_fine);
+    m->m_pLinkScanMaximumDistance->SetValue(c->link_scan_maximum_distance);
+    m->m_pLoopSearchMaximumDistance->SetValue(c->loop_search_maximum_distance);
+    m->m_pLoopMatchMaximumVarianceCoarse->SetValue(c->loop_match_maximum_variance_coarse);
+    m->m_pLoopMatchMinimumResponseCoarse->SetValue(c->loop_match_minimum_response_coarse);
+    m->m_pLoopMatchMinimumResponseFine->SetValue(c->loop_match_minimum_response_fine);
+    m->m_pLoopSearchSpaceDimension->SetValue(c->loop_search_space_dimension);
+    m->m_pLoopSearchSpaceResolution->SetValue(c->loop_search_space_resolution);
+    m->m_pLoopSearchSpaceSmearDeviation->SetValue(c->loop_search_space_smear_deviation);
+    m->m_pMinimumTimeInterval->SetValue(c->minimum_time_interval);
+    m->m_pUseScanBarycenter->SetValue(c->use_scan_barycenter != 0);
     m->m_pUseScanMatching->SetValue(true);
 
     k->dataset = new Dataset();
@@ -365,6 +394,27 @@ int kref_process(void* h, int n_ranges, const double* ranges, const double* odom
     k->err = e.GetErrorMessage();
     return -2;
   }
+}
+
+// pose-graph statistics after the scans processed so far: out[0] = vertices, out[1] = edges (Graph::GetEdges)
+void kref_graph_stats(void* h, int out[2]) {
+  KRef* k = (KRef*)h;
+  out[0] = out[1] = 0;
+  MapperGraph* g = k->mapper->GetGraph();
+  if (!g) return;
+  out[1] = (int)g->GetEdges().size();
+  const Graph<LocalizedRangeScan>::VertexMap& vm = g->GetVertices();
+  for (Graph<LocalizedRangeScan>::VertexMap::const_iterator it = vm.begin(); it != vm.end(); ++it) out[0] += (int)it->second.size();
+}
+// corrected ROBOT pose of processed scan `id` as it stands NOW (a closed loop re-poses the closing scan)
+int kref_scan_pose(void* h, int id, double out_pose[3]) {
+  KRef* k = (KRef*)h;
+  if (!k->mapper->m_pMapperSensorManager) return -1;
+  LocalizedRangeScanVector& v = k->mapper->m_pMapperSensorManager->GetScans(Name(k->name));
+  if (id < 0 || id >= (int)v.size()) return -1;
+  Pose2 p = v[id]->GetCorrectedPose();
+  out_pose[0] = p.GetX(); out_pose[1] = p.GetY(); out_pose[2] = p.GetHeading();
+  return 0;
 }
 
 // number of scans currently in the running-scan window (Mapper.h:1365-1386)

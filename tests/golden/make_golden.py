@@ -9,6 +9,9 @@ karto_match_golden.npz : seeded base window + queries (float32 ranges as a Laser
     CorrelateScan results, the shared correlation grid (sparse), coarse lookup-table and
     search-space-probability digests.
 karto_frontend_golden.npz : a 30-scan trajectory through karto::Mapper::Process (corrected poses).
+karto_loop_golden.npz : a 190-scan CLOSED-LOOP trajectory (a rectangle driven 1.5 times, drifting odometry) through
+    karto::Mapper::Process with loop closing on: corrected pose per scan, graph edge count after each scan, final
+    poses of all vertices.
 hector_golden.npz : from the reference's own lesson4 hector_mapping headers, compiled unmodified as
     oracle/_ref/libhector_ref.so (Eigen from oracle/shim/Eigen): the log-odds map of 4 scans through
     OccGridMapBase::updateByScan, and a 40-scan run of HectorSlamProcessor::update on a 3-level pyramid
@@ -74,6 +77,26 @@ def main():
         ranges.append(r); processed.append(ok); poses.append(pose)
     np.savez_compressed(OUT / "karto_frontend_golden.npz", ranges=np.stack(ranges), odom=odom,
                         processed=np.array(processed), corrected=np.stack(poses))
+    # closed-loop trajectory through karto::Mapper::Process WITH its pose graph: LinkNearChains on the revisits and
+    # TryCloseLoop (no solver attached, like the library itself)
+    lp_cfg = dict(scan_buffer_size=30, scan_buffer_max_scan_distance=8.0, do_loop_closing=1,
+                  link_scan_maximum_distance=1.5, loop_search_maximum_distance=3.0)
+    ref3 = po.RefKarto(po.default_cfg(**lp_cfg), po.laser_struct(laser, 20.0))
+    lworld = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=5)
+    lpath = synth.loop_trajectory(190)
+    lodom = synth.drifting_odometry(lpath)
+    lranges, lproc, lposes, ledges = [], [], [], []
+    for i, (t, o) in enumerate(zip(lpath, lodom)):
+        r = synth.cast_scan(lworld, t, laser, 0.01, 0.01, np.random.default_rng([41, i]))
+        ok, pose = ref3.process(synth.ranges_to_f64(r), o)
+        lranges.append(r); lproc.append(ok); lposes.append(pose); ledges.append(ref3.graph_stats()[1])
+    nv, ne = ref3.graph_stats()
+    assert ne > nv + 2, (nv, ne)  # the revisit added links beyond one per scan
+    final = np.stack([ref3.scan_pose(i) for i in range(nv)])
+    np.savez_compressed(OUT / "karto_loop_golden.npz", ranges=np.stack(lranges), odom=lodom, truth=lpath,
+                        processed=np.array(lproc), corrected=np.stack(lposes), edges=np.array(ledges),
+                        final_poses=final, range_threshold=np.float64(20.0),
+                        **{"cfg_" + k: np.float64(v) for k, v in lp_cfg.items()})
     # hector: from the reference's own hector_mapping headers (oracle/_ref/libhector_ref.so)
     assert po.have_ref_hector(), "needs /root/reference to build oracle/_ref/libhector_ref.so"
     n, cell = 600, 0.05

@@ -73,3 +73,76 @@ def test_streaming_match_plus_map_update(ctx, oracle_lib):
     assert np.array_equal(cmap.occupancy_i8(), gmap.occupancy_i8())
     # drift stays small: matched poses track the truth much better than raw odometry would
     assert np.hypot(*(pose_g[:2] - path[-1][:2])) < 0.5
+
+
+def _loop_frontend(ctx, d, laser):
+    cfg = api.frontend_config(scan_buffer_size=int(d["cfg_scan_buffer_size"]),
+                              scan_buffer_maximum_scan_distance=float(d["cfg_scan_buffer_max_scan_distance"]),
+                              do_loop_closing=int(d["cfg_do_loop_closing"]),
+                              link_scan_maximum_distance=float(d["cfg_link_scan_maximum_distance"]),
+                              loop_search_maximum_distance=float(d["cfg_loop_search_maximum_distance"]))
+    gm = api.ScanMatcher(ctx, api.baseline_config(range_threshold=float(d["range_threshold"])),
+                         api.laser_params(laser, float(d["range_threshold"])))
+    return gm, api.FrontEnd(gm, config=cfg)
+
+
+def test_closed_loop_trajectory_reproduces_reference_graph(ctx):
+    """Mapper::Process WITH its pose graph on a trajectory that revisits (golden vectors from karto::Mapper itself):
+    LinkNearChains' extra matches enter the weighted mean, TryCloseLoop runs the 81x81x21 loop matcher and re-poses
+    the closing scan.  Same poses (<= 1e-9), same edge count after every scan."""
+    d = np.load(G / "karto_loop_golden.npz")
+    laser = synth.Laser()
+    gm, fe = _loop_frontend(ctx, d, laser)
+    for i, (r, o) in enumerate(zip(d["ranges"], d["odom"])):
+        ok, pose, _, _ = fe.Process(r.astype(np.float64), o)
+        assert ok == bool(d["processed"][i])
+        assert np.abs(pose - d["corrected"][i]).max() <= 1e-9, (i, pose, d["corrected"][i])
+        assert fe.stats()["edges"] == int(d["edges"][i]), i
+    st = fe.stats()
+    assert st["chain_matches"] > 0 and st["loop_coarse_matches"] > 0 and st["loops_closed"] > 0, st
+    final = np.stack([fe.scan_pose(i) for i in range(fe.num_scans())])
+    assert np.abs(final - d["final_poses"]).max() <= 1e-9
+    # the loop is worth closing: raw odometry has drifted by more than the corrected poses
+    assert np.hypot(*(final[-1][:2] - d["truth"][-1][:2])) < 0.1 < np.hypot(*(d["odom"][-1][:2] - d["truth"][-1][:2]))
+
+
+def test_closed_loop_against_reference_live(ctx, oracle_lib):
+    """Same, on a different trajectory, against the reference's own Mapper running beside it (oracle/_ref travels to
+    the GPU box) with the lesson6 yaml's graph distances."""
+    if not oracle_lib.have_ref():
+        pytest.skip("oracle/_ref not built")
+    laser = synth.Laser()
+    world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=5)
+    path = synth.loop_trajectory(260, w=8.0, h=5.0, step=0.2, origin=(-4.0, -2.5))
+    odom = synth.drifting_odometry(path, scale=1.03, seed=9)
+    kw = dict(scan_buffer_size=25, scan_buffer_max_scan_distance=6.0, do_loop_closing=1, link_scan_maximum_distance=1.5,
+              loop_search_maximum_distance=3.0, loop_match_minimum_chain_size=8)
+    ref = oracle_lib.RefKarto(oracle_lib.default_cfg(**kw), oracle_lib.laser_struct(laser, 20.0))
+    gm = api.ScanMatcher(ctx, api.baseline_config(range_threshold=20.0), api.laser_params(laser, 20.0))
+    fe = api.FrontEnd(gm, config=api.frontend_config(
+        scan_buffer_size=25, scan_buffer_maximum_scan_distance=6.0, do_loop_closing=1, link_scan_maximum_distance=1.5,
+        loop_search_maximum_distance=3.0, loop_match_minimum_chain_size=8))
+    worst = 0.0
+    for i, (t, o) in enumerate(zip(path, odom)):
+        r = synth.ranges_to_f64(synth.cast_scan(world, t, laser, 0.01, 0.01, np.random.default_rng([43, i])))
+        ok_c, pose_c = ref.process(r, o)
+        ok_g, pose_g, _, _ = fe.Process(r, o)
+        assert ok_c == ok_g
+        worst = max(worst, float(np.abs(pose_c - pose_g).max()))
+        assert worst <= 1e-9, (i, pose_c, pose_g)
+        assert ref.graph_stats()[1] == fe.stats()["edges"], i
+    assert fe.stats()["loops_closed"] > 0
+    print("closed-loop run vs the reference's Mapper: max pose difference", worst, fe.stats())
+
+
+def test_rejected_scan_reports_identity_covariance(ctx):
+    laser = synth.Laser()
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
+    fe = api.FrontEnd(gm)
+    world = synth.square_room(10.0)
+    r = synth.ranges_to_f64(synth.cast_scan(world, (0, 0, 0), laser))
+    assert fe.Process(r, (0.0, 0.0, 0.0))[0]
+    ok, pose, cov, resp = fe.Process(r, (0.01, 0.0, 0.0))  # has not moved enough (Mapper.cpp:2028-2031)
+    assert not ok and np.array_equal(cov, np.eye(3)) and resp == 0.0
+    ok, _, _, _ = fe.Process(r, (0.01, 0.0, 0.0), time_s=4000.0)  # MinimumTimeInterval (3600 s) has passed
+    assert ok
