@@ -174,6 +174,86 @@ def loop_trajectory(n: int, w: float = 10.0, h: float = 6.0, step: float = 0.25,
     return out
 
 
+def _ring_point(a: float, r: float, s: float):
+    """Point + heading at arc length s on a rounded square of half-size a (corner radius r), counter-clockwise from
+    (a, 0) heading +y."""
+    side, arc = 2.0 * (a - r), 0.5 * math.pi * r
+    per = 4.0 * (side + arc)
+    s = (s + 0.5 * side) % per  # measure from the start of the right-hand straight, (a, -(a - r))
+    corners = [(a - r, a - r), (-(a - r), a - r), (-(a - r), -(a - r)), (a - r, -(a - r))]
+    starts = [(a, -(a - r), 0.5 * math.pi), (a - r, a, math.pi), (-a, a - r, -0.5 * math.pi), (-(a - r), -a, 0.0)]
+    for k in range(4):
+        if s < side:
+            x0, y0, th = starts[k]
+            return x0 + s * math.cos(th), y0 + s * math.sin(th), th
+        s -= side
+        if s < arc:
+            cx, cy = corners[k]
+            th0 = starts[k][2]
+            phi = s / r
+            return cx + r * math.cos(th0 - 0.5 * math.pi + phi), cy + r * math.sin(th0 - 0.5 * math.pi + phi), th0 + phi
+        s -= arc
+    raise AssertionError
+
+
+def rings_trajectory(n: int, half_sizes=(44.0, 38.0, 32.0, 26.0, 20.0), laps: int = 2, radius: float = 3.0,
+                     step: float = 0.25, change_len: float = 12.0) -> np.ndarray:
+    """SURVEY.md §8(d) cfg 5: n poses, 0.25 m / <= 5 deg steps, CLOSED LOOPS inside a 100 m x 100 m arena -- concentric
+    rounded squares, each driven `laps` times (every place is revisited: near chains and loop closures), joined by
+    smooth lane changes on the right-hand straight."""
+    out = []
+    k, s, done, shifting = 0, 0.0, 0.0, False
+    a = half_sizes[0]
+    per = lambda aa: 4.0 * (2.0 * (aa - radius) + 0.5 * math.pi * radius)  # noqa: E731
+    while len(out) < n:
+        if not shifting:
+            x, y, th = _ring_point(a, radius, s)
+            out.append((x, y, math.atan2(math.sin(th), math.cos(th))))
+            s += step
+            done += step
+            if done >= laps * per(a) - 1e-9:
+                k += 1
+                if k >= len(half_sizes):
+                    k = 0  # start over on the outermost ring (a jump-free restart is not needed: n ends first)
+                    break
+                shifting, s, done = True, done - laps * per(a), 0.0  # carry the overshoot past (a, 0): no seam
+        else:  # lane change from ring a to half_sizes[k] while driving +y on the right-hand straight
+            a2 = half_sizes[k]
+            t = s / change_len
+            x = a + (a2 - a) * (3 * t * t - 2 * t * t * t)
+            dxdy = (a2 - a) * (6 * t - 6 * t * t) / change_len
+            out.append((x, s, math.atan2(1.0, dxdy)))
+            s += step
+            if s >= change_len - 1e-9:
+                a, shifting = a2, False
+                done = s  # arc length already covered on the new ring, measured from (a2, 0): its laps end there again
+    while len(out) < n:  # more poses than the rings hold: keep circling the last ring
+        x, y, th = _ring_point(a, radius, s)
+        out.append((x, y, math.atan2(math.sin(th), math.cos(th))))
+        s += step
+    return np.asarray(out[:n])
+
+
+def arena_around_path(path: np.ndarray, size: float = 100.0, n_axis: int = 30, n_rot: int = 10, seed: int = 6,
+                      clearance: float = 1.5) -> np.ndarray:
+    """arena() whose boxes keep `clearance` from every pose of `path` (rejection sampling)."""
+    rng = np.random.default_rng(seed)
+    h = size / 2
+    segs = _rect_segments(0.0, 0.0, size, size, 0.0)
+    px, py = path[::2, 0], path[::2, 1]
+    placed = 0
+    while placed < n_axis + n_rot:
+        w, hh = rng.uniform(1.0, 5.0, size=2)
+        cx, cy = rng.uniform(-h + 3.0, h - 3.0, size=2)
+        th = 0.0 if placed < n_axis else rng.uniform(0.0, math.pi)
+        reach = 0.5 * math.hypot(w, hh) + clearance
+        if ((px - cx) ** 2 + (py - cy) ** 2).min() < reach * reach:
+            continue
+        segs += _rect_segments(cx, cy, w, hh, th)
+        placed += 1
+    return np.asarray(segs, dtype=np.float64)
+
+
 def drifting_odometry(path: np.ndarray, scale: float = 1.02, sigma_xy: float = 0.005, sigma_th: float = 0.002,
                       seed: int = 7) -> np.ndarray:
     """Dead-reckoned odometry for `path`: every increment is re-expressed in the drifting frame, stretched by `scale`
