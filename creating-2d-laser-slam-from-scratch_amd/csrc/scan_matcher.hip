@@ -1360,17 +1360,21 @@ k_resp_dense(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1,
 // Reduce of a large coarse lattice (block per scan, global scratch instead of LDS): same steps as
 // k_reduce_coarse.  scratch per scan: latmax[ncand] | probs[side^2] (as uint64 bit patterns: all
 // responses are >= 0, so unsigned integer max == double max) | terms[4*ncand] | mask words
-__global__ void __launch_bounds__(256)
+// NT threads per block: 256 for batches (one block per scan, many scans in flight), 1024 for a handful of scans
+// (TryCloseLoop's single coarse match: the block is the only parallelism there is)
+template <int NT>
+__global__ void __launch_bounds__(NT)
 k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ lat,
                     int32_t* resp, size_t resp_stride, CoarseOut* __restrict__ out,
                     int use_expansion, int pass_index, double* __restrict__ scratch, size_t scratch_stride,
                     const uint8_t* __restrict__ grid, const double2* __restrict__ local, int fb_step) {
   constexpr int kList = 2048;
-  __shared__ double sh[256];
-  __shared__ double chunk[4 * 256];
+  __shared__ double sh[NT];
+  __shared__ double chunk[4 * NT];
   __shared__ int s_list[kList];
   __shared__ int s_nlist, s_status;
   __shared__ double s_avg[3];
+  __shared__ unsigned long long s_bal[NT / 64];
   const int s = blockIdx.x, tid = threadIdx.x;
   const Lattice& L = lat[s];
   if (!L.active) return;
@@ -1378,7 +1382,7 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
     if (tid == 0) { out[s].status = L.status; out[s].expand = 0; out[s].best = 0.0; }
     return;
   }
-  block_generic_fallback(grid, g, pc, L, local + (size_t)s * g.n_beams, resp + (size_t)s * resp_stride, fb_step, tid, 256);
+  block_generic_fallback(grid, g, pc, L, local + (size_t)s * g.n_beams, resp + (size_t)s * resp_stride, fb_step, tid, NT);
   const int ncand = pc.nx * pc.ny, total = ncand * pc.na, words = (total + 31) / 32;
   const int side2 = g.probs_side * g.probs_side;
   double* latmax = scratch + (size_t)s * scratch_stride;
@@ -1391,7 +1395,7 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
     return penalized(r[a * ncand + c], cand_of(c * pc.na + a, pc, center), center, g.n_beams, sc);
   };
   double lm = -1.0;
-  for (int c = tid; c < ncand; c += 256) {
+  for (int c = tid; c < ncand; c += NT) {
     double m = -1.0;
     for (int a = 0; a < pc.na; a++) {
       double v = value(c, a);
@@ -1400,11 +1404,11 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
     latmax[c] = m;
     lm = lm > m ? lm : m;
   }
-  for (int wd = tid; wd < words; wd += 256) mask[wd] = 0u;
-  for (int c = tid; c < side2; c += 256) probs[c] = 0ull;  // Clear (:329) (+0.0)
+  for (int wd = tid; wd < words; wd += NT) mask[wd] = 0u;
+  for (int c = tid; c < side2; c += NT) probs[c] = 0ull;  // Clear (:329) (+0.0)
   if (tid == 0) { s_nlist = 0; s_status = 0; }
-  const double best = block_max(lm, sh, tid, 256);
-  for (int c = tid; c < ncand; c += 256) {
+  const double best = block_max(lm, sh, tid, NT);
+  for (int c = tid; c < ncand; c += NT) {
     if (latmax[c] + kTol < best) continue;  // no angle of this cell can tie
     for (int a = 0; a < pc.na; a++)
       if (double_equal(value(c, a), best)) {
@@ -1414,7 +1418,7 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
   }
   // search-space probabilities (:437-450): max-merge is order independent -> parallel integer max
   const double p_off_x = center[0] - pc.off_x, p_off_y = center[1] - pc.off_y;
-  for (int c = tid; c < ncand; c += 256) {
+  for (int c = tid; c < ncand; c += NT) {
     int xi = c % pc.nx, yi = c / pc.nx;
     double wx = center[0] + (-pc.off_x + (uint32_t)xi * pc.res_x);
     double wy = center[1] + (-pc.off_y + (uint32_t)yi * pc.res_y);
@@ -1432,7 +1436,7 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
   __threadfence();
   __syncthreads();
   // non-empty mask words, in ascending order
-  for (int wd = tid; wd < words; wd += 256)
+  for (int wd = tid; wd < words; wd += NT)
     if (mask[wd]) {
       int pos = atomicAdd(&s_nlist, 1);
       if (pos < kList) s_list[pos] = wd;
@@ -1472,7 +1476,7 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
   }
   __syncthreads();
   const double dx = s_avg[0] - center[0], dy = s_avg[1] - center[1];
-  for (int c = tid; c < ncand; c += 256) {
+  for (int c = tid; c < ncand; c += NT) {
     int xi = c % pc.nx, yi = c / pc.nx;
     double x = -pc.off_x + (uint32_t)xi * pc.res_x;
     double y = -pc.off_y + (uint32_t)yi * pc.res_y;
@@ -1484,18 +1488,24 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
     terms[4 * (size_t)c + 3] = (ksq(y - dy) * rr);
   }
   __syncthreads();
-  // ordered accumulation (:573-594): chunks of 256 cells staged in LDS, summed by one thread
+  // ordered accumulation (:573-594): chunks of NT cells staged in LDS, summed by one thread
   double axx = 0, axy = 0, ayy = 0, norm = 0;
-  for (int c0 = 0; c0 < ncand; c0 += 256) {
+  for (int c0 = 0; c0 < ncand; c0 += NT) {
     if (c0 + tid < ncand)
       for (int q = 0; q < 4; q++) chunk[4 * tid + q] = terms[4 * (size_t)(c0 + tid) + q];
+    // the cells that pass the (best - 0.1) test are few: ballot them, thread 0 walks only the set bits -- same cells,
+    // same (lattice) order, same sums as the reference's loop over all cells (:573-594)
+    const bool sel = c0 + tid < ncand && terms[4 * (size_t)(c0 + tid)] >= (best - 0.1);
+    const unsigned long long bal = __ballot(sel);
+    if ((tid & 63) == 0) s_bal[tid >> 6] = bal;
     __syncthreads();
     if (tid == 0) {
-      const int n = min(256, ncand - c0);
-      for (int i = 0; i < n; i++) {
-        double rr = chunk[4 * i];
-        if (rr >= (best - 0.1)) {
-          norm += rr;
+      for (int w = 0; w < NT / 64; w++) {
+        unsigned long long mb = s_bal[w];
+        while (mb) {
+          const int i = w * 64 + __ffsll((long long)mb) - 1;
+          mb &= mb - 1;
+          norm += chunk[4 * i];
           axx += chunk[4 * i + 1];
           axy += chunk[4 * i + 2];
           ayy += chunk[4 * i + 3];
@@ -2181,8 +2191,12 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
            (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_tbl.p);
     const int lpr = (p.nx + 15) / 16, rpw = 64 / lpr;
     const int n_tiles = (p.ny + rpw * kDenseT - 1) / (rpw * kDenseT);
+    // few scans: split the beams of one (scan, angle, tile) over up to 8 waves (integer atomics combine the slices, still
+    // exact).  Measured for ONE 101x101x21 match: 2/4/8/16/32 slices -> see DESIGN 'tried'; beyond 8 the atomics cost more
+    // than the extra waves bring (LSLAM_DENSE_SLICES overrides for experiments)
     int slices = 1;
-    while (slices < 8 && (long long)S * p.na * n_tiles * slices < 1024) slices *= 2;
+    static const int max_slices = getenv("LSLAM_DENSE_SLICES") ? atoi(getenv("LSLAM_DENSE_SLICES")) : 8;
+    while (slices < max_slices && (long long)S * p.na * n_tiles * slices < 1024) slices *= 2;
     if (slices > 1)
       LSLAM_HIP(ctx, hipMemsetAsync(m->d_resp.p, 0, (size_t)S * resp_stride * sizeof(int32_t), ctx->stream));
     launch(ctx, "resp_dense", k_resp_dense, dim3((unsigned)((long long)S * p.na * n_tiles * slices)), dim3(64), 0,
@@ -2191,9 +2205,14 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     const size_t ncand = (size_t)p.nx * p.ny, total = ncand * p.na;
     const size_t stride = ncand + (size_t)g.probs_side * g.probs_side + 4 * ncand + (total + 63) / 64 + 8;  // doubles
     LSLAM_HIP(ctx, m->d_big.reserve((size_t)S * stride));
-    launch(ctx, "reduce_coarse_big", k_reduce_coarse_big, dim3(S), dim3(256), 0, g, p, sc, (const Lattice*)m->d_lat.p,
-           m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
-           m->d_big.p, stride, (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step);
+if (S <= 16)
+          launch(ctx, "reduce_coarse_big", k_reduce_coarse_big<1024>, dim3(S), dim3(1024), 0, g, p, sc, (const Lattice*)m->d_lat.p,
+             m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
+             m->d_big.p, stride, (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step);
+    else
+          launch(ctx, "reduce_coarse_big", k_reduce_coarse_big<256>, dim3(S), dim3(256), 0, g, p, sc, (const Lattice*)m->d_lat.p,
+             m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
+             m->d_big.p, stride, (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step);
     if (dbg_coarse_sums && pass_index == 0)  // after the reduce: it fills in scans the packed kernel skipped
       LSLAM_HIP(ctx, hipMemcpyAsync(dbg_coarse_sums, m->d_resp.p, (size_t)p.nx * p.ny * p.na * sizeof(int32_t),
                                     hipMemcpyDeviceToDevice, ctx->stream));

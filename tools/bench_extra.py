@@ -289,12 +289,16 @@ def loop_closure(ctx, n_queries):
     t0 = time.perf_counter()
     one = [gm.match_batch(r[i:i + 1], p[i:i + 1], doPenalize=False, doRefineMatch=False)[0] for i in range(min(16, n_queries))]
     lat_s = (time.perf_counter() - t0) / min(16, n_queries)
+    ctx.profile(True); ctx.profile_reset()
+    gm.match_batch(r[:1], p[:1], doPenalize=False, doRefineMatch=False)
+    ctx.profile(False)
+    single_prof = {k: round(v[1], 4) for k, v in sorted(ctx.profile_read().items())}
     t0 = time.perf_counter()
     res = gm.match_batch(r, p, doPenalize=False, doRefineMatch=False)
     gpu_s = time.perf_counter() - t0
     out = {"config": "loop-closure coarse match: 101x101x21 candidates x 1081 beams (231 M byte gathers per match)",
            "queries": n_queries, "gpu_batched_ms_per_match": round(1e3 * gpu_s / n_queries, 4),
-           "gpu_single_ms_per_match": round(1e3 * lat_s, 4)}
+           "gpu_single_ms_per_match": round(1e3 * lat_s, 4), "single_match_kernel_ms": single_prof}
     port = po.PortKarto(po.default_cfg(search_size=10.0), po.laser_struct(laser, 12.0))
     port.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
     k = min(4, n_queries)
