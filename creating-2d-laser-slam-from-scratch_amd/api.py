@@ -254,6 +254,15 @@ def lib() -> C.CDLL:
     L.lslam_map_cells_dev_ptr.argtypes = [vp, i32]
     L.lslam_map_update_batch.argtypes = [vp, i32, vp, vp, vp, vp]
     L.lslam_map_update_batch_dev.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.lslam_pool_create.argtypes = [i32, C.POINTER(MatcherConfig), C.POINTER(LaserParams), C.POINTER(vp)]
+    L.lslam_pool_create_on.argtypes = [vp, i32, C.POINTER(MatcherConfig), C.POINTER(LaserParams), C.POINTER(vp)]
+    L.lslam_pool_destroy.argtypes = [vp]
+    L.lslam_pool_destroy.restype = None
+    L.lslam_pool_devices.argtypes = [vp]
+    L.lslam_pool_last_error.argtypes = [vp]
+    L.lslam_pool_last_error.restype = C.c_char_p
+    L.lslam_pool_set_base_scans.argtypes = [vp, i32, vp, i32, vp, vp, i32]
+    L.lslam_pool_match_batch.argtypes = [vp, i32, vp, i32, vp, i32, i32, vp]
     L.lslam_matcher_set_option.argtypes = [vp, i32, i32]
     L.lslam_matcher_read_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     _LIB = L
@@ -496,6 +505,56 @@ class ScanMatcher:
         out = np.zeros(self.num_beams, dtype=np.uint8)
         self.ctx.check(self.L.lslam_matcher_debug_valid_mask(self.h, r.ctypes.data, p.ctypes.data, v.ctypes.data,
                                                              out.ctypes.data))
+        return out
+
+
+class MatcherPool:
+    """lslam_pool: the batched many-scan mode over several GPUs of one node from ONE process -- one matcher per device,
+    the shared grid copied device-to-device, scans [r*B/W, (r+1)*B/W) on device r, results in scan order."""
+
+    def __init__(self, cfg: MatcherConfig, laser: LaserParams, devices=0):
+        self.L = lib()
+        h = C.c_void_p()
+        if isinstance(devices, int):
+            rc = self.L.lslam_pool_create(devices, C.byref(cfg), C.byref(laser), C.byref(h))
+        else:
+            ids = np.ascontiguousarray(devices, dtype=np.int32)
+            rc = self.L.lslam_pool_create_on(ids.ctypes.data, len(ids), C.byref(cfg), C.byref(laser), C.byref(h))
+        if rc != LSLAM_OK:
+            raise LslamError(rc, self.L.lslam_pool_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lslam_pool_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != LSLAM_OK:
+            raise LslamError(rc, self.L.lslam_pool_last_error(self.h).decode())
+
+    @property
+    def devices(self) -> int:
+        return self.L.lslam_pool_devices(self.h)
+
+    def AddScans(self, base_ranges, base_sensor_poses, center_pose, rebuild_everywhere: bool = False):
+        r, p, c = _f64(base_ranges), _f64(base_sensor_poses), _f64(center_pose)
+        r = r.reshape(-1, r.shape[-1])
+        self._check(self.L.lslam_pool_set_base_scans(self.h, r.shape[0], r.ctypes.data, r.shape[1], p.ctypes.data,
+                                                     c.ctypes.data, int(rebuild_everywhere)))
+
+    def match_batch(self, ranges, sensor_poses, doPenalize: bool = True, doRefineMatch: bool = True) -> np.ndarray:
+        r, p = _f64(ranges), _f64(sensor_poses)
+        r = r.reshape(-1, r.shape[-1])
+        out = np.zeros(r.shape[0], dtype=RESULT_DTYPE)
+        self._check(self.L.lslam_pool_match_batch(self.h, r.shape[0], r.ctypes.data, r.shape[1], p.ctypes.data,
+                                                  int(doPenalize), int(doRefineMatch), out.ctypes.data))
         return out
 
 

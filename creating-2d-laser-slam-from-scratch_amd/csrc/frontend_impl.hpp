@@ -415,6 +415,7 @@ int lslam_frontend_process_stamped(lslam_frontend* f, const double* ranges, int 
   lslam_context* ctx = m->ctx;
   const int n = m->g.n_beams;
   if (n_ranges < n) return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "n_ranges %d < num_beams %d", n_ranges, n);
+  LSLAM_NOT_REENTRANT(m);  // the front-end drives its matcher's grid and workspaces
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
   const lslam_laser* laser = &m->laser;
   double corrected[3] = {odom_pose[0], odom_pose[1], odom_pose[2]};

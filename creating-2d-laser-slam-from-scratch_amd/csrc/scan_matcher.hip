@@ -23,7 +23,9 @@
 // Response numerators stay integers end to end (sum of uint8 <= 255*N); the fp64 part follows
 // the reference's expression order (built with -ffp-contract=off).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -1952,6 +1954,11 @@ struct lslam_matcher {
   uint8_t* d_sub[2] = {nullptr, nullptr};
   bool sub_dirty = true;            // the planes lag behind d_grid
   bool occ_dirty = true;            // so does the row-occupancy bitmap (built on demand: not for tiny batches)
+  // One grid, one set of workspaces per instance -- like the reference's ScanMatcher (Mapper.h:1273-1278) this object
+  // is NOT re-entrant: a second caller (another host thread, or the same matcher driven on a second stream) would
+  // grow / free the shared workspaces (DevBuf::reserve) under kernels still in flight -- the memory fault of round 1's
+  // two-stream experiment.  The core entry points take this flag and refuse to overlap instead.
+  std::atomic<bool> busy{false};
   bool use_row_occupancy = true;    // lslam_matcher_set_option(LSLAM_OPT_ROW_OCCUPANCY)
   bool collect_stats = false;       // lslam_matcher_set_option(LSLAM_OPT_COLLECT_STATS): instrumented coarse kernel
   DevBuf<unsigned long long> d_stats;
@@ -1985,6 +1992,20 @@ struct lslam_matcher {
 };
 
 namespace {
+
+struct BusyGuard {
+  lslam_matcher* m;
+  bool ok;
+  explicit BusyGuard(lslam_matcher* mm) : m(mm), ok(!mm->busy.exchange(true)) {}
+  ~BusyGuard() {
+    if (ok) m->busy.store(false);
+  }
+};
+#define LSLAM_NOT_REENTRANT(m)                                                                                   \
+  BusyGuard busy_guard(m);                                                                                       \
+  if (!busy_guard.ok)                                                                                            \
+    return (m)->ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "matcher used concurrently: a ScanMatcher instance is not " \
+                                                      "re-entrant (one grid + one set of workspaces, Mapper.h:1273-1278)")
 
 int n_angles_of(double off, double res) { return lattice_count(off, res); }
 
@@ -2563,6 +2584,7 @@ int lslam_matcher_read_stats(lslam_matcher* m, uint64_t out[4]) {
 int lslam_matcher_set_base_scans(lslam_matcher* m, int B, const double* ranges, int stride,
                                  const double* sensor_poses, const double center[3]) {
   if (!m || !center || B < 0 || (B > 0 && (!ranges || !sensor_poses))) return LSLAM_ERR_INVALID_ARGUMENT;
+  LSLAM_NOT_REENTRANT(m);
   lslam_context* ctx = m->ctx;
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
   const Geom& g = m->g;
@@ -2584,6 +2606,7 @@ int lslam_matcher_match_batch(lslam_matcher* m, int S, const double* ranges, int
                               int do_penalize, int do_refine, lslam_match_result* out) {
   if (!m || S < 0 || (S > 0 && (!ranges || !poses || !out))) return LSLAM_ERR_INVALID_ARGUMENT;
   if (S == 0) return LSLAM_OK;
+  LSLAM_NOT_REENTRANT(m);
   lslam_context* ctx = m->ctx;
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
   int rc = upload_scans(m, S, ranges, stride, poses);
@@ -2603,6 +2626,7 @@ int lslam_matcher_match_batch_dev_f32(lslam_matcher* m, int S, const float* rang
                                       lslam_match_result* out_dev) {
   if (!m || S < 0 || (S > 0 && (!ranges_dev || !poses_dev || !out_dev))) return LSLAM_ERR_INVALID_ARGUMENT;
   if (stride < m->g.n_beams) return m->ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "ranges_stride < num_beams");
+  LSLAM_NOT_REENTRANT(m);
   return match_batch_impl<float>(m, S, ranges_dev, stride, poses_dev, do_penalize, do_refine, out_dev, nullptr, 0);
 }
 
@@ -2611,6 +2635,7 @@ int lslam_matcher_match_batch_dev_f64(lslam_matcher* m, int S, const double* ran
                                       lslam_match_result* out_dev) {
   if (!m || S < 0 || (S > 0 && (!ranges_dev || !poses_dev || !out_dev))) return LSLAM_ERR_INVALID_ARGUMENT;
   if (stride < m->g.n_beams) return m->ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "ranges_stride < num_beams");
+  LSLAM_NOT_REENTRANT(m);
   return match_batch_impl<double>(m, S, ranges_dev, stride, poses_dev, do_penalize, do_refine, out_dev, nullptr, 0);
 }
 

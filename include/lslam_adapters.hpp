@@ -10,6 +10,7 @@
 // few lines that convert karto::LocalizedRangeScan / hectorslam::DataContainer to these PODs.
 #pragma once
 
+#include <algorithm>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -180,6 +181,46 @@ class GpuFrontEnd {
  private:
   lslam_context* ctx_;
   lslam_frontend* h_ = nullptr;
+};
+
+// Batched many-scan mode over every GPU of the node (one process): scans sharded [r*B/W, (r+1)*B/W), shared grid
+// replicated over xGMI, results in scan order
+class GpuMatcherPool {
+ public:
+  GpuMatcherPool(int nDevices, const lslam_matcher_config& cfg, const lslam_laser& laser) {
+    int rc = lslam_pool_create(nDevices, &cfg, &laser, &h_);
+    if (rc != LSLAM_OK) throw std::runtime_error(lslam_pool_last_error(nullptr));
+  }
+  GpuMatcherPool(const std::vector<int>& devices, const lslam_matcher_config& cfg, const lslam_laser& laser) {
+    int rc = lslam_pool_create_on(devices.data(), (int)devices.size(), &cfg, &laser, &h_);
+    if (rc != LSLAM_OK) throw std::runtime_error(lslam_pool_last_error(nullptr));
+  }
+  ~GpuMatcherPool() { lslam_pool_destroy(h_); }
+  GpuMatcherPool(const GpuMatcherPool&) = delete;
+  GpuMatcherPool& operator=(const GpuMatcherPool&) = delete;
+  int devices() const { return lslam_pool_devices(h_); }
+  // ScanMatcher::AddScans once; the grid travels device-to-device
+  void AddScans(const std::vector<RangeScan>& baseScans, int numBeams, const Pose2& center, bool rebuildEverywhere = false) {
+    std::vector<double> r(baseScans.size() * (size_t)numBeams), p(baseScans.size() * 3);
+    for (size_t i = 0; i < baseScans.size(); i++) {
+      std::copy(baseScans[i].ranges, baseScans[i].ranges + numBeams, r.begin() + i * (size_t)numBeams);
+      p[3 * i] = baseScans[i].sensor_pose.x; p[3 * i + 1] = baseScans[i].sensor_pose.y; p[3 * i + 2] = baseScans[i].sensor_pose.heading;
+    }
+    const double c[3] = {center.x, center.y, center.heading};
+    int rc = lslam_pool_set_base_scans(h_, (int)baseScans.size(), r.data(), numBeams, p.data(), c, rebuildEverywhere ? 1 : 0);
+    if (rc != LSLAM_OK) throw MatcherError(rc, lslam_pool_last_error(h_));
+  }
+  // the search part of MatchScan for n independent scans (ranges: n rows of numBeams doubles, poses: n*3)
+  std::vector<lslam_match_result> MatchBatch(const double* ranges, int numBeams, const double* sensorPoses, int n,
+                                             bool doPenalize = true, bool doRefineMatch = true) {
+    std::vector<lslam_match_result> out((size_t)n);
+    int rc = lslam_pool_match_batch(h_, n, ranges, numBeams, sensorPoses, doPenalize, doRefineMatch, out.data());
+    if (rc != LSLAM_OK) throw MatcherError(rc, lslam_pool_last_error(h_));
+    return out;
+  }
+
+ private:
+  lslam_pool* h_ = nullptr;
 };
 
 // hectorslam::MapRepresentationInterface on the GPU: matchData + updateByScan

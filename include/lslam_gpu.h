@@ -211,6 +211,30 @@ int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges,
                                    uint8_t* out_host);
 
 /* ---------------------------------------------------------------------------------------- */
+/* Batched many-scan mode across the GPUs of one node, one host process:     */
+/* one context + matcher per device, the shared grid replicated device-to-device over xGMI,   */
+/* scans [r*B/W, (r+1)*B/W) matched on device r, results in scan order.  No collective: the   */
+/* units are independent.  (bench.py is the one-process-per-GPU form with RCCL.)              */
+/* ---------------------------------------------------------------------------------------- */
+typedef struct lslam_pool lslam_pool;
+/* n_devices = 0: every visible GPU; more than are visible -> LSLAM_ERR_INVALID_ARGUMENT */
+int lslam_pool_create(int n_devices, const lslam_matcher_config* cfg, const lslam_laser* laser, lslam_pool** out);
+/* explicit device ordinals (repeats allowed: several contexts on one GPU, which is how the 1-GPU tests shard) */
+int lslam_pool_create_on(const int* devices, int n_devices, const lslam_matcher_config* cfg, const lslam_laser* laser,
+                         lslam_pool** out);
+void lslam_pool_destroy(lslam_pool* pool);
+int lslam_pool_devices(const lslam_pool* pool);
+lslam_matcher* lslam_pool_matcher(lslam_pool* pool, int i); /* borrowed */
+const char* lslam_pool_last_error(const lslam_pool* pool);
+/* lslam_matcher_set_base_scans on the first device, then the 4 MB grid goes to the others by hipMemcpyPeerAsync
+ * (replicate_by_rebuild = 0) or every device rasterises the same base scans itself (!= 0) */
+int lslam_pool_set_base_scans(lslam_pool* pool, int n_scans, const double* ranges, int ranges_stride,
+                              const double* sensor_poses, const double center_pose[3], int replicate_by_rebuild);
+/* lslam_matcher_match_batch over the whole pool; out[n_scans] in scan order */
+int lslam_pool_match_batch(lslam_pool* pool, int n_scans, const double* ranges, int ranges_stride,
+                           const double* sensor_poses, int do_penalize, int do_refine, lslam_match_result* out);
+
+/* ---------------------------------------------------------------------------------------- */
 /* Streaming front-end: karto::Mapper::Process (Mapper.cpp:1999-2079) with every processed scan  */
 /* resident in HBM (replaces Mapper::Process as karto_slam.cc:444 calls it; the pose graph's    */
 /* matches run on the device, its bookkeeping on the host, the optional solver stays outside)   */

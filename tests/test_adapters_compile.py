@@ -44,6 +44,35 @@ int main(int argc, char**) {
     for (float v : lo) nz += v != 0.f;
     std::printf("nonzero cells %d\n", nz);
   }
+  // the batched many-scan mode over every GPU of the node (hipGetDeviceCount() devices), and -- so that the sharding
+  // is exercised on a 1-GPU box too -- over two contexts on device 0: both must equal the single-matcher results
+  {
+    const int S = 37;
+    std::vector<double> rr((size_t)S * 360), pp((size_t)S * 3);
+    for (int i = 0; i < S; i++) {
+      for (int k = 0; k < 360; k++) rr[(size_t)i * 360 + k] = b[k];
+      pp[3 * i] = 0.05 + 0.004 * i; pp[3 * i + 1] = 0.003 * i - 0.05; pp[3 * i + 2] = 0.002 * i - 0.03;
+    }
+    const double zero[3] = {0, 0, 0};
+    std::vector<lslam_match_result> one(S);
+    if (lslam_matcher_set_base_scans(m->handle(), 1, a.data(), 360, zero, zero) != LSLAM_OK) return 5;
+    if (lslam_matcher_match_batch(m->handle(), S, rr.data(), 360, pp.data(), 1, 1, one.data()) != LSLAM_OK) return 5;
+    lslam::GpuMatcherPool all(0, cfg, laser);
+    lslam::GpuMatcherPool two(std::vector<int>{0, 0}, cfg, laser);
+    std::printf("pool devices %d / %d\n", all.devices(), two.devices());
+    lslam::GpuMatcherPool* pools[2] = {&all, &two};
+    for (int rebuild = 0; rebuild < 2; rebuild++)
+      for (auto* pool : pools) {
+        pool->AddScans({base}, 360, lslam::Pose2{0, 0, 0}, rebuild != 0);
+        std::vector<lslam_match_result> got = pool->MatchBatch(rr.data(), 360, pp.data(), S);
+        for (int i = 0; i < S; i++)
+          if (std::memcmp(&got[i], &one[i], sizeof(lslam_match_result)) != 0) { std::printf("pool mismatch at %d\n", i); return 6; }
+      }
+    bool threw = false;
+    try { lslam::GpuMatcherPool toomany(all.devices() + 1, cfg, laser); } catch (const std::exception&) { threw = true; }
+    if (!threw) return 7;
+    std::printf("pool ok\n");
+  }
   delete m;
   lslam_destroy(ctx);
   return nz == 71 ? 0 : 4;
@@ -72,4 +101,4 @@ def test_adapters_run_on_gpu(tmp_path):
     exe = _build(tmp_path)
     r = subprocess.run([str(exe), "need-gpu"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "response" in r.stdout and "nonzero cells 71" in r.stdout
+    assert "response" in r.stdout and "nonzero cells 71" in r.stdout and "pool ok" in r.stdout

@@ -143,3 +143,73 @@ def test_many_beam_laser(ctx, oracle_lib):
         assert abs(small["response"][q] - resp) <= 1e-12
     big = gm.match_batch(np.tile(wl.query_ranges, (17, 1)), np.tile(wl.query_poses, (17, 1)))  # 204 scans
     assert big.tobytes() == np.tile(small, 17).tobytes()
+
+
+def test_matcher_pool_shards_like_one_matcher(ctx, workload_spread):
+    """lslam_pool (C++ host, one process): scans sharded [r*B/W, (r+1)*B/W) over the pool's matchers, grid replicated
+    device-to-device (or rebuilt everywhere); byte-identical to one matcher.  On the 1-GPU box the pool holds three
+    contexts on device 0; `devices=0` takes every visible GPU."""
+    wl = workload_spread
+    cfg, lp = api.baseline_config(), api.laser_params(wl.laser)
+    gm = api.ScanMatcher(ctx, cfg, lp)
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    want = gm.match_batch(wl.query_ranges, wl.query_poses)
+    for devices, rebuild in (([0, 0, 0], False), ([0, 0], True), (0, False)):
+        pool = api.MatcherPool(cfg, lp, devices)
+        assert pool.devices == (len(devices) if isinstance(devices, list) else pool.devices) >= 1
+        pool.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose, rebuild_everywhere=rebuild)
+        got = pool.match_batch(wl.query_ranges, wl.query_poses)
+        assert got.tobytes() == want.tobytes()
+        assert pool.match_batch(wl.query_ranges[:0], wl.query_poses[:0]).shape == (0,)
+        pool.close()
+    with pytest.raises(api.LslamError):
+        api.MatcherPool(cfg, lp, 99)
+
+
+def test_two_matchers_one_context_interleaved(ctx, workload):
+    """The sequential and the loop matcher of karto::Mapper (Mapper.cpp:1964-1968, 862-871) are two ScanMatcher instances
+    living side by side: two lslam_matcher handles on ONE context, used alternately, keep their own grids and scratch."""
+    wl = workload
+    a = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(wl.laser))
+    b = api.ScanMatcher(ctx, api.baseline_config(search_size=4.0), api.laser_params(wl.laser))
+    a.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    b.AddScans(wl.base_ranges[:10], wl.base_poses[:10], wl.center_pose)
+    ra0 = a.match_batch(wl.query_ranges, wl.query_poses)
+    rb0 = b.match_batch(wl.query_ranges[:3], wl.query_poses[:3], doPenalize=False, doRefineMatch=False)
+    for _ in range(3):
+        rb = b.match_batch(wl.query_ranges[:3], wl.query_poses[:3], doPenalize=False, doRefineMatch=False)
+        ra = a.match_batch(wl.query_ranges, wl.query_poses)
+        assert ra.tobytes() == ra0.tobytes() and rb.tobytes() == rb0.tobytes()
+
+
+def test_concurrent_use_of_one_matcher_is_refused_not_corrupted(ctx, workload_spread):
+    """A ScanMatcher instance is not re-entrant (its grid and workspaces are shared state, Mapper.h:1273-1278).  Two host
+    threads hammering ONE matcher must each get either a correct result or LSLAM_ERR_INVALID_ARGUMENT -- never a wrong
+    result or a memory fault (round 1's two-stream experiment grew the shared workspaces under running kernels)."""
+    import threading
+
+    wl = workload_spread
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(wl.laser))
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    want = [gm.match_batch(wl.query_ranges[:k], wl.query_poses[:k]).tobytes() for k in (7, 40)]
+    outcome = {"ok": 0, "refused": 0, "wrong": 0}
+    lock = threading.Lock()
+
+    def worker(which):
+        k = (7, 40)[which]
+        for _ in range(40):
+            try:
+                got = gm.match_batch(wl.query_ranges[:k], wl.query_poses[:k]).tobytes()
+                key = "ok" if got == want[which] else "wrong"
+            except api.LslamError as e:
+                key = "refused" if e.code == -1 else "wrong"
+            with lock:
+                outcome[key] += 1
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert outcome["wrong"] == 0 and outcome["ok"] > 0, outcome
+    assert gm.match_batch(wl.query_ranges[:7], wl.query_poses[:7]).tobytes() == want[0]  # still healthy afterwards
