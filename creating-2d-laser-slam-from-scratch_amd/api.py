@@ -128,6 +128,22 @@ def frontend_config(**kw) -> FrontEndConfig:
     return c
 
 
+class HectorScan(C.Structure):
+    """lslam_hector_scan: LaserScan header + the node's filters + the base_link -> laser transform."""
+
+    _fields_ = [(k, C.c_float) for k in (
+        "angle_min", "angle_increment", "range_min", "range_max", "range_cutoff", "sqr_laser_min_dist",
+        "sqr_laser_max_dist", "use_max_scan_range", "laser_z_min", "laser_z_max", "laser_x", "laser_y", "laser_z",
+        "laser_yaw")]
+
+
+def hector_scan(laser, min_dist=0.4, max_dist=30.0, use_max=20.0, cutoff=30.0, z_min=-1.0, z_max=1.0,
+                laser_pose=(0.0, 0.0, 0.0, 0.0)) -> HectorScan:
+    """The hector_slam node's parameters (hector_slam.cc:40-75, 193) for a synth.Laser."""
+    return HectorScan(laser.angle_min, laser.angle_increment, laser.range_min, laser.range_max, cutoff,
+                      min_dist * min_dist, max_dist * max_dist, use_max, z_min, z_max, *laser_pose)
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("total_ms", C.c_double)]
 
@@ -252,6 +268,10 @@ def lib() -> C.CDLL:
     L.lslam_map_read_occupancy_i8.argtypes = [vp, i32, vp]
     L.lslam_map_cells_dev_ptr.restype = vp
     L.lslam_map_cells_dev_ptr.argtypes = [vp, i32]
+    L.lslam_map_set_scan.argtypes = [vp, vp, i32, C.POINTER(HectorScan), C.POINTER(i32)]
+    L.lslam_map_read_container.argtypes = [vp, vp, i32, vp]
+    L.lslam_map_match_container.argtypes = [vp, vp, vp, vp]
+    L.lslam_map_update_by_container.argtypes = [vp, vp]
     L.lslam_map_update_batch.argtypes = [vp, i32, vp, vp, vp, vp]
     L.lslam_map_update_batch_dev.argtypes = [vp, i32, vp, vp, vp, vp]
     L.lslam_pool_create.argtypes = [i32, C.POINTER(MatcherConfig), C.POINTER(LaserParams), C.POINTER(vp)]
@@ -717,6 +737,32 @@ class OccGridMap:
         o = np.ascontiguousarray(origo_xy, dtype=np.float32)
         w = np.ascontiguousarray(robot_pose_world, dtype=np.float32)
         self.ctx.check(self.L.lslam_map_update_by_scan_dev(self.h, points_ptr, n, o.ctypes.data, w.ctypes.data))
+
+    def setScan(self, ranges_f32, scan: HectorScan) -> int:
+        """LaserScan -> DataContainer on the device (hector_slam.cc:193, 320-362); returns the container size."""
+        r = np.ascontiguousarray(ranges_f32, dtype=np.float32)
+        n = C.c_int32()
+        self.ctx.check(self.L.lslam_map_set_scan(self.h, r.ctypes.data, r.shape[0], C.byref(scan), C.byref(n)))
+        return n.value
+
+    def container(self):
+        """-> (points [n,2] float32, origo [2]) of the resident container."""
+        origo = np.zeros(2, np.float32)
+        n = self.L.lslam_map_read_container(self.h, None, 0, origo.ctypes.data)
+        pts = np.zeros((max(n, 0), 2), np.float32)
+        if n > 0:
+            self.L.lslam_map_read_container(self.h, pts.ctypes.data, n, origo.ctypes.data)
+        return pts, origo
+
+    def matchContainer(self, begin_estimate_world):
+        b = np.ascontiguousarray(begin_estimate_world, dtype=np.float32)
+        pose, cov = np.zeros(3, dtype=np.float32), np.zeros(9, dtype=np.float32)
+        self.ctx.check(self.L.lslam_map_match_container(self.h, b.ctypes.data, pose.ctypes.data, cov.ctypes.data))
+        return pose, cov.reshape(3, 3)
+
+    def updateByContainer(self, robot_pose_world):
+        w = np.ascontiguousarray(robot_pose_world, dtype=np.float32)
+        self.ctx.check(self.L.lslam_map_update_by_container(self.h, w.ctypes.data))
 
     def updateByScans(self, points_list, origos_xy, robot_poses_world):
         """Batched update: exactly len(points_list) successive updateByScan calls (every level fed the same scan),

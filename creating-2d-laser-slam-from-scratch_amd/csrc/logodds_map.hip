@@ -350,6 +350,80 @@ k_lo_batch_apply(BatchGeom g, const uint8_t* __restrict__ planes, float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// LaserScan -> Hector DataContainer on the device: what HectorMappingRos::scanCallback does
+// before the map sees a scan -- laser_geometry's projectLaser(scan, cloud, 30.0) (hector_slam.cc:193) and
+// rosPointCloudToDataContainer (hector_slam.cc:320-362).  One block; order-preserving compaction (the container
+// keeps the beams' order, which the once-per-scan cell rule depends on).
+//   projection   p = (double)r * (cos, sin)(angle_min + i * angle_increment), cast to float32 -- the cos/sin table is
+//                built on the HOST once per scan geometry and cached, exactly as laser_geometry caches its
+//                co_sine_map_: the device multiplies, it never evaluates a trigonometric function here
+//   filters      r < cutoff && r >= range_min;  min_dist^2 < d2 < max_dist^2;  !(x < 0 && d2 < 0.5);
+//                d2 <= use_max^2;  z window of the laser frame (hector_slam.cc:336-354)
+//   transform    base_link <- laser (planar: yaw + translation), tf's double arithmetic, then float32 * scaleToMap
+// ------------------------------------------------------------------------------------------
+struct ProjectCfg {
+  int n;
+  float range_min, cutoff, sqr_min, sqr_max;
+  double use_max_sq;
+  float z_min, z_max;
+  double cy, sy, tx, ty, tz;  // base_link -> laser transform: rotation about z (host cos/sin) + origin
+  float scale_to_map;
+};
+
+__global__ void __launch_bounds__(1024)
+k_hector_project(ProjectCfg c, const float* __restrict__ ranges, const double2* __restrict__ cossin,
+                 float* __restrict__ out_xy, int* __restrict__ out_n) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < c.n; i0 += 1024) {
+    const int i = i0 + tid;
+    bool keep = false;
+    float ox = 0.f, oy = 0.f;
+    if (i < c.n) {
+      const float r = ranges[i];
+      if (r < c.cutoff && r >= c.range_min) {  // laser_geometry::projectLaser_ (NaN fails both)
+        const double2 cs = cossin[i];
+        const float x = (float)((double)r * cs.x), y = (float)((double)r * cs.y);  // sensor_msgs/PointCloud: float32
+        const float d2 = x * x + y * y;                                            // hector_slam.cc:336
+        if (d2 > c.sqr_min && d2 < c.sqr_max && !(x < 0.0f && d2 < 0.50f) && !((double)d2 > c.use_max_sq)) {
+          // tf::Transform * tf::Vector3 in double (:349): row . v, then + origin
+          const double bx = (c.cy * (double)x + (-c.sy) * (double)y + 0.0 * 0.0) + c.tx;
+          const double by = (c.sy * (double)x + c.cy * (double)y + 0.0 * 0.0) + c.ty;
+          const double bz = (0.0 * (double)x + 0.0 * (double)y + 1.0 * 0.0) + c.tz;
+          const float zl = (float)(bz - c.tz);  // pointPosLaserFrameZ (:352)
+          if (zl > c.z_min && zl < c.z_max) {
+            keep = true;
+            ox = (float)bx * c.scale_to_map;  // Eigen::Vector2f(x, y) * scaleToMap (:357)
+            oy = (float)by * c.scale_to_map;
+          }
+        }
+      }
+    }
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) s_wave[wv] = __popcll(bal);
+    __syncthreads();
+    int before = s_base;
+    for (int w = 0; w < wv; w++) before += s_wave[w];
+    if (keep) {
+      const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+      out_xy[2 * pos] = ox;
+      out_xy[2 * pos + 1] = oy;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+      for (int w = 0; w < 16; w++) tot += s_wave[w];
+      s_base += tot;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *out_n = s_base;
+}
+
 __global__ void k_occupancy_i8(const float* __restrict__ v, int8_t* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -520,6 +594,14 @@ struct lslam_map {
   int n_cached = 0;
   float cached_origo[2] = {0.f, 0.f};
   DevBuf<float> d_gn_out;
+  // resident container of lslam_map_set_scan (device-side LaserScan -> DataContainer)
+  DevBuf<float> d_scan;         // projected points, then one int: their count
+  DevBuf<float> d_scan_ranges;
+  DevBuf<double2> d_cossin;     // laser_geometry's co_sine_map_, host-built, cached per scan geometry
+  float cs_angle_min = 0.f, cs_angle_inc = 0.f;
+  int cs_n = 0;
+  int n_scan = 0;
+  float scan_origo[2] = {0.f, 0.f};
   DevBuf<uint32_t> d_hash;      // [3][K][slots]: key, first hit beam, first crossing beam
   DevBuf<ScanHdr> d_hdr;
   DevBuf<int8_t> d_i8;
@@ -668,6 +750,9 @@ void lslam_map_destroy(lslam_map* map) {
   map->d_gn_out.release();
   map->d_hash.release();
   map->d_hdr.release();
+  map->d_scan.release();
+  map->d_scan_ranges.release();
+  map->d_cossin.release();
   map->d_i8.release();
   if (map->h_stage) (void)hipHostFree(map->h_stage);
   for (auto e : map->stage_ev)
@@ -896,6 +981,74 @@ int lslam_map_update_batch(lslam_map* map, int n_scans, const float* points_xy, 
   return lslam_map_update_batch_dev(map, n_scans, map->d_pts.p, n_points, origos_xy, poses_world);
 }
 
+int lslam_map_set_scan(lslam_map* map, const float* ranges, int n, const lslam_hector_scan* sp, int* n_points) {
+  if (!map || n < 0 || (n > 0 && !ranges) || !sp) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = map->ctx;
+  if (n > kMaxBeams) return ctx->fail(LSLAM_ERR_UNSUPPORTED, "at most %d readings per scan (got %d)", kMaxBeams, n);
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  LSLAM_HIP(ctx, map->d_scan.reserve((size_t)2 * std::max(n, 1) + 4));
+  LSLAM_HIP(ctx, map->d_scan_ranges.reserve((size_t)std::max(n, 1)));
+  if (n > map->cs_n || sp->angle_min != map->cs_angle_min || sp->angle_increment != map->cs_angle_inc) {
+    // laser_geometry's co_sine_map_ (rebuilt when the scan geometry changes): host libm, like the reference's stack
+    std::vector<double2> cs((size_t)std::max(n, 1));
+    for (int i = 0; i < n; i++) {
+      const double a = (double)sp->angle_min + (double)i * (double)sp->angle_increment;
+      cs[i] = make_double2(cos(a), sin(a));
+    }
+    LSLAM_HIP(ctx, map->d_cossin.reserve(cs.size()));
+    LSLAM_HIP(ctx, hipMemcpyAsync(map->d_cossin.p, cs.data(), cs.size() * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+    LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // cs dies with this scope
+    map->cs_n = n;
+    map->cs_angle_min = sp->angle_min;
+    map->cs_angle_inc = sp->angle_increment;
+  }
+  if (n > 0)
+    LSLAM_HIP(ctx, hipMemcpyAsync(map->d_scan_ranges.p, ranges, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  ProjectCfg c;
+  c.n = n;
+  c.range_min = sp->range_min;
+  c.cutoff = sp->range_cutoff < 0.f ? sp->range_max : sp->range_cutoff;  // laser_geometry: cutoff < 0 -> range_max
+  c.sqr_min = sp->sqr_laser_min_dist;
+  c.sqr_max = sp->sqr_laser_max_dist;
+  c.use_max_sq = (double)sp->use_max_scan_range * (double)sp->use_max_scan_range;
+  c.z_min = sp->laser_z_min;
+  c.z_max = sp->laser_z_max;
+  c.cy = cos((double)sp->laser_yaw);
+  c.sy = sin((double)sp->laser_yaw);
+  c.tx = sp->laser_x; c.ty = sp->laser_y; c.tz = sp->laser_z;
+  c.scale_to_map = map->levels[0].scale_to_map;
+  int* d_n = reinterpret_cast<int*>(map->d_scan.p + (size_t)2 * std::max(n, 1));
+  launch(ctx, "hector_project", k_hector_project, dim3(1), dim3(1024), 0, c, (const float*)map->d_scan_ranges.p,
+         (const double2*)map->d_cossin.p, map->d_scan.p, d_n);
+  int host_n = 0;
+  LSLAM_HIP(ctx, hipMemcpyAsync(&host_n, d_n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  map->n_scan = host_n;
+  // dataContainer.setOrigo(Eigen::Vector2f(laserPos.x(), laserPos.y()) * scaleToMap) (hector_slam.cc:331)
+  map->scan_origo[0] = (float)(double)sp->laser_x * c.scale_to_map;
+  map->scan_origo[1] = (float)(double)sp->laser_y * c.scale_to_map;
+  if (n_points) *n_points = host_n;
+  return LSLAM_OK;
+}
+
+int lslam_map_read_container(lslam_map* map, float* out_xy, int capacity, float origo_xy[2]) {
+  if (!map || capacity < 0 || (capacity > 0 && !out_xy)) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = map->ctx;
+  const int n = std::min(capacity, map->n_scan);
+  if (n > 0) {
+    LSLAM_HIP(ctx, hipMemcpyAsync(out_xy, map->d_scan.p, (size_t)2 * n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (origo_xy) { origo_xy[0] = map->scan_origo[0]; origo_xy[1] = map->scan_origo[1]; }
+  return map->n_scan;
+}
+
+int lslam_map_update_by_container(lslam_map* map, const float pose_world[3]) {
+  if (!map || !pose_world) return LSLAM_ERR_INVALID_ARGUMENT;
+  LSLAM_HIP(map->ctx, hipSetDevice(map->ctx->device));
+  return update_impl(map, map->d_scan.p, map->n_scan, map->scan_origo, pose_world, 0, 0.f, 0.f, 0.0);
+}
+
 int lslam_map_update_just_once(lslam_map* map, const float* pts, int n, const float origo[2], float begin_x,
                                float begin_y, double metres_per_cell) {
   if (!map || n < 0 || (n > 0 && !pts) || !origo || !(metres_per_cell > 0)) return LSLAM_ERR_INVALID_ARGUMENT;
@@ -907,9 +1060,9 @@ int lslam_map_update_just_once(lslam_map* map, const float* pts, int n, const fl
   return update_impl(map, map->d_pts.p, n, origo, pose, 1, begin_x, begin_y, metres_per_cell);
 }
 
-int lslam_map_match_data(lslam_map* map, const float* pts, int n, const float origo[2], const float begin_world[3],
-                         float out_pose[3], float out_cov[9]) {
-  if (!map || n < 0 || (n > 0 && !pts) || !begin_world || !out_pose) return LSLAM_ERR_INVALID_ARGUMENT;
+namespace {
+int match_data_impl(lslam_map* map, const float* pts, int n, bool pts_on_device, const float origo[2],
+                    const float begin_world[3], float out_pose[3], float out_cov[9]) {
   lslam_context* ctx = map->ctx;
   if ((int)map->levels.size() > kGnMaxLevels)
     return ctx->fail(LSLAM_ERR_UNSUPPORTED, "at most %d pyramid levels", kGnMaxLevels);
@@ -922,7 +1075,8 @@ int lslam_map_match_data(lslam_map* map, const float* pts, int n, const float or
   // dataContainers[index-1].setFrom(dataContainer, ...) (MapRepMultiMap.h:161): the container is cached for the
   // next updateByScan -- also when it is empty
   if (n > 0)
-    LSLAM_HIP(ctx, hipMemcpyAsync(map->d_cached.p, pts, (size_t)2 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    LSLAM_HIP(ctx, hipMemcpyAsync(map->d_cached.p, pts, (size_t)2 * n * sizeof(float),
+                                  pts_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
   if (map->levels.size() > 1) {
     map->n_cached = n;
     map->cached_origo[0] = origo ? origo[0] : 0.f;
@@ -946,6 +1100,19 @@ int lslam_map_match_data(lslam_map* map, const float* pts, int n, const float or
   for (int i = 0; i < 3; i++) out_pose[i] = host[i];
   if (out_cov) for (int i = 0; i < 9; i++) out_cov[i] = host[3 + i];
   return LSLAM_OK;
+}
+}  // namespace
+
+int lslam_map_match_data(lslam_map* map, const float* pts, int n, const float origo[2], const float begin_world[3],
+                         float out_pose[3], float out_cov[9]) {
+  if (!map || n < 0 || (n > 0 && !pts) || !begin_world || !out_pose) return LSLAM_ERR_INVALID_ARGUMENT;
+  return match_data_impl(map, pts, n, false, origo, begin_world, out_pose, out_cov);
+}
+
+// matchData on the resident container of lslam_map_set_scan (the container is cached like any other)
+int lslam_map_match_container(lslam_map* map, const float begin_world[3], float out_pose[3], float out_cov[9]) {
+  if (!map || !begin_world || !out_pose) return LSLAM_ERR_INVALID_ARGUMENT;
+  return match_data_impl(map, map->d_scan.p, map->n_scan, true, map->scan_origo, begin_world, out_pose, out_cov);
 }
 
 int lslam_map_cached_points(const lslam_map* map) { return map ? map->n_cached : LSLAM_ERR_INVALID_ARGUMENT; }

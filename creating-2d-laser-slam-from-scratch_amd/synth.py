@@ -369,6 +369,37 @@ def hector_points(ranges_f32: np.ndarray, laser: Laser, scale_to_map: float, min
     return np.ascontiguousarray(pts, dtype=np.float32)
 
 
+def hector_project(ranges_f32: np.ndarray, laser: Laser, scale_to_map: float, min_dist: float = 0.4, max_dist: float = 30.0,
+                   use_max: float = 20.0, cutoff: float = 30.0, z_min: float = -1.0, z_max: float = 1.0,
+                   laser_pose=(0.0, 0.0, 0.0, 0.0)):
+    """HOST evaluation of HectorMappingRos::scanCallback's pre-processing, the checker of the device kernel
+    (k_hector_project): laser_geometry's projection in double (range * cos/sin of angle_min + i * increment, cast to
+    float32), the node's filters, the base_link <- laser transform in tf's double arithmetic, * scaleToMap in float32
+    (hector_slam.cc:193, 320-362).  Returns (points [n,2] float32 in map-cell units, origo [2] float32)."""
+    f32 = np.float32
+    r = np.asarray(ranges_f32, dtype=np.float32)
+    a = np.float64(f32(laser.angle_min)) + np.arange(len(r), dtype=np.float64) * np.float64(f32(laser.angle_increment))
+    cut = f32(laser.range_max) if cutoff < 0 else f32(cutoff)
+    with np.errstate(invalid="ignore"):
+        ok = (r < cut) & (r >= f32(laser.range_min))
+        x = (r.astype(np.float64) * np.cos(a)).astype(np.float32)
+        y = (r.astype(np.float64) * np.sin(a)).astype(np.float32)
+        d2 = x * x + y * y
+        ok &= (d2 > f32(min_dist * min_dist)) & (d2 < f32(max_dist * max_dist))
+        ok &= ~((x < 0) & (d2 < f32(0.5)))
+        ok &= ~(d2.astype(np.float64) > np.float64(f32(use_max)) ** 2)
+    lx, ly, lz, yaw = (np.float64(f32(v)) for v in laser_pose)
+    cy, sy = math.cos(yaw), math.sin(yaw)
+    bx = (cy * x.astype(np.float64) + (-sy) * y.astype(np.float64) + 0.0) + lx
+    by = (sy * x.astype(np.float64) + cy * y.astype(np.float64) + 0.0) + ly
+    zl = f32((0.0 + lz) - lz)
+    ok &= bool(zl > f32(z_min) and zl < f32(z_max))
+    s = f32(scale_to_map)
+    pts = np.stack([bx.astype(np.float32)[ok] * s, by.astype(np.float32)[ok] * s], axis=1)
+    origo = np.array([f32(lx) * s, f32(ly) * s], dtype=np.float32)
+    return np.ascontiguousarray(pts, dtype=np.float32), origo
+
+
 def hector_points_metres(ranges_f32: np.ndarray, laser: Laser) -> np.ndarray:
     """LaserScan -> points in METRES as lesson4's make_hector_map demo builds them
     (hector_mapping.cc:138-165): float angle accumulated by += angle_increment."""

@@ -374,6 +374,27 @@ int lslam_map_update_just_once(lslam_map* map, const float* points_xy, int n,
  * (the last Hessian, ScanMatcher.h:82-86).  n = 0 returns begin_world unchanged (ScanMatcher.h:96). */
 int lslam_map_match_data(lslam_map* map, const float* points_xy, int n, const float origo_xy[2],
                          const float begin_world[3], float out_pose[3], float out_cov[9]);
+/* LaserScan -> DataContainer ON THE DEVICE: HectorMappingRos::scanCallback's pre-processing (hector_slam.cc:186-205):
+ * laser_geometry's projectLaser(scan, cloud, 30.0) and rosPointCloudToDataContainer (hector_slam.cc:320-362).  The
+ * container stays resident in HBM; lslam_map_match_container / lslam_map_update_by_container are matchData /
+ * updateByScan on it (no per-scan point list crosses PCIe, only the float32 ranges).  The cos/sin table of the beam
+ * angles is built on the host once per scan geometry and cached (laser_geometry's co_sine_map_), so the projected
+ * float32 points are bit-identical to a host evaluation.  The base_link -> laser transform is planar (yaw +
+ * translation); a tilted laser needs the host path. */
+typedef struct lslam_hector_scan {
+  float angle_min, angle_increment, range_min, range_max; /* sensor_msgs/LaserScan header */
+  float range_cutoff;         /* projectLaser's range_cutoff (hector_slam.cc:193 passes 30.0); < 0 = range_max */
+  float sqr_laser_min_dist;   /* p_sqr_laser_min_dist_ */
+  float sqr_laser_max_dist;   /* p_sqr_laser_max_dist_ */
+  float use_max_scan_range;   /* p_use_max_scan_range_ */
+  float laser_z_min, laser_z_max; /* p_laser_z_min_value_, p_laser_z_max_value_ */
+  float laser_x, laser_y, laser_z, laser_yaw; /* laserTransform_: base_link -> laser */
+} lslam_hector_scan;
+int lslam_map_set_scan(lslam_map* map, const float* ranges, int n, const lslam_hector_scan* scan, int* n_points);
+/* copies up to `capacity` points of the resident container (+ its origo) to the host; returns the container size */
+int lslam_map_read_container(lslam_map* map, float* out_xy, int capacity, float origo_xy[2]);
+int lslam_map_match_container(lslam_map* map, const float begin_world[3], float out_pose[3], float out_cov[9]);
+int lslam_map_update_by_container(lslam_map* map, const float pose_world[3]);
 /* size of the cached containers (dataContainers[i].getSize()); 0 before the first matchData */
 int lslam_map_cached_points(const lslam_map* map);
 /* LogOddsCell::logOddsVal of every cell, row-major y*size_x+x (H/map/GridMapLogOdds.h:85) */

@@ -280,3 +280,39 @@ def test_batched_update_free_then_occupied_order(ctx, oracle_lib):
         pts = pts[::-1].copy()
     gpu.updateByScans(batch, (0.0, 0.0), np.zeros((6, 3), np.float32))
     assert cpu.logodds().tobytes() == gpu.logodds().tobytes()
+
+
+def test_laserscan_to_container_on_device(ctx, oracle_lib):
+    """LaserScan -> DataContainer on the device (laser_geometry projection + the node's filters + the
+    base_link <- laser transform, hector_slam.cc:193, 320-362) against the host evaluation, for EVERY beam: same points
+    bit for bit, same order, same origo; then matchData / updateByScan on the resident container equal the host-fed path."""
+    laser = synth.Laser()
+    n, cell = 1024, 0.05
+    world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=5)
+    gpu_d = api.OccGridMap(ctx, n, n, cell, (n * cell * 0.5,) * 2, levels=3)  # device-projected
+    gpu_h = api.OccGridMap(ctx, n, n, cell, (n * cell * 0.5,) * 2, levels=3)  # host-projected
+    for m in (gpu_d, gpu_h):
+        m.setUpdateOccupiedFactor(0.9)
+    rng = np.random.default_rng(4)
+    for laser_pose in ((0.0, 0.0, 0.0, 0.0), (0.21, -0.07, 0.35, 0.3)):
+        sp = api.hector_scan(laser, laser_pose=laser_pose)
+        for k in range(6):
+            truth = (0.3 + 0.05 * k, -0.2 + 0.02 * k, 0.1 + 0.01 * k)
+            r = synth.cast_scan(world, truth, laser, 0.01, 0.02, rng)
+            r[5] = np.float32("nan"); r[17] = np.float32(0.05); r[40] = np.float32(29.99)  # filtered one way or another
+            want, origo = synth.hector_project(r, laser, 1.0 / cell, laser_pose=laser_pose)
+            n_pts = gpu_d.setScan(r, sp)
+            got, got_origo = gpu_d.container()
+            assert n_pts == len(want) > 500
+            assert got.tobytes() == want.tobytes()
+            assert got_origo.tobytes() == origo.tobytes()
+            pose = np.asarray(truth, np.float32)
+            pd, Hd = gpu_d.matchContainer(pose)
+            ph, Hh = gpu_h.matchData(pose, want, origo)
+            assert pd.tobytes() == ph.tobytes() and Hd.tobytes() == Hh.tobytes()
+            gpu_d.updateByContainer(pose)
+            gpu_h.updateByScan(want, origo, pose)
+    for lv in range(3):
+        assert np.count_nonzero(gpu_d.logodds(lv)) > 1000
+        assert gpu_d.logodds(lv).tobytes() == gpu_h.logodds(lv).tobytes()
+    assert gpu_d.setScan(np.zeros(0, np.float32), sp) == 0  # an empty LaserScan is legal

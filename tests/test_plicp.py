@@ -12,7 +12,8 @@ import numpy as np
 
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 import lslam  # noqa: E402,F401
-from lslam_amd import plicp, synth  # noqa: E402
+from lslam_amd import synth  # noqa: E402
+from tools import plicp_cpu as plicp  # noqa: E402  (CPU helper for config 1; not part of the GPU package)
 
 
 def _laser360():

@@ -1,4 +1,5 @@
-"""lesson3 PL-ICP frame-to-frame match (BASELINE config 1): CPU plumbing, no GPU.
+"""lesson3 PL-ICP frame-to-frame match (BASELINE config 1: "plumbing, no GPU") -- a CPU HELPER under tools/, NOT part of
+the accelerator package: `creating-2d-laser-slam-from-scratch_amd/` holds only the GPU path and has no CPU fallback.
 
 Mirrors the reference's wrapper around Censi's C Scan Matcher:
   * `PlicpParams`        -- the sm_params the node fills in (lesson3/src/scan_match_plicp.cc:38-157),
