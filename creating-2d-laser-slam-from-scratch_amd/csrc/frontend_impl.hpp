@@ -52,6 +52,7 @@ struct lslam_frontend {
   DevBuf<lslam_match_result> d_res;
   std::vector<double> cos_a, sin_a;        // cos / sin of minimum_angle + i * angular_resolution
   bool have_last = false;
+  unsigned pose_slot = 0;
   int64_t n_chain_matches = 0, n_loop_coarse = 0, n_loop_fine = 0, n_loops_closed = 0, n_edges = 0;
 };
 
@@ -109,11 +110,14 @@ int fe_update_world(lslam_frontend* f, int id) {
   lslam_context* ctx = m->ctx;
   const int n = m->g.n_beams;
   if (n <= 0) return LSLAM_OK;
-  LSLAM_HIP(ctx, hipMemcpyAsync(f->d_q.p, f->scans[id].sensor, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  // No host synchronisation: the pose goes through its own slot of a small ring (the copy of a pageable host buffer is
+  // staged before hipMemcpyAsync returns; the stream orders it before the kernel, and the kernel before the next
+  // grid rebuild that reads these points).
+  double* d_pose = f->d_q.p + 4 + 4 * (f->pose_slot++ & 7);
+  LSLAM_HIP(ctx, hipMemcpyAsync(d_pose, f->scans[id].sensor, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((n + 255) / 256, 1), dim3(256), 0,
-         (const double*)(f->d_ranges + (size_t)id * n), n, (const double*)f->d_q.p, m->g, (double2*)nullptr,
+         (const double*)(f->d_ranges + (size_t)id * n), n, (const double*)d_pose, m->g, (double2*)nullptr,
          f->d_world + (size_t)id * n, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0);
-  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // d_q and the host pose are reused by the next call
   return LSLAM_OK;
 }
 
@@ -333,7 +337,7 @@ int lslam_frontend_create_ex(lslam_matcher* m, const lslam_frontend_config* cfg,
       return rc;
     }
   }
-  if (f->d_q.reserve(4) != hipSuccess || f->d_res.reserve(1) != hipSuccess) {
+  if (f->d_q.reserve(4 + 4 * 8) != hipSuccess || f->d_res.reserve(1) != hipSuccess) {
     lslam_frontend_destroy(f);
     return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the front-end scratch in HBM");
   }

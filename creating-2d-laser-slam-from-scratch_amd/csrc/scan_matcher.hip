@@ -1736,7 +1736,8 @@ __global__ void k_result_no_readings(int S, const double* poses, double coarse_a
 // Every fp64 expression is the reference's.
 __global__ void __launch_bounds__(1024)
 k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, double vx, double vy,
-             uint8_t* __restrict__ valid, int use_lds, int* __restrict__ scratch) {
+             uint8_t* __restrict__ valid, int use_lds, int* __restrict__ scratch, Geom g, uint8_t* __restrict__ grid,
+             uint32_t* __restrict__ list, int* __restrict__ count) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int s_first, s_len;
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -1816,6 +1817,37 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
   __syncthreads();
   if (use_lds)
     for (int i = tid; i < n; i += nt) gv[i] = v[i];
+  // Fused AddScan stage (k_mark_centres' body; the streaming front-end rebuilds the grid once per scan, so a launch and
+  // the valid[] round trip through memory matter): each valid point turns its cell into 100 and the winner lists it.
+  if (grid && use_lds) {
+    for (int i0 = 0; i0 < n; i0 += nt) {  // whole waves iterate together: the shuffles below need every lane
+      const int i = i0 + tid;
+      uint32_t idx = 0xFFFFFFFFu;
+      if (i < n && v[i]) {
+        const double2 q = p[i];
+        const int gx = world_to_grid(q.x, g.off_x, g.scale);
+        const int gy = world_to_grid(q.y, g.off_y, g.scale);
+        if (gx >= 0 && gx < g.roi_w && gy >= 0 && gy < g.roi_h)  // IsUpTo on the ROI (Mapper.cpp:724-729)
+          idx = (uint32_t)((gx + g.border) + (gy + g.border) * g.stride);
+      }
+      const uint32_t left = (uint32_t)__shfl_up((int)idx, 1);
+      const bool contender = idx != 0xFFFFFFFFu && ((tid & 63) == 0 || left != idx);
+      bool winner = false;
+      if (contender) {
+        const int sh = (int)(idx & 3u) * 8;
+        const uint32_t old = atomicOr((uint32_t*)(grid + (idx & ~3u)), (uint32_t)kOccupied << sh);
+        winner = ((old >> sh) & 0xFFu) == 0u;
+      }
+      const unsigned long long won = __ballot(winner);
+      if (won) {
+        const int lane = tid & 63, leader = __ffsll((long long)won) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(count, __popcll(won));
+        base = __shfl(base, leader);
+        if (winner) list[base + __popcll(won & ((1ull << lane) - 1ull))] = idx;
+      }
+    }
+  }
 }
 
 // AddScan (Mapper.cpp:716-748) for every valid point of every base scan in parallel: the thread
@@ -2302,15 +2334,20 @@ int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, i
   const size_t lds = (size_t)n * (sizeof(double2) + 14) + 16;  // points, next, two jump tables, valid, reach
   const int use_lds = lds <= 60 * 1024;
   if (!use_lds) LSLAM_HIP(ctx, m->d_fv_scratch.reserve((size_t)B * 2 * n));
+  const bool fuse_mark = m->kernel_center_only && use_lds;  // find_valid marks the centres itself: one launch fewer
+  if (m->kernel_center_only) {
+    LSLAM_HIP(ctx, m->d_centres.reserve((size_t)B * n + 1));
+    LSLAM_HIP(ctx, hipMemsetAsync(m->d_centres.p, 0, sizeof(uint32_t), ctx->stream));
+  }
   launch(ctx, "find_valid", k_find_valid, dim3(B), dim3(n > 512 ? 1024 : 256), use_lds ? lds : 0, n, d_world, ring_start, cap,
-         center[0], center[1], m->d_valid.p, use_lds, m->d_fv_scratch.p);
+         center[0], center[1], m->d_valid.p, use_lds, m->d_fv_scratch.p, g, fuse_mark ? m->d_grid : (uint8_t*)nullptr,
+         fuse_mark ? m->d_centres.p + 1 : (uint32_t*)nullptr, fuse_mark ? (int*)m->d_centres.p : (int*)nullptr);
   if (m->kernel_center_only) {
     // (1) centres: the first point to reach a cell sets it to 100 and is listed; (2) every listed centre
     // smears, one thread per aligned word of its footprint
-    LSLAM_HIP(ctx, m->d_centres.reserve((size_t)B * n + 1));
-    LSLAM_HIP(ctx, hipMemsetAsync(m->d_centres.p, 0, sizeof(uint32_t), ctx->stream));
-    launch(ctx, "mark_centres", k_mark_centres, dim3((n + 255) / 256, B), dim3(256), 0, B, n, d_world, ring_start, cap,
-           (const uint8_t*)m->d_valid.p, g, m->d_grid, m->d_centres.p + 1, (int*)m->d_centres.p);
+    if (!fuse_mark)
+      launch(ctx, "mark_centres", k_mark_centres, dim3((n + 255) / 256, B), dim3(256), 0, B, n, d_world, ring_start, cap,
+             (const uint8_t*)m->d_valid.p, g, m->d_grid, m->d_centres.p + 1, (int*)m->d_centres.p);
     const int wpr = (g.kernel_size + 3) / 4 + 1;
     const long long threads = (long long)B * n * g.kernel_size * wpr;
     launch(ctx, "smear", k_smear_list, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
@@ -2720,7 +2757,8 @@ int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges, const
     const int use_lds = lds <= 60 * 1024;
     if (!use_lds) LSLAM_HIP(ctx, m->d_fv_scratch.reserve((size_t)2 * g.n_beams));
     launch(ctx, "find_valid", k_find_valid, dim3(1), dim3(g.n_beams > 512 ? 1024 : 256), use_lds ? lds : 0, g.n_beams,
-           (const double2*)m->d_world.p, 0, 1, viewpoint[0], viewpoint[1], m->d_valid.p, use_lds, m->d_fv_scratch.p);
+           (const double2*)m->d_world.p, 0, 1, viewpoint[0], viewpoint[1], m->d_valid.p, use_lds, m->d_fv_scratch.p, g,
+           (uint8_t*)nullptr, (uint32_t*)nullptr, (int*)nullptr);
   }
   LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_valid.p, (size_t)g.n_beams, hipMemcpyDeviceToHost, ctx->stream));
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
