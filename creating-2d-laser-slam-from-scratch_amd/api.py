@@ -449,6 +449,9 @@ class ScanMatcher:
 
     @property
     def grid_dev_ptr(self) -> int:
+        """Device address of the raw grid bytes.  After WRITING through it call set_grid_dev(ptr, offset) with the same
+        pointer: the parity planes, row-occupancy bitmaps and tiled copies derived from the grid are refreshed only
+        when the matcher is told that the grid changed."""
         return self.L.lslam_matcher_grid_dev_ptr(self.h)
 
     def sensor_pose_from_robot(self, robot):
@@ -728,6 +731,11 @@ class OccGridMap:
         return self.L.lslam_map_scale_to_map(self.h, level)
 
     def updateByScan(self, points_xy, origo_xy, robot_pose_world):
+        """MapRepMultiMap::updateByScan.  Level 0 takes this container; the levels above 0 take the container cached
+        by the LAST matchData call (the reference's dataContainers: empty before the first matchData, stale if a
+        different scan was matched).  At most 65536 points (LslamError beyond; the reference has no limit); NaN / Inf
+        / out-of-int-range points are dropped like on the reference's x86 build.  Asynchronous: enqueued when this
+        returns, readers are ordered after it."""
         p = np.ascontiguousarray(points_xy, dtype=np.float32).reshape(-1, 2)
         o = np.ascontiguousarray(origo_xy, dtype=np.float32)
         w = np.ascontiguousarray(robot_pose_world, dtype=np.float32)
