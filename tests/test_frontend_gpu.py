@@ -146,3 +146,40 @@ def test_rejected_scan_reports_identity_covariance(ctx):
     assert not ok and np.array_equal(cov, np.eye(3)) and resp == 0.0
     ok, _, _, _ = fe.Process(r, (0.01, 0.0, 0.0), time_s=4000.0)  # MinimumTimeInterval (3600 s) has passed
     assert ok
+
+
+@pytest.mark.parametrize("variant", ["laser_offset", "response_expansion", "sensor_reference_pose"])
+def test_graph_frontend_variants_against_reference_live(ctx, oracle_lib, variant):
+    """The pose-graph front-end under the parameters a lesson6 deployment changes: a laser mounted off the base centre
+    (Sensor::SetOffsetPose, karto_slam.cc:387-389: HasMovedEnough, SetSensorPose and the barycentre all go through it),
+    response expansion on (use_response_expansion: true in mapper_params.yaml), and scan reference poses taken from the
+    sensor instead of the barycentre (use_scan_barycenter: false) -- each against the reference's Mapper beside it."""
+    if not oracle_lib.have_ref():
+        pytest.skip("oracle/_ref not built")
+    laser = synth.Laser()
+    world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=5)
+    path = synth.loop_trajectory(150, w=6.0, h=4.0, step=0.2, origin=(-3.0, -2.0))
+    odom = synth.drifting_odometry(path, scale=1.02, seed=11)
+    offset = (0.18, -0.05, 0.04) if variant == "laser_offset" else (0.0, 0.0, 0.0)
+    expansion = 1 if variant == "response_expansion" else 0
+    bary = 0 if variant == "sensor_reference_pose" else 1
+    kw = dict(scan_buffer_size=20, scan_buffer_max_scan_distance=5.0, do_loop_closing=1, link_scan_maximum_distance=1.5,
+              loop_search_maximum_distance=3.0, loop_match_minimum_chain_size=6, use_scan_barycenter=bary,
+              use_response_expansion=expansion)
+    ref = oracle_lib.RefKarto(oracle_lib.default_cfg(**kw), oracle_lib.laser_struct(laser, 20.0, offset))
+    gm = api.ScanMatcher(ctx, api.baseline_config(range_threshold=20.0, use_response_expansion=expansion),
+                         api.laser_params(laser, 20.0, offset))
+    fe = api.FrontEnd(gm, config=api.frontend_config(
+        scan_buffer_size=20, scan_buffer_maximum_scan_distance=5.0, do_loop_closing=1, link_scan_maximum_distance=1.5,
+        loop_search_maximum_distance=3.0, loop_match_minimum_chain_size=6, use_scan_barycenter=bary))
+    for i, (t, o) in enumerate(zip(path, odom)):
+        # the scan is cast from where the LASER is: robot pose composed with the mounting offset
+        c, s_ = math.cos(t[2]), math.sin(t[2])
+        lp = (t[0] + c * offset[0] - s_ * offset[1], t[1] + s_ * offset[0] + c * offset[1], t[2] + offset[2])
+        r = synth.ranges_to_f64(synth.cast_scan(world, lp, laser, 0.01, 0.01, np.random.default_rng([47, i])))
+        ok_c, pose_c = ref.process(r, o)
+        ok_g, pose_g, _, _ = fe.Process(r, o)
+        assert ok_c == ok_g, i
+        assert np.abs(pose_c - pose_g).max() <= 1e-9, (variant, i, pose_c, pose_g)
+        assert ref.graph_stats()[1] == fe.stats()["edges"], (variant, i)
+    assert fe.stats()["edges"] > fe.stats()["scans"]
