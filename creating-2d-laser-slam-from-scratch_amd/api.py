@@ -144,6 +144,27 @@ def hector_scan(laser, min_dist=0.4, max_dist=30.0, use_max=20.0, cutoff=30.0, z
                       min_dist * min_dist, max_dist * max_dist, use_max, z_min, z_max, *laser_pose)
 
 
+class DeskewParams(C.Structure):
+    _fields_ = [("angle_min", C.c_float), ("angle_increment", C.c_float), ("range_min", C.c_float), ("range_max", C.c_float),
+                ("scan_time_start", C.c_double), ("time_increment", C.c_double), ("use_imu", C.c_int32),
+                ("use_odom", C.c_int32), ("start_odom_time", C.c_double), ("end_odom_time", C.c_double),
+                ("odom_incre_x", C.c_float), ("odom_incre_y", C.c_float), ("odom_incre_z", C.c_float), ("pad", C.c_float)]
+
+
+def deskew_scan(ctx, ranges_f32, params: DeskewParams, imu_time=None, imu_rot=None):
+    """lesson5 CorrectLaserScan on the device -> (xyz [n,3] float32, valid [n] bool).  imu_rot: [n_imu, 3]."""
+    r = np.ascontiguousarray(ranges_f32, dtype=np.float32)
+    n_imu = 0 if imu_time is None else len(imu_time)
+    it = np.ascontiguousarray(imu_time if n_imu else [0.0], dtype=np.float64)
+    ir = np.ascontiguousarray(np.asarray(imu_rot if n_imu else [[0.0, 0.0, 0.0]], dtype=np.float64).T)
+    xyz = np.zeros((len(r), 3), np.float32)
+    valid = np.zeros(len(r), np.uint8)
+    ctx.check(ctx.L.lslam_deskew_scan(ctx.h, r.ctypes.data, len(r), C.byref(params), it.ctypes.data, ir[0].ctypes.data,
+                                      ir[1].ctypes.data, ir[2].ctypes.data, max(n_imu, 1) if params.use_imu else 0,
+                                      xyz.ctypes.data, valid.ctypes.data))
+    return xyz, valid.astype(bool)
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("total_ms", C.c_double)]
 
@@ -283,6 +304,7 @@ def lib() -> C.CDLL:
     L.lslam_pool_last_error.restype = C.c_char_p
     L.lslam_pool_set_base_scans.argtypes = [vp, i32, vp, i32, vp, vp, i32]
     L.lslam_pool_match_batch.argtypes = [vp, i32, vp, i32, vp, i32, i32, vp]
+    L.lslam_deskew_scan.argtypes = [vp, vp, i32, C.POINTER(DeskewParams), vp, vp, vp, vp, i32, vp, vp]
     L.lslam_matcher_set_option.argtypes = [vp, i32, i32]
     L.lslam_matcher_read_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     _LIB = L

@@ -14,7 +14,7 @@ import subprocess
 PKG = pathlib.Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "liblslam_gpu.so"
-SOURCES = ["context.hip", "scan_matcher.hip", "logodds_map.hip", "occupancy_grid.hip", "pool.hip"]
+SOURCES = ["context.hip", "scan_matcher.hip", "logodds_map.hip", "occupancy_grid.hip", "pool.hip", "deskew.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wno-unused-result"]
 

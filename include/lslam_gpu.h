@@ -404,6 +404,25 @@ int lslam_map_read_logodds(lslam_map* map, int level, float* out_host);
 int lslam_map_read_occupancy_i8(lslam_map* map, int level, int8_t* out_host);
 void* lslam_map_cells_dev_ptr(lslam_map* map, int level); /* float log-odds plane in HBM */
 
+/* ---------------------------------------------------------------------------------------- */
+/* lesson5 lidar motion de-skew (LidarUndistortion::CorrectLaserScan, lesson5/src/            */
+/* lidar_undistortion.cc:339-447) -- SURVEY 8(f) #4.  PARITY UNPINNED: the reference's        */
+/* arithmetic goes through PCL and Eigen inside a ROS node class, none of which is in the     */
+/* tree; the kernel follows the published PCL formula and Eigen 3.3's evaluation orders.      */
+/* ---------------------------------------------------------------------------------------- */
+typedef struct lslam_deskew_params {
+  float angle_min, angle_increment, range_min, range_max; /* sensor_msgs/LaserScan header */
+  double scan_time_start, time_increment;                 /* header.stamp, time_increment (:154-155) */
+  int32_t use_imu, use_odom;
+  double start_odom_time, end_odom_time;                  /* :300-301 */
+  float odom_incre_x, odom_incre_y, odom_incre_z, pad;    /* :331-334 */
+} lslam_deskew_params;
+/* imu_time / imu_rot_*: the integrated gyro samples of this scan (imu_time_[0..current_imu_index_], :205-243),
+ * n_imu = current_imu_index_ + 1.  out_xyz: n x 3 float32 (zeros for the beams the reference skips), out_valid: n */
+int lslam_deskew_scan(lslam_context* ctx, const float* ranges, int n, const lslam_deskew_params* params,
+                      const double* imu_time, const double* imu_rot_x, const double* imu_rot_y, const double* imu_rot_z,
+                      int n_imu, float* out_xyz, uint8_t* out_valid);
+
 #ifdef __cplusplus
 }
 #endif
