@@ -187,19 +187,23 @@ k_logodds_apply(LevelGeom g, const float* __restrict__ pts, int n, const uint32_
 // BATCHED update: K scans, each with its own pose, applied to the map exactly as K successive
 // updateByScan calls would (the float operations of a cell are applied in scan order; cells are
 // independent of each other).  The single-scan path above is bound by two dependent ~10 us kernels
-// per scan; here the K scans are MARKED in parallel and APPLIED by one pass over the map:
-//   k_lo_batch_hits  thread per (scan, beam): end cell -> byte plane[s][cell] = HIT, and the cell is
-//                    entered in scan s's small hash with atomicMin(first beam ending there);
-//   k_lo_batch_rays  wave per (scan, beam), closed-form Bresenham cells: a crossed cell whose byte is not
-//                    HIT gets plane[s][cell] = CROSSED (plain byte store, every writer writes the same
-//                    value); a crossed HIT cell records atomicMin(first beam crossing it) in the hash;
+// per scan; here the K scans are MARKED in parallel and APPLIED by one pass over the touched tiles:
+//   k_lo_batch_hits    thread per (scan, beam): end cell -> byte plane[s][cell] = HIT, and the cell is
+//                      entered in scan s's small hash with atomicMin(first beam ending there);
+//   k_lo_batch_rays    wave per (scan, beam), closed-form Bresenham cells: a crossed cell whose byte is not
+//                      HIT gets plane[s][cell] = CROSSED (plain byte store, every writer writes the same
+//                      value); a crossed HIT cell records atomicMin(first beam crossing it) in the hash;
 //   k_lo_batch_resolve thread per hash entry: a hit cell crossed by an earlier beam of its scan -> byte HIT_UNDO;
-//   k_lo_batch_apply thread per 4 cells: walks the K plane bytes of its cells in scan order and applies
-//                    +free / [(v+free)-free] +occ-if-<50, the float sequence of the sequential reference
-//                    (H/map/OccGridMapBase.h:302-330).
-// Plane bytes carry a 6-bit batch epoch so the planes are cleared once per 63 batches, not per batch.
-// HBM-bound byte work: per batch the apply pass streams K bytes + 8 B per cell (coalesced), the ray
-// pass touches one byte per traversed cell; no atomics on the traversal path.
+//   k_lo_batch_apply   wave per 8x8-cell tile: reads the tile's 64 "touched by scan s" flags in one load, then
+//                      walks ONLY the planes that touched the tile, in scan order, and applies
+//                      +free / [(v+free)-free] +occ-if-<50, the float sequence of the sequential reference
+//                      (H/map/OccGridMapBase.h:302-330).
+// Layout: planes and flags are TILED -- cell (x, y) of plane s is byte s*plane_bytes + tile*64 + (y&7)*8 + (x&7)
+// with tile = (y>>3)*tiles_x + (x>>3): 64 consecutive cells of a ray lie in ~8 tiles (eight 64-byte lines)
+// whichever way the ray runs, instead of 1 line for an x-major and 64 for a y-major ray in a row-major plane; and
+// flags[tile][s] (64 bytes per tile) is what lets the apply pass skip the ~90 % of (tile, scan) pairs no ray went
+// through.  Plane and flag bytes carry a 6-bit batch epoch, so they are cleared once per 63 batches, not per batch.
+// HBM-bound byte work; no atomics on the traversal path.
 // ------------------------------------------------------------------------------------------
 struct ScanHdr {     // one scan of a batch on one pyramid level (host-computed like LevelGeom)
   float c, s, tx, ty;
@@ -208,12 +212,14 @@ struct ScanHdr {     // one scan of a batch on one pyramid level (host-computed 
 };
 struct BatchGeom {
   int sx, sy, K;
+  int tiles_x, n_tiles;
   float factor, lo_free, lo_occ;
   uint32_t tag;      // epoch << 2
   uint32_t hash_mask;  // slots per scan - 1 (power of two >= 2 * max points per scan)
 };
 constexpr uint32_t kCodeCrossed = 1u, kCodeHit = 2u, kCodeHitUndo = 3u;
 constexpr uint32_t kHashEmpty = 0xFFFFFFFFu;
+constexpr int kBatchSlots = 64;  // scans per batch = flag bytes per tile
 
 __device__ __forceinline__ Line batch_line(const BatchGeom& g, const ScanHdr& h, const float* __restrict__ pts, int i) {
   LevelGeom lg;
@@ -222,10 +228,12 @@ __device__ __forceinline__ Line batch_line(const BatchGeom& g, const ScanHdr& h,
   return beam_line(lg, pts + 2 * (size_t)h.pts_off, i);
 }
 __device__ __forceinline__ uint32_t hash_slot0(uint32_t cell, uint32_t mask) { return (cell * 2654435761u) >> 7 & mask; }
+__device__ __forceinline__ uint32_t tile_of(const BatchGeom& g, int x, int y) { return (uint32_t)((y >> 3) * g.tiles_x + (x >> 3)); }
+__device__ __forceinline__ uint32_t in_tile(int x, int y) { return (uint32_t)(((y & 7) << 3) | (x & 7)); }
 
 __global__ void __launch_bounds__(256)
 k_lo_batch_hits(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __restrict__ pts, uint8_t* __restrict__ planes,
-                uint32_t* __restrict__ hkey, uint32_t* __restrict__ hhit) {
+                uint8_t* __restrict__ flags, uint32_t* __restrict__ hkey, uint32_t* __restrict__ hhit) {
   const int sidx = blockIdx.y;
   const ScanHdr h = hdr[sidx];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -233,7 +241,9 @@ k_lo_batch_hits(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __res
   const Line l = batch_line(g, h, pts, i);
   if (!l.valid) return;
   const uint32_t cell = (uint32_t)(l.y1 * g.sx + l.x1);
-  planes[(size_t)sidx * g.sx * g.sy + cell] = (uint8_t)(g.tag | kCodeHit);
+  const uint32_t t = tile_of(g, l.x1, l.y1);
+  planes[((size_t)sidx * g.n_tiles + t) * 64 + in_tile(l.x1, l.y1)] = (uint8_t)(g.tag | kCodeHit);
+  flags[(size_t)t * kBatchSlots + sidx] = (uint8_t)(g.tag | 1u);
   const size_t hb = (size_t)sidx * (g.hash_mask + 1);
   uint32_t slot = hash_slot0(cell, g.hash_mask);
   for (;;) {
@@ -244,30 +254,53 @@ k_lo_batch_hits(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __res
   atomicMin(&hhit[hb + slot], (uint32_t)i);
 }
 
+constexpr int kRayBeamsPerWave = 4;  // consecutive beams one wave walks: fewer, longer waves (dispatch-rate bound otherwise)
 __global__ void __launch_bounds__(256)
 k_lo_batch_rays(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __restrict__ pts, uint8_t* __restrict__ planes,
-                const uint32_t* __restrict__ hkey, uint32_t* __restrict__ hcross, int n_max) {
+                uint8_t* __restrict__ flags, const uint32_t* __restrict__ hkey, uint32_t* __restrict__ hcross, int groups_per_scan) {
   const int lane = threadIdx.x & 63;
-  const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave index = scan * n_max + beam
-  const int sidx = w / n_max, i = w - sidx * n_max;
+  const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave index = scan * groups_per_scan + beam group
+  const int sidx = w / groups_per_scan, grp = w - sidx * groups_per_scan;
   if (sidx >= g.K) return;
   const ScanHdr h = hdr[sidx];
-  if (i >= h.n) return;
-  const Line l = batch_line(g, h, pts, i);
-  if (!l.valid) return;
-  const Ray r = ray_of(l, g.sx);
-  uint8_t* plane = planes + (size_t)sidx * g.sx * g.sy;
+  uint8_t* plane = planes + (size_t)sidx * g.n_tiles * 64;
   const uint32_t crossed = g.tag | kCodeCrossed, hit = g.tag | kCodeHit;
   const size_t hb = (size_t)sidx * (g.hash_mask + 1);
-  for (unsigned c = lane; c < r.abs_da; c += 64) {
-    const unsigned cell = ray_cell(r, c);
-    const uint32_t b = plane[cell];
-    if (b == hit) {  // some beam of this scan ends here: remember the first beam that crosses it
-      uint32_t slot = hash_slot0(cell, g.hash_mask);
-      while (hkey[hb + slot] != cell) slot = (slot + 1) & g.hash_mask;  // entered by k_lo_batch_hits
-      atomicMin(&hcross[hb + slot], (uint32_t)i);
-    } else if (b != crossed) {
-      plane[cell] = (uint8_t)crossed;
+  for (int i = grp * kRayBeamsPerWave; i < min(h.n, (grp + 1) * kRayBeamsPerWave); i++) {
+    const Line l = batch_line(g, h, pts, i);
+    if (!l.valid) continue;
+    // the reference's traversal (H/map/OccGridMapBase.h:240-299) in closed form, here as (x, y): cell c of the ray is c
+    // major steps and q(c) = floor((abs_da/2 + c*abs_db) / abs_da) minor steps from the begin cell (see ray_cell)
+    const int dx = l.x1 - l.x0, dy = l.y1 - l.y0;
+    const unsigned abs_dx = (unsigned)abs(dx), abs_dy = (unsigned)abs(dy);
+    const int sgx = dx > 0 ? 1 : -1, sgy = dy > 0 ? 1 : -1;  // util::sign: sign(0) = -1
+    const bool xmajor = abs_dx >= abs_dy;
+    const unsigned abs_da = xmajor ? abs_dx : abs_dy, abs_db = xmajor ? abs_dy : abs_dx;
+    // q(c): the numerator stays below 2^31 (map sides <= 32768) and the quotient below 2^16, so a float estimate is
+    // within +-1 of it and two integer corrections make it exact (a 64-bit integer division per cell otherwise)
+    const float rcp_da = 1.0f / (float)abs_da;
+    for (unsigned c = lane; c < abs_da; c += 64) {
+      const unsigned num = abs_da / 2 + c * abs_db;
+      unsigned q = (unsigned)((float)num * rcp_da);
+      int rem = (int)(num - q * abs_da);
+      if (rem < 0) { q -= 1; rem += (int)abs_da; }
+      if (rem < 0) { q -= 1; rem += (int)abs_da; }
+      if (rem >= (int)abs_da) { q += 1; rem -= (int)abs_da; }
+      if (rem >= (int)abs_da) { q += 1; }
+      const int x = l.x0 + (xmajor ? (int)c * sgx : (int)q * sgx);
+      const int y = l.y0 + (xmajor ? (int)q * sgy : (int)c * sgy);
+      const uint32_t t = tile_of(g, x, y);
+      const size_t off = (size_t)t * 64 + in_tile(x, y);
+      const uint32_t b = plane[off];
+      if (b == hit) {  // some beam of this scan ends here: remember the first beam that crosses it
+        const uint32_t cell = (uint32_t)(y * g.sx + x);
+        uint32_t slot = hash_slot0(cell, g.hash_mask);
+        while (hkey[hb + slot] != cell) slot = (slot + 1) & g.hash_mask;  // entered by k_lo_batch_hits
+        atomicMin(&hcross[hb + slot], (uint32_t)i);
+      } else if (b != crossed) {
+        plane[off] = (uint8_t)crossed;
+        flags[(size_t)t * kBatchSlots + sidx] = (uint8_t)(g.tag | 1u);
+      }
     }
   }
 }
@@ -283,71 +316,57 @@ k_lo_batch_resolve(BatchGeom g, const uint32_t* __restrict__ hkey, const uint32_
   if (idx >= slots * g.K) return;
   const uint32_t cell = hkey[idx];
   if (cell == kHashEmpty) return;
-  if (hcross[idx] < hhit[idx]) planes[(idx / slots) * (size_t)g.sx * g.sy + cell] = (uint8_t)(g.tag | kCodeHitUndo);
+  if (hcross[idx] < hhit[idx]) {
+    const int x = (int)(cell % (uint32_t)g.sx), y = (int)(cell / (uint32_t)g.sx);
+    planes[((idx / slots) * (size_t)g.n_tiles + tile_of(g, x, y)) * 64 + in_tile(x, y)] = (uint8_t)(g.tag | kCodeHitUndo);
+  }
 }
 
+// one wave per tile: lane = plane slot when reading the flags, lane = cell of the tile when applying
 __global__ void __launch_bounds__(256)
-k_lo_batch_apply(BatchGeom g, const uint8_t* __restrict__ planes, float* __restrict__ logodds) {
-  const size_t cells = (size_t)g.sx * g.sy;
-  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 cells
-  if (q * 4 >= cells) return;
-  const uint32_t tag4 = g.tag * 0x01010101u;
-  const bool full = q * 4 + 4 <= cells;
-  float v[4];
-  if (full) {
-    const float4 f = *reinterpret_cast<const float4*>(logodds + q * 4);
-    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
-  } else {
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = q * 4 + k < cells ? logodds[q * 4 + k] : 0.f;
-  }
+k_lo_batch_apply(BatchGeom g, const uint8_t* __restrict__ planes, const uint8_t* __restrict__ flags,
+                 float* __restrict__ logodds) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (t >= (uint32_t)g.n_tiles) return;
+  const uint32_t f = flags[(size_t)t * kBatchSlots + lane];
+  unsigned long long touched = __ballot(lane < g.K && (f & 0xFCu) == g.tag && (f & 3u) != 0u);  // wave-uniform
+  if (!touched) return;
+  const int x = (int)(t % (uint32_t)g.tiles_x) * 8 + (lane & 7), y = (int)(t / (uint32_t)g.tiles_x) * 8 + (lane >> 3);
+  const bool in_map = x < g.sx && y < g.sy;
+  float v = in_map ? logodds[(size_t)y * g.sx + x] : 0.f;
   bool dirty = false;
-  // the K plane words of these 4 cells, kChunk at a time: all loads of a chunk are issued before the first is used
-  // (one dependent load per scan made this pass latency-bound: 64 round trips per thread)
-  constexpr int kChunk = 16;
-  const uint8_t* pq = planes + q * 4;
-  for (int s0 = 0; s0 < g.K; s0 += kChunk) {
-    uint32_t wv[kChunk];
-    if (full && s0 + kChunk <= g.K) {  // straight-line: 16 independent loads in flight
+  const uint8_t* pt = planes + (size_t)t * 64 + lane;
+  const size_t plane_bytes = (size_t)g.n_tiles * 64;
+  while (touched) {  // ascending slot = scan order; eight planes' bytes in flight at a time (the mask is wave-uniform)
+    int sl[8];
 #pragma unroll
-      for (int u = 0; u < kChunk; u++) wv[u] = *reinterpret_cast<const uint32_t*>(pq + (size_t)(s0 + u) * cells);
-    } else {
-#pragma unroll
-      for (int u = 0; u < kChunk; u++) {
-        wv[u] = 0u;  // epoch 0 never matches a live tag (tags start at 1 << 2)
-        if (s0 + u < g.K)
-          for (size_t k = q * 4; k < cells && k < q * 4 + 4; k++)
-            wv[u] |= (uint32_t)planes[(size_t)(s0 + u) * cells + k] << (8 * (k - q * 4));
-      }
+    for (int u = 0; u < 8; u++) {
+      sl[u] = touched ? __ffsll((long long)touched) - 1 : -1;
+      touched &= touched - 1;  // 0 stays 0
     }
+    uint32_t bv[8];
 #pragma unroll
-    for (int u = 0; u < kChunk; u++) {
-      const uint32_t t = (wv[u] ^ tag4) & 0xFCFCFCFCu;             // a byte of t is 0 iff its epoch is current
-      if (((t - 0x01010101u) & ~t & 0x80808080u) == 0u) continue;  // no byte of this batch in the word
+    for (int u = 0; u < 8; u++) bv[u] = sl[u] >= 0 ? (uint32_t)pt[(size_t)sl[u] * plane_bytes] : 0u;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t b = (wv[u] >> (8 * k)) & 0xFFu;
-        if ((b & 0xFCu) != g.tag) continue;
-        const uint32_t code = b & 3u;
-        if (code == kCodeCrossed) {
-          v[k] += g.lo_free;  // bresenhamCellFree, once per scan (:302-313)
-          dirty = true;
-        } else if (code != 0u) {  // bresenhamCellOcc (:316-330)
-          if (code == kCodeHitUndo) {  // crossed by an EARLIER beam: marked free, then un-marked
-            v[k] += g.lo_free;
-            v[k] -= g.lo_free;
-          }
-          if (v[k] < 50.0f) v[k] += g.lo_occ;  // updateSetOccupied (H/map/GridMapLogOdds.h:108-114)
-          dirty = true;
+    for (int u = 0; u < 8; u++) {
+      const uint32_t b = bv[u];
+      if ((b & 0xFCu) != g.tag) continue;  // also the empty slots (tags start at 1 << 2)
+      const uint32_t code = b & 3u;
+      if (code == kCodeCrossed) {
+        v += g.lo_free;  // bresenhamCellFree, once per scan (:302-313)
+        dirty = true;
+      } else if (code != 0u) {  // bresenhamCellOcc (:316-330)
+        if (code == kCodeHitUndo) {  // crossed by an EARLIER beam: marked free, then un-marked
+          v += g.lo_free;
+          v -= g.lo_free;
         }
+        if (v < 50.0f) v += g.lo_occ;  // updateSetOccupied (H/map/GridMapLogOdds.h:108-114)
+        dirty = true;
       }
     }
   }
-  if (dirty) {
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (q * 4 + k < cells) logodds[q * 4 + k] = v[k];
-  }
+  if (dirty && in_map) logodds[(size_t)y * g.sx + x] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -574,9 +593,10 @@ struct Level {
   uint32_t* d_occ = nullptr;
   uint32_t epoch = 0;
   // batched update (k_lo_batch_*): one byte plane per scan slot, allocated on first use
-  uint8_t* d_planes = nullptr;
+  uint8_t* d_planes = nullptr;  // [plane_slots][n_tiles][64] tiled byte planes
+  uint8_t* d_flags = nullptr;   // [n_tiles][64]: tile touched by the scan in slot s
   int plane_slots = 0;
-  size_t plane_stride = 0;  // bytes per plane = cells rounded up to 4
+  int tiles_x = 0, n_tiles = 0;
   uint32_t batch_epoch = 0;
 };
 
@@ -744,6 +764,7 @@ void lslam_map_destroy(lslam_map* map) {
     if (L.d_free) (void)hipFree(L.d_free);
     if (L.d_occ) (void)hipFree(L.d_occ);
     if (L.d_planes) (void)hipFree(L.d_planes);
+    if (L.d_flags) (void)hipFree(L.d_flags);
   }
   map->d_pts.release();
   map->d_cached.release();
@@ -845,7 +866,7 @@ int lslam_map_update_by_scan(lslam_map* map, const float* pts, int n, const floa
 }
 
 namespace {
-constexpr int kBatchMaxScans = 64;
+constexpr int kBatchMaxScans = kBatchSlots;
 
 // K successive MapRepMultiMap::updateByScan calls (every level fed the same scan, i.e. each scan matched first) in
 // four launches per level.  d_pts: the K containers back to back; counts / origos / poses are host arrays.
@@ -859,6 +880,9 @@ int update_batch_impl(lslam_map* map, int K, const float* d_pts, const int32_t* 
     n_max = std::max(n_max, counts[k]);
   }
   if (n_max == 0) return LSLAM_OK;
+  for (const Level& L : map->levels)
+    if (L.sx > 32768 || L.sy > 32768)
+      return ctx->fail(LSLAM_ERR_UNSUPPORTED, "batched update: map sides up to 32768 cells (k_lo_batch_rays' 32-bit ray arithmetic)");
   uint32_t slots = 64;
   while (slots < 2u * (uint32_t)n_max) slots *= 2;
   LSLAM_HIP(ctx, map->d_hash.reserve((size_t)3 * K * slots));
@@ -891,46 +915,48 @@ int update_batch_impl(lslam_map* map, int K, const float* d_pts, const int32_t* 
   LSLAM_HIP(ctx, hipMemcpyAsync(map->d_hdr.p, hdr.data(), hdr.size() * sizeof(ScanHdr), hipMemcpyHostToDevice, ctx->stream));
   for (size_t li = 0; li < map->levels.size(); li++) {
     Level& L = map->levels[li];
-    const size_t cells = (size_t)L.sx * L.sy;
-    if (L.plane_slots < K) {
-      LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if (L.d_planes) (void)hipFree(L.d_planes);
-      L.d_planes = nullptr;
-      L.plane_slots = 0;
-      L.plane_stride = (cells + 3) & ~(size_t)3;
-      const int want = std::min(kBatchMaxScans, std::max(K, 8));
-      if (hipMalloc((void**)&L.d_planes, L.plane_stride * want) != hipSuccess)
-        return ctx->fail(LSLAM_ERR_HIP, "cannot allocate %d batch planes of %zu bytes", want, L.plane_stride);
-      L.plane_slots = want;
+    if (!L.d_planes) {
+      L.tiles_x = (L.sx + 7) / 8;
+      L.n_tiles = L.tiles_x * ((L.sy + 7) / 8);
+      const size_t plane_bytes = (size_t)L.n_tiles * 64;
+      if (hipMalloc((void**)&L.d_planes, plane_bytes * kBatchSlots) != hipSuccess ||
+          hipMalloc((void**)&L.d_flags, (size_t)L.n_tiles * kBatchSlots) != hipSuccess) {
+        (void)hipGetLastError();
+        if (L.d_planes) (void)hipFree(L.d_planes);
+        L.d_planes = nullptr;
+        return ctx->fail(LSLAM_ERR_HIP, "cannot allocate %d batch planes of %zu bytes", kBatchSlots, plane_bytes);
+      }
+      L.plane_slots = kBatchSlots;
       L.batch_epoch = 0;
     }
-    if (L.batch_epoch == 0 || L.batch_epoch >= 63) {  // 6-bit epoch in the plane bytes
-      LSLAM_HIP(ctx, hipMemsetAsync(L.d_planes, 0, L.plane_stride * L.plane_slots, ctx->stream));
+    if (L.batch_epoch == 0 || L.batch_epoch >= 63) {  // 6-bit epoch in the plane / flag bytes
+      LSLAM_HIP(ctx, hipMemsetAsync(L.d_planes, 0, (size_t)L.n_tiles * 64 * L.plane_slots, ctx->stream));
+      LSLAM_HIP(ctx, hipMemsetAsync(L.d_flags, 0, (size_t)L.n_tiles * kBatchSlots, ctx->stream));
       L.batch_epoch = 0;
     }
     L.batch_epoch++;
     LSLAM_HIP(ctx, hipMemsetAsync(map->d_hash.p, 0xFF, (size_t)3 * K * slots * sizeof(uint32_t), ctx->stream));
     BatchGeom g;
     g.sx = L.sx; g.sy = L.sy; g.K = K;
+    g.tiles_x = L.tiles_x; g.n_tiles = L.n_tiles;
     g.factor = li == 0 ? 1.0f : (float)(1.0 / pow(2.0, (double)li));
     g.lo_free = map->lo_free; g.lo_occ = map->lo_occ;
     g.tag = L.batch_epoch << 2;
     g.hash_mask = slots - 1;
-    // the planes are indexed [slot * cells]: plane_stride == cells whenever cells % 4 == 0; otherwise the kernels'
-    // (size_t)sidx * sx * sy would not match -- keep it simple and require the rounded size to be exact
-    if (L.plane_stride != cells) return ctx->fail(LSLAM_ERR_UNSUPPORTED, "batched update needs size_x*size_y %% 4 == 0");
     uint32_t* hkey = map->d_hash.p;
     uint32_t* hhit = hkey + (size_t)K * slots;
     uint32_t* hcross = hhit + (size_t)K * slots;
     const ScanHdr* d_h = map->d_hdr.p + li * K;
-    launch(ctx, "lo_batch_hits", k_lo_batch_hits, dim3((n_max + 255) / 256, K), dim3(256), 0, g, d_h, d_pts, L.d_planes, hkey, hhit);
-    const long long waves = (long long)K * n_max;
+    launch(ctx, "lo_batch_hits", k_lo_batch_hits, dim3((n_max + 255) / 256, K), dim3(256), 0, g, d_h, d_pts, L.d_planes, L.d_flags,
+           hkey, hhit);
+    const int groups = (n_max + kRayBeamsPerWave - 1) / kRayBeamsPerWave;
+    const long long waves = (long long)K * groups;
     launch(ctx, "lo_batch_rays", k_lo_batch_rays, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, g, d_h, d_pts, L.d_planes,
-           (const uint32_t*)hkey, hcross, n_max);
+           L.d_flags, (const uint32_t*)hkey, hcross, groups);
     launch(ctx, "lo_batch_resolve", k_lo_batch_resolve, dim3((unsigned)(((size_t)K * slots + 255) / 256)), dim3(256), 0, g,
            (const uint32_t*)hkey, (const uint32_t*)hhit, (const uint32_t*)hcross, L.d_planes);
-    launch(ctx, "lo_batch_apply", k_lo_batch_apply, dim3((unsigned)((cells / 4 + 255) / 256 + 1)), dim3(256), 0, g,
-           (const uint8_t*)L.d_planes, L.d_logodds);
+    launch(ctx, "lo_batch_apply", k_lo_batch_apply, dim3((unsigned)((L.n_tiles + 3) / 4)), dim3(256), 0, g,
+           (const uint8_t*)L.d_planes, (const uint8_t*)L.d_flags, L.d_logodds);
   }
   LSLAM_HIP(ctx, hipGetLastError());
   return LSLAM_OK;

@@ -354,7 +354,7 @@ int lslam_map_update_by_scan_dev(lslam_map* map, const float* points_xy_dev, int
  * not read this map (the Karto front-end of BASELINE config 5).
  * points_xy: the containers back to back (sum of n_points[] points, level-0 map-cell units); n_points[n_scans];
  * origos_xy[n_scans][2]; poses_world[n_scans][3].  Every level is fed the same scan (each scan counts as matched
- * first); afterwards the cached container is the last scan's.  size_x*size_y must be a multiple of 4 on every level. */
+ * first); afterwards the cached container is the last scan's. */
 int lslam_map_update_batch(lslam_map* map, int n_scans, const float* points_xy, const int32_t* n_points,
                            const float* origos_xy, const float* poses_world);
 /* same with the points already in HBM (n_points / origos / poses stay host arrays: a few bytes per scan) */
