@@ -53,6 +53,7 @@ struct lslam_frontend {
   std::vector<double> cos_a, sin_a;        // cos / sin of minimum_angle + i * angular_resolution
   bool have_last = false;
   unsigned pose_slot = 0;
+  double pose_stage[8][4] = {};
   int64_t n_chain_matches = 0, n_loop_coarse = 0, n_loop_fine = 0, n_loops_closed = 0, n_edges = 0;
 };
 
@@ -113,8 +114,11 @@ int fe_update_world(lslam_frontend* f, int id) {
   // No host synchronisation: the pose goes through its own slot of a small ring (the copy of a pageable host buffer is
   // staged before hipMemcpyAsync returns; the stream orders it before the kernel, and the kernel before the next
   // grid rebuild that reads these points).
-  double* d_pose = f->d_q.p + 4 + 4 * (f->pose_slot++ & 7);
-  LSLAM_HIP(ctx, hipMemcpyAsync(d_pose, f->scans[id].sensor, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const unsigned slot = f->pose_slot++ & 7;
+  double* d_pose = f->d_q.p + 4 + 4 * slot;
+  double* h_pose = f->pose_stage[slot];  // stable host address (f->scans may reallocate); every slot is seven host
+  for (int i = 0; i < 3; i++) h_pose[i] = f->scans[id].sensor[i];  // synchronisations old when it is reused
+  LSLAM_HIP(ctx, hipMemcpyAsync(d_pose, h_pose, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((n + 255) / 256, 1), dim3(256), 0,
          (const double*)(f->d_ranges + (size_t)id * n), n, (const double*)d_pose, m->g, (double2*)nullptr,
          f->d_world + (size_t)id * n, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0);
