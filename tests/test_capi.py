@@ -67,3 +67,32 @@ def test_pose_helpers_host_only():
     L.lslam_robot_pose_from_sensor(ctypes.byref(lp), sensor.ctypes.data, back.ctypes.data)
     assert np.allclose(back, robot, atol=1e-12)
     assert abs(sensor[2] - 0.8) < 1e-15
+
+
+def test_frontend_config_defaults_are_the_librarys():
+    """lslam_frontend_config_defaults = the Mapper parameter defaults (Mapper.cpp:1457-1604); host only."""
+    import math
+
+    c = api.frontend_config()
+    assert ctypes.sizeof(api.FrontEndConfig) == 16 + 13 * 8
+    assert (c.scan_buffer_size, c.use_scan_barycenter, c.do_loop_closing, c.loop_match_minimum_chain_size) == (70, 1, 1, 10)
+    assert (c.scan_buffer_maximum_scan_distance, c.minimum_travel_distance, c.minimum_time_interval) == (20.0, 0.2, 3600.0)
+    assert abs(c.minimum_travel_heading - math.radians(10.0)) < 1e-15
+    assert (c.link_match_minimum_response_fine, c.link_scan_maximum_distance, c.loop_search_maximum_distance) == (0.8, 10.0, 4.0)
+    assert abs(c.loop_match_maximum_variance_coarse - 0.16) < 1e-15  # math::Square(0.4)
+    assert (c.loop_match_minimum_response_coarse, c.loop_match_minimum_response_fine) == (0.8, 0.8)
+    assert (c.loop_search_space_dimension, c.loop_search_space_resolution, c.loop_search_space_smear_deviation) == (8.0, 0.05, 0.03)
+    with pytest.raises(AttributeError):
+        api.frontend_config(no_such_parameter=1)
+
+
+def test_pool_without_gpu_fails_loudly():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from lslam_amd import synth
+
+    with pytest.raises(api.LslamError) as e:
+        api.MatcherPool(api.baseline_config(), api.laser_params(synth.Laser()), 0)
+    assert e.value.code == -2
