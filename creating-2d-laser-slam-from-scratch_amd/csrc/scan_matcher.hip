@@ -1308,29 +1308,39 @@ k_resp_dense(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1,
 #pragma unroll
       for (int q = 0; q < 4; q++) pe[t][q] = po[t][q] = 0u;
     const int b1 = min(b_hi, b0 + 256);
-    for (int b = b0; b < b1; b++) {
-      const int32_t tv = trow[b];  // wave-uniform
-      if (tv == kInvalidScan) continue;
-      const long long base = pos00 + tv;
-      const uint8_t* src = (base & 1) ? src1 : src0;
-      const long long m0 = (base >> 1) + 16 * k;
-      uint4 d[kDenseT];
+    // kGroup beams per iteration: their table entries (wave-uniform) and all kGroup * kDenseT row loads are issued before the
+    // first byte is used -- one beam per iteration was a chain of dependent loads (135 round trips for a single match)
+    constexpr int kGroup = 4;
+    for (int b = b0; b < b1; b += kGroup) {
+      int32_t tv[kGroup];
 #pragma unroll
-      for (int t = 0; t < kDenseT; t++) {
-        const int j = j_base + t * rpw + r;
-        const long long m = m0 + (long long)j * g.stride;
-        d[t] = make_uint4(0u, 0u, 0u, 0u);
-        if (lane_on && j < pc.ny && m + 16 > 0 && m < (long long)limit) __builtin_memcpy(&d[t], src + m, 16);
-      }
+      for (int u = 0; u < kGroup; u++) tv[u] = b + u < b1 ? trow[b + u] : kInvalidScan;
+      uint4 d[kGroup][kDenseT];
 #pragma unroll
-      for (int t = 0; t < kDenseT; t++) {
-        const uint32_t dw[4] = {d[t].x, d[t].y, d[t].z, d[t].w};
+      for (int u = 0; u < kGroup; u++) {
+        const long long base = pos00 + tv[u];
+        const uint8_t* src = (base & 1) ? src1 : src0;
+        const long long m0 = (base >> 1) + 16 * k;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          pe[t][q] += dw[q] & 0x00FF00FFu;
-          po[t][q] += (dw[q] >> 8) & 0x00FF00FFu;
+        for (int t = 0; t < kDenseT; t++) {
+          const int j = j_base + t * rpw + r;
+          const long long m = m0 + (long long)j * g.stride;
+          d[u][t] = make_uint4(0u, 0u, 0u, 0u);
+          if (tv[u] != kInvalidScan && lane_on && j < pc.ny && m + 16 > 0 && m < (long long)limit)
+            __builtin_memcpy(&d[u][t], src + m, 16);
         }
       }
+#pragma unroll
+      for (int u = 0; u < kGroup; u++)
+#pragma unroll
+        for (int t = 0; t < kDenseT; t++) {
+          const uint32_t dw[4] = {d[u][t].x, d[u][t].y, d[u][t].z, d[u][t].w};
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            pe[t][q] += dw[q] & 0x00FF00FFu;
+            po[t][q] += (dw[q] >> 8) & 0x00FF00FFu;
+          }
+        }
     }
 #pragma unroll
     for (int t = 0; t < kDenseT; t++)
@@ -1352,9 +1362,10 @@ k_resp_dense(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1,
     for (int c = 0; c < 16; c++) {
       const int i = 16 * k + c;
       if (i >= pc.nx) continue;
-      int32_t* o = resp + (size_t)s * resp_stride + (size_t)a * ncand + (size_t)j * pc.nx + i;
-      if (beam_slices == 1) *o = (int32_t)acc[t][c];
-      else atomicAdd(o, (int32_t)acc[t][c]);
+      // beam slices write their partial sums side by side (plain stores; slice q of scan s at resp + (s*slices + q) *
+      // resp_stride); k_big_latmax adds them up -- integer atomics here were 2 M per single 101x101x21 match
+      int32_t* o = resp + ((size_t)s * beam_slices + slice) * resp_stride + (size_t)a * ncand + (size_t)j * pc.nx + i;
+      *o = (int32_t)acc[t][c];
     }
   }
 }
@@ -1362,6 +1373,80 @@ k_resp_dense(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1,
 // Reduce of a large coarse lattice (block per scan, global scratch instead of LDS): same steps as
 // k_reduce_coarse.  scratch per scan: latmax[ncand] | probs[side^2] (as uint64 bit patterns: all
 // responses are >= 0, so unsigned integer max == double max) | terms[4*ncand] | mask words
+// k_big_latmax: the one part of the big-lattice reduce that is pure throughput -- one exact fp64 division per candidate
+// (214 k of them for a 101 x 101 x 21 match) -- spread over as many blocks as the lattice has 256-cell slices instead of
+// the single block (one CU) of k_reduce_coarse_big: per cell the best penalised response over all angles (latmax), per scan
+// the best response (integer atomicMax on the bit pattern of a non-negative double: order-independent).  Scans whose
+// lattice is not uniform are left to the reduce block, which computes their numerators first (block_generic_fallback).
+__global__ void __launch_bounds__(256)
+k_big_latmax(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ lat, int32_t* __restrict__ resp,
+             size_t resp_stride, double* __restrict__ scratch, size_t scratch_stride,
+             unsigned long long* __restrict__ best_bits, int fb_step, const int32_t* __restrict__ part, int slices) {
+  __shared__ double s_ap[kMaxAngles];
+  __shared__ double sh[4];
+  const int s = blockIdx.y, tid = threadIdx.x;
+  const Lattice& L = lat[s];
+  if (!L.active || L.status != 0) return;
+  if (fb_step != 0 && (L.step_x != fb_step || L.step_y != fb_step)) return;
+  const int ncand = pc.nx * pc.ny;
+  const double center2 = L.center[2];
+  for (int a = tid; a < pc.na; a += 256) {
+    const double angle = (center2 - pc.ang_off) + (uint32_t)a * pc.ang_res;  // Mapper.cpp:390-393
+    const double sad = ksq(angle - center2);
+    const double ap = 1.0 - (kAnglePenaltyGain * sad / sc.avp);
+    s_ap[a] = ap > sc.min_ap ? ap : sc.min_ap;
+  }
+  __syncthreads();
+  const int c = blockIdx.x * 256 + tid;
+  double m = -1.0;
+  if (c < ncand) {
+    int32_t* r = resp + (size_t)s * resp_stride;
+    const int32_t* ps = part + (size_t)s * slices * resp_stride;
+    const double denom = (double)((uint32_t)g.n_beams * (uint32_t)kOccupied);
+    double dp = 1.0;
+    if (sc.do_penalize) {
+      const int xi = c % pc.nx, yi = c / pc.nx;
+      const double x = -pc.off_x + (uint32_t)xi * pc.res_x, y = -pc.off_y + (uint32_t)yi * pc.res_y;
+      const double sd = ksq(x) + ksq(y);
+      dp = 1.0 - (kDistPenaltyGain * sd / sc.dvp);
+      dp = dp > sc.min_dp ? dp : sc.min_dp;
+    }
+    constexpr int kBatch = 8, kMaxSlices = 8;
+    for (int a0 = 0; a0 < pc.na; a0 += kBatch) {
+      int32_t rv[kBatch];
+      if (slices > 1) {  // add up the beam slices of k_resp_dense (exact: integers) and publish the sums as the numerators;
+        int32_t pv[kBatch][kMaxSlices];  // all loads of the batch are issued before the first add
+#pragma unroll
+        for (int i = 0; i < kBatch; i++)
+#pragma unroll
+          for (int q = 0; q < kMaxSlices; q++)
+            pv[i][q] = (a0 + i < pc.na && q < slices) ? ps[(size_t)q * resp_stride + (size_t)(a0 + i) * ncand + c] : 0;
+#pragma unroll
+        for (int i = 0; i < kBatch; i++) {
+          int32_t sum = 0;
+#pragma unroll
+          for (int q = 0; q < kMaxSlices; q++) sum += pv[i][q];
+          rv[i] = sum;
+          if (a0 + i < pc.na) r[(size_t)(a0 + i) * ncand + c] = sum;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < kBatch; i++) rv[i] = a0 + i < pc.na ? r[(a0 + i) * ncand + c] : 0;
+      }
+#pragma unroll
+      for (int i = 0; i < kBatch; i++)
+        if (a0 + i < pc.na) {
+          double v = (double)rv[i] / denom;  // GetResponse normalisation (:852)
+          if (sc.do_penalize && !double_equal(v, 0.0)) v *= (dp * s_ap[a0 + i]);
+          m = m > v ? m : v;
+        }
+    }
+    scratch[(size_t)s * scratch_stride + c] = m;
+  }
+  const double bm = block_max(m, sh, tid, 256);
+  if (tid == 0 && bm >= 0.0) atomicMax(&best_bits[s], (unsigned long long)__double_as_longlong(bm));
+}
+
 // NT threads per block: 256 for batches (one block per scan, many scans in flight), 1024 for a handful of scans
 // (TryCloseLoop's single coarse match: the block is the only parallelism there is)
 template <int NT>
@@ -1369,7 +1454,8 @@ __global__ void __launch_bounds__(NT)
 k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ lat,
                     int32_t* resp, size_t resp_stride, CoarseOut* __restrict__ out,
                     int use_expansion, int pass_index, double* __restrict__ scratch, size_t scratch_stride,
-                    const uint8_t* __restrict__ grid, const double2* __restrict__ local, int fb_step) {
+                    const uint8_t* __restrict__ grid, const double2* __restrict__ local, int fb_step,
+                    const unsigned long long* __restrict__ best_bits) {
   constexpr int kList = 2048;
   __shared__ double sh[NT];
   __shared__ double chunk[4 * NT];
@@ -1393,15 +1479,50 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
   uint32_t* mask = (uint32_t*)(terms + 4 * (size_t)ncand);
   const int32_t* r = resp + (size_t)s * resp_stride;
   const double center[3] = {L.center[0], L.center[1], L.center[2]};
-  auto value = [&](int c, int a) -> double {
-    return penalized(r[a * ncand + c], cand_of(c * pc.na + a, pc, center), center, g.n_beams, sc);
+  // penalized(sum, cand_of(c*nA + a)) (Mapper.cpp:399-414, 852) with the per-cell and per-angle factors hoisted: the
+  // distance penalty depends on the cell only, the angle penalty on the angle only, and r *= (dp * ap) is the
+  // reference's own grouping -- no integer division and no cos-free recomputation per candidate
+  __shared__ double s_ap[kMaxAngles];
+  for (int a = tid; a < pc.na; a += NT) {
+    const double angle = (center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;  // :390-393
+    const double sad = ksq(angle - center[2]);
+    const double ap = 1.0 - (kAnglePenaltyGain * sad / sc.avp);
+    s_ap[a] = ap > sc.min_ap ? ap : sc.min_ap;
+  }
+  __syncthreads();
+  const double denom = (double)((uint32_t)g.n_beams * (uint32_t)kOccupied);
+  auto cell_dp = [&](int c) -> double {
+    const int xi = c % pc.nx, yi = c / pc.nx;
+    const double x = -pc.off_x + (uint32_t)xi * pc.res_x;  // Mapper.cpp:342-345
+    const double y = -pc.off_y + (uint32_t)yi * pc.res_y;  // :353-356
+    const double sd = ksq(x) + ksq(y);
+    const double dp = 1.0 - (kDistPenaltyGain * sd / sc.dvp);
+    return dp > sc.min_dp ? dp : sc.min_dp;
   };
+  auto value_of = [&](int32_t sum, double dp, int a) -> double {
+    double v = (double)sum / denom;
+    if (sc.do_penalize && !double_equal(v, 0.0)) v *= (dp * s_ap[a]);
+    return v;
+  };
+  // k_big_latmax has done the per-cell maxima of every scan with a uniform lattice; only a scan whose numerators this
+  // block had to compute itself (block_generic_fallback above) still needs them here
+  const bool have_latmax = !(fb_step != 0 && (L.step_x != fb_step || L.step_y != fb_step));
   double lm = -1.0;
-  for (int c = tid; c < ncand; c += NT) {
+  for (int c = tid; c < ncand && !have_latmax; c += NT) {
     double m = -1.0;
-    for (int a = 0; a < pc.na; a++) {
-      double v = value(c, a);
-      m = m > v ? m : v;
+    const double dp = sc.do_penalize ? cell_dp(c) : 1.0;
+    // the numerators of a cell are fetched eight angles at a time (independent loads in flight)
+    constexpr int kBatch = 8;
+    for (int a0 = 0; a0 < pc.na; a0 += kBatch) {
+      int32_t rv[kBatch];
+#pragma unroll
+      for (int i = 0; i < kBatch; i++) rv[i] = a0 + i < pc.na ? r[(a0 + i) * ncand + c] : 0;
+#pragma unroll
+      for (int i = 0; i < kBatch; i++)
+        if (a0 + i < pc.na) {
+          const double v = value_of(rv[i], dp, a0 + i);
+          m = m > v ? m : v;
+        }
     }
     latmax[c] = m;
     lm = lm > m ? lm : m;
@@ -1409,11 +1530,13 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
   for (int wd = tid; wd < words; wd += NT) mask[wd] = 0u;
   for (int c = tid; c < side2; c += NT) probs[c] = 0ull;  // Clear (:329) (+0.0)
   if (tid == 0) { s_nlist = 0; s_status = 0; }
-  const double best = block_max(lm, sh, tid, NT);
+  double best = block_max(lm, sh, tid, NT);
+  if (have_latmax) best = __longlong_as_double((long long)best_bits[s]);  // >= +0: the unsigned order of the bits is the fp order
   for (int c = tid; c < ncand; c += NT) {
     if (latmax[c] + kTol < best) continue;  // no angle of this cell can tie
+    const double dp = sc.do_penalize ? cell_dp(c) : 1.0;
     for (int a = 0; a < pc.na; a++)
-      if (double_equal(value(c, a), best)) {
+      if (double_equal(value_of(r[a * ncand + c], dp, a), best)) {
         const int k = c * pc.na + a;
         atomicOr(&mask[k >> 5], 1u << (k & 31));
       }
@@ -2018,6 +2141,7 @@ struct lslam_matcher {
   DevBuf<CoarseOut> d_coarse;
   DevBuf<int32_t> d_resp;
   DevBuf<int32_t> d_tbl;     // large lattices: materialised lookup tables [S][nA][N]
+  DevBuf<int32_t> d_part;    // large lattices, few scans: per-beam-slice partial numerators [S][slices][resp_stride]
   DevBuf<double> d_big;      // large lattices: reduce scratch
   DevBuf<lslam_match_result> d_results;
   DevBuf<int32_t> d_dbg;
@@ -2248,24 +2372,32 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     // exact).  Measured for ONE 101x101x21 match: 2/4/8/16/32 slices -> see DESIGN 'tried'; beyond 8 the atomics cost more
     // than the extra waves bring (LSLAM_DENSE_SLICES overrides for experiments)
     int slices = 1;
-    static const int max_slices = getenv("LSLAM_DENSE_SLICES") ? atoi(getenv("LSLAM_DENSE_SLICES")) : 8;
+    static const int max_slices = std::min(8, getenv("LSLAM_DENSE_SLICES") ? atoi(getenv("LSLAM_DENSE_SLICES")) : 8);  // k_big_latmax sums at most 8
     while (slices < max_slices && (long long)S * p.na * n_tiles * slices < 1024) slices *= 2;
-    if (slices > 1)
-      LSLAM_HIP(ctx, hipMemsetAsync(m->d_resp.p, 0, (size_t)S * resp_stride * sizeof(int32_t), ctx->stream));
+    if (slices > 1) LSLAM_HIP(ctx, m->d_part.reserve((size_t)S * slices * resp_stride));
     launch(ctx, "resp_dense", k_resp_dense, dim3((unsigned)((long long)S * p.na * n_tiles * slices)), dim3(64), 0,
            (const uint8_t*)m->d_sub[0], (const uint8_t*)m->d_sub[1], g.data_size / 2, g, p, (const Lattice*)m->d_lat.p,
-           (const int32_t*)m->d_tbl.p, m->d_resp.p, resp_stride, n_tiles, slices);
+           (const int32_t*)m->d_tbl.p, slices > 1 ? m->d_part.p : m->d_resp.p, resp_stride, n_tiles, slices);
     const size_t ncand = (size_t)p.nx * p.ny, total = ncand * p.na;
     const size_t stride = ncand + (size_t)g.probs_side * g.probs_side + 4 * ncand + (total + 63) / 64 + 8;  // doubles
-    LSLAM_HIP(ctx, m->d_big.reserve((size_t)S * stride));
-if (S <= 16)
-          launch(ctx, "reduce_coarse_big", k_reduce_coarse_big<1024>, dim3(S), dim3(1024), 0, g, p, sc, (const Lattice*)m->d_lat.p,
+    LSLAM_HIP(ctx, m->d_big.reserve((size_t)S * stride + S + 1));
+    // per-cell maxima + best response of every scan on (ncand / 256) x S blocks; the reduce block then only does the
+    // order-dependent parts.  best_bits lives behind the scratch of the last scan.
+    unsigned long long* best_bits = (unsigned long long*)(m->d_big.p + (size_t)S * stride);
+    LSLAM_HIP(ctx, hipMemsetAsync(best_bits, 0, (size_t)S * sizeof(unsigned long long), ctx->stream));
+    launch(ctx, "big_latmax", k_big_latmax, dim3((unsigned)((ncand + 255) / 256), S), dim3(256), 0, g, p, sc,
+           (const Lattice*)m->d_lat.p, m->d_resp.p, resp_stride, m->d_big.p, stride, best_bits, fb_step,
+           (const int32_t*)m->d_part.p, slices);
+    if (S <= 16)
+      launch(ctx, "reduce_coarse_big", k_reduce_coarse_big<1024>, dim3(S), dim3(1024), 0, g, p, sc, (const Lattice*)m->d_lat.p,
              m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
-             m->d_big.p, stride, (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step);
+             m->d_big.p, stride, (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step,
+             (const unsigned long long*)best_bits);
     else
-          launch(ctx, "reduce_coarse_big", k_reduce_coarse_big<256>, dim3(S), dim3(256), 0, g, p, sc, (const Lattice*)m->d_lat.p,
+      launch(ctx, "reduce_coarse_big", k_reduce_coarse_big<256>, dim3(S), dim3(256), 0, g, p, sc, (const Lattice*)m->d_lat.p,
              m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
-             m->d_big.p, stride, (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step);
+             m->d_big.p, stride, (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step,
+             (const unsigned long long*)best_bits);
     if (dbg_coarse_sums && pass_index == 0)  // after the reduce: it fills in scans the packed kernel skipped
       LSLAM_HIP(ctx, hipMemcpyAsync(dbg_coarse_sums, m->d_resp.p, (size_t)p.nx * p.ny * p.na * sizeof(int32_t),
                                     hipMemcpyDeviceToDevice, ctx->stream));
@@ -2531,7 +2663,7 @@ void lslam_matcher_destroy(lslam_matcher* m) {
   (void)hipFree(m->d_ptiles);
   m->d_ranges64.release(); m->d_poses.release(); m->d_local.release(); m->d_world.release();
   m->d_valid.release(); m->d_fv_scratch.release(); m->d_centres.release(); m->d_lat.release(); m->d_cossin.release(); m->d_coarse.release(); m->d_resp.release();
-  m->d_tbl.release(); m->d_big.release(); m->d_results.release(); m->d_dbg.release();
+  m->d_tbl.release(); m->d_part.release(); m->d_big.release(); m->d_results.release(); m->d_dbg.release();
   delete m;
 }
 
