@@ -2368,11 +2368,11 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
            (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_tbl.p);
     const int lpr = (p.nx + 15) / 16, rpw = 64 / lpr;
     const int n_tiles = (p.ny + rpw * kDenseT - 1) / (rpw * kDenseT);
-    // few scans: split the beams of one (scan, angle, tile) over up to 8 waves (integer atomics combine the slices, still
-    // exact).  Measured for ONE 101x101x21 match: 2/4/8/16/32 slices -> see DESIGN 'tried'; beyond 8 the atomics cost more
-    // than the extra waves bring (LSLAM_DENSE_SLICES overrides for experiments)
+    // few scans: split the beams of one (scan, angle, tile) over up to 8 waves; every slice writes its own partial sums
+    // (plain stores) and k_big_latmax adds them up -- exact (integers), no atomics.  Measured for ONE 101x101x21 match:
+    // 4 / 8 / 16 slices -> dense pass 0.102 / 0.065 / 0.057 ms, summing pass 0.018 / 0.018 / 0.095 ms: 8 it is.
     int slices = 1;
-    static const int max_slices = std::min(8, getenv("LSLAM_DENSE_SLICES") ? atoi(getenv("LSLAM_DENSE_SLICES")) : 8);  // k_big_latmax sums at most 8
+    constexpr int max_slices = 8;  // = kMaxSlices of k_big_latmax
     while (slices < max_slices && (long long)S * p.na * n_tiles * slices < 1024) slices *= 2;
     if (slices > 1) LSLAM_HIP(ctx, m->d_part.reserve((size_t)S * slices * resp_stride));
     launch(ctx, "resp_dense", k_resp_dense, dim3((unsigned)((long long)S * p.na * n_tiles * slices)), dim3(64), 0,
