@@ -1049,7 +1049,7 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
   __shared__ double s_ap[kMaxAngles];
   __shared__ unsigned long long s_nz[4];
   __shared__ double s_avg[3];
-  __shared__ int s_status, s_bad;
+  __shared__ int s_status, s_bad, s_ntie;
   const int s = blockIdx.x, tid = threadIdx.x;
   const Lattice& L = lat[s];
   if (!L.active) return;
@@ -1061,12 +1061,17 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
   const int ncand = pc.nx * pc.ny;
   const int total = ncand * pc.na;
   const int words = (total + 31) / 32;  // <= 256 (host)
-  double* presp = (double*)smem;
-  double* latmax = presp + total;
-  double* probs = latmax + ncand;
+  // No per-candidate cache in LDS (it was 20 KB of the block's 29 KB and capped the kernel at 5 blocks per CU -- the
+  // kernel is latency-bound, so residency is what it needs): each thread owns the angles of ONE lattice cell half and
+  // keeps only the cell maximum; the few cells that can tie with the best response are re-evaluated below with the
+  // same expression, hence the same bits.
+  double* latmax = (double*)smem;
+  double* lat2 = latmax + ncand;  // second half of the angles of each cell
+  double* probs = lat2 + ncand;
   double* terms = probs + g.probs_side * g.probs_side;  // 4 per lattice cell
   uint32_t* mask = (uint32_t*)(terms + 4 * ncand);
   int* cell = (int*)(mask + words);
+  int* tie = cell + ncand;  // lattice cells that may hold a tie with the best response
   double* dpen = terms;  // distance penalty per lattice cell; dead before `terms` is written
   const int32_t* r = resp + (size_t)s * resp_stride;
   const double center[3] = {L.center[0], L.center[1], L.center[2]};
@@ -1074,7 +1079,7 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
   // per-cell and per-angle penalty factors (Mapper.cpp:399-414) + search-space cell of every lattice
   // position (offset = searchCenter - searchSpaceOffset, :332-333; WorldToGrid of the position, :440)
   const double p_off_x = center[0] - pc.off_x, p_off_y = center[1] - pc.off_y;
-  if (tid == 0) s_bad = 0;
+  if (tid == 0) { s_bad = 0; s_ntie = 0; }
   for (int c = tid; c < ncand; c += 256) {
     const int xi = c % pc.nx, yi = c / pc.nx;
     const double x = -pc.off_x + (uint32_t)xi * pc.res_x;  // Mapper.cpp:342-345
@@ -1096,45 +1101,57 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
   for (int c = tid; c < g.probs_side * g.probs_side; c += 256) probs[c] = 0.0;  // Clear (:329)
   __syncthreads();
 
-  // penalised responses, storage order (angle-major, coalesced) -> candidate order k = c*nA + a in LDS
+  // penalised response of candidate (c, a): GetResponse normalisation (:852) and r *= (dp * ap) (:399-414)
   const double denom = (double)((uint32_t)g.n_beams * (uint32_t)kOccupied);
+  auto value_of = [&](int32_t sum, int c, int a) -> double {
+    double v = (double)sum / denom;
+    if (sc.do_penalize && !double_equal(v, 0.0)) v *= (dpen[c] * s_ap[a]);
+    return v;
+  };
+  // cell maxima: thread -> (cell, half of the angles); numerators are stored angle-major, so neighbouring threads read
+  // neighbouring words; a thread's loads are issued eight at a time
+  const int parts = 2 * ncand <= 256 ? 2 : 1;
   double lm = -1.0;  // bestResponse starts at -1 (Mapper.cpp:431)
-  {
-    int a = tid / ncand, c = tid - a * ncand;
-    auto one = [&](int32_t sum) {
-      double v = (double)sum / denom;  // GetResponse normalisation (:852)
-      if (sc.do_penalize && !double_equal(v, 0.0)) v *= (dpen[c] * s_ap[a]);
-      presp[c * pc.na + a] = v;
-      lm = lm > v ? lm : v;
-      c += 256;
-      while (c >= ncand) { c -= ncand; a++; }
-    };
-    // the numerators of a thread are fetched together (independent loads in flight), 8 at a time
+  for (int idx = tid; idx < ncand * parts; idx += 256) {
+    const int part = idx >= ncand ? 1 : 0, c = idx - part * ncand;
+    const int a_lo = part * pc.na / parts, a_hi = (part + 1) * pc.na / parts;
+    double m = -1.0;
     constexpr int kBatch = 8;
-    int t = tid;
-    for (; t + 256 * (kBatch - 1) < total; t += 256 * kBatch) {
+    for (int a0 = a_lo; a0 < a_hi; a0 += kBatch) {
       int32_t rv[kBatch];
 #pragma unroll
-      for (int i = 0; i < kBatch; i++) rv[i] = r[t + 256 * i];
+      for (int i = 0; i < kBatch; i++) rv[i] = a0 + i < a_hi ? r[(a0 + i) * ncand + c] : 0;
 #pragma unroll
-      for (int i = 0; i < kBatch; i++) one(rv[i]);
+      for (int i = 0; i < kBatch; i++)
+        if (a0 + i < a_hi) {
+          const double v = value_of(rv[i], c, a0 + i);
+          m = m > v ? m : v;
+        }
     }
-    for (; t < total; t += 256) one(r[t]);
+    (part ? lat2 : latmax)[c] = m;
+    lm = lm > m ? lm : m;
   }
-  const double best = block_max(lm, sh, tid, 256);  // contains the barriers that publish presp
+  const double best = block_max(lm, sh, tid, 256);  // contains the barriers that publish latmax / lat2
 
   // best response per lattice cell over all angles, max-merged into the search-space probabilities
   // (Mapper.cpp:437-450); responses are >= +0, so the unsigned order of the bit patterns is the fp order
   for (int c = tid; c < ncand; c += 256) {
-    double m = -1.0;
-    const double* pr = presp + c * pc.na;
-    for (int a = 0; a < pc.na; a++) m = m > pr[a] ? m : pr[a];
+    double m = latmax[c];
+    if (parts == 2) m = m > lat2[c] ? m : lat2[c];
     latmax[c] = m;
     if (cell[c] < 0) s_bad = 1;
     else atomicMax((unsigned long long*)&probs[cell[c]], (unsigned long long)__double_as_longlong(m < 0.0 ? 0.0 : m));
+    // ties with the best response (:452-455): only a cell whose maximum reaches it can hold one
+    if (!(m + 2.0 * kTol < best)) tie[atomicAdd(&s_ntie, 1)] = c;  // conservative filter; the test below is the reference's
   }
-  for (int k = tid; k < total; k += 256)
-    if (double_equal(presp[k], best)) atomicOr(&mask[k >> 5], 1u << (k & 31));
+  __syncthreads();
+  for (int idx = tid, n = s_ntie * pc.na; idx < n; idx += 256) {
+    const int c = tie[idx / pc.na], a = idx % pc.na;
+    if (double_equal(value_of(r[a * ncand + c], c, a), best)) {
+      const int k = c * pc.na + a;
+      atomicOr(&mask[k >> 5], 1u << (k & 31));
+    }
+  }
   __syncthreads();
   {  // which mask words are non-zero (words <= 256 = one per thread)
     const unsigned long long nz = __ballot(tid < words && mask[tid] != 0u);
@@ -2256,6 +2273,11 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     return (cache ? total * 8 : 0) + (size_t)p.nx * p.ny * (8 + 32 + 4) + (size_t)g.probs_side * g.probs_side * 8 +
            ((total + 31) / 32) * 4 + 16;
   };
+  // k_reduce_coarse_lds keeps no per-candidate cache: two cell-maximum arrays instead
+  auto reduce_lds_nocache = [&](const PassCfg& p) -> size_t {
+    size_t total = (size_t)p.nx * p.ny * p.na;
+    return (size_t)p.nx * p.ny * (8 + 8 + 32 + 4 + 4) + (size_t)g.probs_side * g.probs_side * 8 + ((total + 31) / 32) * 4 + 16;
+  };
   // response numerators of one pass: packed row kernel for uniform lattices (step 2 on the parity
   // planes, step 1 on the grid), generic kernel for everything else
   // lattice step the packed kernel of the last pass required (0 = the generic kernel did the pass):
@@ -2416,7 +2438,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       fb_step
     if (cache && ((size_t)p.nx * p.ny * p.na + 31) / 32 <= 256) {
       const bool fuse_fine = n_exp == 0 && do_refine;  // nothing between this pass and the fine pass
-      launch(ctx, "reduce_coarse", k_reduce_coarse_lds, dim3(S), dim3(256), reduce_lds(p, true), g, p, sc,
+      launch(ctx, "reduce_coarse", k_reduce_coarse_lds, dim3(S), dim3(256), reduce_lds_nocache(p), g, p, sc,
              m->d_lat.p, m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
              (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step, pf,
              fuse_fine ? m->d_cossin.p : (double2*)nullptr, 1);
