@@ -270,6 +270,11 @@ def lib() -> C.CDLL:
     L.lslam_occgrid_info.argtypes = [vp, vp, vp, C.POINTER(dbl)]
     L.lslam_occgrid_read_u8.argtypes = [vp, vp]
     L.lslam_occgrid_read_ros_i8.argtypes = [vp, vp]
+    L.lslam_occgrid_scan_bounds.argtypes = [vp, C.POINTER(LaserParams), i32, vp, i32, vp, vp]
+    L.lslam_occgrid_create_partial.argtypes = [vp, C.POINTER(LaserParams), i32, vp, i32, vp, dbl, vp, C.POINTER(vp)]
+    L.lslam_occgrid_counter_words.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.lslam_occgrid_export_counters.argtypes = [vp, vp, i32]
+    L.lslam_occgrid_import_counters.argtypes = [vp, vp, i32, i32]
     L.lslam_map_create.argtypes = [vp, i32, i32, C.c_float, C.c_float, C.c_float, i32, C.POINTER(vp)]
     L.lslam_map_destroy.argtypes = [vp]
     L.lslam_map_destroy.restype = None
@@ -679,6 +684,50 @@ class OccupancyGrid:
         ctx.check(ctx.L.lslam_occgrid_create_from_scans(ctx.h, C.byref(laser), r.shape[0], r.ctypes.data, r.shape[1],
                                                         p.ctypes.data, resolution, C.byref(h)))
         return cls(ctx, h)
+
+    # ---- sharded build: boxes merge by min/max, counters by integer addition, both exact ----
+    @staticmethod
+    def scan_bounds(ctx: Context, laser: LaserParams, ranges, sensor_poses) -> np.ndarray:
+        """Box (minx, miny, maxx, maxy) ComputeDimensions derives from THESE scans; no scans -> the identity box."""
+        r, p = _f64(ranges), _f64(sensor_poses)
+        r = r.reshape(-1, r.shape[-1]) if r.size else r.reshape(0, 1)
+        box = np.zeros(4)
+        ctx.check(ctx.L.lslam_occgrid_scan_bounds(ctx.h, C.byref(laser), r.shape[0], r.ctypes.data, r.shape[1], p.ctypes.data,
+                                                  box.ctypes.data))
+        return box
+
+    @classmethod
+    def CreatePartial(cls, ctx: Context, laser: LaserParams, ranges, sensor_poses, resolution: float, box):
+        """Counters of these scans (possibly none) on the grid of `box`, the merged box of all shards."""
+        r, p, b = _f64(ranges), _f64(sensor_poses), _f64(box)
+        r = r.reshape(-1, r.shape[-1]) if r.size else r.reshape(0, 1)
+        h = C.c_void_p()
+        ctx.check(ctx.L.lslam_occgrid_create_partial(ctx.h, C.byref(laser), r.shape[0], r.ctypes.data, r.shape[1],
+                                                     p.ctypes.data, resolution, b.ctypes.data, C.byref(h)))
+        return cls(ctx, h)
+
+    def counter_words(self) -> int:
+        n = C.c_size_t()
+        self.ctx.check(self.L.lslam_occgrid_counter_words(self.h, C.byref(n)))
+        return int(n.value)
+
+    def export_counters(self) -> np.ndarray:
+        """uint32 [2, stride*height]: pass plane, hit plane."""
+        out = np.zeros(self.counter_words(), dtype=np.uint32)
+        self.ctx.check(self.L.lslam_occgrid_export_counters(self.h, out.ctypes.data, 0))
+        return out.reshape(2, -1)
+
+    def import_counters(self, counters, accumulate: bool = False):
+        c = np.ascontiguousarray(counters, dtype=np.uint32).reshape(-1)
+        if c.size != self.counter_words():
+            raise ValueError(f"expected {self.counter_words()} counter words, got {c.size}")
+        self.ctx.check(self.L.lslam_occgrid_import_counters(self.h, c.ctypes.data, 0, int(accumulate)))
+
+    def export_counters_dev(self, dev_ptr: int):
+        self.ctx.check(self.L.lslam_occgrid_export_counters(self.h, C.c_void_p(dev_ptr), 1))
+
+    def import_counters_dev(self, dev_ptr: int, accumulate: bool = False):
+        self.ctx.check(self.L.lslam_occgrid_import_counters(self.h, C.c_void_p(dev_ptr), 1, int(accumulate)))
 
     def close(self):
         if getattr(self, "h", None):

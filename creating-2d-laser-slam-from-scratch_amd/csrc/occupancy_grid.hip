@@ -12,6 +12,11 @@
 //   k_occ_trace    one wave per beam: TraceLine cells in closed form, atomicAdd on the pass plane,
 //                  hit+pass on a valid end point
 //   k_occ_update   thread per cell: occupied / free / unknown from the two counters
+//
+// Multi-GPU ("offline map build from known poses"): the scan boxes combine by min/max and the counters
+// by integer addition, both exact, so ranks build partial grids of disjoint scan subsets on the grid of the merged
+// box (lslam_occgrid_scan_bounds / _create_partial), all-reduce(sum) the counter planes -- one contiguous buffer,
+// one collective (lslam_occgrid_export_counters / _import_counters; shard.py drives RCCL) -- and classify locally.
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -147,22 +152,27 @@ k_occ_update(OccGeom g, const uint32_t* __restrict__ pass, const uint32_t* __res
 struct lslam_occgrid {
   lslam_context* ctx = nullptr;
   OccGeom g{};
-  uint32_t* d_pass = nullptr;
+  uint32_t* d_pass = nullptr;  // one allocation: pass plane, then the hit plane
   uint32_t* d_hit = nullptr;
+  size_t cells = 0;            // stride * h words per plane
   DevBuf<uint8_t> d_out;
 };
 
-extern "C" {
+namespace {
 
-int lslam_occgrid_create_from_scans(lslam_context* ctx, const lslam_laser* laser, int n_scans, const double* ranges,
-                                    int ranges_stride, const double* sensor_poses, double resolution,
-                                    lslam_occgrid** out) {
-  if (!ctx || !laser || !out || n_scans < 0 || (n_scans > 0 && (!ranges || !sensor_poses)))
-    return LSLAM_ERR_INVALID_ARGUMENT;
-  *out = nullptr;
-  if (n_scans == 0) return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "no scans (the reference returns NULL)");
-  if (resolution == 0.0 || (resolution > -kTol && resolution < kTol))
-    return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "Resolution cannot be 0");  // Karto.h:5627-5630
+__global__ void __launch_bounds__(256)
+k_occ_add(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
+constexpr double kBoxBig = 999999999999999999.99999;  // BoundingBox2() (Karto.h:2765)
+
+// Shared body of the whole and the sharded build.  forced_box == nullptr: the grid is sized from these scans
+// (ComputeDimensions); otherwise from the given box (the union over all shards).  out == nullptr: bounds only.
+int occ_build(lslam_context* ctx, const lslam_laser* laser, int n_scans, const double* ranges, int ranges_stride,
+              const double* sensor_poses, double resolution, const double* forced_box, double* box_out,
+              lslam_occgrid** out) {
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
   OccLaser l;
   l.min_angle = laser->minimum_angle;
@@ -172,37 +182,51 @@ int lslam_occgrid_create_from_scans(lslam_context* ctx, const lslam_laser* laser
   l.range_threshold = laser->range_threshold;
   l.n_beams = (int)(uint32_t)kround((laser->maximum_angle - laser->minimum_angle) / laser->angular_resolution);
   const int n = l.n_beams;
-  if (ranges_stride < n) return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "ranges_stride %d < num_beams %d", ranges_stride, n);
+  if (n_scans > 0 && ranges_stride < n)
+    return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "ranges_stride %d < num_beams %d", ranges_stride, n);
   const size_t total = (size_t)n_scans * std::max(n, 1);
   DevBuf<double> d_ranges, d_poses, d_bbox;
   DevBuf<double2> d_ends;
   DevBuf<uint8_t> d_flags;
   auto cleanup = [&]() { d_ranges.release(); d_poses.release(); d_bbox.release(); d_ends.release(); d_flags.release(); };
-  if (d_ranges.reserve(total) != hipSuccess || d_poses.reserve((size_t)n_scans * 3) != hipSuccess ||
-      d_bbox.reserve(4) != hipSuccess || d_ends.reserve(total) != hipSuccess || d_flags.reserve(total) != hipSuccess) {
-    cleanup();
-    return ctx->fail(LSLAM_ERR_HIP, "cannot allocate occupancy-grid workspaces");
-  }
-  const double big = 999999999999999999.99999;
-  double bbox[4] = {big, big, -big, -big};
-  hipError_t e = hipSuccess;
-  if (n > 0)
-    e = hipMemcpy2DAsync(d_ranges.p, (size_t)n * sizeof(double), ranges, (size_t)ranges_stride * sizeof(double),
-                         (size_t)n * sizeof(double), n_scans, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_poses.p, sensor_poses, (size_t)n_scans * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_bbox.p, bbox, sizeof bbox, hipMemcpyHostToDevice, ctx->stream);
-  if (e != hipSuccess) { cleanup(); return ctx->fail(LSLAM_ERR_HIP, "upload failed: %s", hipGetErrorString(e)); }
-  if (n > 0)
-    launch(ctx, "occ_points", k_occ_points, dim3((n + 255) / 256, n_scans), dim3(256), 0, (const double*)d_ranges.p, n,
-           (const double*)d_poses.p, l, d_ends.p, d_flags.p, d_bbox.p);
-  e = hipMemcpyAsync(bbox, d_bbox.p, sizeof bbox, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) { cleanup(); return ctx->fail(LSLAM_ERR_HIP, "bounding box failed: %s", hipGetErrorString(e)); }
-  if (n == 0)  // scans without readings: the boxes hold the sensor positions only
-    for (int s = 0; s < n_scans; s++) {
-      bbox[0] = std::min(bbox[0], sensor_poses[3 * s]); bbox[1] = std::min(bbox[1], sensor_poses[3 * s + 1]);
-      bbox[2] = std::max(bbox[2], sensor_poses[3 * s]); bbox[3] = std::max(bbox[3], sensor_poses[3 * s + 1]);
+  double bbox[4] = {kBoxBig, kBoxBig, -kBoxBig, -kBoxBig};
+  if (n_scans > 0) {
+    if (d_ranges.reserve(total) != hipSuccess || d_poses.reserve((size_t)n_scans * 3) != hipSuccess ||
+        d_bbox.reserve(4) != hipSuccess || d_ends.reserve(total) != hipSuccess || d_flags.reserve(total) != hipSuccess) {
+      cleanup();
+      return ctx->fail(LSLAM_ERR_HIP, "cannot allocate occupancy-grid workspaces");
     }
+    hipError_t e = hipSuccess;
+    if (n > 0)
+      e = hipMemcpy2DAsync(d_ranges.p, (size_t)n * sizeof(double), ranges, (size_t)ranges_stride * sizeof(double),
+                           (size_t)n * sizeof(double), n_scans, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_poses.p, sensor_poses, (size_t)n_scans * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_bbox.p, bbox, sizeof bbox, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { cleanup(); return ctx->fail(LSLAM_ERR_HIP, "upload failed: %s", hipGetErrorString(e)); }
+    if (n > 0)
+      launch(ctx, "occ_points", k_occ_points, dim3((n + 255) / 256, n_scans), dim3(256), 0, (const double*)d_ranges.p, n,
+             (const double*)d_poses.p, l, d_ends.p, d_flags.p, d_bbox.p);
+    if (!forced_box) {
+      e = hipMemcpyAsync(bbox, d_bbox.p, sizeof bbox, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) { cleanup(); return ctx->fail(LSLAM_ERR_HIP, "bounding box failed: %s", hipGetErrorString(e)); }
+      if (n == 0)  // scans without readings: the boxes hold the sensor positions only
+        for (int s = 0; s < n_scans; s++) {
+          bbox[0] = std::min(bbox[0], sensor_poses[3 * s]); bbox[1] = std::min(bbox[1], sensor_poses[3 * s + 1]);
+          bbox[2] = std::max(bbox[2], sensor_poses[3 * s]); bbox[3] = std::max(bbox[3], sensor_poses[3 * s + 1]);
+        }
+    }
+  }
+  if (forced_box)
+    for (int i = 0; i < 4; i++) bbox[i] = forced_box[i];
+  if (box_out)
+    for (int i = 0; i < 4; i++) box_out[i] = bbox[i];
+  if (!out) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e != hipSuccess) return ctx->fail(LSLAM_ERR_HIP, "bounding box failed: %s", hipGetErrorString(e));
+    return LSLAM_OK;
+  }
   lslam_occgrid* og = new lslam_occgrid();
   og->ctx = ctx;
   OccGeom& g = og->g;
@@ -214,24 +238,107 @@ int lslam_occgrid_create_from_scans(lslam_context* ctx, const lslam_laser* laser
   g.oy = bbox[1];
   g.stride = (g.w + 7) & ~7;  // Grid<kt_int32u>::Resize (Karto.h:4442)
   const size_t cells = (size_t)g.stride * std::max(g.h, 0);
-  if (hipMalloc((void**)&og->d_pass, std::max<size_t>(cells, 1) * 4) != hipSuccess ||
-      hipMalloc((void**)&og->d_hit, std::max<size_t>(cells, 1) * 4) != hipSuccess) {
+  // one allocation, pass plane then hit plane: the sharded build all-reduces both with ONE collective
+  if (hipMalloc((void**)&og->d_pass, std::max<size_t>(cells, 1) * 8) != hipSuccess) {
+    (void)hipGetLastError();
     cleanup();
-    if (og->d_pass) (void)hipFree(og->d_pass);
     delete og;
     return ctx->fail(LSLAM_ERR_HIP, "cannot allocate %d x %d counters", g.w, g.h);
   }
-  (void)hipMemsetAsync(og->d_pass, 0, std::max<size_t>(cells, 1) * 4, ctx->stream);
-  (void)hipMemsetAsync(og->d_hit, 0, std::max<size_t>(cells, 1) * 4, ctx->stream);
-  if (n > 0 && cells > 0) {
+  og->d_hit = og->d_pass + std::max<size_t>(cells, 1);
+  og->cells = cells;
+  (void)hipMemsetAsync(og->d_pass, 0, std::max<size_t>(cells, 1) * 8, ctx->stream);
+  if (n > 0 && n_scans > 0 && cells > 0) {
     const long long beams = (long long)n_scans * n;
     launch(ctx, "occ_trace", k_occ_trace, dim3((unsigned)((beams + 3) / 4)), dim3(256), 0, n_scans, l,
            (const double*)d_poses.p, (const double2*)d_ends.p, (const uint8_t*)d_flags.p, g, og->d_pass, og->d_hit);
   }
-  e = hipStreamSynchronize(ctx->stream);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
   cleanup();
   if (e != hipSuccess) { lslam_occgrid_destroy(og); return ctx->fail(LSLAM_ERR_HIP, "trace failed: %s", hipGetErrorString(e)); }
   *out = og;
+  return LSLAM_OK;
+}
+
+int occ_check(lslam_context* ctx, const lslam_laser* laser, int n_scans, const double* ranges, const double* sensor_poses) {
+  if (!ctx || !laser || n_scans < 0 || (n_scans > 0 && (!ranges || !sensor_poses))) return LSLAM_ERR_INVALID_ARGUMENT;
+  return LSLAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lslam_occgrid_create_from_scans(lslam_context* ctx, const lslam_laser* laser, int n_scans, const double* ranges,
+                                    int ranges_stride, const double* sensor_poses, double resolution,
+                                    lslam_occgrid** out) {
+  if (!out || occ_check(ctx, laser, n_scans, ranges, sensor_poses) != LSLAM_OK) return LSLAM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (n_scans == 0) return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "no scans (the reference returns NULL)");
+  if (resolution == 0.0 || (resolution > -kTol && resolution < kTol))
+    return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "Resolution cannot be 0");  // Karto.h:5627-5630
+  return occ_build(ctx, laser, n_scans, ranges, ranges_stride, sensor_poses, resolution, nullptr, nullptr, out);
+}
+
+int lslam_occgrid_scan_bounds(lslam_context* ctx, const lslam_laser* laser, int n_scans, const double* ranges,
+                              int ranges_stride, const double* sensor_poses, double box[4]) {
+  if (!box || occ_check(ctx, laser, n_scans, ranges, sensor_poses) != LSLAM_OK) return LSLAM_ERR_INVALID_ARGUMENT;
+  return occ_build(ctx, laser, n_scans, ranges, ranges_stride, sensor_poses, 1.0, nullptr, box, nullptr);
+}
+
+int lslam_occgrid_create_partial(lslam_context* ctx, const lslam_laser* laser, int n_scans, const double* ranges,
+                                 int ranges_stride, const double* sensor_poses, double resolution, const double box[4],
+                                 lslam_occgrid** out) {
+  if (!out || !box || occ_check(ctx, laser, n_scans, ranges, sensor_poses) != LSLAM_OK) return LSLAM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (resolution == 0.0 || (resolution > -kTol && resolution < kTol))
+    return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "Resolution cannot be 0");  // Karto.h:5627-5630
+  if (!(box[0] <= box[2] && box[1] <= box[3]))
+    return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "empty bounding box (no scans on any shard: the reference returns NULL)");
+  return occ_build(ctx, laser, n_scans, ranges, ranges_stride, sensor_poses, resolution, box, nullptr, out);
+}
+
+int lslam_occgrid_counter_words(const lslam_occgrid* og, size_t* words) {
+  if (!og || !words) return LSLAM_ERR_INVALID_ARGUMENT;
+  *words = 2 * og->cells;
+  return LSLAM_OK;
+}
+
+int lslam_occgrid_export_counters(lslam_occgrid* og, uint32_t* out, int on_device) {
+  if (!og || (!out && og->cells)) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = og->ctx;
+  if (og->cells == 0) return LSLAM_OK;
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  LSLAM_HIP(ctx, hipMemcpyAsync(out, og->d_pass, 2 * og->cells * sizeof(uint32_t),
+                                on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSLAM_OK;
+}
+
+int lslam_occgrid_import_counters(lslam_occgrid* og, const uint32_t* in, int on_device, int accumulate) {
+  if (!og || (!in && og->cells)) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = og->ctx;
+  if (og->cells == 0) return LSLAM_OK;
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t words = 2 * og->cells;
+  if (!accumulate) {
+    LSLAM_HIP(ctx, hipMemcpyAsync(og->d_pass, in, words * sizeof(uint32_t),
+                                  on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    const uint32_t* src = in;
+    DevBuf<uint32_t> staged;
+    if (!on_device) {
+      LSLAM_HIP(ctx, staged.reserve(words));
+      LSLAM_HIP(ctx, hipMemcpyAsync(staged.p, in, words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+      src = staged.p;
+    }
+    launch(ctx, "occ_add", k_occ_add, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, og->d_pass, src, words);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    staged.release();
+    if (e != hipSuccess) return ctx->fail(LSLAM_ERR_HIP, "counter merge failed: %s", hipGetErrorString(e));
+    return LSLAM_OK;
+  }
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return LSLAM_OK;
 }
 
@@ -239,7 +346,6 @@ void lslam_occgrid_destroy(lslam_occgrid* og) {
   if (!og) return;
   (void)hipStreamSynchronize(og->ctx->stream);
   if (og->d_pass) (void)hipFree(og->d_pass);
-  if (og->d_hit) (void)hipFree(og->d_hit);
   og->d_out.release();
   delete og;
 }

@@ -66,3 +66,71 @@ def broadcast_grid(matcher, device, src: int = 0):
     else:
         matcher.set_grid(g.numpy(), offset)
     return g
+
+
+# ------------------------------------------------------------------------------------------------
+# Offline map build from known poses (last row): the one path with a real exchange step.
+# karto::OccupancyGrid::CreateFromScans depends on the scans only through the union of their boxes (min/max)
+# and per-cell hit/pass counts (integer sums), so W ranks build partial grids of disjoint scan subsets and combine
+# them exactly: one 4-double all-reduce (the box), one all-reduce(sum) of the two counter planes in a single
+# contiguous buffer (at 2005^2 cells: 32 MB; ring all-reduce over xGMI is per-link bound, ~0.4 ms at W=8).
+# ------------------------------------------------------------------------------------------------
+def merge_boxes(box, device="cpu"):
+    """All ranks' (minx, miny, maxx, maxy) -> the union box, bit for bit (negation and max are exact)."""
+    import torch
+    import torch.distributed as dist
+
+    b = np.asarray(box, dtype=np.float64)
+    t = torch.tensor([-b[0], -b[1], b[2], b[3]], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    m = t.cpu().numpy()
+    return np.array([-m[0], -m[1], m[2], m[3]])
+
+
+class GpuOccBackend:
+    """The device path of the sharded build: lslam_occgrid_scan_bounds / _create_partial / counters."""
+
+    def __init__(self, ctx, laser_params, device=None):
+        self.ctx, self.laser, self.device = ctx, laser_params, device
+
+    def scan_bounds(self, ranges, poses):
+        from . import api
+        return api.OccupancyGrid.scan_bounds(self.ctx, self.laser, ranges, poses)
+
+    def create_partial(self, ranges, poses, resolution, box):
+        from . import api
+        return api.OccupancyGrid.CreatePartial(self.ctx, self.laser, ranges, poses, resolution, box)
+
+    def all_reduce_counters(self, part):
+        """In place on the grid's device for RCCL (`nccl`); staged through host memory for gloo."""
+        import torch
+        import torch.distributed as dist
+
+        words = part.counter_words()
+        if words == 0:
+            return
+        if dist.get_backend() == "nccl":
+            t = torch.empty(words, dtype=torch.int32, device=self.device)  # two's complement: same sums as uint32
+            torch.cuda.synchronize(self.device)
+            part.export_counters_dev(t.data_ptr())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize(self.device)
+            part.import_counters_dev(t.data_ptr())
+        else:
+            c = part.export_counters().reshape(-1)
+            t = torch.from_numpy(c.view(np.int32))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            part.import_counters(c)
+
+
+def build_occupancy_grid_sharded(backend, ranges_local, poses_local, resolution, device="cpu"):
+    """This rank's scans (possibly none) in, the occupancy grid of ALL ranks' scans out, identical on every rank
+    and identical to CreateFromScans over the concatenated scans.  None where the reference returns NULL (no
+    scans on any rank).  `backend`: GpuOccBackend, or any object with scan_bounds / create_partial /
+    all_reduce_counters (the CPU tests use the oracle)."""
+    box = merge_boxes(backend.scan_bounds(ranges_local, poses_local), device)
+    if not (box[0] <= box[2] and box[1] <= box[3]):
+        return None
+    part = backend.create_partial(ranges_local, poses_local, resolution, box)
+    backend.all_reduce_counters(part)
+    return part

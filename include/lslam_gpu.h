@@ -311,6 +311,30 @@ int lslam_occgrid_read_u8(lslam_occgrid* og, uint8_t* out_host);
 /* nav_msgs/OccupancyGrid data as karto_slam.cc:546-569 fills it: -1 unknown, 100 occupied, 0 free */
 int lslam_occgrid_read_ros_i8(lslam_occgrid* og, int8_t* out_host);
 
+/* Sharded build over several GPUs / ranks (SURVEY 8(e) "offline map build from known poses").  The reference's
+ * result depends on the scans only through (i) the union of their bounding boxes (ComputeDimensions, Karto.h:
+ * 5799-5817: min/max) and (ii) per-cell hit/pass counts (AddScan/RayTrace, Karto.h:5851-5942: integer sums), so
+ * disjoint scan subsets combine exactly, in any order:
+ *   1. every rank: lslam_occgrid_scan_bounds over ITS scans -> box = {minx, miny, maxx, maxy}
+ *      (n_scans == 0 is allowed: the identity box {+big, +big, -big, -big});
+ *   2. all-reduce the boxes (min on [0..1], max on [2..3]);
+ *   3. every rank: lslam_occgrid_create_partial with the merged box -> the counters of its scans on the common grid;
+ *   4. all-reduce(sum) the counter buffers: lslam_occgrid_export_counters -> collective -> lslam_occgrid_import_
+ *      counters (accumulate = 0).  The buffer is lslam_occgrid_counter_words 32-bit words: the pass plane
+ *      (stride*height, stride = width rounded up to 8) followed by the hit plane, so ONE collective moves both.
+ *      on_device = 1: `buf` is a device pointer on the grid's device (RCCL works on it in place), 0: host memory.
+ *      accumulate = 1 adds a peer's exported buffer instead (one-process / tree merges).
+ *   5. every rank (or only the one that publishes) reads the cells: lslam_occgrid_read_u8 / _read_ros_i8.
+ * An empty merged box (no scans anywhere) -> LSLAM_ERR_INVALID_ARGUMENT, the reference's NULL. */
+int lslam_occgrid_scan_bounds(lslam_context* ctx, const lslam_laser* laser, int n_scans, const double* ranges,
+                              int ranges_stride, const double* sensor_poses, double box[4]);
+int lslam_occgrid_create_partial(lslam_context* ctx, const lslam_laser* laser, int n_scans, const double* ranges,
+                                 int ranges_stride, const double* sensor_poses, double resolution, const double box[4],
+                                 lslam_occgrid** out);
+int lslam_occgrid_counter_words(const lslam_occgrid* og, size_t* words);
+int lslam_occgrid_export_counters(lslam_occgrid* og, uint32_t* buf, int on_device);
+int lslam_occgrid_import_counters(lslam_occgrid* og, const uint32_t* buf, int on_device, int accumulate);
+
 /* ---------------------------------------------------------------------------------------- */
 /* Hector log-odds occupancy grid  (replaces hectorslam::OccGridMapBase<LogOddsCell,...>,    */
 /* H/map/OccGridMapBase.h, H/map/GridMapLogOdds.h, H/map/GridMapBase.h)                      */

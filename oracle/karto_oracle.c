@@ -623,15 +623,14 @@ static void occ_trace_line(occ_t* g, int x0, int y0, int x1, int y1) {
   }
 }
 
-int kor_occgrid_from_scans(const kor_matcher* m, int n_scans, const double* ranges, int ranges_stride,
-                           const double* sposes, double resolution, int32_t dims[2], double offset_xy[2],
-                           uint8_t* out) {
-  if (n_scans <= 0) return -1; /* rScans.empty() -> NULL (Karto.h:5661-5664) */
+/* Scan-box union of ComputeDimensions (Karto.h:5799-5817): a scan's box holds its sensor position and its FILTERED
+ * readings (minRange <= r <= rangeThreshold, Karto.h:5382,5418-5424).  box = minx, miny, maxx, maxy; starts from
+ * BoundingBox2() (Karto.h:2765) -- min/max are exact, so boxes of disjoint scan subsets merge to the box of the union. */
+void kor_occgrid_bounds(const kor_matcher* m, int n_scans, const double* ranges, int ranges_stride,
+                        const double* sposes, double box[4]) {
   const int n = m->n_beams;
-  const double thr = m->laser.range_threshold, rmin = m->laser.minimum_range, rmax = m->laser.maximum_range;
+  const double thr = m->laser.range_threshold, rmin = m->laser.minimum_range;
   double* pts = (double*)malloc(sizeof(double) * 2 * (size_t)(n > 0 ? n : 1));
-  /* ComputeDimensions (Karto.h:5799-5817): union of the scans' bounding boxes; a scan's box holds its
-   * sensor position and its FILTERED readings (minRange <= r <= rangeThreshold, Karto.h:5382,5418-5424) */
   double mnx = 999999999999999999.99999, mny = mnx, mxx = -mnx, mxy = -mnx; /* Karto.h:2765 */
   for (int s = 0; s < n_scans; s++) {
     const double* sp = sposes + 3 * s;
@@ -652,19 +651,25 @@ int kor_occgrid_from_scans(const kor_matcher* m, int n_scans, const double* rang
       if (by[c] > mxy) mxy = by[c];
     }
   }
-  occ_t g;
-  g.scale = 1.0 / resolution;
-  g.w = (int)kround((mxx - mnx) * g.scale);
-  g.h = (int)kround((mxy - mny) * g.scale);
-  g.ox = mnx; g.oy = mny;
-  dims[0] = g.w; dims[1] = g.h;
-  offset_xy[0] = mnx; offset_xy[1] = mny;
-  if (!out) { free(pts); return 0; }
-  g.stride = (g.w + 7) & ~7; /* Grid<kt_int32u>::Resize (Karto.h:4442) */
-  size_t cells = (size_t)g.stride * (g.h > 0 ? g.h : 0);
-  g.pass = (uint32_t*)calloc(cells ? cells : 1, sizeof(uint32_t));
-  g.hit = (uint32_t*)calloc(cells ? cells : 1, sizeof(uint32_t));
-  for (int s = 0; s < n_scans; s++) { /* AddScan (Karto.h:5851-5895) */
+  free(pts);
+  box[0] = mnx; box[1] = mny; box[2] = mxx; box[3] = mxy;
+}
+
+static void occ_dims(const double box[4], double resolution, occ_t* g) {
+  g->scale = 1.0 / resolution;
+  g->w = (int)kround((box[2] - box[0]) * g->scale);
+  g->h = (int)kround((box[3] - box[1]) * g->scale);
+  g->ox = box[0]; g->oy = box[1];
+  g->stride = (g->w + 7) & ~7; /* Grid<kt_int32u>::Resize (Karto.h:4442) */
+}
+
+/* AddScan (Karto.h:5851-5895) of every scan into zeroed counters */
+static void occ_add_scans(const kor_matcher* m, occ_t* g, int n_scans, const double* ranges, int ranges_stride,
+                          const double* sposes) {
+  const int n = m->n_beams;
+  const double thr = m->laser.range_threshold, rmin = m->laser.minimum_range, rmax = m->laser.maximum_range;
+  double* pts = (double*)malloc(sizeof(double) * 2 * (size_t)(n > 0 ? n : 1));
+  for (int s = 0; s < n_scans; s++) {
     const double* sp = sposes + 3 * s;
     const double* r = ranges + (size_t)s * ranges_stride;
     kor_point_readings(m, r, sp, pts);
@@ -679,25 +684,74 @@ int kor_occgrid_from_scans(const kor_matcher* m, int n_scans, const double* rang
         py = sp[1] + ratio * dy;
       }
       int fx, fy, tx, ty; /* RayTrace (Karto.h:5907-5942) */
-      world_to_grid(sp[0], sp[1], g.ox, g.oy, g.scale, &fx, &fy);
-      world_to_grid(px, py, g.ox, g.oy, g.scale, &tx, &ty);
-      occ_trace_line(&g, fx, fy, tx, ty);
-      if (end_valid && is_up_to(tx, g.w) && is_up_to(ty, g.h)) {
-        g.pass[tx + ty * g.stride]++;
-        g.hit[tx + ty * g.stride]++;
+      world_to_grid(sp[0], sp[1], g->ox, g->oy, g->scale, &fx, &fy);
+      world_to_grid(px, py, g->ox, g->oy, g->scale, &tx, &ty);
+      occ_trace_line(g, fx, fy, tx, ty);
+      if (end_valid && is_up_to(tx, g->w) && is_up_to(ty, g->h)) {
+        g->pass[tx + ty * g->stride]++;
+        g->hit[tx + ty * g->stride]++;
       }
     }
   }
-  /* Update / UpdateCell (Karto.h:5950-5990): MinPassThrough = 2, OccupancyThreshold = 0.1 (:5636-5637) */
-  for (int y = 0; y < g.h; y++)
-    for (int x = 0; x < g.w; x++) {
-      uint32_t pc = g.pass[x + y * g.stride], hc = g.hit[x + y * g.stride];
+  free(pts);
+}
+
+/* Update / UpdateCell (Karto.h:5950-5990): MinPassThrough = 2, OccupancyThreshold = 0.1 (:5636-5637) */
+static void occ_update(const occ_t* g, uint8_t* out) {
+  for (int y = 0; y < g->h; y++)
+    for (int x = 0; x < g->w; x++) {
+      uint32_t pc = g->pass[x + y * g->stride], hc = g->hit[x + y * g->stride];
       uint8_t v = 0;
       if (pc > 2) v = ((double)hc / (double)pc > 0.1) ? 100 : 255;
-      out[(size_t)y * g.w + x] = v;
+      out[(size_t)y * g->w + x] = v;
     }
-  free(g.pass); free(g.hit); free(pts);
+}
+
+int kor_occgrid_from_scans(const kor_matcher* m, int n_scans, const double* ranges, int ranges_stride,
+                           const double* sposes, double resolution, int32_t dims[2], double offset_xy[2],
+                           uint8_t* out) {
+  if (n_scans <= 0) return -1; /* rScans.empty() -> NULL (Karto.h:5661-5664) */
+  double box[4];
+  kor_occgrid_bounds(m, n_scans, ranges, ranges_stride, sposes, box);
+  occ_t g;
+  occ_dims(box, resolution, &g);
+  dims[0] = g.w; dims[1] = g.h;
+  offset_xy[0] = g.ox; offset_xy[1] = g.oy;
+  if (!out) return 0;
+  size_t cells = (size_t)g.stride * (g.h > 0 ? g.h : 0);
+  g.pass = (uint32_t*)calloc(cells ? cells : 1, sizeof(uint32_t));
+  g.hit = (uint32_t*)calloc(cells ? cells : 1, sizeof(uint32_t));
+  occ_add_scans(m, &g, n_scans, ranges, ranges_stride, sposes);
+  occ_update(&g, out);
+  free(g.pass); free(g.hit);
   return 0;
+}
+
+/* The sharded build's pieces (test stand-in for the device path): the hit/pass counters of a SUBSET of the scans on
+ * the grid of a given box -- counters[0 .. stride*h) = pass plane, then the hit plane (dims = w, h, stride; counters
+ * NULL = dims only) -- and Update() over summed counters. */
+int kor_occgrid_partial(const kor_matcher* m, int n_scans, const double* ranges, int ranges_stride,
+                        const double* sposes, double resolution, const double box[4], int32_t dims[3],
+                        uint32_t* counters) {
+  occ_t g;
+  occ_dims(box, resolution, &g);
+  dims[0] = g.w; dims[1] = g.h; dims[2] = g.stride;
+  if (!counters) return 0;
+  size_t cells = (size_t)g.stride * (g.h > 0 ? g.h : 0);
+  memset(counters, 0, 2 * cells * sizeof(uint32_t));
+  g.pass = counters;
+  g.hit = counters + cells;
+  occ_add_scans(m, &g, n_scans, ranges, ranges_stride, sposes);
+  return 0;
+}
+
+void kor_occgrid_update(const int32_t dims[3], const uint32_t* counters, uint8_t* out) {
+  occ_t g;
+  g.w = dims[0]; g.h = dims[1]; g.stride = dims[2];
+  size_t cells = (size_t)g.stride * (g.h > 0 ? g.h : 0);
+  g.pass = (uint32_t*)counters;
+  g.hit = (uint32_t*)counters + cells;
+  occ_update(&g, out);
 }
 
 /* Matrix3::InverseFast by cofactors (Karto.h:2460-2493), tolerance 1e-14 as Inverse() passes it */

@@ -108,6 +108,16 @@ int kor_probs(const kor_matcher* m, double* out);
 int kor_occgrid_from_scans(const kor_matcher* m, int n_scans, const double* ranges, int ranges_stride,
                            const double* sensor_poses, double resolution, int32_t dims[2],
                            double offset_xy[2], uint8_t* out);
+/* The same build in shardable pieces (the counters are plain sums and the box a min/max, so disjoint scan subsets
+ * combine exactly): box = minx, miny, maxx, maxy of ComputeDimensions over the given scans; the hit/pass counters
+ * of the given scans on the grid of a given box (dims = w, h, stride; counters = pass plane then hit plane,
+ * stride*h words each; NULL = dims only); Update() over (summed) counters. */
+void kor_occgrid_bounds(const kor_matcher* m, int n_scans, const double* ranges, int ranges_stride,
+                        const double* sensor_poses, double box[4]);
+int kor_occgrid_partial(const kor_matcher* m, int n_scans, const double* ranges, int ranges_stride,
+                        const double* sensor_poses, double resolution, const double box[4], int32_t dims[3],
+                        uint32_t* counters);
+void kor_occgrid_update(const int32_t dims[3], const uint32_t* counters, uint8_t* out);
 
 /* ---- streaming front-end: the pose-relevant part of Mapper::Process (Mapper.cpp:1999-2079) ----
  * lastTransform propagation (:2021-2025), HasMovedEnough (:2087-2120, time test omitted: the

@@ -410,6 +410,11 @@ class PortKarto:
         L.kor_match_scan.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
         L.kor_probs.argtypes = [vp, vp]
         L.kor_occgrid_from_scans.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_double, vp, vp, vp]
+        L.kor_occgrid_bounds.restype = None
+        L.kor_occgrid_bounds.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
+        L.kor_occgrid_partial.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_double, vp, vp, vp]
+        L.kor_occgrid_update.restype = None
+        L.kor_occgrid_update.argtypes = [vp, vp, vp]
         L.kor_frontend_create.restype = vp
         L.kor_frontend_create.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double]
         L.kor_frontend_destroy.argtypes = [vp]
@@ -570,6 +575,36 @@ class PortKarto:
         self.L.kor_occgrid_from_scans(self.h, r.shape[0], r.ctypes.data, r.shape[1], p.ctypes.data, resolution,
                                       d.ctypes.data, off.ctypes.data, out.ctypes.data)
         return out, off
+
+    # the same build in shardable pieces (stand-in for the device path in the CPU multi-rank tests)
+    def occgrid_bounds(self, ranges, sensor_poses):
+        r = np.ascontiguousarray(ranges, dtype=np.float64)
+        r = r.reshape(-1, r.shape[-1])
+        p = np.ascontiguousarray(sensor_poses, dtype=np.float64)
+        box = np.zeros(4)
+        self.L.kor_occgrid_bounds(self.h, r.shape[0], r.ctypes.data, r.shape[1], p.ctypes.data, box.ctypes.data)
+        return box
+
+    def occgrid_partial(self, ranges, sensor_poses, resolution, box):
+        """-> (dims (w, h, stride), counters uint32 [2, h*stride]: pass plane, hit plane)"""
+        r = np.ascontiguousarray(ranges, dtype=np.float64)
+        r = r.reshape(-1, r.shape[-1])
+        p = np.ascontiguousarray(sensor_poses, dtype=np.float64)
+        b = np.ascontiguousarray(box, dtype=np.float64)
+        d = np.zeros(3, dtype=np.int32)
+        self.L.kor_occgrid_partial(self.h, r.shape[0], r.ctypes.data, r.shape[1], p.ctypes.data, resolution,
+                                   b.ctypes.data, d.ctypes.data, None)
+        cnt = np.zeros((2, max(int(d[1]), 0) * int(d[2])), dtype=np.uint32)
+        self.L.kor_occgrid_partial(self.h, r.shape[0], r.ctypes.data, r.shape[1], p.ctypes.data, resolution,
+                                   b.ctypes.data, d.ctypes.data, cnt.ctypes.data)
+        return d, cnt
+
+    def occgrid_update(self, dims, counters):
+        d = np.ascontiguousarray(dims, dtype=np.int32)
+        c = np.ascontiguousarray(counters, dtype=np.uint32)
+        out = np.zeros((max(int(d[1]), 0), max(int(d[0]), 0)), dtype=np.uint8)
+        self.L.kor_occgrid_update(d.ctypes.data, c.ctypes.data, out.ctypes.data)
+        return out
 
     # streaming front-end
     def frontend(self):

@@ -87,3 +87,69 @@ def test_two_rank_gloo_gather_and_broadcast():
         p.join(60)
         assert p.exitcode == 0
     assert out == [(0, True, True), (1, True, True)]
+
+
+# ------------------------------------------------------------------------------------------------
+# Sharded OccupancyGrid::CreateFromScans (last row): the control flow and the two all-reduces, with the
+# CPU oracle standing in for the device kernels.  world_size 2 and 3, uneven shards, one EMPTY shard.
+# ------------------------------------------------------------------------------------------------
+class OracleOccBackend:
+    def __init__(self, port):
+        self.port = port
+
+    def scan_bounds(self, ranges, poses):
+        return self.port.occgrid_bounds(ranges, poses)
+
+    def create_partial(self, ranges, poses, resolution, box):
+        dims, cnt = self.port.occgrid_partial(ranges, poses, resolution, box)
+        return {"dims": dims, "counters": cnt, "box": np.asarray(box).copy()}
+
+    def all_reduce_counters(self, part):
+        import torch.distributed as dist
+        c = part["counters"].reshape(-1)
+        if c.size:
+            dist.all_reduce(torch.from_numpy(c.view(np.int32)), op=dist.ReduceOp.SUM)
+
+
+def _occ_worker(rank, world, port, q, n_scans):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import lslam  # noqa: F401
+    from lslam_amd import shard as sh, synth
+    from oracle import pyoracle as O
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        wl = synth.make_match_workload(n_base=max(n_scans, 1), n_query=1, seed=6)
+        ranges, poses = wl.base_ranges[:n_scans], wl.base_poses[:n_scans]
+        kport = O.PortKarto(O.default_cfg(), O.laser_struct(wl.laser, 20.0))
+        lo, hi = sh.shard_range(n_scans, world, rank)
+        part = sh.build_occupancy_grid_sharded(OracleOccBackend(kport), ranges[lo:hi], poses[lo:hi], 0.05)
+        if n_scans == 0:
+            q.put((rank, part is None))
+            return
+        exp, off = kport.occgrid_from_scans(ranges, poses, 0.05)
+        got = kport.occgrid_update(part["dims"], part["counters"])
+        q.put((rank, bool(np.array_equal(got, exp) and np.array_equal(part["box"][:2], off))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_scans", [(2, 9), (3, 2), (2, 0)])  # (3, 2): rank 0 has no scans
+def test_sharded_occupancy_grid_equals_whole_build(world, n_scans):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_occ_worker, args=(r, world, port, q, n_scans)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert out == [(r, True) for r in range(world)]
