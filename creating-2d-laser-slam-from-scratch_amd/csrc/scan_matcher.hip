@@ -735,6 +735,7 @@ k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc,
 // Mapper.cpp:841-845.
 // ------------------------------------------------------------------------------------------
 constexpr int kPosChunk = 16;
+constexpr int kReduceNarrowMinScans = 2048;  // batches from here on run k_reduce_coarse_lds with 128-thread blocks
 // one work item = (angle a, chunk c of 16 lattice positions) of one scan, done by one wave
 __device__ __forceinline__ void generic_item(const uint8_t* __restrict__ grid, const Geom& g, const PassCfg& pc,
                                              const Lattice& L, const double2* __restrict__ lp, int32_t* r, int a,
@@ -1038,14 +1039,17 @@ k_reduce_coarse(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ la
 //  * the tie average visits only the non-zero mask words (wave ballots), still in lattice order on
 //    one thread; the ordered covariance sums stay on one thread, with their LDS reads batched.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+// NT threads per block: 128 when the batch fills the chip (a block is mostly single-thread ordered sums, so residency --
+// 32 waves per CU = 16 such blocks -- buys more than lanes), 256 for small batches (latency of the one block that runs).
+template <int NT>
+__global__ void __launch_bounds__(NT)
 k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
                     int32_t* resp, size_t resp_stride, CoarseOut* __restrict__ out,
                     int use_expansion, int pass_index, const uint8_t* __restrict__ grid,
                 const double2* __restrict__ local, int fb_step, PassCfg fine_pc,
                     double2* fine_cossin, int fine_step) {
   extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ double sh[256];
+  __shared__ double sh[NT];
   __shared__ double s_ap[kMaxAngles];
   __shared__ unsigned long long s_nz[4];
   __shared__ double s_avg[3];
@@ -1057,7 +1061,7 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
     if (tid == 0) { out[s].status = L.status; out[s].expand = 0; out[s].best = 0.0; }
     return;
   }
-  block_generic_fallback(grid, g, pc, L, local + (size_t)s * g.n_beams, resp + (size_t)s * resp_stride, fb_step, tid, 256);
+  block_generic_fallback(grid, g, pc, L, local + (size_t)s * g.n_beams, resp + (size_t)s * resp_stride, fb_step, tid, NT);
   const int ncand = pc.nx * pc.ny;
   const int total = ncand * pc.na;
   const int words = (total + 31) / 32;  // <= 256 (host)
@@ -1080,7 +1084,7 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
   // position (offset = searchCenter - searchSpaceOffset, :332-333; WorldToGrid of the position, :440)
   const double p_off_x = center[0] - pc.off_x, p_off_y = center[1] - pc.off_y;
   if (tid == 0) { s_bad = 0; s_ntie = 0; }
-  for (int c = tid; c < ncand; c += 256) {
+  for (int c = tid; c < ncand; c += NT) {
     const int xi = c % pc.nx, yi = c / pc.nx;
     const double x = -pc.off_x + (uint32_t)xi * pc.res_x;  // Mapper.cpp:342-345
     const double y = -pc.off_y + (uint32_t)yi * pc.res_y;  // :353-356
@@ -1091,14 +1095,14 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
     const int gx = world_to_grid(wx, p_off_x, g.scale), gy = world_to_grid(wy, p_off_y, g.scale);
     cell[c] = (gx < 0 || gx >= g.probs_side || gy < 0 || gy >= g.probs_side) ? -1 : gy * g.probs_side + gx;
   }
-  for (int a = tid; a < pc.na; a += 256) {
+  for (int a = tid; a < pc.na; a += NT) {
     const double angle = (center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;  // :390-393
     const double sad = ksq(angle - center[2]);
     double ap = 1.0 - (kAnglePenaltyGain * sad / sc.avp);
     s_ap[a] = ap > sc.min_ap ? ap : sc.min_ap;
   }
-  for (int wd = tid; wd < words; wd += 256) mask[wd] = 0u;
-  for (int c = tid; c < g.probs_side * g.probs_side; c += 256) probs[c] = 0.0;  // Clear (:329)
+  for (int wd = tid; wd < words; wd += NT) mask[wd] = 0u;
+  for (int c = tid; c < g.probs_side * g.probs_side; c += NT) probs[c] = 0.0;  // Clear (:329)
   __syncthreads();
 
   // penalised response of candidate (c, a): GetResponse normalisation (:852) and r *= (dp * ap) (:399-414)
@@ -1109,14 +1113,14 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
     return v;
   };
   // cell maxima: thread -> (cell, half of the angles); numerators are stored angle-major, so neighbouring threads read
-  // neighbouring words; a thread's loads are issued eight at a time
-  const int parts = 2 * ncand <= 256 ? 2 : 1;
+  // neighbouring words; a thread's loads are issued eleven at a time
+  const int parts = 2 * ncand <= NT ? 2 : 1;
   double lm = -1.0;  // bestResponse starts at -1 (Mapper.cpp:431)
-  for (int idx = tid; idx < ncand * parts; idx += 256) {
+  for (int idx = tid; idx < ncand * parts; idx += NT) {
     const int part = idx >= ncand ? 1 : 0, c = idx - part * ncand;
     const int a_lo = part * pc.na / parts, a_hi = (part + 1) * pc.na / parts;
     double m = -1.0;
-    constexpr int kBatch = 8;
+    constexpr int kBatch = 11;
     for (int a0 = a_lo; a0 < a_hi; a0 += kBatch) {
       int32_t rv[kBatch];
 #pragma unroll
@@ -1131,11 +1135,11 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
     (part ? lat2 : latmax)[c] = m;
     lm = lm > m ? lm : m;
   }
-  const double best = block_max(lm, sh, tid, 256);  // contains the barriers that publish latmax / lat2
+  const double best = block_max(lm, sh, tid, NT);  // contains the barriers that publish latmax / lat2
 
   // best response per lattice cell over all angles, max-merged into the search-space probabilities
   // (Mapper.cpp:437-450); responses are >= +0, so the unsigned order of the bit patterns is the fp order
-  for (int c = tid; c < ncand; c += 256) {
+  for (int c = tid; c < ncand; c += NT) {
     double m = latmax[c];
     if (parts == 2) m = m > lat2[c] ? m : lat2[c];
     latmax[c] = m;
@@ -1145,7 +1149,7 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
     if (!(m + 2.0 * kTol < best)) tie[atomicAdd(&s_ntie, 1)] = c;  // conservative filter; the test below is the reference's
   }
   __syncthreads();
-  for (int idx = tid, n = s_ntie * pc.na; idx < n; idx += 256) {
+  for (int idx = tid, n = s_ntie * pc.na; idx < n; idx += NT) {
     const int c = tie[idx / pc.na], a = idx % pc.na;
     if (double_equal(value_of(r[a * ncand + c], c, a), best)) {
       const int k = c * pc.na + a;
@@ -1153,9 +1157,10 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
     }
   }
   __syncthreads();
-  {  // which mask words are non-zero (words <= 256 = one per thread)
-    const unsigned long long nz = __ballot(tid < words && mask[tid] != 0u);
-    if ((tid & 63) == 0) s_nz[tid >> 6] = nz;
+  for (int w0 = 0; w0 < 256; w0 += NT) {  // which mask words are non-zero (words <= 256, host)
+    const int wd = w0 + tid;
+    const unsigned long long nz = __ballot(wd < words && mask[wd] != 0u);
+    if ((tid & 63) == 0) s_nz[wd >> 6] = nz;
   }
   __syncthreads();
   if (tid == 0) {
@@ -1197,13 +1202,13 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
   // No expansion passes follow: the block's LAST wave lays out the scan's fine lattice around the mean
   // just found (k_pass_setup, mode 2; one launch fewer) while the other waves go on to the covariance.
   // The lattice record of this pass is not read again below (centre and flags are in registers).
-  if (fine_cossin != nullptr && tid >= 192) {
+  if (fine_cossin != nullptr && tid >= NT - 64) {
     const double center2[3] = {s_avg[0], s_avg[1], s_avg[2]};
-    pass_setup_wave(s, tid - 192, g, fine_pc, center2, s_status == 0, lat, fine_cossin, fine_step);
+    pass_setup_wave(s, tid - (NT - 64), g, fine_pc, center2, s_status == 0, lat, fine_cossin, fine_step);
   }
   // ComputePositionalCovariance terms (Mapper.cpp:573-594), one lattice cell per thread
   const double dx = s_avg[0] - center[0], dy = s_avg[1] - center[1];
-  for (int c = tid; c < ncand; c += 256) {
+  for (int c = tid; c < ncand; c += NT) {
     const int xi = c % pc.nx, yi = c / pc.nx;
     const double x = -pc.off_x + (uint32_t)xi * pc.res_x;
     const double y = -pc.off_y + (uint32_t)yi * pc.res_y;
@@ -1692,13 +1697,14 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
 // ComputeAngularCovariance (Mapper.cpp:641-692): nA more response sums at the best cell,
 // gathered by the whole block; final result record.  Dynamic LDS: mask words.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+template <int NT>  // threads per block: 128 for chip-filling batches (residency), 256 otherwise; see k_reduce_coarse_lds
+__global__ void __launch_bounds__(NT)
 k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc,
               const Lattice* __restrict__ lat, int32_t* resp, size_t resp_stride,
               const double2* __restrict__ local, const CoarseOut* __restrict__ coarse,
               lslam_match_result* __restrict__ out, int do_refine, int fb_step) {
   extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ double sh[256];
+  __shared__ double sh[NT];
   __shared__ int32_t asum[kMaxAngles];
   __shared__ double s_avg[3];
   __shared__ double s_best;
@@ -1729,7 +1735,7 @@ k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc
     }
     return;
   }
-  block_generic_fallback(grid, g, pc, L, local + (size_t)s * g.n_beams, resp + (size_t)s * resp_stride, fb_step, tid, 256);
+  block_generic_fallback(grid, g, pc, L, local + (size_t)s * g.n_beams, resp + (size_t)s * resp_stride, fb_step, tid, NT);
   const int ncand = pc.nx * pc.ny;
   const int total = ncand * pc.na;
   const int32_t* r = resp + (size_t)s * resp_stride;
@@ -1745,24 +1751,24 @@ k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc
   double lm = -1.0;
 #pragma unroll
   for (int i = 0; i < kKeep; i++) {
-    const int k = tid + 256 * i;
+    const int k = tid + NT * i;
     mine[i] = k < total ? value(k) : -1.0;
     lm = lm > mine[i] ? lm : mine[i];
   }
-  for (int k = tid + 256 * kKeep; k < total; k += 256) {
+  for (int k = tid + NT * kKeep; k < total; k += NT) {
     const double v = value(k);
     lm = lm > v ? lm : v;
   }
   const int words = (total + 31) / 32;
-  for (int wd = tid; wd < words; wd += 256) mask[wd] = 0u;
-  if (tid < kMaxAngles) asum[tid] = 0;
-  const double best = block_max(lm, sh, tid, 256);
+  for (int wd = tid; wd < words; wd += NT) mask[wd] = 0u;
+  for (int a = tid; a < kMaxAngles; a += NT) asum[a] = 0;
+  const double best = block_max(lm, sh, tid, NT);
 #pragma unroll
   for (int i = 0; i < kKeep; i++) {
-    const int k = tid + 256 * i;
+    const int k = tid + NT * i;
     if (k < total && double_equal(mine[i], best)) atomicOr(&mask[k >> 5], 1u << (k & 31));
   }
-  for (int k = tid + 256 * kKeep; k < total; k += 256)
+  for (int k = tid + NT * kKeep; k < total; k += NT)
     if (double_equal(value(k), best)) atomicOr(&mask[k >> 5], 1u << (k & 31));
   __syncthreads();
   if (tid == 0) {
@@ -1792,7 +1798,7 @@ k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc
         if (L.gx[xi] + row == s_pos) hit = c;
     }
     if (hit >= 0) {
-      if (tid < pc.na) asum[tid] = r[tid * ncand + hit];
+      for (int a = tid; a < pc.na; a += NT) asum[a] = r[a * ncand + hit];
     } else {
       const double2* lp = local + (size_t)s * g.n_beams;
       const int pos = s_pos;
@@ -1800,7 +1806,7 @@ k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc
         double angle = (center[2] - pc.ang_off) + (uint32_t)a * pc.ang_res;
         double cosine = cos(angle), sine = sin(angle);
         int32_t part = 0;
-        for (int b = tid; b < g.n_beams; b += 256) {
+        for (int b = tid; b < g.n_beams; b += NT) {
           double2 p = lp[b];
           if (isnan(p.x)) continue;
           int t = lookup_offset(p.x, p.y, cosine, sine, g.off_x, g.off_y, g.scale, g.stride);
@@ -2438,10 +2444,16 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       fb_step
     if (cache && ((size_t)p.nx * p.ny * p.na + 31) / 32 <= 256) {
       const bool fuse_fine = n_exp == 0 && do_refine;  // nothing between this pass and the fine pass
-      launch(ctx, "reduce_coarse", k_reduce_coarse_lds, dim3(S), dim3(256), reduce_lds_nocache(p), g, p, sc,
-             m->d_lat.p, m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
-             (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step, pf,
-             fuse_fine ? m->d_cossin.p : (double2*)nullptr, 1);
+      if (S >= kReduceNarrowMinScans)
+        launch(ctx, "reduce_coarse", k_reduce_coarse_lds<128>, dim3(S), dim3(128), reduce_lds_nocache(p), g, p, sc,
+               m->d_lat.p, m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
+               (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step, pf,
+               fuse_fine ? m->d_cossin.p : (double2*)nullptr, 1);
+      else
+        launch(ctx, "reduce_coarse", k_reduce_coarse_lds<256>, dim3(S), dim3(256), reduce_lds_nocache(p), g, p, sc,
+               m->d_lat.p, m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
+               (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step, pf,
+               fuse_fine ? m->d_cossin.p : (double2*)nullptr, 1);
       setup_done = fuse_fine;
     }
     else if (cache)
@@ -2465,9 +2477,14 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     rc = run_responses(pf, 1, "resp_rows_fine");
     if (rc) return rc;
   }
-  launch(ctx, "reduce_fine", k_reduce_fine, dim3(S), dim3(256), (size_t)(((size_t)pf.nx * pf.ny * pf.na + 31) / 32) * 4 + 16,
-         (const uint8_t*)m->d_grid, g, pf, sc, (const Lattice*)m->d_lat.p, m->d_resp.p, resp_stride,
-         (const double2*)m->d_local.p, (const CoarseOut*)m->d_coarse.p, d_out, do_refine, do_refine ? fb_step : 0);
+  if (S >= kReduceNarrowMinScans)
+    launch(ctx, "reduce_fine", k_reduce_fine<128>, dim3(S), dim3(128), (size_t)(((size_t)pf.nx * pf.ny * pf.na + 31) / 32) * 4 + 16,
+           (const uint8_t*)m->d_grid, g, pf, sc, (const Lattice*)m->d_lat.p, m->d_resp.p, resp_stride,
+           (const double2*)m->d_local.p, (const CoarseOut*)m->d_coarse.p, d_out, do_refine, do_refine ? fb_step : 0);
+  else
+    launch(ctx, "reduce_fine", k_reduce_fine<256>, dim3(S), dim3(256), (size_t)(((size_t)pf.nx * pf.ny * pf.na + 31) / 32) * 4 + 16,
+           (const uint8_t*)m->d_grid, g, pf, sc, (const Lattice*)m->d_lat.p, m->d_resp.p, resp_stride,
+           (const double2*)m->d_local.p, (const CoarseOut*)m->d_coarse.p, d_out, do_refine, do_refine ? fb_step : 0);
   LSLAM_HIP(ctx, hipGetLastError());
   return LSLAM_OK;
 }
