@@ -113,26 +113,36 @@ k_scan_prep(const RT* __restrict__ ranges, int stride, const double* __restrict_
     // rSourcePose - m_Transform (Pose2 operator-, Karto.h:2138-2141), heading = normalize(0 - th)
     s_h = normalize_angle(0.0 - s_t.th);
   }
-  __syncthreads();
-  // the first wave of the scan's first block also lays out the coarse search lattice (k_pass_setup, mode 0)
-  if (setup_lat && blockIdx.x == 0 && threadIdx.x < 64) {
+  // Meanwhile the LAST wave of the scan's first block lays out the coarse search lattice (k_pass_setup, mode 0), and
+  // every thread evaluates its first world point: neither needs the transform thread 0 is working on.
+  if (setup_lat && blockIdx.x == 0 && threadIdx.x >= 192) {
     const double center[3] = {sx, sy, sh};
-    pass_setup_wave(s, threadIdx.x, g, setup_pc, center, 1, setup_lat, setup_cossin, setup_step);
+    pass_setup_wave(s, threadIdx.x - 192, g, setup_pc, center, 1, setup_lat, setup_cossin, setup_step);
   }
-  if (b >= g.n_beams) return;
-  double r = (double)ranges[(size_t)s * stride + b];
-  double px, py;
-  beam_world_point(sx, sy, sh, g.min_angle, g.ang_res, (uint32_t)b, r, px, py);
-  size_t o = (size_t)s * g.n_beams + b;
-  if (world) world[o] = make_double2(px, py);
-  if (local) {
-    double lx, ly;
-    if (isnan(r) || isinf(r)) {
-      lx = ly = __builtin_nan("");
-    } else {
-      rot_apply(s_t.inv, px - s_t.tx, py - s_t.ty, s_h, lx, ly);
+  double r = 0.0, px = 0.0, py = 0.0;
+  if (b < g.n_beams) {
+    r = (double)ranges[(size_t)s * stride + b];
+    beam_world_point(sx, sy, sh, g.min_angle, g.ang_res, (uint32_t)b, r, px, py);
+  }
+  __syncthreads();
+  // gridDim.x blocks share the beams of a scan: ONE for chip-filling batches (the single-thread transform above is
+  // then paid once per scan, not once per 256 beams -- it was most of this kernel's time), ceil(n/256) otherwise
+  for (bool first = true; b < g.n_beams; b += gridDim.x * blockDim.x, first = false) {
+    if (!first) {
+      r = (double)ranges[(size_t)s * stride + b];
+      beam_world_point(sx, sy, sh, g.min_angle, g.ang_res, (uint32_t)b, r, px, py);
     }
-    local[o] = make_double2(lx, ly);
+    size_t o = (size_t)s * g.n_beams + b;
+    if (world) world[o] = make_double2(px, py);
+    if (local) {
+      double lx, ly;
+      if (isnan(r) || isinf(r)) {
+        lx = ly = __builtin_nan("");
+      } else {
+        rot_apply(s_t.inv, px - s_t.tx, py - s_t.ty, s_h, lx, ly);
+      }
+      local[o] = make_double2(lx, ly);
+    }
   }
 }
 
@@ -2251,7 +2261,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
                m->cfg.minimum_distance_penalty, m->cfg.minimum_angle_penalty, do_penalize};
 
   // scan_prep also lays out the coarse lattice of pass 0 (mode 0 needs only the pose): one launch fewer
-  launch(ctx, "scan_prep", k_scan_prep<RT>, dim3((g.n_beams + 255) / 256, S), dim3(256), 0, d_ranges,
+  launch(ctx, "scan_prep", k_scan_prep<RT>, dim3(S >= kReduceNarrowMinScans ? 1 : (g.n_beams + 255) / 256, S), dim3(256), 0, d_ranges,
          stride, d_poses, g, m->d_local.p, (double2*)nullptr, pc, m->d_lat.p, m->d_cossin.p, 2);
   bool setup_done = true;  // consumed by the first pass
 
