@@ -1063,7 +1063,7 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
   __shared__ double s_ap[kMaxAngles];
   __shared__ unsigned long long s_nz[4];
   __shared__ double s_avg[3];
-  __shared__ int s_status, s_bad, s_ntie;
+  __shared__ int s_status, s_bad, s_ntie, s_wcnt[NT / 64];
   const int s = blockIdx.x, tid = threadIdx.x;
   const Lattice& L = lat[s];
   if (!L.active) return;
@@ -1216,19 +1216,38 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
     const double center2[3] = {s_avg[0], s_avg[1], s_avg[2]};
     pass_setup_wave(s, tid - (NT - 64), g, fine_pc, center2, s_status == 0, lat, fine_cossin, fine_step);
   }
-  // ComputePositionalCovariance terms (Mapper.cpp:573-594), one lattice cell per thread
+  // ComputePositionalCovariance terms (Mapper.cpp:573-594), one lattice cell per thread.  Only the cells with
+  // response >= best - 0.1 enter the sums (:580): they are compacted IN LATTICE ORDER (wave ballots), so the one thread
+  // that adds them up in the reference's order walks a dozen entries instead of every cell of the lattice.
   const double dx = s_avg[0] - center[0], dy = s_avg[1] - center[1];
-  for (int c = tid; c < ncand; c += NT) {
-    const int xi = c % pc.nx, yi = c / pc.nx;
-    const double x = -pc.off_x + (uint32_t)xi * pc.res_x;
-    const double y = -pc.off_y + (uint32_t)yi * pc.res_y;
-    const double rr = cell[c] >= 0 ? probs[cell[c]] : 0.0;
-    terms[4 * c + 0] = rr;
-    terms[4 * c + 1] = (ksq(x - dx) * rr);
-    terms[4 * c + 2] = ((x - dx) * (y - dy) * rr);
-    terms[4 * c + 3] = (ksq(y - dy) * rr);
+  const double thr = best - 0.1;
+  int n_pass = 0;
+  for (int c0 = 0; c0 < ncand; c0 += NT) {
+    const int c = c0 + tid;
+    double rr = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    bool pass = false;
+    if (c < ncand) {
+      const int xi = c % pc.nx, yi = c / pc.nx;
+      const double x = -pc.off_x + (uint32_t)xi * pc.res_x;
+      const double y = -pc.off_y + (uint32_t)yi * pc.res_y;
+      rr = cell[c] >= 0 ? probs[cell[c]] : 0.0;
+      t1 = (ksq(x - dx) * rr);
+      t2 = ((x - dx) * (y - dy) * rr);
+      t3 = (ksq(y - dy) * rr);
+      pass = rr >= thr;
+    }
+    const unsigned long long bal = __ballot(pass);
+    if ((tid & 63) == 0) s_wcnt[tid >> 6] = __popcll(bal);
+    __syncthreads();
+    int off = n_pass;
+    for (int w = 0; w < (tid >> 6); w++) off += s_wcnt[w];
+    for (int w = 0; w < NT / 64; w++) n_pass += s_wcnt[w];
+    if (pass) {
+      const int k = off + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+      terms[4 * k + 0] = rr; terms[4 * k + 1] = t1; terms[4 * k + 2] = t2; terms[4 * k + 3] = t3;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (tid == 0) {
     CoarseOut o;
     o.status = s_status;
@@ -1241,20 +1260,15 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
         cov[0] = kMaxVariance; cov[4] = kMaxVariance; cov[8] = 4 * ksq(pc.ang_res);
       } else {
         double axx = 0, axy = 0, ayy = 0, norm = 0;
-        const double thr = best - 0.1;
         int c = 0;
-        for (; c + 4 <= ncand; c += 4) {  // y outer, x inner = candidate-cell order; reads batched, adds in order
+        for (; c + 4 <= n_pass; c += 4) {  // lattice order (y outer, x inner); reads batched, adds in order
           double q[16];
   #pragma unroll
           for (int i = 0; i < 16; i++) q[i] = terms[4 * c + i];
   #pragma unroll
-          for (int i = 0; i < 4; i++)
-            if (q[4 * i] >= thr) { norm += q[4 * i]; axx += q[4 * i + 1]; axy += q[4 * i + 2]; ayy += q[4 * i + 3]; }
+          for (int i = 0; i < 4; i++) { norm += q[4 * i]; axx += q[4 * i + 1]; axy += q[4 * i + 2]; ayy += q[4 * i + 3]; }
         }
-        for (; c < ncand; c++) {
-          const double rr = terms[4 * c];
-          if (rr >= thr) { norm += rr; axx += terms[4 * c + 1]; axy += terms[4 * c + 2]; ayy += terms[4 * c + 3]; }
-        }
+        for (; c < n_pass; c++) { norm += terms[4 * c]; axx += terms[4 * c + 1]; axy += terms[4 * c + 2]; ayy += terms[4 * c + 3]; }
         if (norm > kTol) {
           double vxx = axx / norm, vxy = axy / norm, vyy = ayy / norm;
           double vthth = 4 * ksq(pc.ang_res);
