@@ -318,6 +318,10 @@ def test_reference_indoor_default_config(ctx, oracle_lib):
     # 4x4-block fine kernel, with the expansion passes in between -- byte-identical to the small batch
     big = gm.match_batch(np.tile(wl.query_ranges, (20, 1)), np.tile(wl.query_poses, (20, 1)))
     assert big.tobytes() == np.tile(res, 20).tobytes()
+    # 2052 scans: the chip-filling variants (128-thread reduce blocks with more lattice cells than threads, one
+    # scan_prep block per scan) must give the same bytes again
+    huge = gm.match_batch(np.tile(wl.query_ranges, (342, 1)), np.tile(wl.query_poses, (342, 1)))
+    assert huge.tobytes() == np.tile(res, 342).tobytes()
     # full MatchScan too (grid rebuilt with the 13x13 smear around the query)
     mean, cov, resp = port.match_scan(wl.base_ranges, wl.base_poses, wl.query_ranges[1], wl.query_poses[1])
     r, m, c = gm.MatchScan(wl.query_ranges[1], wl.query_poses[1], wl.base_ranges, wl.base_poses)
