@@ -692,11 +692,15 @@ k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc,
   for (int b = lane; b < g.n_beams; b += 64) {
     const double2 pn = lp[min(b + 64, g.n_beams - 1)];  // next point in flight while this one is used
     if (!isnan(p.x)) {  // NaN = INVALID_SCAN
-      int gx, gy;
-      lookup_cell_i32(p.x, p.y, cosine, sine, g.off_x, g.off_y, g.scale, gx, gy);
+      // the table cell exactly as k_resp_rows evaluates it (same fp64 expression tree as lookup_cell_i32;
+      // (int)math::Round(v) taken as trunc(copysign(|v| + 0.5, v)))
+      const double ox = cosine * p.x - sine * p.y, oy = sine * p.x + cosine * p.y;
+      const double vx = ((ox + g.off_x) - g.off_x) * g.scale, vy = ((oy + g.off_y) - g.off_y) * g.scale;
+      const double ax = fabs(vx) + 0.5, ay = fabs(vy) + 0.5;
       int x, y;
       bool ok;
-      if ((((uint32_t)(gx + 32768)) | ((uint32_t)(gy + 32768))) < 65536u) {  // all int32-exact, see k_resp_rows
+      if (fmax(ax, ay) < 32768.0) {  // |gx|, |gy| < 2^15: all int32-exact, see k_resp_rows
+        const int gx = (int)copysign(ax, vx), gy = (int)copysign(ay, vy);
         x = X0 + gx, y = Y0 + gy;
         if ((uint32_t)x >= (uint32_t)g.stride) {  // flat index wrapped into a neighbouring row
           const int base = B0 + gx + __mul24(gy, g.stride);
@@ -705,6 +709,7 @@ k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc,
         }
         ok = y >= -3 && y < g.height;
       } else {
+        const int gx = kround_i32(vx), gy = kround_i32(vy);
         const long long base = (long long)B0 + (int)(gx + gy * g.stride);  // int32 table offset like the reference
         const long long yl = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
         ok = yl >= -3 && yl < g.height;
@@ -712,10 +717,13 @@ k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc,
         x = ok ? (int)(base - yl * g.stride) : 0;
       }
       if (ok) {
-        const uint4 t = tiles[tile4_slot(x >> 1, (y + kTileYPad) >> 1, cols4)];
+        // rows y .. y+2 of the patch are 12 contiguous bytes of the block, 4 bytes in when y is odd: one 12-byte load
+        // (32-bit offset from the buffer base: the host keeps the tiled copy below 4 GB)
+        const uint32_t off = (uint32_t)tile4_slot(x >> 1, (y + kTileYPad) >> 1, cols4) * 16u + ((uint32_t)y & 1u) * 4u;
+        uint32_t rr[3];
+        __builtin_memcpy(rr, __builtin_assume_aligned((const uint8_t*)tiles + off, 4), 12);
         const uint32_t dx = (uint32_t)x & 1u;
-        const bool dy = (y & 1) != 0;
-        const uint32_t r0 = dy ? t.y : t.x, r1 = dy ? t.z : t.y, r2 = dy ? t.w : t.z;
+        const uint32_t r0 = rr[0], r1 = rr[1], r2 = rr[2];
         const uint32_t sel_e = 0x0C020C00u + dx * 0x00010001u;  // bytes dx, dx+2 of one row
         const uint32_t sel_o = 0x0C050C01u + dx * 0x00010001u;  // byte dx+1 of src1 (low) and of src0 (high)
         e0 += __builtin_amdgcn_perm(r0, r0, sel_e);
@@ -2323,7 +2331,8 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     const long long waves = (long long)((S + 7) / 8) * 8 * p.na;
     // fine pass of a batch big enough to fill the chip: one 16-byte load per beam from the 4x4 blocks
     bool tiled = variant == 1 && step == 1 && p.nx == 3 && p.ny == 3 && waves >= kTileMinWaves &&
-                 g.n_beams <= 16384 && !m->tile_failed;
+                 g.n_beams <= 16384 && !m->tile_failed &&
+                 (unsigned long long)g.data_size * 4ull + (1ull << 24) < (1ull << 32);  // k_resp_tile3 uses 32-bit offsets
     if (tiled && !m->d_tiles) {
       m->tile_cols = g.stride / 2;
       m->tile_rows = (g.height + 1) / 2 + kTileYPad / 2 + 1;
