@@ -2511,7 +2511,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     if (rc) return rc;
   }
   if (S >= kReduceNarrowMinScans)
-    launch(ctx, "reduce_fine", k_reduce_fine<128>, dim3(S), dim3(128), (size_t)(((size_t)pf.nx * pf.ny * pf.na + 31) / 32) * 4 + 16,
+    launch(ctx, "reduce_fine", k_reduce_fine<64>, dim3(S), dim3(64), (size_t)(((size_t)pf.nx * pf.ny * pf.na + 31) / 32) * 4 + 16,
            (const uint8_t*)m->d_grid, g, pf, sc, (const Lattice*)m->d_lat.p, m->d_resp.p, resp_stride,
            (const double2*)m->d_local.p, (const CoarseOut*)m->d_coarse.p, d_out, do_refine, do_refine ? fb_step : 0);
   else
