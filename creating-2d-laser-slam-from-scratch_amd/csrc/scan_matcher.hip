@@ -39,6 +39,7 @@ constexpr int kMaxLattice = 128;  // nX, nY per pass (loop-closure matcher: 101 
 constexpr int kMaxAngles = 128;   // nA per pass
 constexpr int kMaxProbsSide = 255; // search-space probability grid side (loop closure: 201)
 constexpr int kDenseMaxNx = 112;   // widest lattice row the dense kernel covers (7 lanes x 16 candidates)
+constexpr int kMaxKernel = 33;    // widest smear kernel k_smear_gather tabulates in LDS (wider: the listed scatter path)
 constexpr int kGuard = 256;       // zero bytes before/after the grid: unaligned row loads may overhang
 
 struct Geom {
@@ -1914,8 +1915,7 @@ __global__ void k_result_no_readings(int S, const double* poses, double coarse_a
 // Every fp64 expression is the reference's.
 __global__ void __launch_bounds__(1024)
 k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, double vx, double vy,
-             uint8_t* __restrict__ valid, int use_lds, int* __restrict__ scratch, Geom g, uint8_t* __restrict__ grid,
-             uint32_t* __restrict__ list, int* __restrict__ count) {
+             uint8_t* __restrict__ valid, int use_lds, int* __restrict__ scratch, Geom g, uint8_t* __restrict__ grid) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int s_first, s_len;
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -1946,10 +1946,21 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
   for (int i = tid; i < n; i += nt) {
     const double fx = p[i].x, fy = p[i].y;
     if (!isnan(fx) && !isnan(fy)) atomicMin(&s_first, i);  // first anchor (Mapper.cpp:774-778)
+    // first later point farther than 10 cm (:780-781); four candidates per step so that their LDS reads are in
+    // flight together (the block waits for its slowest thread: a wall 0.3 m away is 80 points to the successor)
     int j = i + 1;
-    for (; j < n; j++) {
-      double dx = fx - p[j].x, dy = fy - p[j].y;
-      if (ksq(dx) + ksq(dy) > min_sq) break;  // :780-781
+    for (bool found = false; !found && j < n;) {
+      double2 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) q[u] = p[min(j + u, n - 1)];
+      int hit = 4;
+#pragma unroll
+      for (int u = 3; u >= 0; u--) {
+        const double dx = fx - q[u].x, dy = fy - q[u].y;
+        if (ksq(dx) + ksq(dy) > min_sq) hit = u;
+      }
+      if (hit < 4 && j + hit < n) { j += hit; found = true; }
+      else j = min(j + 4, n);
     }
     next[i] = j;
     if (use_lds) chain[i] = j;
@@ -1997,8 +2008,13 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
     for (int i = tid; i < n; i += nt) gv[i] = v[i];
   // Fused AddScan stage (k_mark_centres' body; the streaming front-end rebuilds the grid once per scan, so a launch and
   // the valid[] round trip through memory matter): each valid point turns its cell into 100 and the winner lists it.
+  // Fused AddScan stage (the streaming front-end rebuilds the grid once per scan, so a launch and the valid[] round trip
+  // through memory matter): each valid point turns its cell into 100 with a PLAIN byte store -- every writer writes the
+  // same value, and which point got there first does not matter because k_smear_scan finds the centres in the grid
+  // itself.  (Device-scope atomics that report the winner are executed at the memory side: ~40 k of them per rebuild,
+  // most on cells other scans of the window had already set, were two thirds of this kernel's time.)
   if (grid && use_lds) {
-    for (int i0 = 0; i0 < n; i0 += nt) {  // whole waves iterate together: the shuffles below need every lane
+    for (int i0 = 0; i0 < n; i0 += nt) {  // whole waves iterate together: the shuffle below needs every lane
       const int i = i0 + tid;
       uint32_t idx = 0xFFFFFFFFu;
       if (i < n && v[i]) {
@@ -2008,22 +2024,91 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
         if (gx >= 0 && gx < g.roi_w && gy >= 0 && gy < g.roi_h)  // IsUpTo on the ROI (Mapper.cpp:724-729)
           idx = (uint32_t)((gx + g.border) + (gy + g.border) * g.stride);
       }
-      const uint32_t left = (uint32_t)__shfl_up((int)idx, 1);
-      const bool contender = idx != 0xFFFFFFFFu && ((tid & 63) == 0 || left != idx);
-      bool winner = false;
-      if (contender) {
-        const int sh = (int)(idx & 3u) * 8;
-        const uint32_t old = atomicOr((uint32_t*)(grid + (idx & ~3u)), (uint32_t)kOccupied << sh);
-        winner = ((old >> sh) & 0xFFu) == 0u;
+      const uint32_t left = (uint32_t)__shfl_up((int)idx, 1);  // neighbouring beams mostly hit the same cell
+      if (idx != 0xFFFFFFFFu && ((tid & 63) == 0 || left != idx)) grid[idx] = (uint8_t)kOccupied;
+    }
+  }
+}
+
+// SmearPoint (Mapper.h:971-1005) of every centre k_find_valid marked, as a GATHER over the cleared-and-marked grid: one
+// thread owns 16 consecutive grid bytes and takes, for each of them, the maximum of the kernel values of the centres
+// (bytes equal to 100) within the kernel's reach -- on the FLAT index, like the reference's pointer arithmetic.  No
+// atomics: a thread writes only its own bytes; the smear kernel's only 100 is its own centre (checked at create time),
+// so a neighbour's finished or unfinished bytes are never mistaken for centres, each centre counts exactly once
+// whoever marked it, and the maximum is order-independent.  (The scatter form -- a compare-and-swap per footprint word
+// of every centre -- serialises at the memory-side atomic unit: 57 us for a 70-scan window.)
+// The same pass writes the parity planes F_0 / F_1 of the finished bytes (k_deinterleave): one launch fewer.
+// HK = half kernel size known at compile time (1, 2, 6 = resolutions 0.05, 0.025, 0.01 m at the default smear): the
+// neighbour-row windows live in registers and every byte test is a static shift; HK = 0 is the generic form.
+template <int HK>
+__global__ void __launch_bounds__(256)
+k_smear_gather(Geom g, const uint8_t* __restrict__ kernel, uint8_t* __restrict__ grid, uint8_t* __restrict__ f0,
+               uint8_t* __restrict__ f1) {
+  __shared__ uint8_t s_k[kMaxKernel * kMaxKernel];
+  const int tid = threadIdx.x, ks = g.kernel_size, hk = ks / 2;
+  for (int i = tid; i < ks * ks; i += 256) s_k[i] = kernel[i];
+  __syncthreads();
+  const long long f = ((long long)blockIdx.x * 256 + tid) * 16;
+  if (f >= g.data_size) return;
+  uint32_t out[4];
+  {
+    const uint4 q = *(const uint4*)(grid + f);  // 16-byte aligned; may overhang into the zero guard
+    out[0] = q.x; out[1] = q.y; out[2] = q.z; out[3] = q.w;
+  }
+  bool changed = false;
+  auto raise = [&](int o, uint32_t v) {  // out byte o = max(out byte o, v)
+    const int sh = 8 * (o & 3);
+    if (((out[o >> 2] >> sh) & 0xFFu) < v) {
+      out[o >> 2] = (out[o >> 2] & ~(0xFFu << sh)) | (v << sh);
+      changed = true;
+    }
+  };
+  if constexpr (HK > 0) {
+    // widthStep is a multiple of 8 and f of 16, so every window starts at the same byte phase
+    constexpr int NWIN = 16 + 2 * HK, LEAD = (4 - (HK & 3)) & 3, NW = (LEAD + NWIN + 3) / 4;
+    for (int j = -HK; j <= HK; j++) {  // centre row = my row + j  ->  kernel row HK - j
+      const long long w0 = f + (long long)j * g.stride - HK - LEAD;  // aligned; bytes outside [0, dataSize) read as zero
+      uint32_t w[NW], any = 0u;
+#pragma unroll
+      for (int k = 0; k < NW; k++) {
+        const long long byte = w0 + 4 * k;
+        w[k] = (byte >= 0 && byte < g.data_size) ? *(const uint32_t*)(grid + byte) : 0u;
+        const uint32_t x = w[k] ^ 0x64646464u;  // a byte of 100 becomes 0
+        any |= (x - 0x01010101u) & ~x & 0x80808080u;
       }
-      const unsigned long long won = __ballot(winner);
-      if (won) {
-        const int lane = tid & 63, leader = __ffsll((long long)won) - 1;
-        int base = 0;
-        if (lane == leader) base = atomicAdd(count, __popcll(won));
-        base = __shfl(base, leader);
-        if (winner) list[base + __popcll(won & ((1ull << lane) - 1ull))] = idx;
+      if (!any) continue;
+      const uint8_t* krow = s_k + (2 * HK + 1) * (HK - j);
+#pragma unroll
+      for (int c = 0; c < NWIN; c++) {
+        if (((w[(LEAD + c) >> 2] >> (8 * ((LEAD + c) & 3))) & 0xFFu) != (uint32_t)kOccupied) continue;
+        // centre at column offset c - HK relative to my first byte: reaches my bytes o with |o - (c - HK)| <= HK
+#pragma unroll
+        for (int o = (c - 2 * HK > 0 ? c - 2 * HK : 0); o <= (c < 15 ? c : 15); o++) raise(o, krow[o - c + 2 * HK]);
       }
+    }
+  } else {
+    const int nwin = 16 + 2 * hk;
+    for (int j = -hk; j <= hk; j++) {
+      const long long row = f + (long long)j * g.stride - hk;  // first byte of the window
+      const uint8_t* krow = s_k + ks * (hk - j);
+      for (int c = 0; c < nwin; c++) {
+        const long long cb = row + c;
+        if (cb < 0 || cb >= g.data_size || grid[cb] != (uint8_t)kOccupied) continue;
+        const int lo = max(0, c - 2 * hk), hi = min(15, c);
+        for (int o = lo; o <= hi; o++) raise(o, krow[o - c + 2 * hk]);
+      }
+    }
+  }
+  if (changed) *(uint4*)(grid + f) = make_uint4(out[0], out[1], out[2], out[3]);  // bytes past dataSize stay zero: no centre reaches them
+  if (f0) {  // bytes b0..b7 -> even: b0 b2 b4 b6, odd: b1 b3 b5 b7 (dataSize is a multiple of 8)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      if (f + 8 * h + 8 > g.data_size) break;
+      const uint32_t vx = out[2 * h], vy = out[2 * h + 1];
+      const uint32_t e = (vx & 0xFFu) | ((vx >> 8) & 0xFF00u) | ((vy & 0xFFu) << 16) | ((vy << 8) & 0xFF000000u);
+      const uint32_t o = ((vx >> 8) & 0xFFu) | ((vx >> 16) & 0xFF00u) | ((vy << 8) & 0xFF0000u) | (vy & 0xFF000000u);
+      ((uint32_t*)f0)[f / 8 + h] = e;
+      ((uint32_t*)f1)[f / 8 + h] = o;
     }
   }
 }
@@ -2538,15 +2623,26 @@ int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, i
   const size_t lds = (size_t)n * (sizeof(double2) + 14) + 16;  // points, next, two jump tables, valid, reach
   const int use_lds = lds <= 60 * 1024;
   if (!use_lds) LSLAM_HIP(ctx, m->d_fv_scratch.reserve((size_t)B * 2 * n));
-  const bool fuse_mark = m->kernel_center_only && use_lds;  // find_valid marks the centres itself: one launch fewer
-  if (m->kernel_center_only) {
+  // find_valid marks the centres itself and the smear is a gather: no list, no atomics, two launches fewer
+  const bool fuse_mark = m->kernel_center_only && use_lds && g.kernel_size <= kMaxKernel;
+  if (m->kernel_center_only && !fuse_mark) {
     LSLAM_HIP(ctx, m->d_centres.reserve((size_t)B * n + 1));
     LSLAM_HIP(ctx, hipMemsetAsync(m->d_centres.p, 0, sizeof(uint32_t), ctx->stream));
   }
   launch(ctx, "find_valid", k_find_valid, dim3(B), dim3(n > 512 ? 1024 : 256), use_lds ? lds : 0, n, d_world, ring_start, cap,
-         center[0], center[1], m->d_valid.p, use_lds, m->d_fv_scratch.p, g, fuse_mark ? m->d_grid : (uint8_t*)nullptr,
-         fuse_mark ? m->d_centres.p + 1 : (uint32_t*)nullptr, fuse_mark ? (int*)m->d_centres.p : (int*)nullptr);
-  if (m->kernel_center_only) {
+         center[0], center[1], m->d_valid.p, use_lds, m->d_fv_scratch.p, g, fuse_mark ? m->d_grid : (uint8_t*)nullptr);
+  if (fuse_mark) {
+    const dim3 sg((unsigned)(((size_t)g.data_size + 4095) / 4096));
+#define LSLAM_SMEAR(HK) launch(ctx, "smear", k_smear_gather<HK>, sg, dim3(256), 0, g, (const uint8_t*)m->d_kernel, m->d_grid, m->d_sub[0], m->d_sub[1])
+    switch (g.kernel_size / 2) {
+      case 1: LSLAM_SMEAR(1); break;
+      case 2: LSLAM_SMEAR(2); break;
+      case 6: LSLAM_SMEAR(6); break;
+      default: LSLAM_SMEAR(0);
+    }
+#undef LSLAM_SMEAR
+    m->sub_dirty = false;  // the gather pass wrote the parity planes too
+  } else if (m->kernel_center_only) {
     // (1) centres: the first point to reach a cell sets it to 100 and is listed; (2) every listed centre
     // smears, one thread per aligned word of its footprint
     if (!fuse_mark)
@@ -2962,7 +3058,7 @@ int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges, const
     if (!use_lds) LSLAM_HIP(ctx, m->d_fv_scratch.reserve((size_t)2 * g.n_beams));
     launch(ctx, "find_valid", k_find_valid, dim3(1), dim3(g.n_beams > 512 ? 1024 : 256), use_lds ? lds : 0, g.n_beams,
            (const double2*)m->d_world.p, 0, 1, viewpoint[0], viewpoint[1], m->d_valid.p, use_lds, m->d_fv_scratch.p, g,
-           (uint8_t*)nullptr, (uint32_t*)nullptr, (int*)nullptr);
+           (uint8_t*)nullptr);
   }
   LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_valid.p, (size_t)g.n_beams, hipMemcpyDeviceToHost, ctx->stream));
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
