@@ -64,6 +64,26 @@ def test_valid_mask_and_grid(ctx, oracle_lib, workload):
     assert np.array_equal(gm.grid_info()["offset"], port.grid_info()["offset"])
 
 
+@pytest.mark.parametrize("res,smear,ks", [(0.05, 0.03, 3), (0.025, 0.03, 5), (0.05, 0.08, 7), (0.05, 0.45, 37)])
+def test_grid_rebuild_all_smear_paths(ctx, oracle_lib, workload, res, smear, ks):
+    """AddScans with the smear as a gather pass: the compile-time half sizes (3x3, 5x5), the generic form (7x7) and a
+    kernel wider than the gather tabulates (37x37 -> listed scatter path); grid bytes AND a match equal the oracle's."""
+    wl = workload
+    kw = dict(search_size=1.0 if res >= 0.05 else 0.5, resolution=res, smear_deviation=smear)
+    port, gm = make_pair(ctx, oracle_lib, cfg_kw=kw, range_threshold=20.0)
+    assert gm.grid_info()["kernel_size"] == ks
+    center = wl.query_poses[0]
+    port.set_base_scans(wl.base_ranges[:10], wl.base_poses[:10], center)
+    gm.AddScans(wl.base_ranges[:10], wl.base_poses[:10], center)
+    g_gpu, g_cpu = gm.GetCorrelationGrid(), port.grid()
+    assert g_cpu.any() and np.array_equal(g_gpu, g_cpu)
+    # the coarse pass reads the parity planes the same pass wrote
+    res_g = gm.match_batch(wl.query_ranges[:2], wl.query_poses[:2])
+    for q in range(2):
+        mean, cov, resp = port.match(wl.query_ranges[q], wl.query_poses[q])
+        _assert_result(res_g[q], mean, cov, resp)
+
+
 def test_lookup_tables_bit_exact(ctx, oracle_lib, workload):
     wl = workload
     port, gm = make_pair(ctx, oracle_lib)
