@@ -52,8 +52,6 @@ struct lslam_frontend {
   DevBuf<lslam_match_result> d_res;
   std::vector<double> cos_a, sin_a;        // cos / sin of minimum_angle + i * angular_resolution
   bool have_last = false;
-  unsigned pose_slot = 0;
-  double pose_stage[8][4] = {};
   int64_t n_chain_matches = 0, n_loop_coarse = 0, n_loop_fine = 0, n_loops_closed = 0, n_edges = 0;
 };
 
@@ -114,14 +112,11 @@ int fe_update_world(lslam_frontend* f, int id) {
   // No host synchronisation: the pose goes through its own slot of a small ring (the copy of a pageable host buffer is
   // staged before hipMemcpyAsync returns; the stream orders it before the kernel, and the kernel before the next
   // grid rebuild that reads these points).
-  const unsigned slot = f->pose_slot++ & 7;
-  double* d_pose = f->d_q.p + 4 + 4 * slot;
-  double* h_pose = f->pose_stage[slot];  // stable host address (f->scans may reallocate); every slot is seven host
-  for (int i = 0; i < 3; i++) h_pose[i] = f->scans[id].sensor[i];  // synchronisations old when it is reused
-  LSLAM_HIP(ctx, hipMemcpyAsync(d_pose, h_pose, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  PoseArg pv;  // the pose travels as a kernel argument: no copy on the stream in front of the kernel
+  for (int i = 0; i < 3; i++) pv.v[i] = f->scans[id].sensor[i];
   launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((n + 255) / 256, 1), dim3(256), 0,
-         (const double*)(f->d_ranges + (size_t)id * n), n, (const double*)d_pose, m->g, (double2*)nullptr,
-         f->d_world + (size_t)id * n, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0);
+         (const double*)(f->d_ranges + (size_t)id * n), n, (const double*)nullptr, m->g, (double2*)nullptr,
+         f->d_world + (size_t)id * n, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0, pv);
   return LSLAM_OK;
 }
 
@@ -138,8 +133,14 @@ int fe_match(lslam_frontend* f, lslam_matcher* m, int id, const double sensor[3]
     out->covariance[8] = 4 * ksq(m->cfg.coarse_angle_resolution);
     return LSLAM_OK;
   }
-  LSLAM_HIP(ctx, hipMemcpyAsync(f->d_q.p, sensor, 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  int rc = rebuild_grid_dev(m, f->d_world, first, count, f->cap, sensor);
+  // the grid rebuild's first kernel also carries the query pose into device memory and clears the numerators of the
+  // match's first (beam-sliced) pass: two stream operations fewer per scan
+  RebuildExtras x{};
+  for (int i = 0; i < 3; i++) x.pose[i] = sensor[i];
+  x.pose_dst = f->d_q.p;
+  x.zero = m->d_resp.p;
+  x.zero_words = (int)std::min<size_t>(m->d_resp.cap, (size_t)1 << 16);
+  int rc = rebuild_grid_dev(m, f->d_world, first, count, f->cap, sensor, &x);
   if (rc) return rc;
   rc = match_batch_impl<double>(m, 1, f->d_ranges + (size_t)id * n, n, f->d_q.p, do_penalize, do_refine, f->d_res.p, nullptr, 0);
   if (rc) return rc;

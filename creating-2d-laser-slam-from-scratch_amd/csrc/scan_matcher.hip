@@ -97,14 +97,19 @@ __device__ __forceinline__ void pass_setup_wave(int s, int lane, const Geom& g, 
                                                 const double* center, int active, Lattice* lat,
                                                 double2* cossin, int want_step);  // below
 
+struct PoseArg {
+  double v[3];
+};
 template <typename RT>
 __global__ void __launch_bounds__(256)
 k_scan_prep(const RT* __restrict__ ranges, int stride, const double* __restrict__ poses, Geom g,
             double2* __restrict__ local, double2* __restrict__ world, PassCfg setup_pc, Lattice* setup_lat,
-            double2* setup_cossin, int setup_step) {
+            double2* setup_cossin, int setup_step, PoseArg pose_val) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   int s = blockIdx.y;
-  double sx = poses[3 * s], sy = poses[3 * s + 1], sh = poses[3 * s + 2];
+  // poses == nullptr: ONE scan whose pose is the kernel argument (no copy on the stream in front of the kernel)
+  double sx = poses ? poses[3 * s] : pose_val.v[0], sy = poses ? poses[3 * s + 1] : pose_val.v[1],
+         sh = poses ? poses[3 * s + 2] : pose_val.v[2];
   // the scan's own transform (two rotation matrices, one normalised heading) is the same for all of
   // its beams: one thread of the block evaluates it
   __shared__ SensorXform s_t;
@@ -1896,6 +1901,24 @@ __global__ void k_result_no_readings(int S, const double* poses, double coarse_a
   out[s] = r;
 }
 
+// First kernel of a grid rebuild: Grid::Clear (Mapper.cpp:701) and, for the streaming front-end, two small jobs that
+// would otherwise each be a separate copy / fill on the stream of a latency-bound chain: the query scan's sensor pose
+// (a kernel argument) into device memory, and zeros over the response numerators of the match that follows (its
+// beam-sliced passes accumulate with atomics).
+struct RebuildExtras {
+  double pose[3];
+  double* pose_dst;   // nullptr: nothing to write
+  int32_t* zero;      // nullptr: nothing to clear
+  int zero_words;
+};
+__global__ void __launch_bounds__(256)
+k_rebuild_begin(uint4* __restrict__ grid16, size_t n16, RebuildExtras x) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n16) grid16[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (x.zero && i < (size_t)x.zero_words) x.zero[i] = 0;
+  if (x.pose_dst && i < 3) x.pose_dst[i] = x.pose[i];
+}
+
 // ------------------------------------------------------------------------------------------
 // correlation-grid construction (AddScans, Mapper.cpp:699-748)
 // ------------------------------------------------------------------------------------------
@@ -2280,6 +2303,7 @@ struct lslam_matcher {
   DevBuf<double2> d_cossin;  // [S][kMaxAngles] cos/sin of the pass's candidate angles (k_pass_setup)
   DevBuf<CoarseOut> d_coarse;
   DevBuf<int32_t> d_resp;
+  size_t resp_prezeroed = 0;  // words at the start of d_resp the last grid rebuild cleared for the NEXT match
   DevBuf<int32_t> d_tbl;     // large lattices: materialised lookup tables [S][nA][N]
   DevBuf<int32_t> d_part;    // large lattices, few scans: per-beam-slice partial numerators [S][slices][resp_stride]
   DevBuf<double> d_big;      // large lattices: reduce scratch
@@ -2369,7 +2393,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
 
   // scan_prep also lays out the coarse lattice of pass 0 (mode 0 needs only the pose): one launch fewer
   launch(ctx, "scan_prep", k_scan_prep<RT>, dim3(S >= kReduceNarrowMinScans ? 1 : (g.n_beams + 255) / 256, S), dim3(256), 0, d_ranges,
-         stride, d_poses, g, m->d_local.p, (double2*)nullptr, pc, m->d_lat.p, m->d_cossin.p, 2);
+         stride, d_poses, g, m->d_local.p, (double2*)nullptr, pc, m->d_lat.p, m->d_cossin.p, 2, PoseArg{});
   bool setup_done = true;  // consumed by the first pass
 
 
@@ -2442,8 +2466,10 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       int slices = 1;
       while (slices < 8 && waves * slices < 2048) slices *= 2;
       while ((g.n_beams + 64 * slices - 1) / (64 * slices) > kMaxBeamsPerLane) slices *= 2;  // packed 16-bit sums
-      if (slices > 1)
-        LSLAM_HIP(ctx, hipMemsetAsync(m->d_resp.p, 0, (size_t)S * resp_stride * sizeof(int32_t), ctx->stream));
+      if (slices > 1) {
+        if (m->resp_prezeroed >= (size_t)S * resp_stride) m->resp_prezeroed = 0;  // k_rebuild_begin cleared it; one use
+        else LSLAM_HIP(ctx, hipMemsetAsync(m->d_resp.p, 0, (size_t)S * resp_stride * sizeof(int32_t), ctx->stream));
+      }
       dim3 grid((unsigned)(waves * slices));
       const uint8_t* s0 = step == 2 ? m->d_sub[0] : m->d_grid;
       const uint8_t* s1 = step == 2 ? m->d_sub[1] : m->d_grid;
@@ -2609,13 +2635,20 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
 
 // AddScans on the device (Mapper.cpp:699-748) from world points already resident in HBM:
 // recentre, clear, FindValidPoints, mark + smear.  `world` is a ring of `cap` scans of n points.
-int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, int B, int cap, const double center[3]) {
+int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, int B, int cap, const double center[3],
+                     const RebuildExtras* extras = nullptr) {
   lslam_context* ctx = m->ctx;
   Geom& g = m->g;
   // Mapper.cpp:212-220: offset = scanPose - 0.5*(roi-1)*resolution
   g.off_x = center[0] - (0.5 * (g.roi_w - 1) * (1.0 / g.scale));
   g.off_y = center[1] - (0.5 * (g.roi_h - 1) * (1.0 / g.scale));
-  LSLAM_HIP(ctx, hipMemsetAsync(m->d_grid, 0, (size_t)g.data_size, ctx->stream));  // Grid::Clear (Mapper.cpp:701)
+  {  // Grid::Clear (Mapper.cpp:701); rounds up to 16 bytes inside the zero guard band behind the grid
+    const size_t n16 = ((size_t)g.data_size + 15) / 16;
+    RebuildExtras x{};
+    if (extras) x = *extras;
+    launch(ctx, "grid_clear", k_rebuild_begin, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (uint4*)m->d_grid, n16, x);
+    m->resp_prezeroed = x.zero == m->d_resp.p && x.zero ? (size_t)x.zero_words : 0;
+  }
   m->sub_dirty = m->occ_dirty = m->tile_dirty = m->ptile_dirty = true;
   const int n = g.n_beams;
   if (B <= 0 || n <= 0) return LSLAM_OK;
@@ -2931,7 +2964,7 @@ int lslam_matcher_set_base_scans(lslam_matcher* m, int B, const double* ranges, 
     if (rc) return rc;
     LSLAM_HIP(ctx, m->d_world.reserve((size_t)B * n));
     launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((n + 255) / 256, B), dim3(256), 0,
-           (const double*)m->d_ranges64.p, n, (const double*)m->d_poses.p, g, (double2*)nullptr, m->d_world.p, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0);
+           (const double*)m->d_ranges64.p, n, (const double*)m->d_poses.p, g, (double2*)nullptr, m->d_world.p, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0, PoseArg{});
   }
   int rc = rebuild_grid_dev(m, m->d_world.p, 0, B, B > 0 ? B : 1, center);
   if (rc) return rc;
@@ -3001,7 +3034,7 @@ int lslam_matcher_debug_lookup_table(lslam_matcher* m, const double* ranges, con
   LSLAM_HIP(ctx, m->d_local.reserve((size_t)g.n_beams));
   LSLAM_HIP(ctx, m->d_dbg.reserve((size_t)na * g.n_beams));
   launch(ctx, "scan_prep", k_scan_prep<double>, dim3((g.n_beams + 255) / 256, 1), dim3(256), 0,
-         (const double*)m->d_ranges64.p, g.n_beams, (const double*)m->d_poses.p, g, m->d_local.p, (double2*)nullptr, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0);
+         (const double*)m->d_ranges64.p, g.n_beams, (const double*)m->d_poses.p, g, m->d_local.p, (double2*)nullptr, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0, PoseArg{});
   launch(ctx, "debug_table", k_debug_table, dim3((g.n_beams + 255) / 256, na), dim3(256), 0, g,
          (const double2*)m->d_local.p, angle_center, angle_offset, angle_res, na, m->d_dbg.p);
   LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_dbg.p, (size_t)na * g.n_beams * sizeof(int32_t), hipMemcpyDeviceToHost,
@@ -3051,7 +3084,7 @@ int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges, const
   LSLAM_HIP(ctx, m->d_world.reserve((size_t)g.n_beams));
   LSLAM_HIP(ctx, m->d_valid.reserve((size_t)g.n_beams));
   launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((g.n_beams + 255) / 256, 1), dim3(256), 0,
-         (const double*)m->d_ranges64.p, g.n_beams, (const double*)m->d_poses.p, g, (double2*)nullptr, m->d_world.p, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0);
+         (const double*)m->d_ranges64.p, g.n_beams, (const double*)m->d_poses.p, g, (double2*)nullptr, m->d_world.p, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0, PoseArg{});
   {
     const size_t lds = (size_t)g.n_beams * (sizeof(double2) + 14) + 16;
     const int use_lds = lds <= 60 * 1024;
