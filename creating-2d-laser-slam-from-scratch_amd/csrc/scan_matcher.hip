@@ -1071,7 +1071,7 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
                     int32_t* resp, size_t resp_stride, CoarseOut* __restrict__ out,
                     int use_expansion, int pass_index, const uint8_t* __restrict__ grid,
                 const double2* __restrict__ local, int fb_step, PassCfg fine_pc,
-                    double2* fine_cossin, int fine_step) {
+                    double2* fine_cossin, int fine_step, int zero_fine_words) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double sh[NT];
   __shared__ double s_ap[kMaxAngles];
@@ -1304,7 +1304,11 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
     o.expand = (use_expansion && o.status == 0 && pass_index < 3 && double_equal(o.best, 0.0)) ? 1 : 0;
     out[s] = o;
   }
+  // The fine pass follows at once and its beam-sliced form accumulates with atomics: clear its numerators here (every read
+  // of this scan's coarse numerators is behind the barriers above) instead of a fill operation on the stream.
+  for (int i = tid; i < zero_fine_words; i += NT) resp[(size_t)s * resp_stride + i] = 0;
 }
+
 
 // ------------------------------------------------------------------------------------------
 // Large lattices (the loop-closure matcher: search space 8-15 m -> 81..151 positions per side x 21
@@ -2430,6 +2434,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   // lattice step the packed kernel of the last pass required (0 = the generic kernel did the pass):
   // the reduce kernels compute the numerators of scans with a different (non-uniform) lattice themselves
   int fb_step = 0;
+  bool fine_prezeroed = false;
   auto run_responses = [&](const PassCfg& p, int step, const char* name) -> int {
     const int variant = force_generic ? 0 : (p.nx <= 4 && p.ny <= 4) ? 1 : (p.nx <= 12) ? 2 : (p.nx <= 16) ? 3 : 0;
     fb_step = variant ? step : 0;
@@ -2467,7 +2472,8 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       while (slices < 8 && waves * slices < 2048) slices *= 2;
       while ((g.n_beams + 64 * slices - 1) / (64 * slices) > kMaxBeamsPerLane) slices *= 2;  // packed 16-bit sums
       if (slices > 1) {
-        if (m->resp_prezeroed >= (size_t)S * resp_stride) m->resp_prezeroed = 0;  // k_rebuild_begin cleared it; one use
+        if (step == 1 && fine_prezeroed) fine_prezeroed = false;  // k_reduce_coarse_lds cleared the fine numerators
+        else if (m->resp_prezeroed >= (size_t)S * resp_stride) m->resp_prezeroed = 0;  // k_rebuild_begin cleared it; one use
         else LSLAM_HIP(ctx, hipMemsetAsync(m->d_resp.p, 0, (size_t)S * resp_stride * sizeof(int32_t), ctx->stream));
       }
       dim3 grid((unsigned)(waves * slices));
@@ -2592,13 +2598,14 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
         launch(ctx, "reduce_coarse", k_reduce_coarse_lds<128>, dim3(S), dim3(128), reduce_lds_nocache(p), g, p, sc,
                m->d_lat.p, m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
                (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step, pf,
-               fuse_fine ? m->d_cossin.p : (double2*)nullptr, 1);
+               fuse_fine ? m->d_cossin.p : (double2*)nullptr, 1, fuse_fine ? pf.nx * pf.ny * pf.na : 0);
       else
         launch(ctx, "reduce_coarse", k_reduce_coarse_lds<256>, dim3(S), dim3(256), reduce_lds_nocache(p), g, p, sc,
                m->d_lat.p, m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
                (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step, pf,
-               fuse_fine ? m->d_cossin.p : (double2*)nullptr, 1);
+               fuse_fine ? m->d_cossin.p : (double2*)nullptr, 1, fuse_fine ? pf.nx * pf.ny * pf.na : 0);
       setup_done = fuse_fine;
+      fine_prezeroed = fuse_fine;
     }
     else if (cache)
       launch(ctx, "reduce_coarse", k_reduce_coarse<true>, dim3(S), dim3(256), reduce_lds(p, true), LSLAM_REDUCE_ARGS);
