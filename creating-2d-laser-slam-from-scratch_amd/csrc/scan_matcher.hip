@@ -1591,72 +1591,89 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
     latmax[c] = m;
     lm = lm > m ? lm : m;
   }
-  for (int wd = tid; wd < words; wd += NT) mask[wd] = 0u;
-  for (int c = tid; c < side2; c += NT) probs[c] = 0ull;  // Clear (:329) (+0.0)
+  // Lattice positions are >= 1.5 search-space cells apart (always so on the coarse pass: the step is two cells): the
+  // lattice -> search-space cell map (:440) is injective, every cell's probability is the value its own lattice
+  // position wrote, and m_pSearchSpaceProbs never has to exist -- no clear, no max-merge atomics, no fence.
+  const bool injective = pc.res_x * g.scale >= 1.5 && pc.res_y * g.scale >= 1.5;
+  if (!injective)
+    for (int c = tid; c < side2; c += NT) probs[c] = 0ull;  // Clear (:329) (+0.0)
   if (tid == 0) { s_nlist = 0; s_status = 0; }
   double best = block_max(lm, sh, tid, NT);
   if (have_latmax) best = __longlong_as_double((long long)best_bits[s]);  // >= +0: the unsigned order of the bits is the fp order
+  // ties with the best response (:452-455), as candidate indices k = c * nA + a in an LDS list; only when more than
+  // kList candidates tie (an all-zero response surface) the bitmap in global memory takes over
   for (int c = tid; c < ncand; c += NT) {
     if (latmax[c] + kTol < best) continue;  // no angle of this cell can tie
     const double dp = sc.do_penalize ? cell_dp(c) : 1.0;
     for (int a = 0; a < pc.na; a++)
       if (double_equal(value_of(r[a * ncand + c], dp, a), best)) {
-        const int k = c * pc.na + a;
-        atomicOr(&mask[k >> 5], 1u << (k & 31));
+        const int pos = atomicAdd(&s_nlist, 1);
+        if (pos < kList) s_list[pos] = c * pc.na + a;
       }
   }
-  // search-space probabilities (:437-450): max-merge is order independent -> parallel integer max
-  const double p_off_x = center[0] - pc.off_x, p_off_y = center[1] - pc.off_y;
-  for (int c = tid; c < ncand; c += NT) {
-    int xi = c % pc.nx, yi = c / pc.nx;
-    double wx = center[0] + (-pc.off_x + (uint32_t)xi * pc.res_x);
-    double wy = center[1] + (-pc.off_y + (uint32_t)yi * pc.res_y);
-    int gx = world_to_grid(wx, p_off_x, g.scale), gy = world_to_grid(wy, p_off_y, g.scale);
-    if (gx < 0 || gx >= g.probs_side || gy < 0 || gy >= g.probs_side) {
-      s_status = LSLAM_ERR_PROBABILITY_SEARCH;
-    } else {
-      double v = latmax[c] > 0.0 ? latmax[c] : 0.0;
-      atomicMax(&probs[gy * g.probs_side + gx], (unsigned long long)__double_as_longlong(v));
-    }
-    terms[4 * (size_t)c] = (double)(gy * g.probs_side + gx);  // remember the cell for the covariance pass
-  }
-  // mask / probs were updated with device-scope atomics (served by L2): agent-scope fence so the plain
-  // loads below cannot hit stale lines of this CU's vector L1
-  __threadfence();
   __syncthreads();
-  // non-empty mask words, in ascending order
-  for (int wd = tid; wd < words; wd += NT)
-    if (mask[wd]) {
-      int pos = atomicAdd(&s_nlist, 1);
-      if (pos < kList) s_list[pos] = wd;
+  const bool listed = s_nlist <= kList;
+  if (!listed) {
+    for (int wd = tid; wd < words; wd += NT) mask[wd] = 0u;
+    __threadfence();
+    __syncthreads();
+    for (int c = tid; c < ncand; c += NT) {
+      if (latmax[c] + kTol < best) continue;
+      const double dp = sc.do_penalize ? cell_dp(c) : 1.0;
+      for (int a = 0; a < pc.na; a++)
+        if (double_equal(value_of(r[a * ncand + c], dp, a), best)) {
+          const int k = c * pc.na + a;
+          atomicOr(&mask[k >> 5], 1u << (k & 31));
+        }
     }
+  }
+  // search-space cell of every lattice position (:440); out of the search space -> the reference throws
+  const double p_off_x = center[0] - pc.off_x, p_off_y = center[1] - pc.off_y;
+  auto probs_cell = [&](int c) -> int {
+    const int xi = c % pc.nx, yi = c / pc.nx;
+    const double wx = center[0] + (-pc.off_x + (uint32_t)xi * pc.res_x);
+    const double wy = center[1] + (-pc.off_y + (uint32_t)yi * pc.res_y);
+    const int gx = world_to_grid(wx, p_off_x, g.scale), gy = world_to_grid(wy, p_off_y, g.scale);
+    return (gx < 0 || gx >= g.probs_side || gy < 0 || gy >= g.probs_side) ? -1 : gy * g.probs_side + gx;
+  };
+  for (int c = tid; c < ncand; c += NT) {
+    const int cell = probs_cell(c);
+    if (cell < 0) s_status = LSLAM_ERR_PROBABILITY_SEARCH;
+    else if (!injective)  // max-merge is order independent -> parallel integer max
+      atomicMax(&probs[cell], (unsigned long long)__double_as_longlong(latmax[c] > 0.0 ? latmax[c] : 0.0));
+  }
+  // mask / probs were updated with device-scope atomics: agent-scope fence so the plain loads below cannot hit stale
+  // lines of this CU's vector L1
+  if (!injective || !listed) __threadfence();
   __syncthreads();
   if (tid == 0) {
     int st = s_status;
     double ax = 0, ay = 0, tx = 0, ty = 0;
     int cnt = 0;
-    auto visit_word = [&](int wd) {
-      uint32_t mbits = mask[wd];
-      while (mbits) {
-        int bit = __ffs(mbits) - 1;
-        mbits &= mbits - 1;
-        Cand cd = cand_of(wd * 32 + bit, pc, center);
-        double h = normalize_angle(cd.angle);
-        ax += center[0] + cd.x; ay += center[1] + cd.y;
-        tx += cos(h); ty += sin(h);
-        cnt++;
-      }
+    auto visit = [&](int k) {
+      Cand cd = cand_of(k, pc, center);
+      double h = normalize_angle(cd.angle);
+      ax += center[0] + cd.x; ay += center[1] + cd.y;
+      tx += cos(h); ty += sin(h);
+      cnt++;
     };
-    if (s_nlist <= kList) {
+    if (listed) {
       const int nl = s_nlist;
-      for (int i = 1; i < nl; i++) {  // insertion sort: a handful of entries
+      for (int i = 1; i < nl; i++) {  // insertion sort into lattice order: a handful of entries
         int v = s_list[i], j = i - 1;
         while (j >= 0 && s_list[j] > v) { s_list[j + 1] = s_list[j]; j--; }
         s_list[j + 1] = v;
       }
-      for (int i = 0; i < nl; i++) visit_word(s_list[i]);
+      for (int i = 0; i < nl; i++) visit(s_list[i]);
     } else {
-      for (int wd = 0; wd < words; wd++) visit_word(wd);
+      for (int wd = 0; wd < words; wd++) {
+        uint32_t mbits = mask[wd];
+        while (mbits) {
+          const int bit = __ffs(mbits) - 1;
+          mbits &= mbits - 1;
+          visit(wd * 32 + bit);
+        }
+      }
     }
     if (st == 0 && cnt == 0) st = LSLAM_ERR_NO_BEST_POSE;
     if (cnt) { ax /= cnt; ay /= cnt; tx /= cnt; ty /= cnt; }
@@ -1664,27 +1681,29 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
     s_status = st;
   }
   __syncthreads();
+  // ComputePositionalCovariance (:573-594): the cells that pass the (best - 0.1) test are few -- every thread evaluates
+  // its cell's terms, a ballot picks the passing ones and thread 0 adds them up in lattice order: same cells, same
+  // order, same sums as the reference's loop over all cells
   const double dx = s_avg[0] - center[0], dy = s_avg[1] - center[1];
-  for (int c = tid; c < ncand; c += NT) {
-    int xi = c % pc.nx, yi = c / pc.nx;
-    double x = -pc.off_x + (uint32_t)xi * pc.res_x;
-    double y = -pc.off_y + (uint32_t)yi * pc.res_y;
-    int cell = (int)terms[4 * (size_t)c];
-    double rr = (cell >= 0 && cell < side2) ? __longlong_as_double((long long)probs[cell]) : 0.0;
-    terms[4 * (size_t)c + 0] = rr;
-    terms[4 * (size_t)c + 1] = (ksq(x - dx) * rr);
-    terms[4 * (size_t)c + 2] = ((x - dx) * (y - dy) * rr);
-    terms[4 * (size_t)c + 3] = (ksq(y - dy) * rr);
-  }
-  __syncthreads();
-  // ordered accumulation (:573-594): chunks of NT cells staged in LDS, summed by one thread
   double axx = 0, axy = 0, ayy = 0, norm = 0;
   for (int c0 = 0; c0 < ncand; c0 += NT) {
-    if (c0 + tid < ncand)
-      for (int q = 0; q < 4; q++) chunk[4 * tid + q] = terms[4 * (size_t)(c0 + tid) + q];
-    // the cells that pass the (best - 0.1) test are few: ballot them, thread 0 walks only the set bits -- same cells,
-    // same (lattice) order, same sums as the reference's loop over all cells (:573-594)
-    const bool sel = c0 + tid < ncand && terms[4 * (size_t)(c0 + tid)] >= (best - 0.1);
+    const int c = c0 + tid;
+    bool sel = false;
+    if (c < ncand) {
+      const int xi = c % pc.nx, yi = c / pc.nx;
+      const double x = -pc.off_x + (uint32_t)xi * pc.res_x;
+      const double y = -pc.off_y + (uint32_t)yi * pc.res_y;
+      const int cell = probs_cell(c);
+      double rr = 0.0;
+      if (cell >= 0) rr = injective ? (latmax[c] > 0.0 ? latmax[c] : 0.0) : __longlong_as_double((long long)probs[cell]);
+      sel = rr >= (best - 0.1);
+      if (sel) {
+        chunk[4 * tid + 0] = rr;
+        chunk[4 * tid + 1] = (ksq(x - dx) * rr);
+        chunk[4 * tid + 2] = ((x - dx) * (y - dy) * rr);
+        chunk[4 * tid + 3] = (ksq(y - dy) * rr);
+      }
+    }
     const unsigned long long bal = __ballot(sel);
     if ((tid & 63) == 0) s_bal[tid >> 6] = bal;
     __syncthreads();

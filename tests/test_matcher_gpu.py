@@ -377,3 +377,10 @@ def test_loop_closure_size_lattice(ctx, oracle_lib, search_size, nx):
     res = gm.match_batch(wl.query_ranges[:1], wl.query_poses[:1], doPenalize=False, doRefineMatch=True)
     mean, cov, resp = port.match(wl.query_ranges[0], wl.query_poses[0], False, True)
     _assert_result(res[0], mean, cov, resp)
+    # an all-zero response surface: every one of the 138 k / 214 k candidates ties with the best (0), far more than the
+    # tie list holds -> the bitmap path; the mean is the average over the whole lattice, the covariance the maximum
+    blind = np.full_like(wl.query_ranges[:1], np.nan)
+    res = gm.match_batch(blind, wl.query_poses[:1], doPenalize=False, doRefineMatch=False)
+    mean, cov, resp = port.match(blind[0], wl.query_poses[0], False, False)
+    assert resp == 0.0
+    _assert_result(res[0], mean, cov, resp)
