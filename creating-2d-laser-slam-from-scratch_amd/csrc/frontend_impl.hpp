@@ -50,6 +50,9 @@ struct lslam_frontend {
   double* d_ranges = nullptr;              // [cap][n] readings (kept to re-pose a scan after a closed loop)
   DevBuf<double> d_q;                      // query pose (3)
   DevBuf<lslam_match_result> d_res;
+  lslam_match_result* h_res = nullptr;     // pinned host memory the match's last kernel writes its record to
+  double* h_ranges = nullptr;              // pinned staging of the new scan's readings (n)
+  const double* pending_ranges = nullptr;  // staged readings the next fe_match carries into HBM (its first kernel)
   std::vector<double> cos_a, sin_a;        // cos / sin of minimum_angle + i * angular_resolution
   bool have_last = false;
   int64_t n_chain_matches = 0, n_loop_coarse = 0, n_loop_fine = 0, n_loops_closed = 0, n_edges = 0;
@@ -140,12 +143,19 @@ int fe_match(lslam_frontend* f, lslam_matcher* m, int id, const double sensor[3]
   x.pose_dst = f->d_q.p;
   x.zero = m->d_resp.p;
   x.zero_words = (int)std::min<size_t>(m->d_resp.cap, (size_t)1 << 16);
+  if (f->pending_ranges) {  // the scan's readings were only staged: the same kernel brings them into HBM
+    x.ranges_src = f->pending_ranges;
+    x.ranges_dst = f->d_ranges + (size_t)id * n;
+    x.n_ranges = n;
+    f->pending_ranges = nullptr;
+  }
   int rc = rebuild_grid_dev(m, f->d_world, first, count, f->cap, sensor, &x);
   if (rc) return rc;
-  rc = match_batch_impl<double>(m, 1, f->d_ranges + (size_t)id * n, n, f->d_q.p, do_penalize, do_refine, f->d_res.p, nullptr, 0);
+  // the last kernel of the match writes the 112-byte record straight into pinned host memory: no copy operation
+  rc = match_batch_impl<double>(m, 1, f->d_ranges + (size_t)id * n, n, f->d_q.p, do_penalize, do_refine, f->h_res, nullptr, 0);
   if (rc) return rc;
-  LSLAM_HIP(ctx, hipMemcpyAsync(out, f->d_res.p, sizeof *out, hipMemcpyDeviceToHost, ctx->stream));
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out = *f->h_res;
   if (out->status != LSLAM_OK) return ctx->fail(out->status, "scan matcher: the reference throws here");
   return LSLAM_OK;
 }
@@ -342,7 +352,10 @@ int lslam_frontend_create_ex(lslam_matcher* m, const lslam_frontend_config* cfg,
       return rc;
     }
   }
-  if (f->d_q.reserve(4 + 4 * 8) != hipSuccess || f->d_res.reserve(1) != hipSuccess) {
+  if (f->d_q.reserve(4 + 4 * 8) != hipSuccess || f->d_res.reserve(1) != hipSuccess ||
+      hipHostMalloc((void**)&f->h_res, sizeof(lslam_match_result), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&f->h_ranges, sizeof(double) * (size_t)std::max(m->g.n_beams, 1), hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
     lslam_frontend_destroy(f);
     return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the front-end scratch in HBM");
   }
@@ -384,6 +397,8 @@ void lslam_frontend_destroy(lslam_frontend* f) {
   if (f->d_ranges) (void)hipFree(f->d_ranges);
   f->d_q.release();
   f->d_res.release();
+  if (f->h_res) (void)hipHostFree(f->h_res);
+  if (f->h_ranges) (void)hipHostFree(f->h_ranges);
   delete f;
 }
 
@@ -455,8 +470,14 @@ int lslam_frontend_process_stamped(lslam_frontend* f, const double* ranges, int 
   const int id = (int)f->scans.size();
   int rc = fe_grow(f, id + 1);
   if (rc) return rc;
-  if (n > 0)
-    LSLAM_HIP(ctx, hipMemcpyAsync(f->d_ranges + (size_t)id * n, ranges, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (n > 0) {
+    if (f->have_last) {  // a match follows at once: stage the readings, its first kernel moves them (one operation fewer)
+      memcpy(f->h_ranges, ranges, (size_t)n * sizeof(double));
+      f->pending_ranges = f->h_ranges;
+    } else {
+      LSLAM_HIP(ctx, hipMemcpyAsync(f->d_ranges + (size_t)id * n, ranges, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+  }
   lslam_frontend_scan s;
   for (int i = 0; i < 3; i++) s.odom[i] = odom_pose[i];
   s.time = time_s;

@@ -1926,13 +1926,16 @@ __global__ void k_result_no_readings(int S, const double* poses, double coarse_a
 
 // First kernel of a grid rebuild: Grid::Clear (Mapper.cpp:701) and, for the streaming front-end, two small jobs that
 // would otherwise each be a separate copy / fill on the stream of a latency-bound chain: the query scan's sensor pose
-// (a kernel argument) into device memory, and zeros over the response numerators of the match that follows (its
-// beam-sliced passes accumulate with atomics).
+// (a kernel argument) into device memory, zeros over the response numerators of the match that follows (its
+// beam-sliced passes accumulate with atomics), and the new scan's readings from pinned host memory into their row.
 struct RebuildExtras {
   double pose[3];
-  double* pose_dst;   // nullptr: nothing to write
-  int32_t* zero;      // nullptr: nothing to clear
+  double* pose_dst;          // nullptr: nothing to write
+  int32_t* zero;             // nullptr: nothing to clear
   int zero_words;
+  const double* ranges_src;  // nullptr, or the new scan's readings in pinned host memory (read over the bus) ...
+  double* ranges_dst;        // ... and their resident row in HBM
+  int n_ranges;
 };
 __global__ void __launch_bounds__(256)
 k_rebuild_begin(uint4* __restrict__ grid16, size_t n16, RebuildExtras x) {
@@ -1940,6 +1943,7 @@ k_rebuild_begin(uint4* __restrict__ grid16, size_t n16, RebuildExtras x) {
   if (i < n16) grid16[i] = make_uint4(0u, 0u, 0u, 0u);
   if (x.zero && i < (size_t)x.zero_words) x.zero[i] = 0;
   if (x.pose_dst && i < 3) x.pose_dst[i] = x.pose[i];
+  if (x.ranges_src && i < (size_t)x.n_ranges) x.ranges_dst[i] = x.ranges_src[i];
 }
 
 // ------------------------------------------------------------------------------------------
