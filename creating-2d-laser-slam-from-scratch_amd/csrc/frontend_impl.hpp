@@ -48,6 +48,7 @@ struct lslam_frontend {
   int cap = 0;                             // scans the device arrays hold
   double2* d_world = nullptr;              // [cap][n] world points at the scans' current poses
   double* d_ranges = nullptr;              // [cap][n] readings (kept to re-pose a scan after a closed loop)
+  int* d_next = nullptr;                   // [cap][n + 1] k_anchor_chain rows: FindValidPoints' anchors of the world points
   DevBuf<double> d_q;                      // query pose (3)
   DevBuf<lslam_match_result> d_res;
   lslam_match_result* h_res = nullptr;     // pinned host memory the match's last kernel writes its record to
@@ -61,6 +62,7 @@ struct lslam_frontend {
 namespace {
 
 inline double sq_dist2(const double* a, const double* b) { return ksq(a[0] - b[0]) + ksq(a[1] - b[1]); }
+inline size_t fe_anchor_lds(int n) { return (size_t)n * (sizeof(double2) + 13) + 16; }  // points, three tables, reach
 
 int fe_grow(lslam_frontend* f, int need) {
   if (need <= f->cap) return LSLAM_OK;
@@ -70,20 +72,27 @@ int fe_grow(lslam_frontend* f, int need) {
   while (cap < need) cap *= 2;
   double2* w = nullptr;
   double* r = nullptr;
+  int* nx = nullptr;
   if (hipMalloc((void**)&w, (size_t)cap * n * sizeof(double2)) != hipSuccess ||
-      hipMalloc((void**)&r, (size_t)cap * n * sizeof(double)) != hipSuccess) {
+      hipMalloc((void**)&r, (size_t)cap * n * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&nx, (size_t)cap * (n + 1) * sizeof(int)) != hipSuccess) {
+    (void)hipGetLastError();
     if (w) (void)hipFree(w);
+    if (r) (void)hipFree(r);
     return ctx->fail(LSLAM_ERR_HIP, "cannot keep %d scans resident in HBM", cap);
   }
   if (f->cap > 0) {
     LSLAM_HIP(ctx, hipMemcpyAsync(w, f->d_world, (size_t)f->cap * n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
     LSLAM_HIP(ctx, hipMemcpyAsync(r, f->d_ranges, (size_t)f->cap * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    LSLAM_HIP(ctx, hipMemcpyAsync(nx, f->d_next, (size_t)f->cap * (n + 1) * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
     LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(f->d_world);
     (void)hipFree(f->d_ranges);
+    (void)hipFree(f->d_next);
   }
   f->d_world = w;
   f->d_ranges = r;
+  f->d_next = nx;
   f->cap = cap;
   return LSLAM_OK;
 }
@@ -117,9 +126,17 @@ int fe_update_world(lslam_frontend* f, int id) {
   // grid rebuild that reads these points).
   PoseArg pv;  // the pose travels as a kernel argument: no copy on the stream in front of the kernel
   for (int i = 0; i < 3; i++) pv.v[i] = f->scans[id].sensor[i];
-  launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((n + 255) / 256, 1), dim3(256), 0,
-         (const double*)(f->d_ranges + (size_t)id * n), n, (const double*)nullptr, m->g, (double2*)nullptr,
-         f->d_world + (size_t)id * n, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0, pv);
+  if (fe_anchor_lds(n) <= 60 * 1024) {
+    // world points AND FindValidPoints' anchor chain of the scan at this pose in one launch: the chain once here, not once
+    // per rebuild of every window the scan will be part of
+    launch(ctx, "scan_prep_base", k_anchor_chain, dim3(1), dim3(n > 512 ? 1024 : 256), fe_anchor_lds(n), n,
+           f->d_world + (size_t)id * n, f->d_next + (size_t)id * (n + 1), (const double*)(f->d_ranges + (size_t)id * n), pv,
+           m->g);
+  } else {
+    launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((n + 255) / 256, 1), dim3(256), 0,
+           (const double*)(f->d_ranges + (size_t)id * n), n, (const double*)nullptr, m->g, (double2*)nullptr,
+           f->d_world + (size_t)id * n, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0, pv);
+  }
   return LSLAM_OK;
 }
 
@@ -142,6 +159,7 @@ int fe_match(lslam_frontend* f, lslam_matcher* m, int id, const double sensor[3]
   for (int i = 0; i < 3; i++) x.pose[i] = sensor[i];
   x.pose_dst = f->d_q.p;
   x.zero = m->d_resp.p;
+  x.anchor_ring = fe_anchor_lds(n) <= 60 * 1024 ? f->d_next : nullptr;
   x.zero_words = (int)std::min<size_t>(m->d_resp.cap, (size_t)1 << 16);
   if (f->pending_ranges) {  // the scan's readings were only staged: the same kernel brings them into HBM
     x.ranges_src = f->pending_ranges;
@@ -395,6 +413,7 @@ void lslam_frontend_destroy(lslam_frontend* f) {
   if (f->loop_m) lslam_matcher_destroy(f->loop_m);
   if (f->d_world) (void)hipFree(f->d_world);
   if (f->d_ranges) (void)hipFree(f->d_ranges);
+  if (f->d_next) (void)hipFree(f->d_next);
   f->d_q.release();
   f->d_res.release();
   if (f->h_res) (void)hipHostFree(f->h_res);

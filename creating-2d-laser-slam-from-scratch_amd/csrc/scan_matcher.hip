@@ -1936,6 +1936,7 @@ struct RebuildExtras {
   const double* ranges_src;  // nullptr, or the new scan's readings in pinned host memory (read over the bus) ...
   double* ranges_dst;        // ... and their resident row in HBM
   int n_ranges;
+  const int* anchor_ring;    // nullptr, or k_anchor_chain's rows (n + 1 ints) of every resident scan, same ring as the world points
 };
 __global__ void __launch_bounds__(256)
 k_rebuild_begin(uint4* __restrict__ grid16, size_t n16, RebuildExtras x) {
@@ -1963,9 +1964,46 @@ k_rebuild_begin(uint4* __restrict__ grid16, size_t n16, RebuildExtras x) {
 //       scans walks the chain on one thread),
 //   (3) every anchor evaluates its side test and marks its run [anchor, next[anchor]) -- in parallel.
 // Every fp64 expression is the reference's.
+// first later point farther than 10 cm from point i (Mapper.cpp:780-781), n if none; four candidates per step so that
+// their LDS reads are in flight together (a block waits for its slowest thread: a wall 0.3 m away is 80 points away)
+__device__ __forceinline__ int successor_of(const double2* p, int n, int i, double min_sq) {
+  const double fx = p[i].x, fy = p[i].y;
+  int j = i + 1;
+  for (bool found = false; !found && j < n;) {
+    double2 q[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) q[u] = p[min(j + u, n - 1)];
+    int hit = 4;
+#pragma unroll
+    for (int u = 3; u >= 0; u--) {
+      const double dx = fx - q[u].x, dy = fy - q[u].y;
+      if (ksq(dx) + ksq(dy) > min_sq) hit = u;
+    }
+    if (hit < 4 && j + hit < n) { j += hit; found = true; }
+    else j = min(j + 4, n);
+  }
+  return j;
+}
+// reach[] = the points reachable from `first` through the successor table ja (= the anchors), by pointer doubling:
+// round k marks chain distances [2^k, 2^(k+1)).  ja / jb are overwritten.  Ends with a barrier.
+__device__ __forceinline__ void mark_reachable(int n, int first, int* ja, int* jb, uint8_t* reach, int tid, int nt) {
+  if (tid == 0 && first < n) reach[first] = 1;
+  __syncthreads();
+  for (int span = 1; span < n; span <<= 1) {
+    for (int i = tid; i < n; i += nt) {
+      const int j = ja[i];
+      if (reach[i] && j < n) reach[j] = 1;
+      jb[i] = j < n ? ja[j] : n;
+    }
+    __syncthreads();
+    int* t = ja; ja = jb; jb = t;
+  }
+}
+
 __global__ void __launch_bounds__(1024)
 k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, double vx, double vy,
-             uint8_t* __restrict__ valid, int use_lds, int* __restrict__ scratch, Geom g, uint8_t* __restrict__ grid) {
+             uint8_t* __restrict__ valid, int use_lds, int* __restrict__ scratch, Geom g, uint8_t* __restrict__ grid,
+             const int* __restrict__ anchor_ring) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int s_first, s_len;
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -1992,30 +2030,6 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
   }
   if (tid == 0) { s_first = n; s_len = 0; }
   __syncthreads();
-  const double min_sq = ksq(0.1);
-  for (int i = tid; i < n; i += nt) {
-    const double fx = p[i].x, fy = p[i].y;
-    if (!isnan(fx) && !isnan(fy)) atomicMin(&s_first, i);  // first anchor (Mapper.cpp:774-778)
-    // first later point farther than 10 cm (:780-781); four candidates per step so that their LDS reads are in
-    // flight together (the block waits for its slowest thread: a wall 0.3 m away is 80 points to the successor)
-    int j = i + 1;
-    for (bool found = false; !found && j < n;) {
-      double2 q[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) q[u] = p[min(j + u, n - 1)];
-      int hit = 4;
-#pragma unroll
-      for (int u = 3; u >= 0; u--) {
-        const double dx = fx - q[u].x, dy = fy - q[u].y;
-        if (ksq(dx) + ksq(dy) > min_sq) hit = u;
-      }
-      if (hit < 4 && j + hit < n) { j += hit; found = true; }
-      else j = min(j + 4, n);
-    }
-    next[i] = j;
-    if (use_lds) chain[i] = j;
-  }
-  __syncthreads();
   // the side test of anchor a against its successor f, and the run it keeps (:788-806)
   auto keep_run = [&](int a, int f, bool first) {
     const double fx = p[a].x, fy = p[a].y, cx = p[f].x, cy = p[f].y;
@@ -2026,41 +2040,44 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
     if (!(ss < 0.0))
       for (int t = (first ? 0 : a); t < f; t++) v[t] = 1;
   };
-  if (use_lds) {
-    const int first = s_first;
-    if (tid == 0 && first < n) reach[first] = 1;
+  // The anchors depend on the scan's points only, not on the viewpoint: the streaming front-end lists them once per
+  // (re)posed scan (k_anchor_chain: row = count, anchors in order) instead of once per rebuild of every window the scan
+  // is part of; only the side tests and the marking are left here.
+  const int* ain = (anchor_ring && use_lds) ? anchor_ring + (size_t)((ring_start + b) % cap) * (n + 1) : nullptr;
+  if (ain) {
+    const int cnt = ain[0];
+    for (int k = tid; k + 1 < cnt; k += nt) keep_run(ain[1 + k], ain[2 + k], k == 0);
+  } else {
+    const double min_sq = ksq(0.1);
+    for (int i = tid; i < n; i += nt) {
+      const double fx = p[i].x, fy = p[i].y;
+      if (!isnan(fx) && !isnan(fy)) atomicMin(&s_first, i);  // first anchor (Mapper.cpp:774-778)
+      next[i] = successor_of(p, n, i, min_sq);
+      if (use_lds) chain[i] = next[i];
+    }
     __syncthreads();
-    int* ja = chain;
-    int* jb = jump2;
-    for (int span = 1; span < n; span <<= 1) {  // ja = next^span; marks chain distances [span, 2 span)
-      for (int i = tid; i < n; i += nt) {
-        const int j = ja[i];
-        if (reach[i] && j < n) reach[j] = 1;
-        jb[i] = j < n ? ja[j] : n;
+    if (use_lds) {
+      const int first = s_first;
+      mark_reachable(n, first, chain, jump2, reach, tid, nt);
+      for (int a = tid; a < n; a += nt)
+        if (reach[a] && next[a] < n) keep_run(a, next[a], a == first);
+    } else {
+      if (tid == 0) {
+        int len = 0;
+        for (int a = s_first; a < n; a = next[a]) chain[len++] = a;
+        s_len = len;
       }
       __syncthreads();
-      int* t = ja; ja = jb; jb = t;
+      const int len = s_len;
+      for (int k = tid; k + 1 < len; k += nt) keep_run(chain[k], chain[k + 1], k == 0);
     }
-    for (int a = tid; a < n; a += nt)
-      if (reach[a] && next[a] < n) keep_run(a, next[a], a == first);
-  } else {
-    if (tid == 0) {
-      int len = 0;
-      for (int a = s_first; a < n; a = next[a]) chain[len++] = a;
-      s_len = len;
-    }
-    __syncthreads();
-    const int len = s_len;
-    for (int k = tid; k + 1 < len; k += nt) keep_run(chain[k], chain[k + 1], k == 0);
   }
   __syncthreads();
   if (use_lds)
     for (int i = tid; i < n; i += nt) gv[i] = v[i];
-  // Fused AddScan stage (k_mark_centres' body; the streaming front-end rebuilds the grid once per scan, so a launch and
-  // the valid[] round trip through memory matter): each valid point turns its cell into 100 and the winner lists it.
   // Fused AddScan stage (the streaming front-end rebuilds the grid once per scan, so a launch and the valid[] round trip
   // through memory matter): each valid point turns its cell into 100 with a PLAIN byte store -- every writer writes the
-  // same value, and which point got there first does not matter because k_smear_scan finds the centres in the grid
+  // same value, and which point got there first does not matter because k_smear_gather finds the centres in the grid
   // itself.  (Device-scope atomics that report the winner are executed at the memory side: ~40 k of them per rebuild,
   // most on cells other scans of the window had already set, were two thirds of this kernel's time.)
   if (grid && use_lds) {
@@ -2078,6 +2095,59 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
       if (idx != 0xFFFFFFFFu && ((tid & 63) == 0 || left != idx)) grid[idx] = (uint8_t)kOccupied;
     }
   }
+}
+
+// The anchor chain of FindValidPoints for ONE scan (see k_find_valid), as row = [count, anchor indices in order]: launched
+// by the streaming front-end when a scan's world points are (re)computed, off the per-scan critical path.
+// With `ranges` it first evaluates the world points themselves (k_scan_prep's world branch: LocalizedRangeScan::Update,
+// Karto.h:5384-5388, at the pose passed as a kernel argument) and stores them: one launch for both.
+__global__ void __launch_bounds__(1024)
+k_anchor_chain(int n, double2* __restrict__ world, int* __restrict__ row, const double* __restrict__ ranges, PoseArg pose,
+               Geom g) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ int s_first, s_wc[16];
+  double2* p = (double2*)smem;
+  int* next = (int*)(p + n);
+  int* ja = next + n;
+  int* jb = ja + n;
+  uint8_t* reach = (uint8_t*)(jb + n);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < n; i += nt) {
+    double2 q;
+    if (ranges) {
+      beam_world_point(pose.v[0], pose.v[1], pose.v[2], g.min_angle, g.ang_res, (uint32_t)i, ranges[i], q.x, q.y);
+      world[i] = q;
+    } else {
+      q = world[i];
+    }
+    p[i] = q;
+    reach[i] = 0;
+  }
+  if (tid == 0) s_first = n;
+  __syncthreads();
+  const double min_sq = ksq(0.1);
+  for (int i = tid; i < n; i += nt) {
+    if (!isnan(p[i].x) && !isnan(p[i].y)) atomicMin(&s_first, i);  // first anchor (Mapper.cpp:774-778)
+    next[i] = successor_of(p, n, i, min_sq);
+    ja[i] = next[i];
+  }
+  __syncthreads();
+  mark_reachable(n, s_first, ja, jb, reach, tid, nt);
+  __syncthreads();
+  int base = 0;
+  for (int i0 = 0; i0 < n; i0 += nt) {  // ordered compaction of the anchors
+    const int i = i0 + tid;
+    const bool is_anchor = i < n && reach[i];
+    const unsigned long long bal = __ballot(is_anchor);
+    if ((tid & 63) == 0) s_wc[tid >> 6] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < (tid >> 6); w++) off += s_wc[w];
+    for (int w = 0; w < (nt >> 6); w++) base += s_wc[w];
+    if (is_anchor) row[1 + off + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = i;
+    __syncthreads();
+  }
+  if (tid == 0) row[0] = base;
 }
 
 // SmearPoint (Mapper.h:971-1005) of every centre k_find_valid marked, as a GATHER over the cleared-and-marked grid: one
@@ -2693,7 +2763,8 @@ int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, i
     LSLAM_HIP(ctx, hipMemsetAsync(m->d_centres.p, 0, sizeof(uint32_t), ctx->stream));
   }
   launch(ctx, "find_valid", k_find_valid, dim3(B), dim3(n > 512 ? 1024 : 256), use_lds ? lds : 0, n, d_world, ring_start, cap,
-         center[0], center[1], m->d_valid.p, use_lds, m->d_fv_scratch.p, g, fuse_mark ? m->d_grid : (uint8_t*)nullptr);
+         center[0], center[1], m->d_valid.p, use_lds, m->d_fv_scratch.p, g, fuse_mark ? m->d_grid : (uint8_t*)nullptr,
+         extras ? extras->anchor_ring : (const int*)nullptr);
   if (fuse_mark) {
     const dim3 sg((unsigned)(((size_t)g.data_size + 4095) / 4096));
 #define LSLAM_SMEAR(HK) launch(ctx, "smear", k_smear_gather<HK>, sg, dim3(256), 0, g, (const uint8_t*)m->d_kernel, m->d_grid, m->d_sub[0], m->d_sub[1])
@@ -3121,7 +3192,7 @@ int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges, const
     if (!use_lds) LSLAM_HIP(ctx, m->d_fv_scratch.reserve((size_t)2 * g.n_beams));
     launch(ctx, "find_valid", k_find_valid, dim3(1), dim3(g.n_beams > 512 ? 1024 : 256), use_lds ? lds : 0, g.n_beams,
            (const double2*)m->d_world.p, 0, 1, viewpoint[0], viewpoint[1], m->d_valid.p, use_lds, m->d_fv_scratch.p, g,
-           (uint8_t*)nullptr);
+           (uint8_t*)nullptr, (const int*)nullptr);
   }
   LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_valid.p, (size_t)g.n_beams, hipMemcpyDeviceToHost, ctx->stream));
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
