@@ -161,10 +161,12 @@ int fe_match(lslam_frontend* f, lslam_matcher* m, int id, const double sensor[3]
   x.zero = m->d_resp.p;
   x.anchor_ring = fe_anchor_lds(n) <= 60 * 1024 ? f->d_next : nullptr;
   x.zero_words = (int)std::min<size_t>(m->d_resp.cap, (size_t)1 << 16);
+  x.prep_ranges = f->d_ranges + (size_t)id * n;  // the match's k_scan_prep rides along too (extra blocks)
   if (f->pending_ranges) {  // the scan's readings were only staged: the same kernel brings them into HBM
     x.ranges_src = f->pending_ranges;
     x.ranges_dst = f->d_ranges + (size_t)id * n;
     x.n_ranges = n;
+    x.prep_ranges = f->pending_ranges;  // ... and its prep blocks read the staged copy (the row is being written)
     f->pending_ranges = nullptr;
   }
   int rc = rebuild_grid_dev(m, f->d_world, first, count, f->cap, sensor, &x);

@@ -100,16 +100,13 @@ __device__ __forceinline__ void pass_setup_wave(int s, int lane, const Geom& g, 
 struct PoseArg {
   double v[3];
 };
+// One 256-thread block of the prep: block bx of nbx shares the beams of scan s, posed at (sx, sy, sh).
 template <typename RT>
-__global__ void __launch_bounds__(256)
-k_scan_prep(const RT* __restrict__ ranges, int stride, const double* __restrict__ poses, Geom g,
-            double2* __restrict__ local, double2* __restrict__ world, PassCfg setup_pc, Lattice* setup_lat,
-            double2* setup_cossin, int setup_step, PoseArg pose_val) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  int s = blockIdx.y;
-  // poses == nullptr: ONE scan whose pose is the kernel argument (no copy on the stream in front of the kernel)
-  double sx = poses ? poses[3 * s] : pose_val.v[0], sy = poses ? poses[3 * s + 1] : pose_val.v[1],
-         sh = poses ? poses[3 * s + 2] : pose_val.v[2];
+__device__ __forceinline__ void scan_prep_block(const RT* __restrict__ ranges, int stride, double sx, double sy, double sh,
+                                                const Geom& g, double2* __restrict__ local, double2* __restrict__ world,
+                                                const PassCfg& setup_pc, Lattice* setup_lat, double2* setup_cossin,
+                                                int setup_step, int bx, int nbx, int s) {
+  int b = bx * 256 + threadIdx.x;
   // the scan's own transform (two rotation matrices, one normalised heading) is the same for all of
   // its beams: one thread of the block evaluates it
   __shared__ SensorXform s_t;
@@ -121,7 +118,7 @@ k_scan_prep(const RT* __restrict__ ranges, int stride, const double* __restrict_
   }
   // Meanwhile the LAST wave of the scan's first block lays out the coarse search lattice (k_pass_setup, mode 0), and
   // every thread evaluates its first world point: neither needs the transform thread 0 is working on.
-  if (setup_lat && blockIdx.x == 0 && threadIdx.x >= 192) {
+  if (setup_lat && bx == 0 && threadIdx.x >= 192) {
     const double center[3] = {sx, sy, sh};
     pass_setup_wave(s, threadIdx.x - 192, g, setup_pc, center, 1, setup_lat, setup_cossin, setup_step);
   }
@@ -131,9 +128,9 @@ k_scan_prep(const RT* __restrict__ ranges, int stride, const double* __restrict_
     beam_world_point(sx, sy, sh, g.min_angle, g.ang_res, (uint32_t)b, r, px, py);
   }
   __syncthreads();
-  // gridDim.x blocks share the beams of a scan: ONE for chip-filling batches (the single-thread transform above is
+  // nbx blocks share the beams of a scan: ONE for chip-filling batches (the single-thread transform above is
   // then paid once per scan, not once per 256 beams -- it was most of this kernel's time), ceil(n/256) otherwise
-  for (bool first = true; b < g.n_beams; b += gridDim.x * blockDim.x, first = false) {
+  for (bool first = true; b < g.n_beams; b += nbx * 256, first = false) {
     if (!first) {
       r = (double)ranges[(size_t)s * stride + b];
       beam_world_point(sx, sy, sh, g.min_angle, g.ang_res, (uint32_t)b, r, px, py);
@@ -150,6 +147,19 @@ k_scan_prep(const RT* __restrict__ ranges, int stride, const double* __restrict_
       local[o] = make_double2(lx, ly);
     }
   }
+}
+
+template <typename RT>
+__global__ void __launch_bounds__(256)
+k_scan_prep(const RT* __restrict__ ranges, int stride, const double* __restrict__ poses, Geom g,
+            double2* __restrict__ local, double2* __restrict__ world, PassCfg setup_pc, Lattice* setup_lat,
+            double2* setup_cossin, int setup_step, PoseArg pose_val) {
+  const int s = blockIdx.y;
+  // poses == nullptr: ONE scan whose pose is the kernel argument (no copy on the stream in front of the kernel)
+  const double sx = poses ? poses[3 * s] : pose_val.v[0], sy = poses ? poses[3 * s + 1] : pose_val.v[1],
+               sh = poses ? poses[3 * s + 2] : pose_val.v[2];
+  scan_prep_block(ranges, stride, sx, sy, sh, g, local, world, setup_pc, setup_lat, setup_cossin, setup_step, (int)blockIdx.x,
+                  (int)gridDim.x, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1937,9 +1947,24 @@ struct RebuildExtras {
   double* ranges_dst;        // ... and their resident row in HBM
   int n_ranges;
   const int* anchor_ring;    // nullptr, or k_anchor_chain's rows (n + 1 ints) of every resident scan, same ring as the world points
+  // k_scan_prep of the ONE query scan of the match that follows (its pose is `pose`), run by extra blocks of the same
+  // launch: the prep needs nothing of the grid, so it runs beside the clear instead of behind the whole rebuild
+  const double* prep_ranges;  // nullptr: no prep
+  double2* prep_local;
+  Lattice* prep_lat;
+  double2* prep_cossin;
+  PassCfg prep_pc;
+  Geom prep_g;
+  int clear_blocks;
 };
 __global__ void __launch_bounds__(256)
 k_rebuild_begin(uint4* __restrict__ grid16, size_t n16, RebuildExtras x) {
+  if (x.prep_ranges && (int)blockIdx.x >= x.clear_blocks) {
+    scan_prep_block(x.prep_ranges, x.prep_g.n_beams, x.pose[0], x.pose[1], x.pose[2], x.prep_g, x.prep_local,
+                    (double2*)nullptr, x.prep_pc, x.prep_lat, x.prep_cossin, 2, (int)blockIdx.x - x.clear_blocks,
+                    (int)gridDim.x - x.clear_blocks, 0);
+    return;
+  }
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n16) grid16[i] = make_uint4(0u, 0u, 0u, 0u);
   if (x.zero && i < (size_t)x.zero_words) x.zero[i] = 0;
@@ -2401,6 +2426,7 @@ struct lslam_matcher {
   DevBuf<CoarseOut> d_coarse;
   DevBuf<int32_t> d_resp;
   size_t resp_prezeroed = 0;  // words at the start of d_resp the last grid rebuild cleared for the NEXT match
+  bool prep_done = false;     // the last grid rebuild also ran k_scan_prep for the ONE scan of the next match
   DevBuf<int32_t> d_tbl;     // large lattices: materialised lookup tables [S][nA][N]
   DevBuf<int32_t> d_part;    // large lattices, few scans: per-beam-slice partial numerators [S][slices][resp_stride]
   DevBuf<double> d_big;      // large lattices: reduce scratch
@@ -2426,6 +2452,21 @@ struct BusyGuard {
 
 int n_angles_of(double off, double res) { return lattice_count(off, res); }
 
+// coarse pass geometry (Mapper.cpp:228-240)
+PassCfg coarse_pass_cfg(const lslam_matcher* m, const Geom& g) {
+  const double res = 1.0 / g.scale;  // GetResolution() (Karto.h:4335-4338)
+  PassCfg pc;
+  pc.off_x = pc.off_y = 0.5 * ((double)g.probs_side - 1) * res;
+  pc.res_x = pc.res_y = 2 * res;
+  pc.ang_off = m->cfg.coarse_search_angle_offset;
+  pc.ang_res = m->cfg.coarse_angle_resolution;
+  pc.nx = lattice_count(pc.off_x, pc.res_x);
+  pc.ny = lattice_count(pc.off_y, pc.res_y);
+  pc.na = n_angles_of(pc.ang_off, pc.ang_res);
+  pc.mode = 0;
+  return pc;
+}
+
 template <typename RT>
 int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, const double* d_poses,
                      int do_penalize, int do_refine, lslam_match_result* d_out,
@@ -2440,16 +2481,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     return LSLAM_OK;
   }
   const double res = 1.0 / g.scale;  // GetResolution() (Karto.h:4335-4338)
-  // coarse pass geometry (Mapper.cpp:228-240)
-  PassCfg pc;
-  pc.off_x = pc.off_y = 0.5 * ((double)g.probs_side - 1) * res;
-  pc.res_x = pc.res_y = 2 * res;
-  pc.ang_off = m->cfg.coarse_search_angle_offset;
-  pc.ang_res = m->cfg.coarse_angle_resolution;
-  pc.nx = lattice_count(pc.off_x, pc.res_x);
-  pc.ny = lattice_count(pc.off_y, pc.res_y);
-  pc.na = n_angles_of(pc.ang_off, pc.ang_res);
-  pc.mode = 0;
+  const PassCfg pc = coarse_pass_cfg(m, g);
   // fine pass geometry (:276-281)
   PassCfg pf;
   pf.off_x = pf.off_y = pc.res_x * 0.5;
@@ -2489,8 +2521,12 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
                m->cfg.minimum_distance_penalty, m->cfg.minimum_angle_penalty, do_penalize};
 
   // scan_prep also lays out the coarse lattice of pass 0 (mode 0 needs only the pose): one launch fewer
-  launch(ctx, "scan_prep", k_scan_prep<RT>, dim3(S >= kReduceNarrowMinScans ? 1 : (g.n_beams + 255) / 256, S), dim3(256), 0, d_ranges,
-         stride, d_poses, g, m->d_local.p, (double2*)nullptr, pc, m->d_lat.p, m->d_cossin.p, 2, PoseArg{});
+  if (m->prep_done && S == 1)  // k_rebuild_begin's extra blocks did it (streaming front-end)
+    m->prep_done = false;
+  else
+    launch(ctx, "scan_prep", k_scan_prep<RT>, dim3(S >= kReduceNarrowMinScans ? 1 : (g.n_beams + 255) / 256, S), dim3(256), 0, d_ranges,
+           stride, d_poses, g, m->d_local.p, (double2*)nullptr, pc, m->d_lat.p, m->d_cossin.p, 2, PoseArg{});
+  m->prep_done = false;
   bool setup_done = true;  // consumed by the first pass
 
 
@@ -2746,7 +2782,29 @@ int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, i
     const size_t n16 = ((size_t)g.data_size + 15) / 16;
     RebuildExtras x{};
     if (extras) x = *extras;
-    launch(ctx, "grid_clear", k_rebuild_begin, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (uint4*)m->d_grid, n16, x);
+    unsigned blocks = (unsigned)((n16 + 255) / 256);
+    m->prep_done = false;
+    if (x.prep_ranges && g.n_beams > 0) {
+      const PassCfg pc = coarse_pass_cfg(m, g);
+      if (pc.nx <= kMaxLattice && pc.ny <= kMaxLattice && pc.na <= kMaxAngles && pc.nx >= 1 && pc.na >= 1) {
+        LSLAM_HIP(ctx, m->d_local.reserve((size_t)g.n_beams));
+        LSLAM_HIP(ctx, m->d_lat.reserve(1));
+        LSLAM_HIP(ctx, m->d_cossin.reserve((size_t)kMaxAngles));
+        x.prep_local = m->d_local.p;
+        x.prep_lat = m->d_lat.p;
+        x.prep_cossin = m->d_cossin.p;
+        x.prep_pc = pc;
+        x.prep_g = g;  // with the new grid offset
+        x.clear_blocks = (int)blocks;
+        blocks += (unsigned)((g.n_beams + 255) / 256);
+        m->prep_done = true;
+      } else {
+        x.prep_ranges = nullptr;
+      }
+    } else {
+      x.prep_ranges = nullptr;
+    }
+    launch(ctx, "grid_clear", k_rebuild_begin, dim3(blocks), dim3(256), 0, (uint4*)m->d_grid, n16, x);
     m->resp_prezeroed = x.zero == m->d_resp.p && x.zero ? (size_t)x.zero_words : 0;
   }
   m->sub_dirty = m->occ_dirty = m->tile_dirty = m->ptile_dirty = true;
