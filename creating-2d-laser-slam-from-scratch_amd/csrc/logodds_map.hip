@@ -254,6 +254,43 @@ k_lo_batch_hits(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __res
   atomicMin(&hhit[hb + slot], (uint32_t)i);
 }
 
+// The same marking with the scan's hash built in LDS: one block per scan.  The compare-and-swap that claims a slot
+// returns a value, and a returning device-scope atomic is executed at the memory side -- a microsecond-class round trip
+// per probe; in LDS it is a few dozen cycles.  The finished table is written out with plain stores for k_lo_batch_rays.
+__global__ void __launch_bounds__(1024)
+k_lo_batch_hits_lds(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __restrict__ pts, uint8_t* __restrict__ planes,
+                    uint8_t* __restrict__ flags, uint32_t* __restrict__ hkey, uint32_t* __restrict__ hhit) {
+  extern __shared__ uint32_t sh_hash[];
+  const uint32_t slots = g.hash_mask + 1;
+  uint32_t* key = sh_hash;
+  uint32_t* first = sh_hash + slots;
+  const int sidx = blockIdx.x, tid = threadIdx.x;
+  const ScanHdr h = hdr[sidx];
+  for (uint32_t i = tid; i < 2 * slots; i += 1024) sh_hash[i] = kHashEmpty;
+  __syncthreads();
+  for (int i = tid; i < h.n; i += 1024) {
+    const Line l = batch_line(g, h, pts, i);
+    if (!l.valid) continue;
+    const uint32_t cell = (uint32_t)(l.y1 * g.sx + l.x1);
+    const uint32_t t = tile_of(g, l.x1, l.y1);
+    planes[((size_t)sidx * g.n_tiles + t) * 64 + in_tile(l.x1, l.y1)] = (uint8_t)(g.tag | kCodeHit);
+    flags[(size_t)t * kBatchSlots + sidx] = (uint8_t)(g.tag | 1u);
+    uint32_t slot = hash_slot0(cell, g.hash_mask);
+    for (;;) {
+      const uint32_t old = atomicCAS(&key[slot], kHashEmpty, cell);
+      if (old == kHashEmpty || old == cell) break;
+      slot = (slot + 1) & g.hash_mask;
+    }
+    atomicMin(&first[slot], (uint32_t)i);
+  }
+  __syncthreads();
+  const size_t hb = (size_t)sidx * slots;
+  for (uint32_t i = tid; i < slots; i += 1024) {
+    hkey[hb + i] = key[i];
+    hhit[hb + i] = first[i];
+  }
+}
+
 constexpr int kRayBeamsPerWave = 4;  // consecutive beams one wave walks: fewer, longer waves (dispatch-rate bound otherwise)
 __global__ void __launch_bounds__(256)
 k_lo_batch_rays(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __restrict__ pts, uint8_t* __restrict__ planes,
@@ -935,7 +972,11 @@ int update_batch_impl(lslam_map* map, int K, const float* d_pts, const int32_t* 
       L.batch_epoch = 0;
     }
     L.batch_epoch++;
-    LSLAM_HIP(ctx, hipMemsetAsync(map->d_hash.p, 0xFF, (size_t)3 * K * slots * sizeof(uint32_t), ctx->stream));
+    const bool lds_hash = (size_t)slots * 8 <= 64 * 1024;  // k_lo_batch_hits_lds writes the key and first-hit tables whole
+    if (lds_hash)
+      LSLAM_HIP(ctx, hipMemsetAsync(map->d_hash.p + (size_t)2 * K * slots, 0xFF, (size_t)K * slots * sizeof(uint32_t), ctx->stream));
+    else
+      LSLAM_HIP(ctx, hipMemsetAsync(map->d_hash.p, 0xFF, (size_t)3 * K * slots * sizeof(uint32_t), ctx->stream));
     BatchGeom g;
     g.sx = L.sx; g.sy = L.sy; g.K = K;
     g.tiles_x = L.tiles_x; g.n_tiles = L.n_tiles;
@@ -947,8 +988,12 @@ int update_batch_impl(lslam_map* map, int K, const float* d_pts, const int32_t* 
     uint32_t* hhit = hkey + (size_t)K * slots;
     uint32_t* hcross = hhit + (size_t)K * slots;
     const ScanHdr* d_h = map->d_hdr.p + li * K;
-    launch(ctx, "lo_batch_hits", k_lo_batch_hits, dim3((n_max + 255) / 256, K), dim3(256), 0, g, d_h, d_pts, L.d_planes, L.d_flags,
-           hkey, hhit);
+    if (lds_hash)
+      launch(ctx, "lo_batch_hits", k_lo_batch_hits_lds, dim3(K), dim3(1024), (size_t)slots * 8, g, d_h, d_pts, L.d_planes,
+             L.d_flags, hkey, hhit);
+    else
+      launch(ctx, "lo_batch_hits", k_lo_batch_hits, dim3((n_max + 255) / 256, K), dim3(256), 0, g, d_h, d_pts, L.d_planes,
+             L.d_flags, hkey, hhit);
     const int groups = (n_max + kRayBeamsPerWave - 1) / kRayBeamsPerWave;
     const long long waves = (long long)K * groups;
     launch(ctx, "lo_batch_rays", k_lo_batch_rays, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, g, d_h, d_pts, L.d_planes,
