@@ -2028,7 +2028,7 @@ __device__ __forceinline__ void mark_reachable(int n, int first, int* ja, int* j
 __global__ void __launch_bounds__(1024)
 k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, double vx, double vy,
              uint8_t* __restrict__ valid, int use_lds, int* __restrict__ scratch, Geom g, uint8_t* __restrict__ grid,
-             const int* __restrict__ anchor_ring) {
+             const int* __restrict__ anchor_ring, int mark_value) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int s_first, s_len;
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -2101,9 +2101,10 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
   if (use_lds)
     for (int i = tid; i < n; i += nt) gv[i] = v[i];
   // Fused AddScan stage (the streaming front-end rebuilds the grid once per scan, so a launch and the valid[] round trip
-  // through memory matter): each valid point turns its cell into 100 with a PLAIN byte store -- every writer writes the
-  // same value, and which point got there first does not matter because k_smear_gather finds the centres in the grid
-  // itself.  (Device-scope atomics that report the winner are executed at the memory side: ~40 k of them per rebuild,
+  // through memory matter): each valid point tags its cell in the MARK plane with a PLAIN byte store of this rebuild's
+  // epoch (1..255) -- every writer writes the same value, which point got there first does not matter because
+  // k_smear_gather finds the centres in the plane itself, and neither the plane nor the grid is ever cleared (the gather
+  // writes every grid byte; the plane is reset when the epoch wraps).  (Device-scope atomics that report the winner are executed at the memory side: ~40 k of them per rebuild,
   // most on cells other scans of the window had already set, were two thirds of this kernel's time.)
   if (grid && use_lds) {
     for (int i0 = 0; i0 < n; i0 += nt) {  // whole waves iterate together: the shuffle below needs every lane
@@ -2117,7 +2118,7 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
           idx = (uint32_t)((gx + g.border) + (gy + g.border) * g.stride);
       }
       const uint32_t left = (uint32_t)__shfl_up((int)idx, 1);  // neighbouring beams mostly hit the same cell
-      if (idx != 0xFFFFFFFFu && ((tid & 63) == 0 || left != idx)) grid[idx] = (uint8_t)kOccupied;
+      if (idx != 0xFFFFFFFFu && ((tid & 63) == 0 || left != idx)) grid[idx] = (uint8_t)mark_value;
     }
   }
 }
@@ -2187,45 +2188,50 @@ k_anchor_chain(int n, double2* __restrict__ world, int* __restrict__ row, const 
 // neighbour-row windows live in registers and every byte test is a static shift; HK = 0 is the generic form.
 template <int HK>
 __global__ void __launch_bounds__(256)
-k_smear_gather(Geom g, const uint8_t* __restrict__ kernel, uint8_t* __restrict__ grid, uint8_t* __restrict__ f0,
-               uint8_t* __restrict__ f1) {
+k_smear_gather(Geom g, const uint8_t* __restrict__ kernel, const uint8_t* __restrict__ marks, uint32_t epoch,
+               uint8_t* __restrict__ grid, uint8_t* __restrict__ f0, uint8_t* __restrict__ f1) {
   __shared__ uint8_t s_k[kMaxKernel * kMaxKernel];
   const int tid = threadIdx.x, ks = g.kernel_size, hk = ks / 2;
   for (int i = tid; i < ks * ks; i += 256) s_k[i] = kernel[i];
   __syncthreads();
   const long long f = ((long long)blockIdx.x * 256 + tid) * 16;
   if (f >= g.data_size) return;
+  const uint32_t ep4 = epoch * 0x01010101u;
   uint32_t out[4];
-  {
-    const uint4 q = *(const uint4*)(grid + f);  // 16-byte aligned; may overhang into the zero guard
-    out[0] = q.x; out[1] = q.y; out[2] = q.z; out[3] = q.w;
+  {  // my own bytes: a centre is 100, everything else starts from zero
+    const uint4 q = *(const uint4*)(marks + f);  // 16-byte aligned; may overhang into the guard (never marked)
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t o = 0u;
+#pragma unroll
+      for (int bb = 0; bb < 4; bb++)
+        if (((w[k] >> (8 * bb)) & 0xFFu) == epoch) o |= (uint32_t)kOccupied << (8 * bb);
+      out[k] = o;
+    }
   }
-  bool changed = false;
   auto raise = [&](int o, uint32_t v) {  // out byte o = max(out byte o, v)
     const int sh = 8 * (o & 3);
-    if (((out[o >> 2] >> sh) & 0xFFu) < v) {
-      out[o >> 2] = (out[o >> 2] & ~(0xFFu << sh)) | (v << sh);
-      changed = true;
-    }
+    if (((out[o >> 2] >> sh) & 0xFFu) < v) out[o >> 2] = (out[o >> 2] & ~(0xFFu << sh)) | (v << sh);
   };
   if constexpr (HK > 0) {
     // widthStep is a multiple of 8 and f of 16, so every window starts at the same byte phase
     constexpr int NWIN = 16 + 2 * HK, LEAD = (4 - (HK & 3)) & 3, NW = (LEAD + NWIN + 3) / 4;
     for (int j = -HK; j <= HK; j++) {  // centre row = my row + j  ->  kernel row HK - j
-      const long long w0 = f + (long long)j * g.stride - HK - LEAD;  // aligned; bytes outside [0, dataSize) read as zero
+      const long long w0 = f + (long long)j * g.stride - HK - LEAD;  // aligned; bytes outside [0, dataSize) hold no centre
       uint32_t w[NW], any = 0u;
 #pragma unroll
       for (int k = 0; k < NW; k++) {
         const long long byte = w0 + 4 * k;
-        w[k] = (byte >= 0 && byte < g.data_size) ? *(const uint32_t*)(grid + byte) : 0u;
-        const uint32_t x = w[k] ^ 0x64646464u;  // a byte of 100 becomes 0
+        w[k] = (byte >= 0 && byte < g.data_size) ? *(const uint32_t*)(marks + byte) : 0u;
+        const uint32_t x = w[k] ^ ep4;  // a byte tagged with this epoch becomes 0
         any |= (x - 0x01010101u) & ~x & 0x80808080u;
       }
       if (!any) continue;
       const uint8_t* krow = s_k + (2 * HK + 1) * (HK - j);
 #pragma unroll
       for (int c = 0; c < NWIN; c++) {
-        if (((w[(LEAD + c) >> 2] >> (8 * ((LEAD + c) & 3))) & 0xFFu) != (uint32_t)kOccupied) continue;
+        if (((w[(LEAD + c) >> 2] >> (8 * ((LEAD + c) & 3))) & 0xFFu) != epoch) continue;
         // centre at column offset c - HK relative to my first byte: reaches my bytes o with |o - (c - HK)| <= HK
 #pragma unroll
         for (int o = (c - 2 * HK > 0 ? c - 2 * HK : 0); o <= (c < 15 ? c : 15); o++) raise(o, krow[o - c + 2 * HK]);
@@ -2238,13 +2244,15 @@ k_smear_gather(Geom g, const uint8_t* __restrict__ kernel, uint8_t* __restrict__
       const uint8_t* krow = s_k + ks * (hk - j);
       for (int c = 0; c < nwin; c++) {
         const long long cb = row + c;
-        if (cb < 0 || cb >= g.data_size || grid[cb] != (uint8_t)kOccupied) continue;
+        if (cb < 0 || cb >= g.data_size || (uint32_t)marks[cb] != epoch) continue;
         const int lo = max(0, c - 2 * hk), hi = min(15, c);
         for (int o = lo; o <= hi; o++) raise(o, krow[o - c + 2 * hk]);
       }
     }
   }
-  if (changed) *(uint4*)(grid + f) = make_uint4(out[0], out[1], out[2], out[3]);  // bytes past dataSize stay zero: no centre reaches them
+  // every grid byte is written, so the grid needs no clear; the tail of the last chunk lies in the guard band and gets
+  // its zeros back (no centre reaches past dataSize: the ROI keeps a border)
+  *(uint4*)(grid + f) = make_uint4(out[0], out[1], out[2], out[3]);
   if (f0) {  // bytes b0..b7 -> even: b0 b2 b4 b6, odd: b1 b3 b5 b7 (dataSize is a multiple of 8)
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -2389,6 +2397,9 @@ struct lslam_matcher {
   // device state
   uint8_t* d_grid_alloc = nullptr;  // kGuard + data_size + kGuard
   uint8_t* d_grid = nullptr;        // d_grid_alloc + kGuard
+  uint8_t* d_marks_alloc = nullptr; // mark plane of the atomics-free rebuild (same geometry), allocated on first use
+  uint8_t* d_marks = nullptr;
+  int mark_epoch = 0;               // 1..255: a cell is a centre of THIS rebuild iff its mark byte equals it
   uint8_t* d_kernel = nullptr;
   uint8_t* d_sub_alloc = nullptr;   // two parity planes F_0, F_1, each kGuard + data_size/2 + kGuard
   uint8_t* d_sub[2] = {nullptr, nullptr};
@@ -2778,11 +2789,35 @@ int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, i
   // Mapper.cpp:212-220: offset = scanPose - 0.5*(roi-1)*resolution
   g.off_x = center[0] - (0.5 * (g.roi_w - 1) * (1.0 / g.scale));
   g.off_y = center[1] - (0.5 * (g.roi_h - 1) * (1.0 / g.scale));
-  {  // Grid::Clear (Mapper.cpp:701); rounds up to 16 bytes inside the zero guard band behind the grid
-    const size_t n16 = ((size_t)g.data_size + 15) / 16;
+  const int n = g.n_beams;
+  const size_t lds = (size_t)n * (sizeof(double2) + 14) + 16;  // points, next, two jump tables, valid, reach
+  const int use_lds = lds <= 60 * 1024;
+  // The atomics-free rebuild: k_find_valid tags the centres in a mark plane with this rebuild's epoch and the smear is
+  // a gather that writes EVERY grid byte -- no list, no atomics, and no clear of anything (the plane is reset when the
+  // 8-bit epoch wraps).
+  bool fuse_mark = m->kernel_center_only && use_lds && g.kernel_size <= kMaxKernel && B > 0 && n > 0;
+  if (fuse_mark && !m->d_marks_alloc) {
+    if (hipMalloc((void**)&m->d_marks_alloc, (size_t)g.data_size + 2 * kGuard) != hipSuccess) {
+      (void)hipGetLastError();
+      m->d_marks_alloc = nullptr;
+      fuse_mark = false;
+    } else {
+      m->d_marks = m->d_marks_alloc + kGuard;
+      m->mark_epoch = 0;
+    }
+  }
+  if (fuse_mark && (m->mark_epoch == 0 || m->mark_epoch >= 255)) {
+    LSLAM_HIP(ctx, hipMemsetAsync(m->d_marks_alloc, 0, (size_t)g.data_size + 2 * kGuard, ctx->stream));
+    m->mark_epoch = 0;
+  }
+  if (fuse_mark) m->mark_epoch++;
+  {  // first launch: Grid::Clear (Mapper.cpp:701) unless the gather will write the whole grid, + the front-end's extras
+    const size_t n16 = fuse_mark ? 0 : ((size_t)g.data_size + 15) / 16;  // rounds up inside the zero guard band
     RebuildExtras x{};
     if (extras) x = *extras;
-    unsigned blocks = (unsigned)((n16 + 255) / 256);
+    const size_t threads = std::max<size_t>(std::max<size_t>(n16, 3), std::max<size_t>(x.zero ? (size_t)x.zero_words : 0,
+                                                                                           x.ranges_src ? (size_t)x.n_ranges : 0));
+    unsigned blocks = (unsigned)((threads + 255) / 256);
     m->prep_done = false;
     if (x.prep_ranges && g.n_beams > 0) {
       const PassCfg pc = coarse_pass_cfg(m, g);
@@ -2804,28 +2839,24 @@ int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, i
     } else {
       x.prep_ranges = nullptr;
     }
-    launch(ctx, "grid_clear", k_rebuild_begin, dim3(blocks), dim3(256), 0, (uint4*)m->d_grid, n16, x);
+    if (n16 > 0 || x.pose_dst || x.zero || x.ranges_src || x.prep_ranges)
+      launch(ctx, "grid_clear", k_rebuild_begin, dim3(blocks), dim3(256), 0, (uint4*)m->d_grid, n16, x);
     m->resp_prezeroed = x.zero == m->d_resp.p && x.zero ? (size_t)x.zero_words : 0;
   }
   m->sub_dirty = m->occ_dirty = m->tile_dirty = m->ptile_dirty = true;
-  const int n = g.n_beams;
   if (B <= 0 || n <= 0) return LSLAM_OK;
   LSLAM_HIP(ctx, m->d_valid.reserve((size_t)B * n));
-  const size_t lds = (size_t)n * (sizeof(double2) + 14) + 16;  // points, next, two jump tables, valid, reach
-  const int use_lds = lds <= 60 * 1024;
   if (!use_lds) LSLAM_HIP(ctx, m->d_fv_scratch.reserve((size_t)B * 2 * n));
-  // find_valid marks the centres itself and the smear is a gather: no list, no atomics, two launches fewer
-  const bool fuse_mark = m->kernel_center_only && use_lds && g.kernel_size <= kMaxKernel;
   if (m->kernel_center_only && !fuse_mark) {
     LSLAM_HIP(ctx, m->d_centres.reserve((size_t)B * n + 1));
     LSLAM_HIP(ctx, hipMemsetAsync(m->d_centres.p, 0, sizeof(uint32_t), ctx->stream));
   }
   launch(ctx, "find_valid", k_find_valid, dim3(B), dim3(n > 512 ? 1024 : 256), use_lds ? lds : 0, n, d_world, ring_start, cap,
-         center[0], center[1], m->d_valid.p, use_lds, m->d_fv_scratch.p, g, fuse_mark ? m->d_grid : (uint8_t*)nullptr,
-         extras ? extras->anchor_ring : (const int*)nullptr);
+         center[0], center[1], m->d_valid.p, use_lds, m->d_fv_scratch.p, g, fuse_mark ? m->d_marks : (uint8_t*)nullptr,
+         extras ? extras->anchor_ring : (const int*)nullptr, m->mark_epoch);
   if (fuse_mark) {
     const dim3 sg((unsigned)(((size_t)g.data_size + 4095) / 4096));
-#define LSLAM_SMEAR(HK) launch(ctx, "smear", k_smear_gather<HK>, sg, dim3(256), 0, g, (const uint8_t*)m->d_kernel, m->d_grid, m->d_sub[0], m->d_sub[1])
+#define LSLAM_SMEAR(HK) launch(ctx, "smear", k_smear_gather<HK>, sg, dim3(256), 0, g, (const uint8_t*)m->d_kernel, (const uint8_t*)m->d_marks, (uint32_t)m->mark_epoch, m->d_grid, m->d_sub[0], m->d_sub[1])
     switch (g.kernel_size / 2) {
       case 1: LSLAM_SMEAR(1); break;
       case 2: LSLAM_SMEAR(2); break;
@@ -3014,6 +3045,7 @@ void lslam_matcher_destroy(lslam_matcher* m) {
   (void)hipSetDevice(m->ctx->device);
   (void)hipStreamSynchronize(m->ctx->stream);
   (void)hipFree(m->d_grid_alloc);
+  if (m->d_marks_alloc) (void)hipFree(m->d_marks_alloc);
   (void)hipFree(m->d_kernel);
   (void)hipFree(m->d_sub_alloc);
   (void)hipFree(m->d_occ_t);
@@ -3250,7 +3282,7 @@ int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges, const
     if (!use_lds) LSLAM_HIP(ctx, m->d_fv_scratch.reserve((size_t)2 * g.n_beams));
     launch(ctx, "find_valid", k_find_valid, dim3(1), dim3(g.n_beams > 512 ? 1024 : 256), use_lds ? lds : 0, g.n_beams,
            (const double2*)m->d_world.p, 0, 1, viewpoint[0], viewpoint[1], m->d_valid.p, use_lds, m->d_fv_scratch.p, g,
-           (uint8_t*)nullptr, (const int*)nullptr);
+           (uint8_t*)nullptr, (const int*)nullptr, 0);
   }
   LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_valid.p, (size_t)g.n_beams, hipMemcpyDeviceToHost, ctx->stream));
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
