@@ -106,7 +106,8 @@ __device__ __forceinline__ void scan_prep_block(const RT* __restrict__ ranges, i
                                                 const Geom& g, double2* __restrict__ local, double2* __restrict__ world,
                                                 const PassCfg& setup_pc, Lattice* setup_lat, double2* setup_cossin,
                                                 int setup_step, int bx, int nbx, int s) {
-  int b = bx * 256 + threadIdx.x;
+  const int nt = (int)blockDim.x;  // 256 (k_scan_prep) or 1024 (riding in k_find_valid's launch)
+  int b = bx * nt + threadIdx.x;
   // the scan's own transform (two rotation matrices, one normalised heading) is the same for all of
   // its beams: one thread of the block evaluates it
   __shared__ SensorXform s_t;
@@ -118,9 +119,9 @@ __device__ __forceinline__ void scan_prep_block(const RT* __restrict__ ranges, i
   }
   // Meanwhile the LAST wave of the scan's first block lays out the coarse search lattice (k_pass_setup, mode 0), and
   // every thread evaluates its first world point: neither needs the transform thread 0 is working on.
-  if (setup_lat && bx == 0 && threadIdx.x >= 192) {
+  if (setup_lat && bx == 0 && (int)threadIdx.x >= nt - 64) {
     const double center[3] = {sx, sy, sh};
-    pass_setup_wave(s, threadIdx.x - 192, g, setup_pc, center, 1, setup_lat, setup_cossin, setup_step);
+    pass_setup_wave(s, (int)threadIdx.x - (nt - 64), g, setup_pc, center, 1, setup_lat, setup_cossin, setup_step);
   }
   double r = 0.0, px = 0.0, py = 0.0;
   if (b < g.n_beams) {
@@ -130,7 +131,7 @@ __device__ __forceinline__ void scan_prep_block(const RT* __restrict__ ranges, i
   __syncthreads();
   // nbx blocks share the beams of a scan: ONE for chip-filling batches (the single-thread transform above is
   // then paid once per scan, not once per 256 beams -- it was most of this kernel's time), ceil(n/256) otherwise
-  for (bool first = true; b < g.n_beams; b += nbx * 256, first = false) {
+  for (bool first = true; b < g.n_beams; b += nbx * nt, first = false) {
     if (!first) {
       r = (double)ranges[(size_t)s * stride + b];
       beam_world_point(sx, sy, sh, g.min_angle, g.ang_res, (uint32_t)b, r, px, py);
@@ -2028,10 +2029,27 @@ __device__ __forceinline__ void mark_reachable(int n, int first, int* ja, int* j
 __global__ void __launch_bounds__(1024)
 k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, double vx, double vy,
              uint8_t* __restrict__ valid, int use_lds, int* __restrict__ scratch, Geom g, uint8_t* __restrict__ grid,
-             const int* __restrict__ anchor_ring, int mark_value) {
+             const int* __restrict__ anchor_ring, int mark_value, int n_scans, RebuildExtras x) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int s_first, s_len;
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  if (b >= n_scans) {
+    // Extra blocks behind the base scans (streaming front-end, clear-free rebuild): the jobs of k_rebuild_begin that
+    // nothing in this launch depends on -- the query scan's prep, its pose and readings into device memory, zeros over
+    // the next match's sliced numerators -- so the rebuild needs no launch of its own for them.
+    const int e = b - n_scans, prep_blocks = x.prep_ranges ? (x.prep_g.n_beams + nt - 1) / nt : 0;
+    if (e < prep_blocks) {
+      scan_prep_block(x.prep_ranges, x.prep_g.n_beams, x.pose[0], x.pose[1], x.pose[2], x.prep_g, x.prep_local,
+                      (double2*)nullptr, x.prep_pc, x.prep_lat, x.prep_cossin, 2, e, prep_blocks, 0);
+    } else {
+      if (x.zero)
+        for (int i = tid; i < x.zero_words; i += nt) x.zero[i] = 0;
+      if (x.ranges_src)
+        for (int i = tid; i < x.n_ranges; i += nt) x.ranges_dst[i] = x.ranges_src[i];
+      if (x.pose_dst && tid < 3) x.pose_dst[tid] = x.pose[tid];
+    }
+    return;
+  }
   const double2* gp = world + (size_t)((ring_start + b) % cap) * n;
   uint8_t* gv = valid + (size_t)b * n;
   const double2* p = gp;
@@ -2811,38 +2829,40 @@ int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, i
     m->mark_epoch = 0;
   }
   if (fuse_mark) m->mark_epoch++;
-  {  // first launch: Grid::Clear (Mapper.cpp:701) unless the gather will write the whole grid, + the front-end's extras
-    const size_t n16 = fuse_mark ? 0 : ((size_t)g.data_size + 15) / 16;  // rounds up inside the zero guard band
-    RebuildExtras x{};
-    if (extras) x = *extras;
-    const size_t threads = std::max<size_t>(std::max<size_t>(n16, 3), std::max<size_t>(x.zero ? (size_t)x.zero_words : 0,
-                                                                                           x.ranges_src ? (size_t)x.n_ranges : 0));
-    unsigned blocks = (unsigned)((threads + 255) / 256);
-    m->prep_done = false;
-    if (x.prep_ranges && g.n_beams > 0) {
-      const PassCfg pc = coarse_pass_cfg(m, g);
-      if (pc.nx <= kMaxLattice && pc.ny <= kMaxLattice && pc.na <= kMaxAngles && pc.nx >= 1 && pc.na >= 1) {
-        LSLAM_HIP(ctx, m->d_local.reserve((size_t)g.n_beams));
-        LSLAM_HIP(ctx, m->d_lat.reserve(1));
-        LSLAM_HIP(ctx, m->d_cossin.reserve((size_t)kMaxAngles));
-        x.prep_local = m->d_local.p;
-        x.prep_lat = m->d_lat.p;
-        x.prep_cossin = m->d_cossin.p;
-        x.prep_pc = pc;
-        x.prep_g = g;  // with the new grid offset
-        x.clear_blocks = (int)blocks;
-        blocks += (unsigned)((g.n_beams + 255) / 256);
-        m->prep_done = true;
-      } else {
-        x.prep_ranges = nullptr;
-      }
+  // The front-end's extras (query pose, readings, zeros, the query scan's prep) ride in k_find_valid's launch when the
+  // rebuild is clear-free; otherwise a first launch clears the grid (Grid::Clear, Mapper.cpp:701) and carries them.
+  RebuildExtras x{};
+  if (extras) x = *extras;
+  m->prep_done = false;
+  if (x.prep_ranges && g.n_beams > 0) {
+    const PassCfg pc = coarse_pass_cfg(m, g);
+    if (pc.nx <= kMaxLattice && pc.ny <= kMaxLattice && pc.na <= kMaxAngles && pc.nx >= 1 && pc.na >= 1) {
+      LSLAM_HIP(ctx, m->d_local.reserve((size_t)g.n_beams));
+      LSLAM_HIP(ctx, m->d_lat.reserve(1));
+      LSLAM_HIP(ctx, m->d_cossin.reserve((size_t)kMaxAngles));
+      x.prep_local = m->d_local.p;
+      x.prep_lat = m->d_lat.p;
+      x.prep_cossin = m->d_cossin.p;
+      x.prep_pc = pc;
+      x.prep_g = g;  // with the new grid offset
+      m->prep_done = true;
     } else {
       x.prep_ranges = nullptr;
     }
-    if (n16 > 0 || x.pose_dst || x.zero || x.ranges_src || x.prep_ranges)
-      launch(ctx, "grid_clear", k_rebuild_begin, dim3(blocks), dim3(256), 0, (uint4*)m->d_grid, n16, x);
-    m->resp_prezeroed = x.zero == m->d_resp.p && x.zero ? (size_t)x.zero_words : 0;
+  } else {
+    x.prep_ranges = nullptr;
   }
+  const bool have_extras = x.pose_dst || x.zero || x.ranges_src || x.prep_ranges;
+  if (!fuse_mark) {
+    const size_t n16 = ((size_t)g.data_size + 15) / 16;  // rounds up inside the zero guard band behind the grid
+    const size_t threads = std::max<size_t>(n16, std::max<size_t>(x.zero ? (size_t)x.zero_words : 0,
+                                                                  x.ranges_src ? (size_t)x.n_ranges : 0));
+    unsigned blocks = (unsigned)((threads + 255) / 256);
+    x.clear_blocks = (int)blocks;
+    if (x.prep_ranges) blocks += (unsigned)((g.n_beams + 255) / 256);
+    launch(ctx, "grid_clear", k_rebuild_begin, dim3(blocks), dim3(256), 0, (uint4*)m->d_grid, n16, x);
+  }
+  m->resp_prezeroed = x.zero == m->d_resp.p && x.zero ? (size_t)x.zero_words : 0;
   m->sub_dirty = m->occ_dirty = m->tile_dirty = m->ptile_dirty = true;
   if (B <= 0 || n <= 0) return LSLAM_OK;
   LSLAM_HIP(ctx, m->d_valid.reserve((size_t)B * n));
@@ -2851,9 +2871,11 @@ int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, i
     LSLAM_HIP(ctx, m->d_centres.reserve((size_t)B * n + 1));
     LSLAM_HIP(ctx, hipMemsetAsync(m->d_centres.p, 0, sizeof(uint32_t), ctx->stream));
   }
-  launch(ctx, "find_valid", k_find_valid, dim3(B), dim3(n > 512 ? 1024 : 256), use_lds ? lds : 0, n, d_world, ring_start, cap,
-         center[0], center[1], m->d_valid.p, use_lds, m->d_fv_scratch.p, g, fuse_mark ? m->d_marks : (uint8_t*)nullptr,
-         extras ? extras->anchor_ring : (const int*)nullptr, m->mark_epoch);
+  const int fv_threads = n > 512 ? 1024 : 256;
+  const int extra_blocks = (fuse_mark && have_extras) ? (x.prep_ranges ? (n + fv_threads - 1) / fv_threads : 0) + 1 : 0;
+  launch(ctx, "find_valid", k_find_valid, dim3(B + extra_blocks), dim3(fv_threads), use_lds ? lds : 0, n, d_world, ring_start,
+         cap, center[0], center[1], m->d_valid.p, use_lds, m->d_fv_scratch.p, g, fuse_mark ? m->d_marks : (uint8_t*)nullptr,
+         extras ? extras->anchor_ring : (const int*)nullptr, m->mark_epoch, B, x);
   if (fuse_mark) {
     const dim3 sg((unsigned)(((size_t)g.data_size + 4095) / 4096));
 #define LSLAM_SMEAR(HK) launch(ctx, "smear", k_smear_gather<HK>, sg, dim3(256), 0, g, (const uint8_t*)m->d_kernel, (const uint8_t*)m->d_marks, (uint32_t)m->mark_epoch, m->d_grid, m->d_sub[0], m->d_sub[1])
@@ -3282,7 +3304,7 @@ int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges, const
     if (!use_lds) LSLAM_HIP(ctx, m->d_fv_scratch.reserve((size_t)2 * g.n_beams));
     launch(ctx, "find_valid", k_find_valid, dim3(1), dim3(g.n_beams > 512 ? 1024 : 256), use_lds ? lds : 0, g.n_beams,
            (const double2*)m->d_world.p, 0, 1, viewpoint[0], viewpoint[1], m->d_valid.p, use_lds, m->d_fv_scratch.p, g,
-           (uint8_t*)nullptr, (const int*)nullptr, 0);
+           (uint8_t*)nullptr, (const int*)nullptr, 0, 1, RebuildExtras{});
   }
   LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_valid.p, (size_t)g.n_beams, hipMemcpyDeviceToHost, ctx->stream));
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
