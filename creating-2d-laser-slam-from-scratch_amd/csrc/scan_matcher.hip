@@ -1348,6 +1348,9 @@ k_table_big(int S, Geom g, PassCfg pc, const Lattice* __restrict__ lat, const do
 }
 
 constexpr int kDenseT = 4;  // row slots per lane
+// T = row slots per lane: 4 for batches (fewer table reads per candidate), 1 for a lone match (4x the waves: the kernel is
+// a chain of dependent loads at 3 waves per CU otherwise)
+template <int T>
 __global__ void __launch_bounds__(64)
 k_resp_dense(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int limit, Geom g, PassCfg pc,
              const Lattice* __restrict__ lat, const int32_t* __restrict__ tbl, int32_t* __restrict__ resp,
@@ -1364,40 +1367,46 @@ k_resp_dense(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1,
   const int rpw = 64 / lpr;           // lattice rows per wave-wide load
   const int r = lane / lpr, k = lane % lpr;
   const bool lane_on = r < rpw;
-  const int j_base = tile * rpw * kDenseT;
+  const int j_base = tile * rpw * T;
   const long long pos00 = (long long)L.gx[0] + (long long)L.gy[0] * g.stride;
   const int32_t* trow = tbl + ((size_t)s * pc.na + a) * g.n_beams;
   const int per = (g.n_beams + beam_slices - 1) / beam_slices;
   const int b_lo = slice * per, b_hi = min(g.n_beams, b_lo + per);
 
-  uint32_t acc[kDenseT][16];
+  uint32_t acc[T][16];
 #pragma unroll
-  for (int t = 0; t < kDenseT; t++)
+  for (int t = 0; t < T; t++)
 #pragma unroll
     for (int c = 0; c < 16; c++) acc[t][c] = 0u;
 
   for (int b0 = b_lo; b0 < b_hi; b0 += 256) {
-    uint32_t pe[kDenseT][4], po[kDenseT][4];
+    uint32_t pe[T][4], po[T][4];
 #pragma unroll
-    for (int t = 0; t < kDenseT; t++)
+    for (int t = 0; t < T; t++)
 #pragma unroll
       for (int q = 0; q < 4; q++) pe[t][q] = po[t][q] = 0u;
     const int b1 = min(b_hi, b0 + 256);
-    // kGroup beams per iteration: their table entries (wave-uniform) and all kGroup * kDenseT row loads are issued before the
+    // kGroup beams per iteration: their table entries (wave-uniform) and all kGroup * T row loads are issued before the
     // first byte is used -- one beam per iteration was a chain of dependent loads (135 round trips for a single match)
     constexpr int kGroup = 4;
+    int32_t tv_next[kGroup];
+#pragma unroll
+    for (int u = 0; u < kGroup; u++) tv_next[u] = b0 + u < b1 ? trow[b0 + u] : kInvalidScan;
     for (int b = b0; b < b1; b += kGroup) {
       int32_t tv[kGroup];
 #pragma unroll
-      for (int u = 0; u < kGroup; u++) tv[u] = b + u < b1 ? trow[b + u] : kInvalidScan;
-      uint4 d[kGroup][kDenseT];
+      for (int u = 0; u < kGroup; u++) tv[u] = tv_next[u];
+      // the next group's table entries are requested before this group's rows: one round trip per iteration, not two
+#pragma unroll
+      for (int u = 0; u < kGroup; u++) tv_next[u] = b + kGroup + u < b1 ? trow[b + kGroup + u] : kInvalidScan;
+      uint4 d[kGroup][T];
 #pragma unroll
       for (int u = 0; u < kGroup; u++) {
         const long long base = pos00 + tv[u];
         const uint8_t* src = (base & 1) ? src1 : src0;
         const long long m0 = (base >> 1) + 16 * k;
 #pragma unroll
-        for (int t = 0; t < kDenseT; t++) {
+        for (int t = 0; t < T; t++) {
           const int j = j_base + t * rpw + r;
           const long long m = m0 + (long long)j * g.stride;
           d[u][t] = make_uint4(0u, 0u, 0u, 0u);
@@ -1408,7 +1417,7 @@ k_resp_dense(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1,
 #pragma unroll
       for (int u = 0; u < kGroup; u++)
 #pragma unroll
-        for (int t = 0; t < kDenseT; t++) {
+        for (int t = 0; t < T; t++) {
           const uint32_t dw[4] = {d[u][t].x, d[u][t].y, d[u][t].z, d[u][t].w};
 #pragma unroll
           for (int q = 0; q < 4; q++) {
@@ -1418,7 +1427,7 @@ k_resp_dense(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1,
         }
     }
 #pragma unroll
-    for (int t = 0; t < kDenseT; t++)
+    for (int t = 0; t < T; t++)
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         acc[t][4 * q + 0] += pe[t][q] & 0xFFFFu;
@@ -1430,7 +1439,7 @@ k_resp_dense(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1,
   if (!lane_on) return;
   const int ncand = pc.nx * pc.ny;
 #pragma unroll
-  for (int t = 0; t < kDenseT; t++) {
+  for (int t = 0; t < T; t++) {
     const int j = j_base + t * rpw + r;
     if (j >= pc.ny) continue;
 #pragma unroll
@@ -2703,7 +2712,9 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     launch(ctx, "table_big", k_table_big, dim3((g.n_beams + 255) / 256, p.na, S), dim3(256), 0, S, g, p,
            (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_tbl.p);
     const int lpr = (p.nx + 15) / 16, rpw = 64 / lpr;
-    const int n_tiles = (p.ny + rpw * kDenseT - 1) / (rpw * kDenseT);
+    const bool lone = (long long)S * p.na * ((p.ny + rpw * kDenseT - 1) / (rpw * kDenseT)) * 8 < 4096;  // few waves even with 8 slices
+    const int dense_t = lone ? 1 : kDenseT;
+    const int n_tiles = (p.ny + rpw * dense_t - 1) / (rpw * dense_t);
     // few scans: split the beams of one (scan, angle, tile) over up to 8 waves; every slice writes its own partial sums
     // (plain stores) and k_big_latmax adds them up -- exact (integers), no atomics.  Measured for ONE 101x101x21 match:
     // 4 / 8 / 16 slices -> dense pass 0.102 / 0.065 / 0.057 ms, summing pass 0.018 / 0.018 / 0.095 ms: 8 it is.
@@ -2711,9 +2722,14 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     constexpr int max_slices = 8;  // = kMaxSlices of k_big_latmax
     while (slices < max_slices && (long long)S * p.na * n_tiles * slices < 1024) slices *= 2;
     if (slices > 1) LSLAM_HIP(ctx, m->d_part.reserve((size_t)S * slices * resp_stride));
-    launch(ctx, "resp_dense", k_resp_dense, dim3((unsigned)((long long)S * p.na * n_tiles * slices)), dim3(64), 0,
-           (const uint8_t*)m->d_sub[0], (const uint8_t*)m->d_sub[1], g.data_size / 2, g, p, (const Lattice*)m->d_lat.p,
-           (const int32_t*)m->d_tbl.p, slices > 1 ? m->d_part.p : m->d_resp.p, resp_stride, n_tiles, slices);
+    if (lone)
+      launch(ctx, "resp_dense", k_resp_dense<1>, dim3((unsigned)((long long)S * p.na * n_tiles * slices)), dim3(64), 0,
+             (const uint8_t*)m->d_sub[0], (const uint8_t*)m->d_sub[1], g.data_size / 2, g, p, (const Lattice*)m->d_lat.p,
+             (const int32_t*)m->d_tbl.p, slices > 1 ? m->d_part.p : m->d_resp.p, resp_stride, n_tiles, slices);
+    else
+      launch(ctx, "resp_dense", k_resp_dense<kDenseT>, dim3((unsigned)((long long)S * p.na * n_tiles * slices)), dim3(64), 0,
+             (const uint8_t*)m->d_sub[0], (const uint8_t*)m->d_sub[1], g.data_size / 2, g, p, (const Lattice*)m->d_lat.p,
+             (const int32_t*)m->d_tbl.p, slices > 1 ? m->d_part.p : m->d_resp.p, resp_stride, n_tiles, slices);
     const size_t ncand = (size_t)p.nx * p.ny, total = ncand * p.na;
     const size_t stride = ncand + (size_t)g.probs_side * g.probs_side + 4 * ncand + (total + 63) / 64 + 8;  // doubles
     LSLAM_HIP(ctx, m->d_big.reserve((size_t)S * stride + S + 1));

@@ -20,6 +20,7 @@ from lslam_amd import api, synth  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scans", type=int, default=600)
+    ap.add_argument("--loop", action="store_true", help="pose graph with loop closing on (cfg 5's settings)")
     args = ap.parse_args()
     import bench
     laser = synth.Laser()
@@ -30,7 +31,12 @@ def main():
     r64 = [synth.ranges_to_f64(r) for r in scans32]
     ctx = api.Context(0)
     gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
-    fe = api.FrontEnd(gm)  # defaults: graph bookkeeping on, loop closing off
+    if args.loop:
+        fe = api.FrontEnd(gm, config=api.frontend_config(scan_buffer_size=70, scan_buffer_maximum_scan_distance=20.0, do_loop_closing=1,
+                                                         link_scan_maximum_distance=1.5, loop_search_maximum_distance=3.0,
+                                                         loop_match_minimum_chain_size=10))
+    else:
+        fe = api.FrontEnd(gm)  # defaults: graph bookkeeping on, loop closing off
     for r, o in zip(r64[:80], odom[:80]):
         fe.Process(r, o)
     fe.reset()
@@ -52,6 +58,8 @@ def main():
            "kernel_us_per_scan": {k: round(1e3 * v[1] / n, 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
            "launches_per_scan": round(sum(v[0] for v in prof.values()) / n, 1)}
     out["kernel_us_total"] = round(sum(out["kernel_us_per_scan"].values()), 1)
+    out["launches"] = {k: v[0] for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+    out["graph"] = fe.stats()
     print(json.dumps(out))
 
 
