@@ -12,8 +12,15 @@ from lslam_amd import api, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2])
-def test_random_world_batches_vs_reference(ctx, oracle_lib, seed):
+import os
+
+# (seed, batch): 256 = the wide-block reduce kernels, 2304 = the chip-filling variants (128 / 64-thread reduce blocks,
+# one scan_prep block per scan).  LSLAM_SOAK_SEEDS="10,11,12" adds 2304-scan batches for those seeds (ad-hoc soak).
+_CASES = [(0, 256), (1, 256), (2, 256), (3, 2304)] + [(int(x), 2304) for x in os.environ.get("LSLAM_SOAK_SEEDS", "").split(",") if x]
+
+
+@pytest.mark.parametrize("seed,B", _CASES)
+def test_random_world_batches_vs_reference(ctx, oracle_lib, seed, B):
     po = oracle_lib
     rng = np.random.default_rng(100 + seed)
     laser = synth.Laser()
@@ -23,7 +30,6 @@ def test_random_world_batches_vs_reference(ctx, oracle_lib, seed):
                                    world=world, query_spread=rng.uniform(0.5, 4.0))
     gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
     gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
-    B = 256
     idx = np.arange(B) % 32
     poses = synth.perturb(wl.truth_poses[idx], rng.uniform(0.05, 0.45), math.radians(rng.uniform(2, 18)), 400 + seed)
     ranges = wl.query_ranges[idx].copy()
