@@ -1481,7 +1481,13 @@ k_big_latmax(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ lat, 
     s_ap[a] = ap > sc.min_ap ? ap : sc.min_ap;
   }
   __syncthreads();
-  const int c = blockIdx.x * 256 + tid;
+  // 64 lattice cells x 4 groups of angles per block: a thread's loads (its angles x the beam slices) are ONE batch in
+  // flight, and a lone 101x101 match spreads over 160 blocks instead of 40 (it was a chain of three dependent batches
+  // per thread on a sixth of the chip)
+  __shared__ double s_m[4][64];
+  const int cl = tid & 63, grp = tid >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int a_per = (pc.na + 3) / 4, a_lo = grp * a_per, a_hi = min(pc.na, a_lo + a_per);
   double m = -1.0;
   if (c < ncand) {
     int32_t* r = resp + (size_t)s * resp_stride;
@@ -1496,7 +1502,7 @@ k_big_latmax(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ lat, 
       dp = dp > sc.min_dp ? dp : sc.min_dp;
     }
     constexpr int kBatch = 8, kMaxSlices = 8;
-    for (int a0 = 0; a0 < pc.na; a0 += kBatch) {
+    for (int a0 = a_lo; a0 < a_hi; a0 += kBatch) {
       int32_t rv[kBatch];
       if (slices > 1) {  // add up the beam slices of k_resp_dense (exact: integers) and publish the sums as the numerators;
         int32_t pv[kBatch][kMaxSlices];  // all loads of the batch are issued before the first add
@@ -1504,28 +1510,35 @@ k_big_latmax(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ lat, 
         for (int i = 0; i < kBatch; i++)
 #pragma unroll
           for (int q = 0; q < kMaxSlices; q++)
-            pv[i][q] = (a0 + i < pc.na && q < slices) ? ps[(size_t)q * resp_stride + (size_t)(a0 + i) * ncand + c] : 0;
+            pv[i][q] = (a0 + i < a_hi && q < slices) ? ps[(size_t)q * resp_stride + (size_t)(a0 + i) * ncand + c] : 0;
 #pragma unroll
         for (int i = 0; i < kBatch; i++) {
           int32_t sum = 0;
 #pragma unroll
           for (int q = 0; q < kMaxSlices; q++) sum += pv[i][q];
           rv[i] = sum;
-          if (a0 + i < pc.na) r[(size_t)(a0 + i) * ncand + c] = sum;
+          if (a0 + i < a_hi) r[(size_t)(a0 + i) * ncand + c] = sum;
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < kBatch; i++) rv[i] = a0 + i < pc.na ? r[(a0 + i) * ncand + c] : 0;
+        for (int i = 0; i < kBatch; i++) rv[i] = a0 + i < a_hi ? r[(a0 + i) * ncand + c] : 0;
       }
 #pragma unroll
       for (int i = 0; i < kBatch; i++)
-        if (a0 + i < pc.na) {
+        if (a0 + i < a_hi) {
           double v = (double)rv[i] / denom;  // GetResponse normalisation (:852)
           if (sc.do_penalize && !double_equal(v, 0.0)) v *= (dp * s_ap[a0 + i]);
           m = m > v ? m : v;
         }
     }
-    scratch[(size_t)s * scratch_stride + c] = m;
+  }
+  s_m[grp][cl] = m;
+  __syncthreads();
+  if (grp == 0 && c < ncand) {
+    double mm = m;
+#pragma unroll
+    for (int q = 1; q < 4; q++) mm = mm > s_m[q][cl] ? mm : s_m[q][cl];
+    scratch[(size_t)s * scratch_stride + c] = mm;
   }
   const double bm = block_max(m, sh, tid, 256);
   if (tid == 0 && bm >= 0.0) atomicMax(&best_bits[s], (unsigned long long)__double_as_longlong(bm));
@@ -2737,7 +2750,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     // order-dependent parts.  best_bits lives behind the scratch of the last scan.
     unsigned long long* best_bits = (unsigned long long*)(m->d_big.p + (size_t)S * stride);
     LSLAM_HIP(ctx, hipMemsetAsync(best_bits, 0, (size_t)S * sizeof(unsigned long long), ctx->stream));
-    launch(ctx, "big_latmax", k_big_latmax, dim3((unsigned)((ncand + 255) / 256), S), dim3(256), 0, g, p, sc,
+    launch(ctx, "big_latmax", k_big_latmax, dim3((unsigned)((ncand + 63) / 64), S), dim3(256), 0, g, p, sc,
            (const Lattice*)m->d_lat.p, m->d_resp.p, resp_stride, m->d_big.p, stride, best_bits, fb_step,
            (const int32_t*)m->d_part.p, slices);
     if (S <= 16)
