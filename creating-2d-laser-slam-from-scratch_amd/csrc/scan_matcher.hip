@@ -1557,7 +1557,10 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
   __shared__ double sh[NT];
   __shared__ double chunk[4 * NT];
   __shared__ int s_list[kList];
-  __shared__ int s_nlist, s_status;
+  __shared__ int s_nlist, s_status, s_ncell, s_npass;
+  __shared__ int s_cells[kList];
+  __shared__ unsigned long long s_bal2[16][NT / 64];  // covariance pass: ballots of up to 16 chunks of NT cells
+  __shared__ int s_pref[16][NT / 64];
   __shared__ double s_avg[3];
   __shared__ unsigned long long s_bal[NT / 64];
   const int s = blockIdx.x, tid = threadIdx.x;
@@ -1630,19 +1633,37 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
   const bool injective = pc.res_x * g.scale >= 1.5 && pc.res_y * g.scale >= 1.5;
   if (!injective)
     for (int c = tid; c < side2; c += NT) probs[c] = 0ull;  // Clear (:329) (+0.0)
-  if (tid == 0) { s_nlist = 0; s_status = 0; }
+  if (tid == 0) { s_nlist = 0; s_status = 0; s_ncell = 0; s_npass = -1; }
   double best = block_max(lm, sh, tid, NT);
   if (have_latmax) best = __longlong_as_double((long long)best_bits[s]);  // >= +0: the unsigned order of the bits is the fp order
   // ties with the best response (:452-455), as candidate indices k = c * nA + a in an LDS list; only when more than
   // kList candidates tie (an all-zero response surface) the bitmap in global memory takes over
-  for (int c = tid; c < ncand; c += NT) {
-    if (latmax[c] + kTol < best) continue;  // no angle of this cell can tie
-    const double dp = sc.do_penalize ? cell_dp(c) : 1.0;
-    for (int a = 0; a < pc.na; a++)
-      if (double_equal(value_of(r[a * ncand + c], dp, a), best)) {
+  // the few cells whose maximum reaches the best are listed first, then all threads share their (cell, angle) pairs:
+  // one load each -- the thread that owns the best cell alone was a chain of nA dependent round trips
+  for (int c = tid; c < ncand; c += NT)
+    if (!(latmax[c] + kTol < best)) {
+      const int pos = atomicAdd(&s_ncell, 1);
+      if (pos < kList) s_cells[pos] = c;
+    }
+  __syncthreads();
+  if (s_ncell <= kList) {
+    for (int idx = tid, n = s_ncell * pc.na; idx < n; idx += NT) {
+      const int c = s_cells[idx / pc.na], a = idx % pc.na;
+      if (double_equal(value_of(r[a * ncand + c], sc.do_penalize ? cell_dp(c) : 1.0, a), best)) {
         const int pos = atomicAdd(&s_nlist, 1);
         if (pos < kList) s_list[pos] = c * pc.na + a;
       }
+    }
+  } else {  // an all-zero surface: every cell
+    for (int c = tid; c < ncand; c += NT) {
+      if (latmax[c] + kTol < best) continue;
+      const double dp = sc.do_penalize ? cell_dp(c) : 1.0;
+      for (int a = 0; a < pc.na; a++)
+        if (double_equal(value_of(r[a * ncand + c], dp, a), best)) {
+          const int pos = atomicAdd(&s_nlist, 1);
+          if (pos < kList) s_list[pos] = c * pc.na + a;
+        }
+    }
   }
   __syncthreads();
   const bool listed = s_nlist <= kList;
@@ -1669,11 +1690,16 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
     const int gx = world_to_grid(wx, p_off_x, g.scale), gy = world_to_grid(wy, p_off_y, g.scale);
     return (gx < 0 || gx >= g.probs_side || gy < 0 || gy >= g.probs_side) ? -1 : gy * g.probs_side + gx;
   };
-  for (int c = tid; c < ncand; c += NT) {
-    const int cell = probs_cell(c);
-    if (cell < 0) s_status = LSLAM_ERR_PROBABILITY_SEARCH;
-    else if (!injective)  // max-merge is order independent -> parallel integer max
-      atomicMax(&probs[cell], (unsigned long long)__double_as_longlong(latmax[c] > 0.0 ? latmax[c] : 0.0));
+  if (injective) {
+    // world_to_grid is monotone in each coordinate: the lattice leaves the search space iff one of two opposite corners does
+    if (tid == 0 && (probs_cell(0) < 0 || probs_cell(ncand - 1) < 0)) s_status = LSLAM_ERR_PROBABILITY_SEARCH;
+  } else {
+    for (int c = tid; c < ncand; c += NT) {
+      const int cell = probs_cell(c);
+      if (cell < 0) s_status = LSLAM_ERR_PROBABILITY_SEARCH;
+      else  // max-merge is order independent -> parallel integer max
+        atomicMax(&probs[cell], (unsigned long long)__double_as_longlong(latmax[c] > 0.0 ? latmax[c] : 0.0));
+    }
   }
   // mask / probs were updated with device-scope atomics: agent-scope fence so the plain loads below cannot hit stale
   // lines of this CU's vector L1
@@ -1719,7 +1745,53 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
   // order, same sums as the reference's loop over all cells
   const double dx = s_avg[0] - center[0], dy = s_avg[1] - center[1];
   double axx = 0, axy = 0, ayy = 0, norm = 0;
-  for (int c0 = 0; c0 < ncand; c0 += NT) {
+  const int nch = (ncand + NT - 1) / NT;
+  bool done = false;
+  if (injective && nch <= 16 && s_status == 0) {
+    // every chunk's ballot first (no serial work in between), one exclusive prefix over (chunk, wave), then each passing
+    // cell writes its terms at its lattice-order rank and thread 0 adds the list up: a handful of barriers, not two per chunk
+    uint32_t mine = 0u;  // bit ch: my cell of chunk ch passes
+    for (int ch = 0; ch < nch; ch++) {
+      const int c = ch * NT + tid;
+      const bool sel = c < ncand && (latmax[c] > 0.0 ? latmax[c] : 0.0) >= (best - 0.1);
+      const unsigned long long bal = __ballot(sel);
+      if ((tid & 63) == 0) s_bal2[ch][tid >> 6] = bal;
+      mine |= (uint32_t)sel << ch;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int ch = 0; ch < nch; ch++)
+        for (int w = 0; w < NT / 64; w++) { s_pref[ch][w] = run; run += __popcll(s_bal2[ch][w]); }
+      s_npass = run;
+    }
+    __syncthreads();
+    if (s_npass <= NT) {  // the list fits `chunk`
+      for (int ch = 0; ch < nch; ch++) {
+        if (!((mine >> ch) & 1u)) continue;
+        const int c = ch * NT + tid;
+        const int xi = c % pc.nx, yi = c / pc.nx;
+        const double x = -pc.off_x + (uint32_t)xi * pc.res_x;
+        const double y = -pc.off_y + (uint32_t)yi * pc.res_y;
+        const double rr = latmax[c] > 0.0 ? latmax[c] : 0.0;
+        const int rank = s_pref[ch][tid >> 6] + __popcll(s_bal2[ch][tid >> 6] & ((1ull << (tid & 63)) - 1ull));
+        chunk[4 * rank + 0] = rr;
+        chunk[4 * rank + 1] = (ksq(x - dx) * rr);
+        chunk[4 * rank + 2] = ((x - dx) * (y - dy) * rr);
+        chunk[4 * rank + 3] = (ksq(y - dy) * rr);
+      }
+      __syncthreads();
+      if (tid == 0)
+        for (int i = 0, n = s_npass; i < n; i++) {
+          norm += chunk[4 * i];
+          axx += chunk[4 * i + 1];
+          axy += chunk[4 * i + 2];
+          ayy += chunk[4 * i + 3];
+        }
+      done = true;
+    }
+  }
+  for (int c0 = 0; c0 < ncand && !done; c0 += NT) {
     const int c = c0 + tid;
     bool sel = false;
     if (c < ncand) {
