@@ -1082,7 +1082,7 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
                     int32_t* resp, size_t resp_stride, CoarseOut* __restrict__ out,
                     int use_expansion, int pass_index, const uint8_t* __restrict__ grid,
                 const double2* __restrict__ local, int fb_step, PassCfg fine_pc,
-                    double2* fine_cossin, int fine_step, int zero_fine_words) {
+                    double2* fine_cossin, int fine_step, int zero_fine_words, int parts) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double sh[NT];
   __shared__ double s_ap[kMaxAngles];
@@ -1104,9 +1104,8 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
   // kernel is latency-bound, so residency is what it needs): each thread owns the angles of ONE lattice cell half and
   // keeps only the cell maximum; the few cells that can tie with the best response are re-evaluated below with the
   // same expression, hence the same bits.
-  double* latmax = (double*)smem;
-  double* lat2 = latmax + ncand;  // second half of the angles of each cell
-  double* probs = lat2 + ncand;
+  double* latmax = (double*)smem;  // `parts` rows of ncand: the angles of a cell are split over `parts` threads (host:
+  double* probs = latmax + (size_t)parts * ncand;  // as many as fit the block, so that a thread's loads are one batch)
   double* terms = probs + g.probs_side * g.probs_side;  // 4 per lattice cell
   uint32_t* mask = (uint32_t*)(terms + 4 * ncand);
   int* cell = (int*)(mask + words);
@@ -1149,10 +1148,9 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
   };
   // cell maxima: thread -> (cell, half of the angles); numerators are stored angle-major, so neighbouring threads read
   // neighbouring words; a thread's loads are issued eleven at a time
-  const int parts = 2 * ncand <= NT ? 2 : 1;
   double lm = -1.0;  // bestResponse starts at -1 (Mapper.cpp:431)
   for (int idx = tid; idx < ncand * parts; idx += NT) {
-    const int part = idx >= ncand ? 1 : 0, c = idx - part * ncand;
+    const int part = idx / ncand, c = idx - part * ncand;
     const int a_lo = part * pc.na / parts, a_hi = (part + 1) * pc.na / parts;
     double m = -1.0;
     constexpr int kBatch = 11;
@@ -1167,16 +1165,16 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
           m = m > v ? m : v;
         }
     }
-    (part ? lat2 : latmax)[c] = m;
+    latmax[(size_t)part * ncand + c] = m;
     lm = lm > m ? lm : m;
   }
-  const double best = block_max(lm, sh, tid, NT);  // contains the barriers that publish latmax / lat2
+  const double best = block_max(lm, sh, tid, NT);  // contains the barriers that publish the latmax rows
 
   // best response per lattice cell over all angles, max-merged into the search-space probabilities
   // (Mapper.cpp:437-450); responses are >= +0, so the unsigned order of the bit patterns is the fp order
   for (int c = tid; c < ncand; c += NT) {
     double m = latmax[c];
-    if (parts == 2) m = m > lat2[c] ? m : lat2[c];
+    for (int q = 1; q < parts; q++) m = m > latmax[(size_t)q * ncand + c] ? m : latmax[(size_t)q * ncand + c];
     latmax[c] = m;
     if (cell[c] < 0) s_bad = 1;
     else atomicMax((unsigned long long*)&probs[cell[c]], (unsigned long long)__double_as_longlong(m < 0.0 ? 0.0 : m));
@@ -1195,7 +1193,7 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
   for (int w0 = 0; w0 < 256; w0 += NT) {  // which mask words are non-zero (words <= 256, host)
     const int wd = w0 + tid;
     const unsigned long long nz = __ballot(wd < words && mask[wd] != 0u);
-    if ((tid & 63) == 0) s_nz[wd >> 6] = nz;
+    if ((tid & 63) == 0 && wd < 256) s_nz[wd >> 6] = nz;
   }
   __syncthreads();
   if (tid == 0) {
@@ -2677,9 +2675,10 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
            ((total + 31) / 32) * 4 + 16;
   };
   // k_reduce_coarse_lds keeps no per-candidate cache: two cell-maximum arrays instead
-  auto reduce_lds_nocache = [&](const PassCfg& p) -> size_t {
+  auto reduce_parts = [&](const PassCfg& p, int nt) -> int { return std::max(1, std::min(8, nt / (p.nx * p.ny))); };
+  auto reduce_lds_nocache = [&](const PassCfg& p, int parts) -> size_t {
     size_t total = (size_t)p.nx * p.ny * p.na;
-    return (size_t)p.nx * p.ny * (8 + 8 + 32 + 4 + 4) + (size_t)g.probs_side * g.probs_side * 8 + ((total + 31) / 32) * 4 + 16;
+    return (size_t)p.nx * p.ny * (8 * parts + 32 + 4 + 4) + (size_t)g.probs_side * g.probs_side * 8 + ((total + 31) / 32) * 4 + 16;
   };
   // response numerators of one pass: packed row kernel for uniform lattices (step 2 on the parity
   // planes, step 1 on the grid), generic kernel for everything else
@@ -2853,16 +2852,17 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       fb_step
     if (cache && ((size_t)p.nx * p.ny * p.na + 31) / 32 <= 256) {
       const bool fuse_fine = n_exp == 0 && do_refine;  // nothing between this pass and the fine pass
-      if (S >= kReduceNarrowMinScans)
-        launch(ctx, "reduce_coarse", k_reduce_coarse_lds<128>, dim3(S), dim3(128), reduce_lds_nocache(p), g, p, sc,
-               m->d_lat.p, m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
-               (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step, pf,
-               fuse_fine ? m->d_cossin.p : (double2*)nullptr, 1, fuse_fine ? pf.nx * pf.ny * pf.na : 0);
-      else
-        launch(ctx, "reduce_coarse", k_reduce_coarse_lds<256>, dim3(S), dim3(256), reduce_lds_nocache(p), g, p, sc,
-               m->d_lat.p, m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
-               (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step, pf,
-               fuse_fine ? m->d_cossin.p : (double2*)nullptr, 1, fuse_fine ? pf.nx * pf.ny * pf.na : 0);
+#define LSLAM_RC_LDS(NT)                                                                                                 \
+  launch(ctx, "reduce_coarse", k_reduce_coarse_lds<NT>, dim3(S), dim3(NT), reduce_lds_nocache(p, reduce_parts(p, NT)), g, p,  \
+         sc, m->d_lat.p, m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,            \
+         (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step, pf,                                               \
+         fuse_fine ? m->d_cossin.p : (double2*)nullptr, 1, fuse_fine ? pf.nx * pf.ny * pf.na : 0, reduce_parts(p, NT))
+      // 128 threads: residency for chip-filling batches; 1024: a lone block (streaming front-end, MatchScan) splits a cell's
+      // angles over 8 threads -- its fill phase was 11 fp64 divisions in a row per thread
+      if (S >= kReduceNarrowMinScans) LSLAM_RC_LDS(128);
+      else if (S <= 8) LSLAM_RC_LDS(1024);
+      else LSLAM_RC_LDS(256);
+#undef LSLAM_RC_LDS
       setup_done = fuse_fine;
       fine_prezeroed = fuse_fine;
     }
