@@ -1434,22 +1434,30 @@ k_resp_dense(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1,
         acc[t][4 * q + 3] += po[t][q] >> 16;
       }
   }
-  if (!lane_on) return;
+  // The wave's rows j_base .. j_base + T*rpw - 1 are ONE contiguous run of the output (rows are nX ints apart): staged
+  // through LDS and written with consecutive lanes on consecutive words.  Lane by lane (16 words each, 64 bytes apart)
+  // every store instruction was ~60 separate write requests: 1.8 M of them per lone match, and THAT -- not the loads --
+  // was this kernel's time.
+  __shared__ int32_t stage[T * 1024];  // rpw * nX <= 64 * 16
   const int ncand = pc.nx * pc.ny;
+  if (lane_on) {
 #pragma unroll
-  for (int t = 0; t < T; t++) {
-    const int j = j_base + t * rpw + r;
-    if (j >= pc.ny) continue;
+    for (int t = 0; t < T; t++) {
+      const int jl = t * rpw + r;
+      if (j_base + jl >= pc.ny) continue;
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
-      const int i = 16 * k + c;
-      if (i >= pc.nx) continue;
-      // beam slices write their partial sums side by side (plain stores; slice q of scan s at resp + (s*slices + q) *
-      // resp_stride); k_big_latmax adds them up -- integer atomics here were 2 M per single 101x101x21 match
-      int32_t* o = resp + ((size_t)s * beam_slices + slice) * resp_stride + (size_t)a * ncand + (size_t)j * pc.nx + i;
-      *o = (int32_t)acc[t][c];
+      for (int c = 0; c < 16; c++) {
+        const int i2 = 16 * k + c;
+        if (i2 < pc.nx) stage[jl * pc.nx + i2] = (int32_t)acc[t][c];
+      }
     }
   }
+  __syncthreads();
+  // beam slices write their partial sums side by side (slice q of scan s at resp + (s*slices + q) * resp_stride);
+  // k_big_latmax adds them up -- integer atomics here were 2 M per single 101x101x21 match
+  const int rows_here = min(T * rpw, pc.ny - j_base);
+  int32_t* o = resp + ((size_t)s * beam_slices + slice) * resp_stride + (size_t)a * ncand + (size_t)j_base * pc.nx;
+  for (int idx = lane, n_out = rows_here * pc.nx; idx < n_out; idx += 64) o[idx] = stage[idx];
 }
 
 // Reduce of a large coarse lattice (block per scan, global scratch instead of LDS): same steps as
