@@ -25,6 +25,14 @@
 #undef private
 #undef protected
 
+// -DHREF_GPU (oracle/Makefile target ref_gpu -> oracle/_ref_gpu/libhector_ref_gpu.so): the SAME reference
+// HectorSlamProcessor, but its `mapRep` is the MI355X implementation of MapRepresentationInterface
+// (integration/hector_map_rep_gpu.hpp) instead of the reference's MapRepMultiMap -- the reference's orchestrator
+// driving the HIP kernels through the C ABI.  Everything else in this file is unchanged.
+#ifdef HREF_GPU
+#include "hector_map_rep_gpu.hpp"
+#endif
+
 using hectorslam::DataContainer;
 using hectorslam::GridMap;
 
@@ -80,6 +88,11 @@ struct href_proc {
 extern "C" {
 
 int href_abi(void) { return 1; }
+#ifdef HREF_GPU
+int href_is_gpu(void) { return 1; }
+#else
+int href_is_gpu(void) { return 0; }
+#endif
 int href_sizeof_cell(void) { return (int)sizeof(LogOddsCell); }
 
 // ---- single GridMap (H/map/GridMap.h:38) --------------------------------------------------------------------
@@ -204,6 +217,20 @@ href_proc* href_proc_create(float map_resolution, int size_x, int size_y, float 
   CoutSilencer quiet;
   href_proc* p = new href_proc;
   p->proc = new hectorslam::HectorSlamProcessor(map_resolution, size_x, size_y, Eigen::Vector2f(start_x, start_y), levels);
+#ifdef HREF_GPU
+  // swap the map representation behind the reference's processor (HectorSlamProcessor.h:61,141)
+  static lslam_context* ctx = nullptr;
+  if (!ctx && lslam_create(0, &ctx) != LSLAM_OK) {
+    std::cerr << "href_proc_create (gpu): " << lslam_last_error(nullptr) << std::endl;
+    delete p->proc;
+    delete p;
+    return nullptr;
+  }
+  delete p->proc->mapRep;
+  p->proc->mapRep = new lslam::HectorMapRepGpu(ctx, map_resolution, size_x, size_y, (unsigned)levels,
+                                               Eigen::Vector2f(start_x, start_y));
+  p->proc->reset();
+#endif
   return p;
 }
 void href_proc_destroy(href_proc* p) {

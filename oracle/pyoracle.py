@@ -134,11 +134,17 @@ def have_ref() -> bool:
 class RefKarto:
     """The reference's own karto::ScanMatcher / karto::Mapper behind oracle/ref_driver.cpp."""
 
-    def __init__(self, cfg: KrefCfg, laser: KrefLaser):
-        path = HERE / "_ref" / "libkarto_ref.so"
+    def __init__(self, cfg: KrefCfg, laser: KrefLaser, gpu: bool = False):
+        """gpu=True loads oracle/_ref_gpu/libkarto_ref_gpu.so instead: the SAME reference objects (Karto.o, Mapper.o,
+        this driver), with karto::ScanMatcher::MatchScan substituted at link time by integration/
+        karto_scan_matcher_gpu.cpp -- the reference's Mapper / MapperGraph orchestrating, the HIP kernels matching."""
+        path = HERE / "_ref_gpu" / "libkarto_ref_gpu.so" if gpu else HERE / "_ref" / "libkarto_ref.so"
         if not path.exists():
-            raise FileNotFoundError(f"{path} (build it here with `make -C oracle ref`)")
+            raise FileNotFoundError(f"{path} (build it here with `make -C oracle {'ref_gpu' if gpu else 'ref'}`)")
         L = C.CDLL(str(path))
+        self.gpu = gpu
+        if gpu:
+            L.lslam_karto_gpu_match_calls.restype = C.c_longlong
         L.kref_create.restype = C.c_void_p
         L.kref_create.argtypes = [C.POINTER(KrefCfg), C.POINTER(KrefLaser)]
         L.kref_destroy.argtypes = [C.c_void_p]
@@ -188,6 +194,10 @@ class RefKarto:
             self.close()
         except Exception:
             pass
+
+    def gpu_match_calls(self) -> int:
+        """MatchScan calls that ran on the device so far (process-wide; gpu=True only)."""
+        return int(self.L.lslam_karto_gpu_match_calls()) if self.gpu else 0
 
     @property
     def num_beams(self) -> int:
@@ -810,6 +820,11 @@ def have_ref_hector() -> bool:
     return (HERE / "_ref" / "libhector_ref.so").exists()
 
 
+def have_ref_gpu() -> bool:
+    """the reference's orchestrators linked against the HIP path (make -C oracle ref_gpu)"""
+    return (HERE / "_ref_gpu" / "libkarto_ref_gpu.so").exists() and (HERE / "_ref_gpu" / "libhector_ref_gpu.so").exists()
+
+
 def _f32(a, shape=None):
     a = np.ascontiguousarray(a, dtype=np.float32)
     return a.reshape(shape) if shape is not None else a
@@ -821,13 +836,27 @@ class _HrefLib:
     `make -C oracle ref_hector` ran with /root/reference present -- travels to the GPU box)."""
 
     _L = None
+    _Lgpu = None
 
     @classmethod
-    def lib(cls):
+    def lib(cls, gpu: bool = False):
+        if gpu:  # the -DHREF_GPU twin: HectorSlamProcessor's mapRep is integration/hector_map_rep_gpu.hpp
+            if cls._Lgpu is None:
+                path = HERE / "_ref_gpu" / "libhector_ref_gpu.so"
+                if not path.exists():
+                    raise FileNotFoundError(f"{path} (build it here with `make -C oracle ref_gpu`)")
+                cls._Lgpu = cls._load(path)
+            return cls._Lgpu
         if cls._L is None:
             path = HERE / "_ref" / "libhector_ref.so"
             if not path.exists():
                 build("ref_hector")
+            cls._L = cls._load(path)
+        return cls._L
+
+    @staticmethod
+    def _load(path):
+        if True:
             L = C.CDLL(str(path))
             vp, i, f = C.c_void_p, C.c_int, C.c_float
             sig = {
@@ -876,12 +905,12 @@ class _HrefLib:
                 "href_pose_difference_larger_than": (i, [vp, vp, f, f]),
                 "href_normalize_angle": (f, [f]),
                 "href_sizeof_cell": (i, []),
+                "href_is_gpu": (i, []),
             }
             for name, (res, args) in sig.items():
                 fn = getattr(L, name)
                 fn.restype, fn.argtypes = res, args
-            cls._L = L
-        return cls._L
+            return L
 
 
 class RefHector:
@@ -1032,9 +1061,12 @@ class RefHectorRep:
 class RefHectorProcessor:
     """hectorslam::HectorSlamProcessor of the reference (H/slam_main/HectorSlamProcessor.h)."""
 
-    def __init__(self, map_resolution, size_x, size_y, start=(0.5, 0.5), levels=3, p_free=None, p_occ=None):
-        self.L = _HrefLib.lib()
+    def __init__(self, map_resolution, size_x, size_y, start=(0.5, 0.5), levels=3, p_free=None, p_occ=None, gpu=False):
+        self.L = _HrefLib.lib(gpu)
+        assert bool(self.L.href_is_gpu()) == bool(gpu)
         self.h = self.L.href_proc_create(map_resolution, size_x, size_y, start[0], start[1], levels)
+        if not self.h:
+            raise RuntimeError("href_proc_create failed")
         if p_free is not None:
             self.L.href_proc_set_factors(self.h, p_free, p_occ)
 

@@ -103,13 +103,18 @@ struct KRef {
   std::string err;
 };
 
+#ifndef KREF_NAME_PREFIX
+#define KREF_NAME_PREFIX "kref_laser_"
+#endif
 static int g_counter = 0;
 
 void* kref_create(const kref_cfg* c, const kref_laser* l) {
   try {
     KRef* k = new KRef();
     std::ostringstream nm;
-    nm << "kref_laser_" << (g_counter++);
+    // the GPU-driven twin of this library (-DKREF_NAME_PREFIX, oracle/Makefile target ref_gpu) may live in the same
+    // process: SensorManager is a process-wide singleton, so the two register their lasers under different names
+    nm << KREF_NAME_PREFIX << (g_counter++);
     k->name = nm.str();
     k->mapper = new Mapper();
     Mapper* m = k->mapper;

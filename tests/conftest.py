@@ -41,6 +41,7 @@ def oracle_lib():
     pyoracle.build("restate")
     if (pathlib.Path("/root/reference/lesson6/lib/open_karto").is_dir()):
         pyoracle.build("ref")
+        pyoracle.build("ref_gpu")  # no-op unless liblslam_gpu.so has been built
     return pyoracle
 
 

@@ -1,0 +1,155 @@
+"""the reference's OWN orchestrators driving the HIP path through the C ABI.
+
+* Karto: oracle/_ref_gpu/libkarto_ref_gpu.so is the reference's Karto.o + Mapper.o with ONE symbol substituted at link
+  time -- karto::ScanMatcher::MatchScan is integration/karto_scan_matcher_gpu.cpp, which takes the reference's
+  `LocalizedRangeScan*` / `LocalizedRangeScanVector`, builds its `lslam_laser` from the scan's `LaserRangeFinder` and
+  calls lslam_matcher_match_scan.  karto::Mapper::Process, MapperGraph::AddEdges / LinkNearChains / TryCloseLoop,
+  ScanManager, the dataset: all the reference's compiled code.  Expected: the same poses and the same graph as the pure
+  reference (oracle/_ref/libkarto_ref.so) on closed-loop trajectories.
+* Hector: oracle/_ref_gpu/libhector_ref_gpu.so is the reference's HectorSlamProcessor with `mapRep` swapped for
+  integration/hector_map_rep_gpu.hpp (`HectorMapRepGpu : MapRepresentationInterface`).  Expected: the same map-update
+  decisions, poses within the fp32 tolerance of the device Gauss-Newton matcher, maps equal where poses are.
+
+Both twins are built in the container that holds /root/reference (`make -C oracle ref_gpu`) and travel to the GPU box.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from lslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def po(oracle_lib):
+    if not (oracle_lib.have_ref() and oracle_lib.have_ref_gpu()):
+        pytest.skip("oracle/_ref or oracle/_ref_gpu not built (needs /root/reference at build time)")
+    return oracle_lib
+
+
+def _run_pair(po, kw, laser, thr, offset, path, odom, world, seed):
+    cfg = po.default_cfg(**kw)
+    cpu = po.RefKarto(cfg, po.laser_struct(laser, thr, offset))
+    gpu = po.RefKarto(cfg, po.laser_struct(laser, thr, offset), gpu=True)
+    calls0 = gpu.gpu_match_calls()
+    worst = 0.0
+    for i, (t, o) in enumerate(zip(path, odom)):
+        c, s_ = math.cos(t[2]), math.sin(t[2])
+        lp = (t[0] + c * offset[0] - s_ * offset[1], t[1] + s_ * offset[0] + c * offset[1], t[2] + offset[2])
+        r = synth.ranges_to_f64(synth.cast_scan(world, lp, laser, 0.01, 0.01, np.random.default_rng([seed, i])))
+        ok_c, pose_c = cpu.process(r, o)
+        ok_g, pose_g = gpu.process(r, o)
+        assert ok_c == ok_g, i
+        worst = max(worst, float(np.abs(pose_c - pose_g).max()))
+        assert worst <= 1e-9, (i, pose_c, pose_g)
+        assert cpu.graph_stats() == gpu.graph_stats(), i
+    n = cpu.graph_stats()[0]
+    final_c = np.stack([cpu.scan_pose(i) for i in range(n)])
+    final_g = np.stack([gpu.scan_pose(i) for i in range(n)])
+    assert np.abs(final_c - final_g).max() <= 1e-9
+    return cpu, gpu, worst, gpu.gpu_match_calls() - calls0
+
+
+def test_reference_mapper_on_gpu_matcher_closed_loop(po):
+    """karto::Mapper (the reference's, unmodified) + GPU MatchScan == karto::Mapper + its own MatchScan on a trajectory
+    that closes loops: sequential matches, near-chain matches and the 81x81x21 loop matcher all go to the device."""
+    laser = synth.Laser()
+    world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=5)
+    path = synth.loop_trajectory(260, w=8.0, h=5.0, step=0.2, origin=(-4.0, -2.5))
+    odom = synth.drifting_odometry(path, scale=1.03, seed=9)
+    kw = dict(scan_buffer_size=25, scan_buffer_max_scan_distance=6.0, do_loop_closing=1, link_scan_maximum_distance=1.5,
+              loop_search_maximum_distance=3.0, loop_match_minimum_chain_size=8)
+    cpu, gpu, worst, calls = _run_pair(po, kw, laser, 20.0, (0.0, 0.0, 0.0), path, odom, world, 43)
+    v, e = cpu.graph_stats()
+    assert e > v > 100  # loop / near-chain links exist on both sides (equal counts asserted per scan)
+    # every processed scan but the first is matched at least once on the device (Mapper.cpp:2040)
+    assert calls >= v - 1, (calls, v)
+    print("reference Mapper + GPU MatchScan vs pure reference: max pose difference", worst, "device MatchScan calls", calls,
+          "vertices/edges", (v, e))
+
+
+@pytest.mark.parametrize("variant", ["laser_offset", "response_expansion"])
+def test_reference_mapper_on_gpu_matcher_variants(po, variant):
+    """The lslam_laser built from the reference's LaserRangeFinder carries the mounting offset (Sensor::SetOffsetPose,
+    karto_slam.cc:387-389); response expansion is read from the Mapper parameter like Mapper.cpp:238."""
+    laser = synth.Laser()
+    world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=5)
+    path = synth.loop_trajectory(120, w=6.0, h=4.0, step=0.2, origin=(-3.0, -2.0))
+    odom = synth.drifting_odometry(path, scale=1.02, seed=11)
+    offset = (0.18, -0.05, 0.04) if variant == "laser_offset" else (0.0, 0.0, 0.0)
+    kw = dict(scan_buffer_size=20, scan_buffer_max_scan_distance=5.0, do_loop_closing=1, link_scan_maximum_distance=1.5,
+              loop_search_maximum_distance=3.0, loop_match_minimum_chain_size=6,
+              use_response_expansion=1 if variant == "response_expansion" else 0)
+    _run_pair(po, kw, laser, 20.0, offset, path, odom, world, 47)
+
+
+def test_reference_match_scan_entry_on_gpu(po, workload):
+    """One ScanMatcher::MatchScan call through the reference's signature (LocalizedRangeScan*, vector, Pose2&, Matrix3&):
+    response identical, pose / covariance <= 1e-12, with and without penalties / refinement."""
+    wl = workload
+    cpu = po.RefKarto(po.default_cfg(), po.laser_struct(wl.laser))
+    gpu = po.RefKarto(po.default_cfg(), po.laser_struct(wl.laser), gpu=True)
+    for q in range(4):
+        for pen, fine in ((True, True), (False, False), (False, True)):
+            a = cpu.match(wl.base_ranges, wl.base_poses, wl.query_ranges[q], wl.query_poses[q], pen, fine)
+            b = gpu.match(wl.base_ranges, wl.base_poses, wl.query_ranges[q], wl.query_poses[q], pen, fine)
+            assert a[2] == b[2]
+            assert np.abs(a[0] - b[0]).max() <= 1e-12
+            assert np.abs(a[1] - b[1]).max() <= 1e-12 * max(1.0, np.abs(a[1]).max())
+
+
+def test_reference_hector_processor_on_gpu_map_rep(po):
+    """HectorSlamProcessor::update (H/slam_main/HectorSlamProcessor.h:84-110), the reference's own, with mapRep =
+    HectorMapRepGpu: 60 scans, pose chain fed back as the next start estimate (hector_slam.cc:200-204).  The device
+    Gauss-Newton matcher is fp32 with device libm (tolerance 1e-4); the map-update decisions are the
+    reference's own predicate on those poses and must agree; the maps are compared cell for cell."""
+    laser = synth.Laser()
+    n, cell, LV = 1024, 0.05, 3
+    cpu = po.RefHectorProcessor(cell, n, n, (0.5, 0.5), LV, p_free=0.4, p_occ=0.9)
+    gpu = po.RefHectorProcessor(cell, n, n, (0.5, 0.5), LV, p_free=0.4, p_occ=0.9, gpu=True)
+    world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=5)
+    est_c = np.zeros(3, np.float32)
+    est_g = np.zeros(3, np.float32)
+    updates, worst = 0, 0.0
+    for k in range(60):
+        truth = (0.04 * k, 0.015 * k, 0.004 * k)
+        pts = synth.hector_points(synth.cast_scan(world, truth, laser), laser, 1.0 / cell)
+        did_c = cpu.update(pts, est_c)
+        did_g = gpu.update(pts, est_g)
+        assert did_c == did_g, k
+        updates += did_c
+        est_c, cov_c = cpu.last_pose()
+        est_g, cov_g = gpu.last_pose()
+        worst = max(worst, float(np.abs(est_c - est_g).max()))
+        assert worst <= 1e-4, (k, est_c, est_g)
+        assert np.abs(cov_c - cov_g).max() <= 2e-3 * max(1.0, float(np.abs(cov_c).max())), k
+    assert 4 <= updates <= 10
+    assert np.abs(est_g - np.array(truth)).max() < 0.05
+    for lv in range(LV):
+        a, b = cpu.logodds(lv), gpu.logodds(lv)
+        differing = int(np.count_nonzero(a != b))
+        # poses differ by <= 1e-4 (fp32 matcher), so a handful of ray end cells may land one cell over
+        assert differing <= 0.002 * np.count_nonzero(a), (lv, differing)
+    print("reference HectorSlamProcessor + GPU map rep: max pose difference", worst, "map updates", updates)
+
+
+def test_reference_hector_processor_on_gpu_map_rep_without_matching(po):
+    """map_without_matching = true (the mapping-only mode of HectorSlamProcessor::update): no matcher in the loop, so the
+    pyramid the reference's processor builds through the GPU map rep is BIT-equal to its own -- level 0 only, because
+    levels > 0 are fed from containers cached by matchData (MapRepMultiMap.h:161,186), which never runs here: they stay
+    empty on both sides."""
+    laser = synth.Laser()
+    n, cell, LV = 512, 0.05, 3
+    cpu = po.RefHectorProcessor(cell, n, n, (0.5, 0.5), LV, p_free=0.4, p_occ=0.9)
+    gpu = po.RefHectorProcessor(cell, n, n, (0.5, 0.5), LV, p_free=0.4, p_occ=0.9, gpu=True)
+    world = synth.arena(size=30.0, n_axis=8, n_rot=3, seed=6)
+    for k in range(25):
+        pose = np.array([0.1 * k - 1.0, 0.05 * k, 0.03 * k], np.float32)
+        pts = synth.hector_points(synth.cast_scan(world, pose, laser), laser, 1.0 / cell, use_max=10.0)
+        assert cpu.update(pts, pose, map_without_matching=True)
+        assert gpu.update(pts, pose, map_without_matching=True)
+    for lv in range(LV):
+        assert cpu.logodds(lv).tobytes() == gpu.logodds(lv).tobytes(), lv
+    assert np.count_nonzero(cpu.logodds(0)) > 1000
