@@ -20,6 +20,14 @@ timed separately and reported as `gather_ms`.
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed on the stream it
 runs on) and `cpu_baseline` (the reference's own CorrelateScan, oracle/_ref, on this box's host
 cores; falls back to the plain-C port where _ref is absent).
+
+At N=1 the same run also measures the other north-star configs (`secondary`, ~10 s of GPU work): config 2
+(log-odds update, one scan per call and the batched entry, each against the HBM peak), config 3 (ms per complete
+MatchScan) and a closed-loop slice of config 5 (streaming front-end with its pose graph on the 4000x4000@0.025 m
+map), every one with the reference's CPU figure beside it and checked against it; plus a `sustained` leg of the
+headline step (>= 1 s, clocks ramped).  The CPU legs run in worker processes forked BEFORE the GPU is touched; they
+are released only after the headline's timed region, so the headline number is measured on a quiet host.  A compact
+copy of the secondary numbers is also nested under `roofline.secondary` / `cpu_baseline.secondary`.
 """
 from __future__ import annotations
 
@@ -99,29 +107,388 @@ def query_poses(world, anchor, n, spread, seed):
     return out
 
 
-def _cpu_worker(args):
-    """One host core: the reference's own CorrelateScan (oracle/_ref) on its share of the sample."""
-    base_ranges, base_poses, center, q_r, q_p, laser = args
+# ------------------------------------------------------------------------------------------------------
+# CPU legs: worker processes forked before CUDA / HIP are touched.  Inputs travel by fork (module global
+# _JOB), results by pickle.  Every task waits for GO, which the main process sets after the headline's
+# timed region.  The reference library (oracle/_ref) chats on std::cout, also at exit: workers' fd 1 goes
+# to /dev/null.
+# ------------------------------------------------------------------------------------------------------
+GO = None
+GO_MULTI = None  # the all-core leg starts only after the single-core headline baseline has finished
+_JOB = {}
+
+
+def _quiet_worker():
+    dn = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(dn, 1)
+
+
+def _cpu_cfg4_share(_):
+    """One host core: the reference's own CorrelateScan (oracle/_ref) on 200 of the sample's scans."""
+    GO_MULTI.wait()
     from oracle import pyoracle as po
 
-    ref = po.RefKarto(po.default_cfg(), po.laser_struct(laser))
-    ref.set_base_scans(base_ranges, base_poses, center)
+    wl, q_r, q_p = _JOB["wl"], _JOB["q_r"][:200], _JOB["q_p"][:200]
+    ref = po.RefKarto(po.default_cfg(), po.laser_struct(wl.laser))
+    ref.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
     sec, _, _, _ = ref.match_fixed_grid(q_r, q_p)
     return sec * len(q_r), len(q_r)
 
 
-def cpu_multicore(wl, q_r, q_p, cores):
-    """Embarrassingly parallel CPU number (SURVEY.md §8(d) ii): one independent matcher per process."""
-    import multiprocessing as mp
+def _cpu_cfg4_single(_):
+    """cpu_baseline of the headline: coarse+fine CorrelateScan of the sample against the shared grid, one core."""
+    GO.wait()
+    from oracle import pyoracle as po
 
-    job = (wl.base_ranges, wl.base_poses, wl.center_pose, q_r, q_p, wl.laser)
+    wl, q_r, q_p = _JOB["wl"], _JOB["q_r"], _JOB["q_p"]
+    sample = len(q_r)
+    if po.have_ref():
+        ref = po.RefKarto(po.default_cfg(), po.laser_struct(wl.laser))
+        ref.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
+        sec, c_poses, _, c_resp = ref.match_fixed_grid(q_r, q_p)
+        kind = "reference"
+    else:
+        po.build("restate")
+        port = po.PortKarto(po.default_cfg(), po.laser_struct(wl.laser))
+        port.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
+        t1 = time.perf_counter()
+        c_poses, c_resp = np.zeros((sample, 3)), np.zeros(sample)
+        for i in range(sample):
+            m, _, r = port.match(q_r[i], q_p[i])
+            c_poses[i], c_resp[i] = m, r
+        sec = (time.perf_counter() - t1) / sample
+        kind = "port"
+    return {"sec_per_match": sec, "poses": c_poses, "resp": c_resp, "kind": kind}
+
+
+def _sha(a):
+    import hashlib
+
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _cpu_cfg2(_):
+    """config 2 on one host core: lesson4's own OccGridMapBase::updateByScan (oracle/_ref/libhector_ref.so) over the
+    same 1081-beam scans; the restated oracle beside it counts the Bresenham cell visits (algorithmic bytes)."""
+    GO.wait()
+    from oracle import pyoracle as po
+
+    d = _JOB["cfg2"]
+    n, cell, off = d["n"], d["cell"], d["off"]
+    po.build("restate")
+    port = po.PortHector(n, n, cell, off)
+    port.setUpdateOccupiedFactor(0.9)
+    visits = 0
     t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(cores) as pool:
-        out = pool.map(_cpu_worker, [job] * cores)
-    wall = time.perf_counter() - t0
-    busy = max(o[0] for o in out)
-    n = sum(o[1] for o in out)
-    return n / busy, busy, wall
+    for pts, pose in zip(d["pts"], d["poses"]):
+        port.updateByScan(pts, (0.0, 0.0), pose)
+        visits += port.last_cell_visits()
+    port_s = time.perf_counter() - t0
+    out = {"visits": int(visits), "port_scans_per_s": len(d["pts"]) / port_s, "map_sha": _sha(port.logodds()), "kind": "port",
+           "scans_per_s": len(d["pts"]) / port_s}
+    if po.have_ref_hector():
+        ref = po.RefHector(n, n, cell, off)
+        ref.setUpdateOccupiedFactor(0.9)
+        t0 = time.perf_counter()
+        for pts, pose in zip(d["pts"], d["poses"]):
+            ref.updateByScan(pts, (0.0, 0.0), pose)
+        ref_s = time.perf_counter() - t0
+        out.update({"kind": "reference", "scans_per_s": len(d["pts"]) / ref_s, "ref_equals_port": _sha(ref.logodds()) == out["map_sha"]})
+    return out
+
+
+def _cpu_cfg3(_):
+    """config 3 on one host core: the reference's complete MatchScan (grid rebuilt from the 70-scan window per call)."""
+    GO.wait()
+    from oracle import pyoracle as po
+
+    wl, idx = _JOB["cfg3"]["wl"], _JOB["cfg3"]["idx"]
+    if not po.have_ref():
+        return None
+    ref = po.RefKarto(po.default_cfg(), po.laser_struct(wl.laser))
+    t0 = time.perf_counter()
+    out = [ref.match(wl.base_ranges, wl.base_poses, wl.query_ranges[i], wl.query_poses[i]) for i in idx]
+    sec = (time.perf_counter() - t0) / len(idx)
+    return {"ms_per_match": 1e3 * sec, "poses": np.stack([o[0] for o in out]), "resp": np.array([o[2] for o in out])}
+
+
+CFG5_GRAPH = dict(scan_buffer_size=70, do_loop_closing=1, link_scan_maximum_distance=1.5, loop_search_maximum_distance=3.0,
+                  loop_match_minimum_chain_size=10)
+
+
+def _cpu_cfg5(_):
+    """config 5 slice on one host core: the reference's own karto::Mapper::Process with its pose graph."""
+    GO.wait()
+    from oracle import pyoracle as po
+
+    d = _JOB["cfg5"]
+    if not po.have_ref():
+        return None
+    ref = po.RefKarto(po.default_cfg(scan_buffer_max_scan_distance=20.0, **CFG5_GRAPH), po.laser_struct(d["laser"]))
+    poses = np.zeros((len(d["r64"]), 3))
+    t0 = time.perf_counter()
+    for i, (r, o) in enumerate(zip(d["r64"], d["odom"])):
+        _, poses[i] = ref.process(r, o)
+    sec = time.perf_counter() - t0
+    v, e = ref.graph_stats()
+    return {"scans_per_s": len(poses) / sec, "seconds": sec, "poses": poses, "vertices": int(v), "edges": int(e)}
+
+
+# ------------------------------------------------------------------------------------------------------
+# secondary configs: workloads (numpy, before the fork) and GPU legs
+# ------------------------------------------------------------------------------------------------------
+def secondary_workloads(n_map_scans, n_single, n_stream, procs):
+    """cfg 2 / 3 / 5 inputs as SURVEY.md 8(d) describes them (seeds fixed)."""
+    import math
+
+    from lslam_amd import synth
+
+    laser = synth.Laser()
+    out = {}
+    # cfg 2: 1081-beam scans from distinct poses into a 1000x1000 @ 0.05 m map, p_free 0.4 / p_occ 0.9 (seed 3)
+    n, cell = 1000, 0.05
+    world = synth.arena(size=44.0, n_axis=12, n_rot=4, seed=3)
+    rng = np.random.default_rng(3)
+    poses = []
+    while len(poses) < n_map_scans:
+        x, y = rng.uniform(-4, 4, 2)
+        if synth.point_is_free(world, x, y, 0.8):
+            poses.append((x, y, rng.uniform(-math.pi, math.pi)))
+    poses = np.asarray(poses)
+    r32 = cast_scans(world, laser, poses, 0, 3, procs)
+    out["cfg2"] = {"n": n, "cell": cell, "off": (n * cell * 0.5, n * cell * 0.5),
+                   "pts": [synth.hector_points(r, laser, 1.0 / cell, use_max=20.0) for r in r32],
+                   "poses": poses.astype(np.float32)}
+    # cfg 3: 70-scan running window (seed 4), query = next pose + odometry error
+    out["cfg3"] = {"wl": synth.make_match_workload(n_base=70, n_query=16, seed=4), "idx": np.arange(n_single) % 16}
+    # cfg 5 slice: closed loops inside the 100 m arena (one ring of the full trajectory's family, driven > 2 laps so
+    # that near chains link and loops close within the slice), 0.25 m steps, drifting odometry (seed 6)
+    path = synth.rings_trajectory(n_stream, half_sizes=(9.0,), laps=3)
+    world5 = synth.arena_around_path(path, size=100.0, n_axis=30, n_rot=10, seed=6)
+    odom = synth.drifting_odometry(path, scale=1.01, sigma_xy=0.004, sigma_th=0.0015, seed=6)
+    s32 = cast_scans(world5, laser, path, 0, 6, procs)
+    out["cfg5"] = {"laser": laser, "path": path, "odom": odom, "r64": [synth.ranges_to_f64(r) for r in s32],
+                   "pts": [synth.hector_points(r, laser, 1.0 / 0.025, use_max=20.0) for r in s32]}
+    return out
+
+
+def gpu_cfg2(ctx, api, d):
+    """config 2 on the GPU: one scan per call (points resident in HBM, asynchronous updates) and the batched entry."""
+    n, cell, off = d["n"], d["cell"], d["off"]
+    scans = list(zip(d["pts"], d["poses"]))
+    gmap = api.OccGridMap(ctx, n, n, cell, off)
+    gmap.setUpdateOccupiedFactor(0.9)
+    ptrs = []
+    for pts, _ in scans:
+        p = ctx.alloc(max(pts.nbytes, 8))
+        ctx.upload(p, pts)
+        ptrs.append(p)
+    for (pts, pose), p in list(zip(scans, ptrs))[:5]:
+        gmap.updateByScan_dev(p, len(pts), (0.0, 0.0), pose)
+    gmap.reset()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for (pts, pose), p in zip(scans, ptrs):
+        gmap.updateByScan_dev(p, len(pts), (0.0, 0.0), pose)
+    ctx.synchronize()
+    single_s = time.perf_counter() - t0
+    single_sha = _sha(gmap.logodds())
+    gmap.reset()
+    ctx.profile(True); ctx.profile_only(None); ctx.profile_reset()
+    for (pts, pose), p in zip(scans, ptrs):
+        gmap.updateByScan_dev(p, len(pts), (0.0, 0.0), pose)
+    ctx.synchronize()
+    ctx.profile(False)
+    single_prof = ctx.profile_read()
+    for p in ptrs:
+        ctx.free(p)
+    gmap.close()
+    allpts = np.ascontiguousarray(np.concatenate([p for p, _ in scans]), dtype=np.float32)
+    counts = np.array([len(p) for p, _ in scans], dtype=np.int32)
+    d_all = ctx.alloc(allpts.nbytes)
+    ctx.upload(d_all, allpts)
+    bmap = api.OccGridMap(ctx, n, n, cell, off)
+    bmap.setUpdateOccupiedFactor(0.9)
+    bmap.updateByScans_dev(d_all, counts[:64], (0.0, 0.0), d["poses"][:64])  # allocates the byte planes
+    bmap.reset()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    bmap.updateByScans_dev(d_all, counts, (0.0, 0.0), d["poses"])
+    ctx.synchronize()
+    batch_s = time.perf_counter() - t0
+    batch_sha = _sha(bmap.logodds())
+    bmap.reset()
+    ctx.profile(True); ctx.profile_reset()
+    bmap.updateByScans_dev(d_all, counts, (0.0, 0.0), d["poses"])
+    ctx.synchronize()
+    ctx.profile(False)
+    batch_prof = ctx.profile_read()
+    ctx.free(d_all)
+    bmap.close()
+    return {"single_s": single_s, "single_sha": single_sha, "single_prof": single_prof, "batch_s": batch_s,
+            "batch_sha": batch_sha, "batch_prof": batch_prof, "points": int(counts.sum())}
+
+
+def gpu_cfg3(ctx, api, d):
+    wl, idx = d["wl"], d["idx"]
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(wl.laser))
+    gm.MatchScan(wl.query_ranges[0], wl.query_poses[0], wl.base_ranges, wl.base_poses)
+    t0 = time.perf_counter()
+    out = [gm.MatchScan(wl.query_ranges[i], wl.query_poses[i], wl.base_ranges, wl.base_poses) for i in idx]
+    sec = (time.perf_counter() - t0) / len(idx)
+    gm.close()
+    return {"ms_per_match": 1e3 * sec, "poses": np.stack([o[1] for o in out]), "resp": np.array([o[0] for o in out])}
+
+
+def gpu_cfg5(ctx, api, d):
+    """Streaming front-end: Mapper::Process with its pose graph per scan + log-odds update of the 4000x4000@0.025 m map
+    (the Karto matcher does not read that map, so its updates are applied 64 accepted scans at a time)."""
+    n, cell = 4000, 0.025
+    off = (n * cell * 0.5, n * cell * 0.5)
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(d["laser"]))
+    fe = api.FrontEnd(gm, config=api.frontend_config(scan_buffer_maximum_scan_distance=20.0, **CFG5_GRAPH))
+    gmap = api.OccGridMap(ctx, n, n, cell, off)
+    gmap.setUpdateOccupiedFactor(0.9)
+    r64, odom, pts_all = d["r64"], d["odom"], d["pts"]
+    fe.Process(r64[0], odom[0]); fe.Process(r64[1], odom[1]); fe.reset()
+    gmap.updateByScans(pts_all[:64], (0.0, 0.0), np.zeros((64, 3), np.float32)); gmap.reset()
+    ctx.synchronize()
+
+    def run():
+        poses, pend_pts, pend_pose, upd = [], [], [], []
+        t0 = time.perf_counter()
+        for i, (r, o, pts) in enumerate(zip(r64, odom, pts_all)):
+            ok, pose, _, _ = fe.Process(r, o)
+            poses.append(pose)
+            if ok:
+                pend_pts.append(pts); pend_pose.append(pose.astype(np.float32)); upd.append(i)
+                if len(pend_pts) == 64:
+                    gmap.updateByScans(pend_pts, (0.0, 0.0), np.stack(pend_pose)); pend_pts, pend_pose = [], []
+        if pend_pts:
+            gmap.updateByScans(pend_pts, (0.0, 0.0), np.stack(pend_pose))
+        ctx.synchronize()
+        return time.perf_counter() - t0, np.array(poses), upd
+
+    sec, poses, upd = run()
+    st = fe.stats()
+    logodds = gmap.logodds()
+    # per-kernel view of the same run (HIP events around every launch; slower, so not the throughput figure)
+    fe.reset(); gmap.reset()
+    ctx.profile(True); ctx.profile_only(None); ctx.profile_reset()
+    run()
+    ctx.profile(False)
+    prof = ctx.profile_read()
+    gmap.close(); fe.close(); gm.close()
+    return {"seconds": sec, "poses": poses, "updated": upd, "stats": st, "logodds": logodds, "prof": prof, "n": n, "cell": cell, "off": off}
+
+
+def _traffic(name):
+    """PMC figures per launch from profiles/traffic.json (static: `rocprofv3 --pmc` passes, tools/pmc_passes.sh)."""
+    try:
+        return json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(name, {})
+    except Exception:
+        return {}
+
+
+def build_secondary(gpu, cpu, job, args):
+    """The `secondary` block: cfg 2 / 3 / 5 GPU figures, each beside and checked against its CPU leg."""
+    from oracle import pyoracle as po
+
+    out = {"note": "measured in this run after the headline's timed region; CPU legs = the reference's own code "
+                   "(oracle/_ref) on one host core each, in worker processes running beside the GPU legs"}
+    roof, cpus = {}, {}
+    # ---- cfg 2: Hector log-odds update, 1081-beam scans into 1000x1000 @ 0.05 m --------------------------------------
+    g, c = gpu.get("cfg2", {}), cpu.get("cfg2")
+    if "error" in g or not c:
+        out["cfg2"] = g or {"error": "no CPU leg"}
+    else:
+        n = len(job["cfg2"]["pts"])
+        alg = c["visits"] * 16 + g["points"] * 8  # SURVEY 8(d): (8 B read + 8 B write) per traversed cell + 8 B per point in
+        k_single = sum(v[1] for v in g["single_prof"].values()) * 1e-3
+        k_batch = sum(v[1] for v in g["batch_prof"].values()) * 1e-3
+        tr = _traffic("logodds_batched")
+        out["cfg2"] = {
+            "config": "BASELINE configs[1]: Hector log-odds update, %d 1081-beam scans into 1000x1000@0.05 m (H/map/OccGridMapBase.h:118-330)" % n,
+            "cell_visits_per_scan": round(c["visits"] / n), "algorithmic_bytes_per_scan": round(alg / n),
+            "single_scan_per_call": {
+                "scans_per_s": round(n / g["single_s"], 1), "us_per_scan": round(1e6 * g["single_s"] / n, 2),
+                "cell_updates_per_s": round(c["visits"] / g["single_s"]),
+                "algorithmic_GBs": round(alg / g["single_s"] / 1e9, 2), "frac_of_hbm_peak": round(alg / g["single_s"] / 1e9 / HBM_PEAK_GBS, 5),
+                "kernel_us_per_scan": {k: round(1e3 * v[1] / n, 2) for k, v in sorted(g["single_prof"].items())},
+                "launches_per_scan": round(sum(v[0] for v in g["single_prof"].values()) / n, 2),
+                "kernel_algorithmic_GBs": round(alg / k_single / 1e9, 2) if k_single else None,
+                "bit_exact_vs_cpu": g["single_sha"] == c["map_sha"]},
+            "batched_64_per_call": {
+                "scans_per_s": round(n / g["batch_s"], 1), "cell_updates_per_s": round(c["visits"] / g["batch_s"]),
+                "algorithmic_GBs": round(alg / g["batch_s"] / 1e9, 2), "frac_of_hbm_peak": round(alg / g["batch_s"] / 1e9 / HBM_PEAK_GBS, 5),
+                "kernel_ms": {k: round(v[1], 3) for k, v in sorted(g["batch_prof"].items())},
+                "kernel_algorithmic_GBs": round(alg / k_batch / 1e9, 2) if k_batch else None,
+                "measured_hbm_bytes_per_64_scan_call": tr.get("hbm_bytes_per_launch"),
+                "measured_hbm_source": tr.get("source"),
+                "bit_exact_vs_cpu": g["batch_sha"] == c["map_sha"]},
+            "cpu": {"scans_per_s": round(c["scans_per_s"], 1), "kind": c["kind"], "cores": 1,
+                    "restated_oracle_scans_per_s": round(c["port_scans_per_s"], 1), "reference_equals_restatement": c.get("ref_equals_port")},
+        }
+        roof["cfg2_single_frac_of_hbm"] = out["cfg2"]["single_scan_per_call"]["frac_of_hbm_peak"]
+        roof["cfg2_single_scans_per_s"] = out["cfg2"]["single_scan_per_call"]["scans_per_s"]
+        roof["cfg2_batched_frac_of_hbm"] = out["cfg2"]["batched_64_per_call"]["frac_of_hbm_peak"]
+        roof["cfg2_batched_scans_per_s"] = out["cfg2"]["batched_64_per_call"]["scans_per_s"]
+        roof["cfg2_bit_exact"] = bool(g["single_sha"] == c["map_sha"] and g["batch_sha"] == c["map_sha"])
+        cpus["cfg2_scans_per_s"] = round(c["scans_per_s"], 1)
+        cpus["cfg2_kind"] = c["kind"]
+    # ---- cfg 3: one complete MatchScan per call ------------------------------------------------------------------
+    g, c = gpu.get("cfg3", {}), cpu.get("cfg3")
+    if "error" in g:
+        out["cfg3"] = g
+    else:
+        out["cfg3"] = {"config": "BASELINE configs[2]: single-scan MatchScan (AddScans of the 70-scan window + coarse/fine search, "
+                                 "Mapper.cpp:184-291), host entry point incl. the PCIe upload of the window",
+                       "calls": len(job["cfg3"]["idx"]), "gpu_ms_per_match": round(g["ms_per_match"], 4)}
+        if c:
+            out["cfg3"].update({"cpu_reference_ms_per_match": round(c["ms_per_match"], 4), "cpu_cores": 1,
+                                "max_pose_err_vs_reference": float(np.abs(g["poses"] - c["poses"]).max()),
+                                "max_response_err_vs_reference": float(np.abs(g["resp"] - c["resp"]).max())})
+            cpus["cfg3_ms_per_match"] = out["cfg3"]["cpu_reference_ms_per_match"]
+            roof["cfg3_max_pose_err"] = out["cfg3"]["max_pose_err_vs_reference"]
+        roof["cfg3_ms_per_match"] = out["cfg3"]["gpu_ms_per_match"]
+    # ---- cfg 5: streaming front-end slice ------------------------------------------------------------------------
+    g, c = gpu.get("cfg5", {}), cpu.get("cfg5")
+    if "error" in g:
+        out["cfg5"] = g
+    else:
+        d = job["cfg5"]
+        n = len(d["r64"])
+        st = g["stats"]
+        # map parity: the restated Hector update (pinned to the reference's headers) fed the GPU's poses
+        po.build("restate")
+        cmap = po.PortHector(g["n"], g["n"], g["cell"], g["off"])
+        cmap.setUpdateOccupiedFactor(0.9)
+        for i in g["updated"]:
+            cmap.updateByScan(d["pts"][i], (0.0, 0.0), g["poses"][i].astype(np.float32))
+        ref_map = cmap.logodds()
+        chain = {k: round(1e3 * v[1] / n, 2) for k, v in sorted(g["prof"].items(), key=lambda kv: -kv[1][1])}
+        out["cfg5"] = {
+            "config": "BASELINE configs[4] slice: %d-scan closed-loop trajectory (0.25 m steps, drifting odometry) in the 100 m arena; "
+                      "per scan Mapper::Process with its pose graph (70-scan running window, LinkNearChains, TryCloseLoop on the "
+                      "81x81x21 loop matcher; Mapper.cpp:1999-2079) + log-odds update of the 4000x4000@0.025 m map, 64 scans per call" % n,
+            "scans": n, "gpu_scans_per_s": round(n / g["seconds"], 1), "gpu_us_per_scan": round(1e6 * g["seconds"] / n, 1),
+            "graph": st, "kernel_us_per_scan": dict(list(chain.items())[:12]), "kernel_us_per_scan_total": round(sum(chain.values()), 1),
+            "map_bit_exact": bool(g["logodds"].tobytes() == ref_map.tobytes()), "map_cells_touched": int(np.count_nonzero(ref_map)),
+            "max_pose_err_vs_truth_xy": float(np.hypot(*(g["poses"][:, :2] - d["path"][:, :2]).T).max()),
+            "odometry_drift_max_xy": float(np.hypot(*(d["odom"][:, :2] - d["path"][:, :2]).T).max()),
+        }
+        if c:
+            out["cfg5"].update({"cpu_reference_scans_per_s": round(c["scans_per_s"], 2), "cpu_reference_seconds": round(c["seconds"], 1),
+                                "cpu_cores": 1, "max_pose_err_vs_reference": float(np.abs(g["poses"] - c["poses"]).max()),
+                                "reference_graph_edges": c["edges"], "edges_equal": bool(c["edges"] == st["edges"])})
+            cpus["cfg5_scans_per_s"] = out["cfg5"]["cpu_reference_scans_per_s"]
+            roof["cfg5_max_pose_err"] = out["cfg5"]["max_pose_err_vs_reference"]
+            roof["cfg5_edges_equal"] = out["cfg5"]["edges_equal"]
+        roof["cfg5_scans_per_s"] = out["cfg5"]["gpu_scans_per_s"]
+        roof["cfg5_loops_closed"] = st.get("loops_closed")
+        roof["cfg5_map_bit_exact"] = out["cfg5"]["map_bit_exact"]
+    out["roofline_summary"], out["cpu_summary"] = roof, cpus
+    return out
 
 
 def _free_port():
@@ -152,6 +519,11 @@ def main():
     ap.add_argument("--broadcast-grid", action="store_true", help="build the grid on rank 0 and RCCL-broadcast it")
     ap.add_argument("--no-diagnostics", action="store_true", help="skip the untimed pruning statistics / pruning-off step")
     ap.add_argument("--dump-results", default="", help="write the gathered 112-byte result records of the last step to this .npy")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the cfg 2 / 3 / 5 legs (N=1 only anyway)")
+    ap.add_argument("--map-scans", type=int, default=1000, help="cfg 2: scans integrated into the 1000x1000 map")
+    ap.add_argument("--single", type=int, default=200, help="cfg 3: complete MatchScan calls")
+    ap.add_argument("--stream-scans", type=int, default=600, help="cfg 5 slice: scans of the closed-loop trajectory")
+    ap.add_argument("--sustained-s", type=float, default=1.5, help="seconds of the untimed-by-contract sustained leg (0 = off)")
     args = ap.parse_args()
     backend = os.environ.get("LSLAM_BENCH_BACKEND", "nccl")  # gloo: the N>1 control flow on a 1-GPU box (tests)
 
@@ -202,6 +574,36 @@ def main():
     t_gen = time.perf_counter() - t_gen
     my_odom = np.ascontiguousarray(odom[lo:hi])
     n_mine = hi - lo
+
+    # ---- CPU legs: fork the workers now (no HIP / CUDA state in this process yet); they start when GO is set ------
+    global GO, GO_MULTI
+    do_cpu = (not args.no_cpu) and world_size == 1
+    do_secondary = do_cpu and not args.no_secondary
+    pool, tasks = None, {}
+    cores = args.cpu_cores or min(os.cpu_count() or 1, 64)
+    if do_cpu:
+        import multiprocessing as mp
+
+        from oracle import pyoracle as po
+
+        sample = max(8, min(args.cpu_sample, n_mine))
+        _JOB.update({"wl": wl, "q_r": synth.ranges_to_f64(my_ranges[:sample]), "q_p": my_odom[:sample]})
+        if do_secondary:
+            t_sec = time.perf_counter()
+            _JOB.update(secondary_workloads(args.map_scans, args.single, args.stream_scans, procs))
+            t_gen_secondary = time.perf_counter() - t_sec
+        fork = mp.get_context("fork")
+        GO, GO_MULTI = fork.Event(), fork.Event()
+        n_workers = 1 + (cores if po.have_ref() else 0) + (3 if do_secondary else 0)
+        pool = fork.Pool(n_workers, initializer=_quiet_worker)
+        if do_secondary:  # longest first
+            tasks["cfg5"] = pool.apply_async(_cpu_cfg5, (0,))
+        tasks["cfg4"] = pool.apply_async(_cpu_cfg4_single, (0,))
+        if do_secondary:
+            tasks["cfg3"] = pool.apply_async(_cpu_cfg3, (0,))
+            tasks["cfg2"] = pool.apply_async(_cpu_cfg2, (0,))
+        if po.have_ref():
+            tasks["cfg4_multi"] = [pool.apply_async(_cpu_cfg4_share, (i,)) for i in range(cores)]
 
     import torch
 
@@ -281,6 +683,17 @@ def main():
     prof = ctx.profile_read()  # the dominant kernel, timed live over the timed region
     ctx.profile_only(None)
 
+    # ---- sustained leg: the same step for >= --sustained-s seconds (clocks ramped, visible to a 1 Hz busy sampler).
+    # Reported beside `value`, never as it: `value` is the K steps of the contract above.
+    sustained = None
+    if args.sustained_s > 0 and n_mine:
+        n_sus = max(args.steps, int(args.sustained_s / max(elapsed / args.steps, 1e-6)) + 1)
+        el_sus = timed(n_sus)
+        sustained = {"steps": n_sus, "seconds": round(el_sus, 3), "ms_per_step": round(1e3 * el_sus / n_sus, 4),
+                     "value": round(n_total * n_sus / el_sus, 1), "unit": "scan-matches/s"}
+    if GO is not None:
+        GO.set()  # the host is free now: release the CPU legs
+
     # ---- "poses out": gather every rank's result records (112 B/scan), timed on its own --------------------------
     res_local = results[:n_mine]
     res_np = res_local.cpu().numpy().view(api.RESULT_DTYPE).reshape(-1)
@@ -330,6 +743,15 @@ def main():
         if distributed:
             dist.destroy_process_group()
         return
+
+    # ---- secondary configs on the GPU (the CPU legs are running beside them in their own processes) --------------
+    sec_gpu = {}
+    if do_secondary:
+        for name, fn in (("cfg2", gpu_cfg2), ("cfg3", gpu_cfg3), ("cfg5", gpu_cfg5)):
+            try:
+                sec_gpu[name] = fn(ctx, api, _JOB[name])
+            except Exception as e:  # a failed leg is reported, it does not take the headline down
+                sec_gpu[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     total_matches = n_total * args.steps
     value = total_matches / elapsed
@@ -393,48 +815,39 @@ def main():
             },
         })
 
-    # ---- CPU baseline on this box's host cores (rank 0, N=1 only) ------------------------------------------------
+    # ---- CPU baseline on this box's host cores (rank 0, N=1 only): collect the worker results -------------------
     cpu_baseline = None
-    if not args.no_cpu and world_size == 1:
-        from oracle import pyoracle as po
-
-        sample = max(8, min(args.cpu_sample, n_mine))
-        q_r, q_p = synth.ranges_to_f64(my_ranges[:sample]), my_odom[:sample]
-        if po.have_ref():
-            ref = po.RefKarto(po.default_cfg(), po.laser_struct(laser))
-            ref.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
-            sec, c_poses, c_covs, c_resp = ref.match_fixed_grid(q_r, q_p)
-            kind = "reference"
-        else:
-            po.build("restate")
-            port = po.PortKarto(po.default_cfg(), po.laser_struct(laser))
-            port.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
-            t1 = time.perf_counter()
-            c_poses = np.zeros((sample, 3))
-            c_resp = np.zeros(sample)
-            for i in range(sample):
-                m, _, r = port.match(q_r[i], q_p[i])
-                c_poses[i], c_resp[i] = m, r
-            sec = (time.perf_counter() - t1) / sample
-            kind = "port"
-        # the same run doubles as a parity check of the timed GPU results
-        g = res_np[:sample]
-        pose_err = float(np.abs(g["pose"] - c_poses).max())
-        resp_err = float(np.abs(g["response"] - c_resp).max())
+    secondary = None
+    if do_cpu:
+        c4 = tasks["cfg4"].get()
+        GO_MULTI.set()
+        sec, kind, sample = c4["sec_per_match"], c4["kind"], len(c4["poses"])
+        g = res_np[:sample]  # the same run doubles as a parity check of the timed GPU results
         cpu_baseline = {
             "value": round(1.0 / sec, 2), "unit": "scan-matches/s", "cores": 1, "kind": kind,
             "sample": f"{sample} of the batch's scans (coarse+fine CorrelateScan vs the same shared grid), "
                       f"{sec * sample:.1f} s on 1 of {os.cpu_count()} host cores",
-            "max_pose_err_vs_gpu": pose_err, "max_response_err_vs_gpu": resp_err,
+            "max_pose_err_vs_gpu": float(np.abs(g["pose"] - c4["poses"]).max()),
+            "max_response_err_vs_gpu": float(np.abs(g["response"] - c4["resp"]).max()),
         }
-        if kind == "reference":
+        if "cfg4_multi" in tasks:
             try:  # all-core figure beside the single-core one; never the headline baseline
-                cores = args.cpu_cores or min(os.cpu_count() or 1, 64)
-                rate, busy, wall = cpu_multicore(wl, q_r[:200], q_p[:200], cores)
-                cpu_baseline["multicore"] = {"value": round(rate, 1), "unit": "scan-matches/s", "cores": cores,
-                                             "sample": f"200 scan-matches per process, slowest process {busy:.2f} s"}
+                out = [t.get() for t in tasks["cfg4_multi"]]
+                busy = max(o[0] for o in out)
+                cpu_baseline["multicore"] = {"value": round(sum(o[1] for o in out) / busy, 1), "unit": "scan-matches/s",
+                                             "cores": cores, "sample": f"200 scan-matches per process, slowest process {busy:.2f} s"}
             except Exception as e:  # pragma: no cover
                 cpu_baseline["multicore"] = {"error": str(e)[:120]}
+    if do_secondary:
+        secondary = build_secondary(sec_gpu, {k: tasks[k].get() for k in ("cfg2", "cfg3", "cfg5")}, _JOB, args)
+        secondary["workload_gen_s"] = round(t_gen_secondary, 2)
+        # compact copies where the driver's record keeps nested objects
+        if roofline is not None:
+            roofline["secondary"] = secondary.get("roofline_summary")
+        cpu_baseline["secondary"] = secondary.get("cpu_summary")
+    if pool is not None:
+        pool.close()
+        pool.join()
 
     line = {
         "metric": "scan-matches/sec (1081-beam vs 2000x2000 grid)",
@@ -465,12 +878,15 @@ def main():
         # every kernel of one (untimed) profiled step; the dominant kernel's figure in `roofline` is the
         # live average over the timed region
         "kernel_ms_per_step": {k: round(v[1], 4) for k, v in sorted(prof_all.items())},
-        "roofline": roofline,
         "pruning": pruning,
+        "sustained": sustained,
+        "roofline": roofline,
         "cpu_baseline": cpu_baseline,
+        "secondary": secondary,
     }
     json_out.write(json.dumps(line) + "\n")
     json_out.flush()
+    os.dup2(os.open(os.devnull, os.O_WRONLY), 1)  # the reference library's exit chatter (std::cout) goes nowhere
     if distributed:
         dist.destroy_process_group()
 
