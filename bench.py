@@ -382,6 +382,15 @@ def gpu_cfg5(ctx, api, d):
     return {"seconds": sec, "poses": poses, "updated": upd, "stats": st, "logodds": logodds, "prof": prof, "n": n, "cell": cell, "off": off}
 
 
+def _source_sha(path):
+    import hashlib
+
+    try:
+        return hashlib.sha256(pathlib.Path(path).read_bytes()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def _traffic(name):
     """PMC figures per launch from profiles/traffic.json (static: `rocprofv3 --pmc` passes, tools/pmc_passes.sh)."""
     try:
@@ -797,7 +806,17 @@ def main():
         else:
             roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(hbm_alg, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(hbm_alg / HBM_PEAK_GBS, 5)}
+        # the PMC inputs are static files: tools/make_traffic.py records the hash of the kernel source they were
+        # collected from; a different source today means `frac` / `traffic` describe an older kernel
+        meta = {}
+        try:
+            meta = json.loads(tfile.read_text()).get("_meta", {})
+        except Exception:
+            pass
+        src_now = _source_sha(ROOT / "creating-2d-laser-slam-from-scratch_amd" / "csrc" / "scan_matcher.hip")
         roofline.update({
+            "pmc_inputs_stale": (meta.get("source_sha256", {}).get("scan_matcher.hip") != src_now),
+            "pmc_inputs_source_sha256": meta.get("source_sha256", {}).get("scan_matcher.hip"),
             "avg_launch_ms": round(avg_ms, 4),
             "traffic": rec.get("hbm_bytes_per_launch"),
             "traffic_source": (rec.get("source", "profiles/traffic.json") + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "

@@ -63,7 +63,8 @@ __device__ __forceinline__ Aff3 mul(const Aff3& a, const Aff3& b) {
 struct DeskewCfg {
   int n, n_imu_last;  // n_imu_last = current_imu_index_ (index of the last integrated IMU sample)
   float range_min, range_max;
-  double angle_min, angle_inc, t0, dt;
+  float angle_min, angle_inc;  // the LaserScan message's float32 fields
+  double t0, dt;
   int use_imu, use_odom;
   double odom_t0, odom_t1;
   float odom_dx, odom_dy, odom_dz;
@@ -120,7 +121,10 @@ k_deskew(DeskewCfg c, const float* __restrict__ ranges, const double* __restrict
     valid[i] = ok ? 1 : 0;
     float x = 0.f, y = 0.f, z = 0.f;
     if (ok) {
-      const double a = c.angle_min + (double)i * c.angle_inc;  // a_cos_ / a_sin_ (:164-173): double cos/sin per beam
+      // CreateAngleCache (:164-173): the angle is evaluated in FLOAT32 (angle_min + i * angle_increment on the message's
+      // float fields), then widened for the double cos / sin
+      const float af = c.angle_min + (float)i * c.angle_inc;
+      const double a = (double)af;
       const double px = (double)ranges[i] * cos(a), py = (double)ranges[i] * sin(a), pz = 1.0;  // :361-362, :343
       const Aff3 bt = mul(s_start_inv, transform_at(c, i, imu_time, rx, ry, rz));             // :386-390
       x = (float)((((double)bt.l[0] * px + (double)bt.l[1] * py) + (double)bt.l[2] * pz) + (double)bt.t[0]);  // :394-396
@@ -168,7 +172,7 @@ int lslam_deskew_scan(lslam_context* ctx, const float* ranges, int n, const lsla
   DeskewCfg c;
   c.n = n; c.n_imu_last = ni - 1;
   c.range_min = p->range_min; c.range_max = p->range_max;
-  c.angle_min = (double)p->angle_min; c.angle_inc = (double)p->angle_increment;
+  c.angle_min = p->angle_min; c.angle_inc = p->angle_increment;
   c.t0 = p->scan_time_start; c.dt = p->time_increment;
   c.use_imu = p->use_imu; c.use_odom = p->use_odom;
   c.odom_t0 = p->start_odom_time; c.odom_t1 = p->end_odom_time;

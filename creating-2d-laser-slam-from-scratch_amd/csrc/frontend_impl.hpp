@@ -67,6 +67,7 @@ inline size_t fe_anchor_lds(int n) { return (size_t)n * (sizeof(double2) + 13) +
 int fe_grow(lslam_frontend* f, int need) {
   if (need <= f->cap) return LSLAM_OK;
   lslam_context* ctx = f->m->ctx;
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));  // a pool may have left the calling thread on another device
   const size_t n = (size_t)std::max(f->m->g.n_beams, 1);
   int cap = std::max(256, f->cap);
   while (cap < need) cap *= 2;
@@ -358,6 +359,7 @@ int lslam_frontend_create_ex(lslam_matcher* m, const lslam_frontend_config* cfg,
   if (!m || !cfg || !out || cfg->scan_buffer_size < 1) return LSLAM_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   lslam_context* ctx = m->ctx;
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));  // every allocation below belongs to the matcher's device
   lslam_frontend* f = new lslam_frontend();
   f->m = m;
   f->cfg = *cfg;
@@ -411,6 +413,7 @@ int lslam_frontend_create(lslam_matcher* m, int scan_buffer_size, double scan_bu
 
 void lslam_frontend_destroy(lslam_frontend* f) {
   if (!f) return;
+  (void)hipSetDevice(f->m->ctx->device);
   (void)hipStreamSynchronize(f->m->ctx->stream);
   if (f->loop_m) lslam_matcher_destroy(f->loop_m);
   if (f->d_world) (void)hipFree(f->d_world);

@@ -22,6 +22,7 @@
 // cells; nothing here is GEMM-shaped.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -181,6 +182,100 @@ k_logodds_apply(LevelGeom g, const float* __restrict__ pts, int n, const uint32_
       logodds[eoff] = v;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// ONE-LAUNCH single-scan update (containers of <= kOneMaxPoints points; BASELINE config 2 as stated: one 1081-beam
+// scan per call).  The two kernels above are two dependent ~10 us launches whose only link is "apply needs every mark".
+// Here the order-dependent part is confined to the scan's HIT cells, and those are few (<= n):
+//   phase 0  every block builds, in LDS, the complete set of the scan's end cells with the smallest beam index ending in
+//            each (open addressing, LDS atomics): n beam_line evaluations per block -- redundant, but ~1 us and it removes
+//            the grid-wide dependency;
+//   phase 1  wave per beam, closed-form Bresenham cells.  A crossed cell that is NOT an end cell gets +free from whichever
+//            beam ARRIVES first (returning atomicMax on the free-key plane: old epoch != this scan's -> first).  The value
+//            added is the same whoever wins, and the winner is the cell's only writer in this launch, so the float plane
+//            is bit-identical to the sequential walk.  A crossed END cell only records its key (min crossing beam index).
+//   phase 2  the LAST block to finish (agent-scope ticket) walks its own LDS set: for each end cell, "crossed by a beam
+//            with a smaller index than the first beam ending here" -> (v + free) - free, then +occ if v < 50
+//            (H/map/OccGridMapBase.h:316-330).  No spinning, no co-residency requirement.
+// ------------------------------------------------------------------------------------------
+constexpr int kOneMaxPoints = 2048;
+constexpr int kOneSlots = 4096;  // LDS hash: 2 x 16 KB
+constexpr int kOneThreads = 1024;
+
+__global__ void __launch_bounds__(kOneThreads)
+k_logodds_one(LevelGeom g, const float* __restrict__ pts, int n, uint32_t* __restrict__ free_key,
+              float* __restrict__ logodds, unsigned* __restrict__ ticket) {
+  __shared__ uint32_t s_key[kOneSlots];   // end cell + 1 (0 = empty)
+  __shared__ uint32_t s_beam[kOneSlots];  // smallest beam index ending there
+  __shared__ unsigned s_last;
+  for (int t = threadIdx.x; t < kOneSlots; t += kOneThreads) {
+    s_key[t] = 0u;
+    s_beam[t] = 0xffffffffu;
+  }
+  __syncthreads();
+  // ---- phase 0: the scan's end cells ------------------------------------------------------------------------------
+  for (int b = threadIdx.x; b < n; b += kOneThreads) {
+    const Line l = beam_line(g, pts, b);
+    if (!l.valid) continue;
+    const uint32_t cell = (uint32_t)(l.y1 * g.sx + l.x1);
+    uint32_t slot = (cell * 2654435761u) >> 20;  // 12 bits
+    for (;;) {
+      const uint32_t old = atomicCAS(&s_key[slot], 0u, cell + 1u);
+      if (old == 0u || old == cell + 1u) break;
+      slot = (slot + 1u) & (kOneSlots - 1);
+    }
+    atomicMin(&s_beam[slot], (uint32_t)b);
+  }
+  __syncthreads();
+  // ---- phase 1: the rays ---------------------------------------------------------------------------------------------
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (kOneThreads >> 6) + (threadIdx.x >> 6);
+  if (i < n) {
+    const Line l = beam_line(g, pts, i);
+    if (l.valid) {
+      const uint32_t key = (g.epoch << kBeamBits) | (kBeamMask - (uint32_t)i);
+      const Ray r = ray_of(l, g.sx);
+      for (unsigned c = lane; c < r.abs_da; c += 64) {
+        const unsigned cell = ray_cell(r, c);
+        bool is_end = false;
+        uint32_t slot = (cell * 2654435761u) >> 20;
+        for (;;) {
+          const uint32_t k = s_key[slot];
+          if (k == 0u) break;
+          if (k == cell + 1u) {
+            is_end = true;
+            break;
+          }
+          slot = (slot + 1u) & (kOneSlots - 1);
+        }
+        const uint32_t old = atomicMax(&free_key[cell], key);
+        if (!is_end && (old >> kBeamBits) != g.epoch) logodds[cell] = logodds[cell] + g.lo_free;  // first arrival: the one writer
+      }
+    }
+  }
+  // ---- phase 2: the last block applies the end cells ---------------------------------------------------------------
+  __threadfence();  // release: this block's keys and float stores are visible device-wide before its ticket
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();  // acquire
+  for (int t = threadIdx.x; t < kOneSlots; t += kOneThreads) {
+    const uint32_t k = s_key[t];
+    if (k == 0u) continue;
+    const unsigned cell = k - 1u;
+    const uint32_t me = kBeamMask - s_beam[t];
+    const uint32_t fk = __hip_atomic_load(&free_key[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float v = logodds[cell];  // nobody touched an end cell's float in this launch
+    if ((fk >> kBeamBits) == g.epoch && (fk & kBeamMask) > me) {  // crossed by an EARLIER beam: free then unset (:323-326)
+      v += g.lo_free;
+      v -= g.lo_free;
+    }
+    if (v < 50.0f) v += g.lo_occ;  // updateSetOccupied (H/map/GridMapLogOdds.h:108-114)
+    logodds[cell] = v;
+  }
+  if (threadIdx.x == 0) *ticket = 0u;  // ready for the next launch (stream order)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -659,9 +754,11 @@ struct lslam_map {
   int cs_n = 0;
   int n_scan = 0;
   float scan_origo[2] = {0.f, 0.f};
+  DevBuf<unsigned> d_ticket;    // k_logodds_one's finished-block counter (returns to 0 at the end of every launch)
   DevBuf<uint32_t> d_hash;      // [3][K][slots]: key, first hit beam, first crossing beam
   DevBuf<ScanHdr> d_hdr;
   DevBuf<int8_t> d_i8;
+  bool force_two_kernels = false;  // LSLAM_MAP_TWO_KERNELS=1: the round-1/2 mark + apply pair (A/B measurements, tests)
   // host -> device staging of the per-scan points: a ring of pinned slots, so updateByScan only enqueues
   // (copy + two kernels per level) and returns; a slot is reused when its copy has completed
   static constexpr int kStageSlots = 8;
@@ -734,7 +831,10 @@ int update_impl(lslam_map* map, const float* d_pts, int n, const float* origo, c
     float byf = (g.s * ox + g.c * oy) + my;
     g.bx = (int)(bxf + 0.5f);                   // :135
     g.by = (int)(byf + 0.5f);
-    if (n > 0) {
+    if (n > 0 && n <= kOneMaxPoints && !map->force_two_kernels) {
+      launch(ctx, "logodds_one", k_logodds_one, dim3((n + (kOneThreads >> 6) - 1) / (kOneThreads >> 6)), dim3(kOneThreads), 0,
+             g, d_pts, n, L.d_free, L.d_logodds, map->d_ticket.p);
+    } else if (n > 0) {
       dim3 grid((n + 3) / 4), block(256);  // 4 waves per block, one wave per beam
       launch(ctx, "logodds_mark", k_logodds_mark, grid, block, 0, g, d_pts, n, L.d_free, L.d_occ);
       launch(ctx, "logodds_apply", k_logodds_apply, grid, block, 0, g, d_pts, n, (const uint32_t*)L.d_free,
@@ -787,6 +887,15 @@ int lslam_map_create(lslam_context* ctx, int size_x, int size_y, float cell_leng
     sy /= 2;
     cl *= 2.0f;  // :84
   }
+  if (map->d_ticket.reserve(1) != hipSuccess) {
+    lslam_map_destroy(map);
+    return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the map's scratch in HBM");
+  }
+  (void)hipMemsetAsync(map->d_ticket.p, 0, sizeof(unsigned), ctx->stream);
+  {
+    const char* e = getenv("LSLAM_MAP_TWO_KERNELS");
+    map->force_two_kernels = e && e[0] == '1';
+  }
   (void)hipStreamSynchronize(ctx->stream);
   *out = map;
   return LSLAM_OK;
@@ -807,6 +916,7 @@ void lslam_map_destroy(lslam_map* map) {
   map->d_cached.release();
   map->d_gn_out.release();
   map->d_hash.release();
+  map->d_ticket.release();
   map->d_hdr.release();
   map->d_scan.release();
   map->d_scan_ranges.release();

@@ -111,6 +111,15 @@ int lslam_pool_set_base_scans(lslam_pool* p, int n_scans, const double* ranges, 
       return rc;
     }
   }
+  // the peer copies read device 0's grid: nobody may rebuild it (a second set_base_scans, direct use of matcher 0)
+  // before they have landed
+  for (size_t d = 1; d < p->m.size(); d++) {
+    rc = lslam_synchronize(p->ctx[d]);
+    if (rc) {
+      p->last_error = lslam_last_error(p->ctx[d]);
+      return rc;
+    }
+  }
   return LSLAM_OK;
 }
 

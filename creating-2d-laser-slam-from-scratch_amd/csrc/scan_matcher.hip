@@ -2602,6 +2602,12 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
                      int32_t* dbg_coarse_sums /*device, optional*/, int force_generic) {
   lslam_context* ctx = m->ctx;
   Geom g = m->g;
+  // what the last grid rebuild prepared for THIS match (streaming front-end); consumed here whatever path the match
+  // takes, error returns included, so that no later match can find stale flags
+  const bool prep_was_done = m->prep_done;
+  size_t prezeroed = m->resp_prezeroed;
+  m->prep_done = false;
+  m->resp_prezeroed = 0;
   if (S <= 0) return LSLAM_OK;
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
   if (g.n_beams == 0) {
@@ -2650,12 +2656,10 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
                m->cfg.minimum_distance_penalty, m->cfg.minimum_angle_penalty, do_penalize};
 
   // scan_prep also lays out the coarse lattice of pass 0 (mode 0 needs only the pose): one launch fewer
-  if (m->prep_done && S == 1)  // k_rebuild_begin's extra blocks did it (streaming front-end)
-    m->prep_done = false;
-  else
+  if (prep_was_done && S == 1) {  // k_rebuild_begin's extra blocks did it (streaming front-end)
+  } else
     launch(ctx, "scan_prep", k_scan_prep<RT>, dim3(S >= kReduceNarrowMinScans ? 1 : (g.n_beams + 255) / 256, S), dim3(256), 0, d_ranges,
            stride, d_poses, g, m->d_local.p, (double2*)nullptr, pc, m->d_lat.p, m->d_cossin.p, 2, PoseArg{});
-  m->prep_done = false;
   bool setup_done = true;  // consumed by the first pass
 
 
@@ -2732,7 +2736,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       while ((g.n_beams + 64 * slices - 1) / (64 * slices) > kMaxBeamsPerLane) slices *= 2;  // packed 16-bit sums
       if (slices > 1) {
         if (step == 1 && fine_prezeroed) fine_prezeroed = false;  // k_reduce_coarse_lds cleared the fine numerators
-        else if (m->resp_prezeroed >= (size_t)S * resp_stride) m->resp_prezeroed = 0;  // k_rebuild_begin cleared it; one use
+        else if (prezeroed >= (size_t)S * resp_stride) prezeroed = 0;  // k_rebuild_begin cleared it; one use
         else LSLAM_HIP(ctx, hipMemsetAsync(m->d_resp.p, 0, (size_t)S * resp_stride * sizeof(int32_t), ctx->stream));
       }
       dim3 grid((unsigned)(waves * slices));

@@ -80,7 +80,7 @@ def restated_deskew(r, p, imu_time, imu_rot):
         if not np.isfinite(ri) or ri < f32(p.range_min) or ri > f32(p.range_max):
             continue
         valid[i] = True
-        a = float(f32(p.angle_min)) + i * float(f32(p.angle_increment))
+        a = float(f32(f32(p.angle_min) + f32(i) * f32(p.angle_increment)))  # float32 like CreateAngleCache (:169)
         px, py, pz = float(ri) * math.cos(a), float(ri) * math.sin(a), 1.0
         cur = transform_at(i)
         if start_inv is None:

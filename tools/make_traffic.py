@@ -55,6 +55,14 @@ def main(path, scans):
             rec["l2_hit"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3)
         rec = {k: v for k, v in rec.items() if v is not None}
         out[short] = rec
+    # which kernel source these counters describe: bench.py flags `roofline` as stale when the file has changed since
+    import hashlib
+    import pathlib
+
+    csrc = pathlib.Path(__file__).resolve().parent.parent / "creating-2d-laser-slam-from-scratch_amd" / "csrc"
+    out["_meta"] = {"source_sha256": {f: hashlib.sha256((csrc / f).read_bytes()).hexdigest()[:16]
+                                      for f in ("scan_matcher.hip", "logodds_map.hip")},
+                    "note": "hash of the kernel sources at the time of the PMC passes (tools/pmc_passes.sh)"}
     json.dump(out, sys.stdout, indent=1)
     print()
 
