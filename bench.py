@@ -643,7 +643,7 @@ def main():
     if args.broadcast_grid and distributed:
         if rank == 0:
             gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
-        shard.broadcast_grid(gm, coll_dev, src=0)  # RCCL broadcast of the 4 MB grid
+        shard.broadcast_grid(gm, coll_dev, src=0, install_device=dev)  # RCCL broadcast of the 4 MB grid
     else:
         gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)  # redundant build: cheaper than the broadcast
     ranges32 = torch.from_numpy(np.ascontiguousarray(my_ranges)).to(dev)
@@ -668,6 +668,7 @@ def main():
             step()
         barrier()  # stream + device sync, then the RCCL barrier: the timed region is bracketed on both sides
         el = time.perf_counter() - t0
+        timed.local = el  # this rank's own clock over the region (reported per rank in the N > 1 line)
         if distributed:
             t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -691,6 +692,12 @@ def main():
     ctx.profile(False)
     prof = ctx.profile_read()  # the dominant kernel, timed live over the timed region
     ctx.profile_only(None)
+    per_rank_ms = None
+    if distributed:  # every rank's own time per step: a measured scaling curve can be diagnosed (stragglers, small-batch floor)
+        t = torch.tensor([timed.local], dtype=torch.float64, device=coll_dev)
+        parts = [torch.zeros_like(t) for _ in range(world_size)]
+        dist.all_gather(parts, t)
+        per_rank_ms = [round(1e3 * float(x.item()) / args.steps, 4) for x in parts]
 
     # ---- sustained leg: the same step for >= --sustained-s seconds (clocks ramped, visible to a 1 Hz busy sampler).
     # Reported beside `value`, never as it: `value` is the K steps of the contract above.
@@ -893,6 +900,7 @@ def main():
         },
         "results_ok": n_ok_all,
         "gather_ms": None if gather_ms is None else round(gather_ms, 4),
+        "per_rank_ms_per_step": per_rank_ms,
         "workload_gen_s": round(t_gen, 2),
         # every kernel of one (untimed) profiled step; the dominant kernel's figure in `roofline` is the
         # live average over the timed region

@@ -275,6 +275,10 @@ def lib() -> C.CDLL:
     L.lslam_occgrid_counter_words.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.lslam_occgrid_export_counters.argtypes = [vp, vp, i32]
     L.lslam_occgrid_import_counters.argtypes = [vp, vp, i32, i32]
+    L.lslam_occgrid_counters_dev_ptr.restype = vp
+    L.lslam_occgrid_counters_dev_ptr.argtypes = [vp]
+    L.lslam_occgrid_create_sharded.argtypes = [vp, C.POINTER(LaserParams), i32, vp, i32, vp, dbl, vp, C.POINTER(vp)]
+    L.lslam_pool_occgrid_from_scans.argtypes = [vp, C.POINTER(LaserParams), i32, vp, i32, vp, dbl, C.POINTER(vp)]
     L.lslam_map_create.argtypes = [vp, i32, i32, C.c_float, C.c_float, C.c_float, i32, C.POINTER(vp)]
     L.lslam_map_destroy.argtypes = [vp]
     L.lslam_map_destroy.restype = None
@@ -599,6 +603,23 @@ class MatcherPool:
         self._check(self.L.lslam_pool_set_base_scans(self.h, r.shape[0], r.ctypes.data, r.shape[1], p.ctypes.data,
                                                      c.ctypes.data, int(rebuild_everywhere)))
 
+    def CreateOccupancyGrid(self, laser: LaserParams, ranges, sensor_poses, resolution: float):
+        """OccupancyGrid::CreateFromScans sharded over the pool's devices in this one process: RCCL (ncclCommInitAll +
+        all-reduce) when the devices are distinct, counter addition on the first device otherwise.  Returns
+        (cells [h, w] uint8, offset_xy)."""
+        r, p = _f64(ranges), _f64(sensor_poses)
+        r = r.reshape(-1, r.shape[-1])
+        h = C.c_void_p()
+        self._check(self.L.lslam_pool_occgrid_from_scans(self.h, C.byref(laser), r.shape[0], r.ctypes.data, r.shape[1],
+                                                         p.ctypes.data, float(resolution), C.byref(h)))
+        dims, off, res = np.zeros(2, np.int32), np.zeros(2), C.c_double()
+        self.L.lslam_occgrid_info(h, dims.ctypes.data, off.ctypes.data, C.byref(res))
+        out = np.zeros((int(dims[1]), int(dims[0])), dtype=np.uint8)
+        rc = self.L.lslam_occgrid_read_u8(h, out.ctypes.data)
+        self.L.lslam_occgrid_destroy(h)
+        self._check(rc)
+        return out, off
+
     def match_batch(self, ranges, sensor_poses, doPenalize: bool = True, doRefineMatch: bool = True) -> np.ndarray:
         r, p = _f64(ranges), _f64(sensor_poses)
         r = r.reshape(-1, r.shape[-1])
@@ -704,6 +725,17 @@ class OccupancyGrid:
         h = C.c_void_p()
         ctx.check(ctx.L.lslam_occgrid_create_partial(ctx.h, C.byref(laser), r.shape[0], r.ctypes.data, r.shape[1],
                                                      p.ctypes.data, resolution, b.ctypes.data, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def CreateSharded(cls, ctx: Context, laser: LaserParams, ranges, sensor_poses, resolution: float, nccl_comm: int):
+        """This rank's scans in, the grid of ALL ranks' scans out: box all-reduce + ONE counter all-reduce, RCCL called by
+        the library itself on the context stream (lslam_occgrid_create_sharded).  nccl_comm: an ncclComm_t handle."""
+        r, p = _f64(ranges), _f64(sensor_poses)
+        r = r.reshape(-1, r.shape[-1]) if r.size else r.reshape(0, 1)
+        h = C.c_void_p()
+        ctx.check(ctx.L.lslam_occgrid_create_sharded(ctx.h, C.byref(laser), r.shape[0], r.ctypes.data, r.shape[1], p.ctypes.data,
+                                                     float(resolution), C.c_void_p(nccl_comm), C.byref(h)))
         return cls(ctx, h)
 
     def counter_words(self) -> int:

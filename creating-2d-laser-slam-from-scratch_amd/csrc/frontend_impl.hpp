@@ -39,9 +39,20 @@ struct lslam_frontend_scan {
   std::vector<std::pair<int, int>> edges;  // Vertex::m_Edges: (source, target) in insertion order
 };
 
+// One more loop matcher on its own HIP stream: the candidate chains of one TryCloseLoop are matched side by side
+struct lslam_loop_slot {
+  lslam_context* ctx = nullptr;  // owned: a second stream on the matcher's device
+  lslam_matcher* m = nullptr;    // owned: same parameters as loop_m
+  DevBuf<double> d_q;
+  lslam_match_result* h_res = nullptr;  // pinned
+};
+
 struct lslam_frontend {
   lslam_matcher* m = nullptr;
   lslam_matcher* loop_m = nullptr;  // MapperGraph::m_pLoopScanMatcher (owned)
+  std::vector<lslam_loop_slot> loop_pool;  // slots 1..P-1 of the speculative loop search (slot 0 = loop_m itself)
+  hipEvent_t ev_ready = nullptr;           // "everything the main stream wrote so far", awaited by the pool streams
+  int64_t n_loop_discarded = 0;            // speculative coarse matches thrown away because an earlier chain closed
   lslam_frontend_config cfg;
   std::vector<lslam_frontend_scan> scans;  // MapperSensorManager::GetScans, by state id
   int run_start = 0, run_count = 0;        // running scans = ids [run_start, run_start + run_count)
@@ -142,23 +153,16 @@ int fe_update_world(lslam_frontend* f, int id) {
 }
 
 // ScanMatcher::MatchScan(pScan, chain, mean, covariance, doPenalize, doRefineMatch) (Mapper.cpp:184-291) of resident
-// scan `id`, posed at `sensor`, against the resident scans [first, first + count)
-int fe_match(lslam_frontend* f, lslam_matcher* m, int id, const double sensor[3], int first, int count, int do_penalize,
-             int do_refine, lslam_match_result* out) {
-  lslam_context* ctx = m->ctx;
+// scan `id`, posed at `sensor`, against the resident scans [first, first + count): ENQUEUE on m's stream (grid rebuild +
+// search; the last kernel writes the 112-byte record into the pinned h_res), fe_match_finish waits for it.
+int fe_match_enqueue(lslam_frontend* f, lslam_matcher* m, double* d_q, lslam_match_result* h_res, int id, const double sensor[3],
+                     int first, int count, int do_penalize, int do_refine) {
   const int n = f->m->g.n_beams;
-  if (n <= 0) {  // scan without readings (Mapper.cpp:199-209): rMean = scanPose
-    memset(out, 0, sizeof *out);
-    for (int i = 0; i < 3; i++) out->pose[i] = sensor[i];
-    out->covariance[0] = out->covariance[4] = kMaxVariance;
-    out->covariance[8] = 4 * ksq(m->cfg.coarse_angle_resolution);
-    return LSLAM_OK;
-  }
   // the grid rebuild's first kernel also carries the query pose into device memory and clears the numerators of the
   // match's first (beam-sliced) pass: two stream operations fewer per scan
   RebuildExtras x{};
   for (int i = 0; i < 3; i++) x.pose[i] = sensor[i];
-  x.pose_dst = f->d_q.p;
+  x.pose_dst = d_q;
   x.zero = m->d_resp.p;
   x.anchor_ring = fe_anchor_lds(n) <= 60 * 1024 ? f->d_next : nullptr;
   x.zero_words = (int)std::min<size_t>(m->d_resp.cap, (size_t)1 << 16);
@@ -173,12 +177,30 @@ int fe_match(lslam_frontend* f, lslam_matcher* m, int id, const double sensor[3]
   int rc = rebuild_grid_dev(m, f->d_world, first, count, f->cap, sensor, &x);
   if (rc) return rc;
   // the last kernel of the match writes the 112-byte record straight into pinned host memory: no copy operation
-  rc = match_batch_impl<double>(m, 1, f->d_ranges + (size_t)id * n, n, f->d_q.p, do_penalize, do_refine, f->h_res, nullptr, 0);
-  if (rc) return rc;
+  return match_batch_impl<double>(m, 1, f->d_ranges + (size_t)id * n, n, d_q, do_penalize, do_refine, h_res, nullptr, 0);
+}
+int fe_match_finish(lslam_matcher* m, const lslam_match_result* h_res, lslam_match_result* out) {
+  lslam_context* ctx = m->ctx;
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  *out = *f->h_res;
+  *out = *h_res;
   if (out->status != LSLAM_OK) return ctx->fail(out->status, "scan matcher: the reference throws here");
   return LSLAM_OK;
+}
+int fe_match(lslam_frontend* f, lslam_matcher* m, int id, const double sensor[3], int first, int count, int do_penalize,
+             int do_refine, lslam_match_result* out) {
+  const int n = f->m->g.n_beams;
+  if (n <= 0) {  // scan without readings (Mapper.cpp:199-209): rMean = scanPose
+    memset(out, 0, sizeof *out);
+    for (int i = 0; i < 3; i++) out->pose[i] = sensor[i];
+    out->covariance[0] = out->covariance[4] = kMaxVariance;
+    out->covariance[8] = 4 * ksq(m->cfg.coarse_angle_resolution);
+    return LSLAM_OK;
+  }
+  int rc = fe_match_enqueue(f, m, f->d_q.p, f->h_res, id, sensor, first, count, do_penalize, do_refine);
+  if (rc) return rc;
+  rc = fe_match_finish(m, f->h_res, out);
+  if (rc && m->ctx != f->m->ctx) f->m->ctx->last_error = m->ctx->last_error;
+  return rc;
 }
 
 // MapperGraph::AddEdge + LinkScans (Mapper.cpp:1072-1121): a new edge unless `from` already has one whose target is `to`
@@ -294,39 +316,102 @@ std::pair<int, int> fe_possible_loop_closure(const lslam_frontend* f, int id, co
   return {first, count};  // the reference returns whatever is left when the scans run out
 }
 
-// TryCloseLoop (Mapper.cpp:976-1051), one sensor
+// TryCloseLoop (Mapper.cpp:976-1051), one sensor.
+//
+// The reference matches the candidate chains strictly one after another; 98.7 % of those coarse matches close nothing
+// (10 000-scan run), and each is a lone ~0.1 ms chain of small kernels on an otherwise idle chip.  A chain's coarse
+// match reads only the graph and the poses as they stand, and neither changes unless a loop CLOSES.  So the next few
+// chains FindPossibleLoopClosure would return are enumerated up front, their coarse matches run side by side on a small
+// pool of loop matchers (own grids and workspaces, own streams), and the results are consumed in the reference's order.
+// When a chain closes (scan re-posed, edge added) the speculative results behind it are discarded and the search resumes
+// from the reference's rStartNum with the new state -- every accepted result is the one the sequential walk computes.
+int fe_close_after_coarse(lslam_frontend* f, int id, const std::pair<int, int>& chain, const lslam_match_result& coarse,
+                          bool* closed) {
+  *closed = false;
+  if (coarse.response > f->cfg.loop_match_minimum_response_coarse &&
+      coarse.covariance[0] < f->cfg.loop_match_maximum_variance_coarse &&
+      coarse.covariance[4] < f->cfg.loop_match_maximum_variance_coarse) {
+    lslam_match_result fine;  // tmpScan.SetSensorPose(bestPose); MatchScan(&tmpScan, chain, ..., false)
+    int rc = fe_match(f, f->m, id, coarse.pose, chain.first, chain.second, 0, 1, &fine);
+    if (rc) return rc;
+    f->n_loop_fine++;
+    if (!(fine.response < f->cfg.loop_match_minimum_response_fine)) {
+      fe_set_sensor_pose(f, f->scans[id], fine.pose);  // pScan->SetSensorPose(bestPose)
+      rc = fe_update_world(f, id);
+      if (rc) return rc;
+      fe_link_chain_to_scan(f, chain.first, chain.second, id);
+      f->n_loops_closed++;  // CorrectPoses(): no ScanSolver attached
+      *closed = true;
+    }
+  }
+  return LSLAM_OK;
+}
+
 int fe_try_close_loop(lslam_frontend* f, int id) {
+  lslam_context* ctx = f->m->ctx;
   int start_num = 0;
-  auto next_chain = [&]() {
+  // speculation is off while kernels are being timed (the pool's streams are not the profiled one)
+  const size_t width = ctx->timer.enabled ? 1 : 1 + f->loop_pool.size();
+  for (;;) {
     // FindPossibleLoopClosure recomputes the near-linked set on every call (the graph may have gained an edge)
     std::vector<char> linked(f->scans.size(), 0);
     for (int v : fe_near_linked(f, id, f->cfg.loop_search_maximum_distance)) linked[v] = 1;
-    return fe_possible_loop_closure(f, id, linked, start_num);
-  };
-  std::pair<int, int> chain = next_chain();
-  while (chain.second > 0) {
-    lslam_match_result coarse;
-    int rc = fe_match(f, f->loop_m, id, f->scans[id].sensor, chain.first, chain.second, 0, 0, &coarse);
-    if (rc) return rc;
-    f->n_loop_coarse++;
-    if (coarse.response > f->cfg.loop_match_minimum_response_coarse &&
-        coarse.covariance[0] < f->cfg.loop_match_maximum_variance_coarse &&
-        coarse.covariance[4] < f->cfg.loop_match_maximum_variance_coarse) {
-      lslam_match_result fine;  // tmpScan.SetSensorPose(bestPose); MatchScan(&tmpScan, chain, ..., false)
-      rc = fe_match(f, f->m, id, coarse.pose, chain.first, chain.second, 0, 1, &fine);
+    std::vector<std::pair<int, int>> chains;
+    std::vector<int> resume;  // rStartNum after each chain was found
+    int sn = start_num;
+    while (chains.size() < width) {
+      const std::pair<int, int> c = fe_possible_loop_closure(f, id, linked, sn);
+      if (c.second <= 0) break;
+      chains.push_back(c);
+      resume.push_back(sn);
+    }
+    if (chains.empty()) return LSLAM_OK;
+    bool closed = false;
+    if (chains.size() == 1) {
+      lslam_match_result coarse;
+      int rc = fe_match(f, f->loop_m, id, f->scans[id].sensor, chains[0].first, chains[0].second, 0, 0, &coarse);
       if (rc) return rc;
-      f->n_loop_fine++;
-      if (!(fine.response < f->cfg.loop_match_minimum_response_fine)) {
-        fe_set_sensor_pose(f, f->scans[id], fine.pose);  // pScan->SetSensorPose(bestPose)
-        rc = fe_update_world(f, id);
-        if (rc) return rc;
-        fe_link_chain_to_scan(f, chain.first, chain.second, id);
-        f->n_loops_closed++;  // CorrectPoses(): no ScanSolver attached
+      f->n_loop_coarse++;
+      rc = fe_close_after_coarse(f, id, chains[0], coarse, &closed);
+      if (rc) return rc;
+      start_num = resume[0];
+      continue;  // closed or not: the next round re-reads the graph, like the reference's next FindPossibleLoopClosure
+    }
+    // ---- several chains: all coarse matches in flight at once ----
+    LSLAM_HIP(ctx, hipEventRecord(f->ev_ready, ctx->stream));  // the scan's world points etc. are ordered before this
+    for (size_t k = 0; k < chains.size(); k++) {
+      lslam_matcher* lm = k == 0 ? f->loop_m : f->loop_pool[k - 1].m;
+      if (k > 0) LSLAM_HIP(ctx, hipStreamWaitEvent(lm->ctx->stream, f->ev_ready, 0));
+      int rc = fe_match_enqueue(f, lm, k == 0 ? f->d_q.p : f->loop_pool[k - 1].d_q.p, k == 0 ? f->h_res : f->loop_pool[k - 1].h_res,
+                                id, f->scans[id].sensor, chains[k].first, chains[k].second, 0, 0);
+      if (rc) {
+        if (k > 0) ctx->last_error = lm->ctx->last_error;
+        for (size_t j = 0; j < k; j++) (void)hipStreamSynchronize((j == 0 ? f->loop_m : f->loop_pool[j - 1].m)->ctx->stream);
+        return rc;
       }
     }
-    chain = next_chain();
+    // wait for all of them (the slowest sets the pace either way), then consume in the reference's order
+    std::vector<lslam_match_result> res(chains.size());
+    std::vector<int> rcs(chains.size(), LSLAM_OK);
+    for (size_t k = 0; k < chains.size(); k++) {
+      lslam_matcher* lm = k == 0 ? f->loop_m : f->loop_pool[k - 1].m;
+      rcs[k] = fe_match_finish(lm, k == 0 ? f->h_res : f->loop_pool[k - 1].h_res, &res[k]);
+      if (rcs[k] && k > 0) ctx->last_error = lm->ctx->last_error;
+    }
+    size_t used = 0;
+    for (size_t k = 0; k < chains.size(); k++) {
+      if (closed) {  // a chain before this one closed the loop: the sequential walk would match this one against the new state
+        f->n_loop_discarded++;
+        continue;
+      }
+      if (rcs[k]) return rcs[k];
+      f->n_loop_coarse++;
+      used = k;
+      int rc = fe_close_after_coarse(f, id, chains[k], res[k], &closed);
+      if (rc) return rc;
+    }
+    start_num = resume[used];
   }
-  return LSLAM_OK;
 }
 
 }  // namespace
@@ -373,6 +458,30 @@ int lslam_frontend_create_ex(lslam_matcher* m, const lslam_frontend_config* cfg,
       delete f;
       return rc;
     }
+    // the speculative loop search: P - 1 more loop matchers, each on its own stream of the same device
+    // (LSLAM_FE_LOOP_POOL = P, default 4; 1 = the strictly sequential walk)
+    int P = 4;
+    if (const char* e = getenv("LSLAM_FE_LOOP_POOL")) P = std::max(1, std::min(16, atoi(e)));
+    for (int k = 1; k < P; k++) {
+      lslam_loop_slot sl;
+      rc = lslam_create(ctx->device, &sl.ctx);
+      if (rc == LSLAM_OK) rc = lslam_matcher_create(sl.ctx, &lc, &m->laser, &sl.m);
+      if (rc == LSLAM_OK && (sl.d_q.reserve(4 + 4 * 8) != hipSuccess ||
+                             hipHostMalloc((void**)&sl.h_res, sizeof(lslam_match_result), hipHostMallocDefault) != hipSuccess)) {
+        (void)hipGetLastError();
+        rc = ctx->fail(LSLAM_ERR_HIP, "cannot allocate a loop-matcher slot");
+      }
+      f->loop_pool.push_back(sl);  // pushed even when incomplete: lslam_frontend_destroy releases what exists
+      if (rc) {
+        lslam_frontend_destroy(f);
+        return rc;
+      }
+    }
+    if (hipEventCreateWithFlags(&f->ev_ready, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      lslam_frontend_destroy(f);
+      return ctx->fail(LSLAM_ERR_HIP, "hipEventCreate failed");
+    }
   }
   if (f->d_q.reserve(4 + 4 * 8) != hipSuccess || f->d_res.reserve(1) != hipSuccess ||
       hipHostMalloc((void**)&f->h_res, sizeof(lslam_match_result), hipHostMallocDefault) != hipSuccess ||
@@ -416,6 +525,14 @@ void lslam_frontend_destroy(lslam_frontend* f) {
   (void)hipSetDevice(f->m->ctx->device);
   (void)hipStreamSynchronize(f->m->ctx->stream);
   if (f->loop_m) lslam_matcher_destroy(f->loop_m);
+  for (auto& sl : f->loop_pool) {
+    if (sl.ctx) (void)hipStreamSynchronize(sl.ctx->stream);
+    if (sl.m) lslam_matcher_destroy(sl.m);
+    sl.d_q.release();
+    if (sl.h_res) (void)hipHostFree(sl.h_res);
+    if (sl.ctx) lslam_destroy(sl.ctx);
+  }
+  if (f->ev_ready) (void)hipEventDestroy(f->ev_ready);
   if (f->d_world) (void)hipFree(f->d_world);
   if (f->d_ranges) (void)hipFree(f->d_ranges);
   if (f->d_next) (void)hipFree(f->d_next);
@@ -431,7 +548,7 @@ int lslam_frontend_reset(lslam_frontend* f) {
   f->scans.clear();
   f->run_start = f->run_count = 0;
   f->have_last = false;
-  f->n_chain_matches = f->n_loop_coarse = f->n_loop_fine = f->n_loops_closed = f->n_edges = 0;
+  f->n_chain_matches = f->n_loop_coarse = f->n_loop_fine = f->n_loops_closed = f->n_edges = f->n_loop_discarded = 0;
   return LSLAM_OK;
 }
 

@@ -304,6 +304,8 @@ int lslam_occgrid_counter_words(const lslam_occgrid* og, size_t* words) {
   return LSLAM_OK;
 }
 
+void* lslam_occgrid_counters_dev_ptr(lslam_occgrid* og) { return og ? (void*)og->d_pass : nullptr; }
+
 int lslam_occgrid_export_counters(lslam_occgrid* og, uint32_t* out, int on_device) {
   if (!og || (!out && og->cells)) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_context* ctx = og->ctx;

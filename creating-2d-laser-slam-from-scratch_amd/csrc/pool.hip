@@ -4,16 +4,19 @@
 // the only inter-GPU traffic of the path); scans [r*B/W, (r+1)*B/W) go to device r, one host thread per device drives
 // its upload -> match -> download; results land in the caller's array in scan order (the "gather" is the D2H copy).
 // No collective: the units are independent.  (The one-process-per-GPU form with RCCL is bench.py / shard.py.)
+#include <set>
 #include <thread>
 #include <vector>
 
 #include "common.hpp"
+#include "rccl_dyn.hpp"
 
 struct lslam_pool {
   std::vector<lslam_context*> ctx;
   std::vector<lslam_matcher*> m;
   std::string last_error;
   bool peer_copy = true;
+  std::vector<ncclComm_t> comms;  // one RCCL communicator per device (ncclCommInitAll), created on first use
 };
 
 extern "C" {
@@ -64,6 +67,8 @@ int lslam_pool_create(int n_devices, const lslam_matcher_config* cfg, const lsla
 void lslam_pool_destroy(lslam_pool* p) {
   if (!p) return;
   for (auto* mm : p->m) lslam_matcher_destroy(mm);
+  if (!p->comms.empty() && lslam::Rccl::get().ok())
+    for (auto c : p->comms) (void)lslam::Rccl::get().CommDestroy(c);
   for (auto* c : p->ctx) lslam_destroy(c);
   delete p;
 }
@@ -144,6 +149,152 @@ int lslam_pool_match_batch(lslam_pool* p, int n_scans, const double* ranges, int
       p->last_error = lslam_last_error(p->ctx[r]);
       return rcs[r];
     }
+  return LSLAM_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Offline map build from known poses, sharded (SURVEY.md 8(e) last row; karto::OccupancyGrid::CreateFromScans,
+// Karto.h:5659-5673): the one path with a real exchange step, with RCCL called directly from the C++ host.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+int rccl_fail(lslam_context* ctx, const char* what, ncclResult_t r) {
+  lslam::Rccl& R = lslam::Rccl::get();
+  return ctx->fail(LSLAM_ERR_HIP, "%s: %s", what, R.GetErrorString ? R.GetErrorString(r) : "rccl error");
+}
+}  // namespace
+
+// ONE RANK's part (one process per GPU, or one thread per device inside ncclGroupStart/End): this rank's scans in,
+// the grid of ALL ranks' scans out.  nccl_comm is the caller's ncclComm_t for ctx's device.  Everything runs on the
+// context stream: box of the local scans -> all-reduce(max) of (-minx, -miny, maxx, maxy) -> local counters on the
+// merged box -> ONE all-reduce(sum) over both counter planes, in place in HBM.
+int lslam_occgrid_create_sharded(lslam_context* ctx, const lslam_laser* laser, int n_scans, const double* ranges,
+                                 int ranges_stride, const double* sensor_poses, double resolution, void* nccl_comm,
+                                 lslam_occgrid** out) {
+  if (!ctx || !out || !nccl_comm) return LSLAM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  lslam::Rccl& R = lslam::Rccl::get();
+  if (!R.ok()) return ctx->fail(LSLAM_ERR_UNSUPPORTED, "%s", R.error.c_str());
+  ncclComm_t comm = (ncclComm_t)nccl_comm;
+  double box[4];
+  int rc = lslam_occgrid_scan_bounds(ctx, laser, n_scans, ranges, ranges_stride, sensor_poses, box);
+  if (rc) return rc;
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  double* d_box = nullptr;
+  LSLAM_HIP(ctx, hipMalloc((void**)&d_box, 4 * sizeof(double)));
+  const double neg[4] = {-box[0], -box[1], box[2], box[3]};  // negation and max are exact: the union box bit for bit
+  hipError_t e = hipMemcpyAsync(d_box, neg, sizeof neg, hipMemcpyHostToDevice, ctx->stream);
+  ncclResult_t nr = ncclSuccess;
+  if (e == hipSuccess) nr = R.AllReduce(d_box, d_box, 4, ncclDouble, ncclMax, comm, ctx->stream);
+  double merged[4] = {0, 0, 0, 0};
+  if (e == hipSuccess && nr == ncclSuccess) e = hipMemcpyAsync(merged, d_box, sizeof merged, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && nr == ncclSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_box);
+  if (nr != ncclSuccess) return rccl_fail(ctx, "ncclAllReduce(box)", nr);
+  if (e != hipSuccess) return ctx->fail(LSLAM_ERR_HIP, "box exchange failed: %s", hipGetErrorString(e));
+  const double ubox[4] = {-merged[0], -merged[1], merged[2], merged[3]};
+  lslam_occgrid* part = nullptr;
+  rc = lslam_occgrid_create_partial(ctx, laser, n_scans, ranges, ranges_stride, sensor_poses, resolution, ubox, &part);
+  if (rc) return rc;  // an empty union box (no scans on any rank) is the reference's NULL
+  size_t words = 0;
+  lslam_occgrid_counter_words(part, &words);
+  if (words) {
+    void* cnt = lslam_occgrid_counters_dev_ptr(part);
+    nr = R.AllReduce(cnt, cnt, words, ncclUint32, ncclSum, comm, ctx->stream);
+    if (nr != ncclSuccess) {
+      lslam_occgrid_destroy(part);
+      return rccl_fail(ctx, "ncclAllReduce(counters)", nr);
+    }
+    e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      lslam_occgrid_destroy(part);
+      return ctx->fail(LSLAM_ERR_HIP, "counter all-reduce failed: %s", hipGetErrorString(e));
+    }
+  }
+  *out = part;
+  return LSLAM_OK;
+}
+
+// The same over the devices of a pool, in one process: scans [r*n/W, (r+1)*n/W) to device r, one host thread per
+// device, the communicators from ncclCommInitAll.  A pool that names one GPU several times (how the 1-GPU tests
+// shard) cannot form an RCCL clique; its partial grids are merged on the first device instead (exact all the same).
+// The grid of ALL scans is returned on the pool's first device.
+int lslam_pool_occgrid_from_scans(lslam_pool* p, const lslam_laser* laser, int n_scans, const double* ranges,
+                                  int ranges_stride, const double* sensor_poses, double resolution, lslam_occgrid** out) {
+  if (!p || p->ctx.empty() || !laser || !out || n_scans < 0 || (n_scans > 0 && (!ranges || !sensor_poses)))
+    return LSLAM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  const int W = (int)p->ctx.size();
+  std::set<int> distinct;
+  for (auto* c : p->ctx) distinct.insert(c->device);
+  lslam::Rccl& R = lslam::Rccl::get();
+  const bool use_rccl = (int)distinct.size() == W && R.ok();
+  auto lo_of = [&](int r) { return (long long)r * n_scans / W; };
+  std::vector<lslam_occgrid*> parts(W, nullptr);
+  std::vector<int> rcs(W, LSLAM_OK);
+  if (use_rccl) {
+    if (p->comms.empty()) {
+      std::vector<int> devs;
+      for (auto* c : p->ctx) devs.push_back(c->device);
+      p->comms.resize(W);
+      ncclResult_t nr = R.CommInitAll(p->comms.data(), W, devs.data());
+      if (nr != ncclSuccess) {
+        p->comms.clear();
+        p->last_error = std::string("ncclCommInitAll: ") + R.GetErrorString(nr);
+        return LSLAM_ERR_HIP;
+      }
+    }
+    std::vector<std::thread> th;
+    for (int r = 0; r < W; r++)
+      th.emplace_back([&, r]() {
+        const long long lo = lo_of(r), hi = lo_of(r + 1);
+        rcs[r] = lslam_occgrid_create_sharded(p->ctx[r], laser, (int)(hi - lo), ranges + (size_t)lo * ranges_stride, ranges_stride,
+                                              sensor_poses + 3 * lo, resolution, (void*)p->comms[r], &parts[r]);
+      });
+    for (auto& t : th) t.join();
+    for (int r = 0; r < W; r++)
+      if (rcs[r]) {
+        p->last_error = lslam_last_error(p->ctx[r]);
+        for (auto* g : parts) lslam_occgrid_destroy(g);
+        return rcs[r];
+      }
+    for (int r = 1; r < W; r++) lslam_occgrid_destroy(parts[r]);  // every rank holds the full grid; keep the first
+    *out = parts[0];
+    return LSLAM_OK;
+  }
+  // ---- no RCCL clique: boxes merged on the host, partial counters added on the first device ----
+  double ubox[4] = {1e300, 1e300, -1e300, -1e300};
+  for (int r = 0; r < W; r++) {
+    const long long lo = lo_of(r), hi = lo_of(r + 1);
+    double b[4];
+    int rc = lslam_occgrid_scan_bounds(p->ctx[r], laser, (int)(hi - lo), ranges + (size_t)lo * ranges_stride, ranges_stride,
+                                       sensor_poses + 3 * lo, b);
+    if (rc) {
+      p->last_error = lslam_last_error(p->ctx[r]);
+      return rc;
+    }
+    ubox[0] = std::min(ubox[0], b[0]); ubox[1] = std::min(ubox[1], b[1]);
+    ubox[2] = std::max(ubox[2], b[2]); ubox[3] = std::max(ubox[3], b[3]);
+  }
+  for (int r = 0; r < W; r++) {
+    const long long lo = lo_of(r), hi = lo_of(r + 1);
+    int rc = lslam_occgrid_create_partial(p->ctx[r], laser, (int)(hi - lo), ranges + (size_t)lo * ranges_stride, ranges_stride,
+                                          sensor_poses + 3 * lo, resolution, ubox, &parts[r]);
+    if (rc == LSLAM_OK && r > 0) {
+      size_t words = 0;
+      lslam_occgrid_counter_words(parts[r], &words);
+      std::vector<uint32_t> host(words);
+      rc = lslam_occgrid_export_counters(parts[r], host.data(), 0);
+      if (rc == LSLAM_OK) rc = lslam_occgrid_import_counters(parts[0], host.data(), 0, 1);
+    }
+    if (rc) {
+      p->last_error = lslam_last_error(p->ctx[r]);
+      for (auto* g : parts) lslam_occgrid_destroy(g);
+      return rc;
+    }
+  }
+  for (int r = 1; r < W; r++) lslam_occgrid_destroy(parts[r]);
+  *out = parts[0];
   return LSLAM_OK;
 }
 

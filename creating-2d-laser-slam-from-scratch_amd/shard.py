@@ -40,10 +40,12 @@ def all_gather_results(results, world: int):
     return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
 
 
-def broadcast_grid(matcher, device, src: int = 0):
+def broadcast_grid(matcher, device, src: int = 0, install_device=None):
     """Replicates rank `src`'s correlation grid (bytes + offset) onto every rank's matcher.
     `matcher` needs GetCorrelationGrid(), grid_info()['offset'] and set_grid(grid, offset) /
-    set_grid_dev(ptr, offset)."""
+    set_grid_dev(ptr, offset).  `device`: where the collective runs (the GPU for RCCL, "cpu" for gloo);
+    `install_device`: a GPU to stage a CPU-side result on so that it is still installed through the device entry
+    point set_grid_dev (how the 2-rank gloo test on a 1-GPU box exercises the path an RCCL run takes)."""
     import torch
     import torch.distributed as dist
 
@@ -59,6 +61,8 @@ def broadcast_grid(matcher, device, src: int = 0):
     dist.broadcast(g, src)
     dist.broadcast(off, src)
     offset = off.cpu().numpy()
+    if not g.is_cuda and install_device is not None:
+        g = g.to(install_device)
     if g.is_cuda:
         torch.cuda.synchronize()
         matcher.set_grid_dev(g.data_ptr(), offset)

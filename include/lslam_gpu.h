@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LSLAM_ABI_VERSION 2
+#define LSLAM_ABI_VERSION 3
 
 typedef enum lslam_status {
   LSLAM_OK = 0,
@@ -332,8 +332,25 @@ int lslam_occgrid_create_partial(lslam_context* ctx, const lslam_laser* laser, i
                                  int ranges_stride, const double* sensor_poses, double resolution, const double box[4],
                                  lslam_occgrid** out);
 int lslam_occgrid_counter_words(const lslam_occgrid* og, size_t* words);
+/* device address of the counter buffer (pass plane, then hit plane; lslam_occgrid_counter_words uint32 words): a caller
+ * with its own RCCL communicator all-reduces it in place */
+void* lslam_occgrid_counters_dev_ptr(lslam_occgrid* og);
 int lslam_occgrid_export_counters(lslam_occgrid* og, uint32_t* buf, int on_device);
 int lslam_occgrid_import_counters(lslam_occgrid* og, const uint32_t* buf, int on_device, int accumulate);
+
+/* Steps 1-4 above as ONE call per rank, with RCCL called directly from this library (librccl is dlopen'ed on first use;
+ * LSLAM_ERR_UNSUPPORTED if it cannot be loaded).  nccl_comm: the caller's ncclComm_t for ctx's device (one process per
+ * GPU: ncclCommInitRank; one process, one thread per device: ncclCommInitAll).  n_scans = 0 is a valid shard.  Two
+ * collectives on the context stream: all-reduce(max) of (-minx, -miny, maxx, maxy), then ONE all-reduce(sum, uint32)
+ * over both counter planes in place in HBM (32 MB at 2005^2 cells).  *out holds the grid of ALL ranks' scans. */
+int lslam_occgrid_create_sharded(lslam_context* ctx, const lslam_laser* laser, int n_scans, const double* ranges,
+                                 int ranges_stride, const double* sensor_poses, double resolution, void* nccl_comm,
+                                 lslam_occgrid** out);
+/* The same over the devices of an lslam_pool in ONE process (scans [r*n/W, (r+1)*n/W) to device r, one host thread per
+ * device, communicators from ncclCommInitAll); the grid is returned on the pool's first device.  A pool that names one
+ * GPU more than once cannot form an RCCL clique: its partial grids are then merged by counter addition instead. */
+int lslam_pool_occgrid_from_scans(lslam_pool* pool, const lslam_laser* laser, int n_scans, const double* ranges,
+                                  int ranges_stride, const double* sensor_poses, double resolution, lslam_occgrid** out);
 
 /* ---------------------------------------------------------------------------------------- */
 /* Hector log-odds occupancy grid  (replaces hectorslam::OccGridMapBase<LogOddsCell,...>,    */

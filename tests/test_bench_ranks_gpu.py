@@ -41,6 +41,17 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert two["gather_ms"] is not None
 
 
+def test_broadcast_grid_equals_rebuild(tmp_path):
+    """--broadcast-grid: rank 0 rasterises the window, shard.broadcast_grid replicates the 4 MB grid and every other
+    rank installs it through lslam_matcher_set_grid_u8_dev (no AddScans there).  Gathered records byte-equal to the
+    default path, where every rank rebuilds the grid itself."""
+    one, r1 = run_bench(tmp_path, 1)
+    two, r2 = run_bench(tmp_path, 2, extra=("--broadcast-grid",), backend="gloo")
+    assert two["n_gpus"] == 2 and two["results_ok"] == 1024
+    assert r1.tobytes() == r2.tobytes()
+    assert len(two["per_rank_ms_per_step"]) == 2
+
+
 def test_weak_scaling_mode_and_gpu_count_check(tmp_path):
     two, r2 = run_bench(tmp_path, 2, extra=("--scaling", "weak"), backend="gloo")
     assert two["scaling"] == "weak" and two["config"]["scans_per_step"] == 2048 and r2.shape == (2048, 112)

@@ -1,0 +1,96 @@
+"""BASELINE config 5 AT ITS STATED SIZE: the streaming front-end with its pose graph on the first 3600 scans of the
+10 000-scan closed-loop trajectory, the log-odds map 4000 x 4000 @ 0.025 m -- against the reference's own
+karto::Mapper::Process, recorded in tests/golden/karto_cfg5_golden.npz by tests/golden/make_cfg5_golden.py (the
+reference takes ~6 min of CPU for this; the GPU side ~1 s).  3600 scans reach well into lap 2 of the outermost ring:
+near-chain links, hundreds of loop-closure coarse matches (several chains per scan: the speculative pool is exercised)
+and closed loops are all part of what is compared -- pose of every scan at the time it was processed, edge count after
+every scan, final poses of all vertices.  The map is compared bit for bit with the restated Hector update fed the same
+poses.  A second, shorter run checks the strictly sequential loop search (LSLAM_FE_LOOP_POOL=1) against the same record.
+"""
+import hashlib
+import importlib.util
+import pathlib
+
+import numpy as np
+import pytest
+
+from lslam_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+G = pathlib.Path(__file__).resolve().parent / "golden"
+
+GRAPH = dict(scan_buffer_size=70, scan_buffer_maximum_scan_distance=20.0, do_loop_closing=1, link_scan_maximum_distance=1.5,
+             loop_search_maximum_distance=3.0, loop_match_minimum_chain_size=10)
+
+
+@pytest.fixture(scope="module")
+def cfg5():
+    d = np.load(G / "karto_cfg5_golden.npz", allow_pickle=False)
+    spec = importlib.util.spec_from_file_location("make_cfg5_golden", G / "make_cfg5_golden.py")
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    n = int(d["n"])
+    laser, path, odom, scans32 = mk.workload(n=n)
+    if hashlib.sha256(scans32.tobytes()).hexdigest() != str(d["ranges_sha256"]):
+        pytest.skip("the synthetic generator produced different ranges here than where the golden record was made")
+    return d, laser, path, odom, scans32
+
+
+def _run(ctx, laser, odom, scans32, n, with_map):
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
+    fe = api.FrontEnd(gm, config=api.frontend_config(**GRAPH))
+    gmap = None
+    if with_map:
+        size, cell = 4000, 0.025
+        gmap = api.OccGridMap(ctx, size, size, cell, (size * cell * 0.5, size * cell * 0.5))
+        gmap.setUpdateOccupiedFactor(0.9)
+    poses, edges, ok_all, pend_pts, pend_pose, upd = np.zeros((n, 3)), np.zeros(n, np.int64), np.zeros(n, bool), [], [], []
+    for i in range(n):
+        ok, poses[i], _, _ = fe.Process(synth.ranges_to_f64(scans32[i]), odom[i])
+        ok_all[i] = ok
+        edges[i] = fe.stats()["edges"]
+        if ok and with_map:
+            pend_pts.append(synth.hector_points(scans32[i], laser, 1.0 / 0.025, use_max=20.0))
+            pend_pose.append(poses[i].astype(np.float32))
+            upd.append(i)
+            if len(pend_pts) == 64:
+                gmap.updateByScans(pend_pts, (0.0, 0.0), np.stack(pend_pose))
+                pend_pts, pend_pose = [], []
+    if with_map and pend_pts:
+        gmap.updateByScans(pend_pts, (0.0, 0.0), np.stack(pend_pose))
+    final = np.stack([fe.scan_pose(i) for i in range(fe.num_scans())])
+    return fe, gmap, poses, edges, ok_all, final, upd
+
+
+def test_cfg5_full_size_against_the_reference_record(ctx, cfg5, oracle_lib):
+    d, laser, path, odom, scans32 = cfg5
+    n = int(d["n"])
+    fe, gmap, poses, edges, ok_all, final, upd = _run(ctx, laser, odom, scans32, n, with_map=True)
+    assert np.array_equal(ok_all, d["processed"].astype(bool))
+    err = np.abs(poses - d["corrected"]).max(axis=1)
+    assert err.max() <= 1e-9, (int(err.argmax()), err.max())
+    assert np.array_equal(edges, d["edges"].astype(np.int64)), int(np.flatnonzero(edges != d["edges"])[0])
+    assert np.abs(final - d["final_poses"]).max() <= 1e-9
+    st = fe.stats()
+    assert st["loops_closed"] > 0 and st["loop_coarse_matches"] > 1000 and st["edges"] > st["scans"] + 100, st
+    # the map at the stated size, bit for bit against the restated update (pinned to the reference's headers) fed the same poses
+    size, cell = 4000, 0.025
+    cmap = oracle_lib.PortHector(size, size, cell, (size * cell * 0.5, size * cell * 0.5))
+    cmap.setUpdateOccupiedFactor(0.9)
+    for i in upd:
+        cmap.updateByScan(synth.hector_points(scans32[i], laser, 1.0 / cell, use_max=20.0), (0.0, 0.0), poses[i].astype(np.float32))
+    ref_map = cmap.logodds()
+    assert np.count_nonzero(ref_map) > 1_000_000
+    assert gmap.logodds().tobytes() == ref_map.tobytes()
+    print("cfg 5, %d scans at full size vs the reference record: max pose difference %.3g, graph %s" % (n, err.max(), st))
+
+
+def test_cfg5_sequential_loop_search_gives_the_same_record(ctx, cfg5, monkeypatch):
+    """LSLAM_FE_LOOP_POOL=1: every chain matched strictly one after another, the reference's own order of work."""
+    d, laser, path, odom, scans32 = cfg5
+    n = 1800  # past the first closed loops (edges > vertices from ~scan 1400 on)
+    monkeypatch.setenv("LSLAM_FE_LOOP_POOL", "1")
+    fe, _, poses, edges, ok_all, _, _ = _run(ctx, laser, odom, scans32, n, with_map=False)
+    assert np.abs(poses - d["corrected"][:n]).max() <= 1e-9
+    assert np.array_equal(edges, d["edges"][:n].astype(np.int64))
+    assert fe.stats()["loop_coarse_matches"] > 100

@@ -316,3 +316,44 @@ def test_laserscan_to_container_on_device(ctx, oracle_lib):
         assert np.count_nonzero(gpu_d.logodds(lv)) > 1000
         assert gpu_d.logodds(lv).tobytes() == gpu_h.logodds(lv).tobytes()
     assert gpu_d.setScan(np.zeros(0, np.float32), sp) == 0  # an empty LaserScan is legal
+
+
+def test_one_launch_and_two_kernel_paths_agree(ctx, oracle_lib, monkeypatch):
+    """Containers of <= 2048 points take the ONE-launch kernel (k_logodds_one: LDS end-cell set, first-arrival frees,
+    last block applies the hits); LSLAM_MAP_TWO_KERNELS=1 (read at map creation) keeps the mark + apply pair.  Both must
+    reproduce the sequential reference bit for bit, incl. the order-dependent (v + free) - free cells, the clamp and a
+    3-level pyramid fed from cached containers."""
+    n, cell, LV = 512, 0.05, 3
+    off = (n * cell * 0.5, n * cell * 0.5)
+    one = api.OccGridMap(ctx, n, n, cell, off, levels=LV)
+    monkeypatch.setenv("LSLAM_MAP_TWO_KERNELS", "1")
+    two = api.OccGridMap(ctx, n, n, cell, off, levels=LV)
+    monkeypatch.delenv("LSLAM_MAP_TWO_KERNELS")
+    cpu = oracle_lib.PortHectorRep(cell, n, n, LV)
+    for m in (one, two):
+        m.setUpdateOccupiedFactor(0.97)
+    cpu.setUpdateFactorOccupied(0.97)
+    scans = scans_for_map(10, seed=11, map_cells=n)
+    for k, (pts, pose) in enumerate(scans * 2):
+        pts = pts[(np.abs(pts) < 230).all(axis=1)]
+        if k % 3 == 0:  # every third scan is matched first: the levels above 0 get a fresh cached container
+            hint = pose + np.array([0.02, -0.01, 0.01], np.float32)
+            for m in (one, two):
+                m.matchData(hint, pts)
+            cpu.matchData(pts, hint)
+        for m in (one, two):
+            m.updateByScan(pts, (0.0, 0.0), pose)
+        cpu.updateByScan(pts, (0.0, 0.0), pose)
+    ctx.profile(True); ctx.profile_reset()
+    one.updateByScan(scans[0][0], (0.0, 0.0), scans[0][1])
+    two.updateByScan(scans[0][0], (0.0, 0.0), scans[0][1])
+    cpu.updateByScan(scans[0][0], (0.0, 0.0), scans[0][1])
+    ctx.synchronize()
+    ctx.profile(False)
+    names = set(ctx.profile_read())
+    assert {"logodds_one", "logodds_mark", "logodds_apply"} <= names, names
+    for lv in range(LV):
+        ref = cpu.logodds(lv)
+        assert np.count_nonzero(ref) > 1000
+        assert one.logodds(lv).tobytes() == ref.tobytes(), lv
+        assert two.logodds(lv).tobytes() == ref.tobytes(), lv

@@ -144,3 +144,48 @@ def test_two_ranks_build_the_same_grid_as_one(ctx, oracle_lib):
     for rank, w, h, goff, cells in out:
         assert (h, w) == exp.shape and goff == off.tolist()
         assert cells == exp.tobytes()
+
+
+# ---- RCCL called directly from the C++ host (lslam_occgrid_create_sharded / lslam_pool_occgrid_from_scans) ----
+def test_pool_occupancy_grid_rccl_clique_and_merge_path(oracle_lib):
+    """One process, the pool's devices: [0] forms an RCCL clique of one (ncclCommInitAll + both all-reduces run, on the
+    context stream); [0, 0, 0] cannot (one GPU named three times) and takes the counter-addition path.  Both must equal
+    the oracle's grid of all scans.  On an 8-GPU node `MatcherPool(cfg, laser, 0)` is the clique of eight."""
+    wl, lp = _workload(19)
+    port = oracle_lib.PortKarto(oracle_lib.default_cfg(), oracle_lib.laser_struct(wl.laser, 20.0))
+    exp, off = port.occgrid_from_scans(wl.base_ranges, wl.base_poses, 0.05)
+    for devices in ([0], [0, 0, 0]):
+        pool = api.MatcherPool(api.baseline_config(range_threshold=20.0), lp, devices)
+        got, goff = pool.CreateOccupancyGrid(lp, wl.base_ranges, wl.base_poses, 0.05)
+        pool.close()
+        assert got.shape == exp.shape and np.array_equal(goff, off), devices
+        assert np.array_equal(got, exp), devices
+
+
+def test_create_sharded_with_a_callers_communicator(ctx, oracle_lib):
+    """lslam_occgrid_create_sharded with an ncclComm_t made by the CALLER (ncclGetUniqueId + ncclCommInitRank through
+    ctypes on librccl, world size 1 on this box; one per process on an 8-GPU node)."""
+    import ctypes as C
+
+    rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    wl, lp = _workload(11)
+    port = oracle_lib.PortKarto(oracle_lib.default_cfg(), oracle_lib.laser_struct(wl.laser, 20.0))
+    exp, off = port.occgrid_from_scans(wl.base_ranges, wl.base_poses, 0.05)
+    g = api.OccupancyGrid.CreateSharded(ctx, lp, wl.base_ranges, wl.base_poses, 0.05, comm.value)
+    assert np.array_equal(g.data(), exp)
+    g.close()
+    # a rank without scans in a world of one: the union box is empty -> the reference's NULL
+    with pytest.raises(api.LslamError):
+        api.OccupancyGrid.CreateSharded(ctx, lp, np.zeros((0, 1081)), np.zeros((0, 3)), 0.05, comm.value)
+    rccl.ncclCommDestroy(comm)
