@@ -28,4 +28,13 @@ for B in (1, 4, 16, 64, 96, 128, 192, 256, 384, 512, 1024, 2048, 4096, 8192):
         gm.match_batch_dev(B, r.data_ptr(), wl.query_ranges.shape[1], p.data_ptr(), out.data_ptr(), dtype="f32")
     ctx.synchronize()
     dt = (time.perf_counter() - t0) / n
-    print(f"B={B:5d}  {dt*1e3:8.3f} ms/batch  {B/dt:12.0f} matches/s")
+    line = f"B={B:5d}  {dt*1e3:8.3f} ms/batch  {B/dt:12.0f} matches/s"
+    if B in (256, 512, 1024, 4096):  # per-kernel view (HIP events around every launch of 20 batches)
+        ctx.profile(True); ctx.profile_only(None); ctx.profile_reset()
+        for _ in range(20):
+            gm.match_batch_dev(B, r.data_ptr(), wl.query_ranges.shape[1], p.data_ptr(), out.data_ptr(), dtype="f32")
+        ctx.synchronize()
+        ctx.profile(False)
+        prof = ctx.profile_read()
+        line += "   kernels [us]: " + ", ".join(f"{k} {1e3 * v[1] / v[0]:.1f}" for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1]))
+    print(line, flush=True)
