@@ -756,6 +756,8 @@ def main():
     if args.dump_results and rank == 0:
         np.save(args.dump_results, all_np.view(np.uint8).reshape(-1, 112))
     if rank != 0:
+        gm.close()
+        ctx.close()
         if distributed:
             dist.destroy_process_group()
         return
@@ -914,6 +916,8 @@ def main():
     json_out.write(json.dumps(line) + "\n")
     json_out.flush()
     os.dup2(os.open(os.devnull, os.O_WRONLY), 1)  # the reference library's exit chatter (std::cout) goes nowhere
+    gm.close()   # device handles are released while everything they point into is still alive
+    ctx.close()
     if distributed:
         dist.destroy_process_group()
 

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import math
 import weakref
 
@@ -296,6 +297,7 @@ def lib() -> C.CDLL:
     L.lslam_map_cached_points.argtypes = [vp]
     L.lslam_map_read_logodds.argtypes = [vp, i32, vp]
     L.lslam_map_read_occupancy_i8.argtypes = [vp, i32, vp]
+    L.lslam_map_flush.argtypes = [vp]
     L.lslam_map_cells_dev_ptr.restype = vp
     L.lslam_map_cells_dev_ptr.argtypes = [vp, i32]
     L.lslam_map_set_scan.argtypes = [vp, vp, i32, C.POINTER(HectorScan), C.POINTER(i32)]
@@ -352,6 +354,10 @@ class Context:
             self.h = None
 
     def __del__(self):
+        # at interpreter shutdown the order of finalisers is arbitrary (a context may already be gone under a handle
+        # that points into it) and the process is exiting anyway: release explicitly, or not at all
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -427,6 +433,10 @@ class ScanMatcher:
             self.h = None
 
     def __del__(self):
+        # at interpreter shutdown the order of finalisers is arbitrary (a context may already be gone under a handle
+        # that points into it) and the process is exiting anyway: release explicitly, or not at all
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -584,6 +594,10 @@ class MatcherPool:
             self.h = None
 
     def __del__(self):
+        # at interpreter shutdown the order of finalisers is arbitrary (a context may already be gone under a handle
+        # that points into it) and the process is exiting anyway: release explicitly, or not at all
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -652,6 +666,10 @@ class FrontEnd:
             self.h = None
 
     def __del__(self):
+        # at interpreter shutdown the order of finalisers is arbitrary (a context may already be gone under a handle
+        # that points into it) and the process is exiting anyway: release explicitly, or not at all
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -767,6 +785,10 @@ class OccupancyGrid:
             self.h = None
 
     def __del__(self):
+        # at interpreter shutdown the order of finalisers is arbitrary (a context may already be gone under a handle
+        # that points into it) and the process is exiting anyway: release explicitly, or not at all
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -807,6 +829,10 @@ class OccGridMap:
             self.h = None
 
     def __del__(self):
+        # at interpreter shutdown the order of finalisers is arbitrary (a context may already be gone under a handle
+        # that points into it) and the process is exiting anyway: release explicitly, or not at all
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

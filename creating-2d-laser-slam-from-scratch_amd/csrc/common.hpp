@@ -70,6 +70,9 @@ struct lslam_context {
   std::string last_error;
   lslam::KernelTimer timer;
   hipDeviceProp_t prop;
+  // work that objects of this context have deferred and that must be on the stream before a synchronise means
+  // "everything is done" (the log-odds map's pipelined apply): (object, flush function)
+  std::vector<std::pair<void*, int (*)(void*)>> pre_sync;
 
   int fail(int code, const char* fmt, ...) {
     char buf[512];

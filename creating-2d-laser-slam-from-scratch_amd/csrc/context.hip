@@ -51,6 +51,10 @@ const char* lslam_last_error(const lslam_context* ctx) {
 
 int lslam_synchronize(lslam_context* ctx) {
   if (!ctx) return LSLAM_ERR_INVALID_ARGUMENT;
+  for (auto& f : ctx->pre_sync) {
+    int rc = f.second(f.first);
+    if (rc) return rc;
+  }
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return LSLAM_OK;
 }

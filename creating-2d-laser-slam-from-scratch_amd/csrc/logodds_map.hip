@@ -114,13 +114,13 @@ __device__ __forceinline__ unsigned ray_cell(const Ray& r, unsigned i) {
   return r.start + (unsigned)((int)i * r.offset_a) + (unsigned)((int)q * r.offset_b);
 }
 
-// one wave per beam
-__global__ void __launch_bounds__(256)
-k_logodds_mark(LevelGeom g, const float* __restrict__ pts, int n, uint32_t* __restrict__ free_key,
-               uint32_t* __restrict__ occ_key) {
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+// one wave per beam; `wave` = index of this wave among the kernel's mark (resp. apply) waves
+__device__ __forceinline__ void logodds_mark_wave(const LevelGeom& g, const float* __restrict__ pts, int n, int wave, int lane,
+                                                  uint32_t* __restrict__ free_key, uint32_t* __restrict__ occ_key,
+                                                  float* __restrict__ pts_copy) {
+  const int i = wave;
   if (i >= n) return;
+  if (pts_copy && lane < 2) pts_copy[2 * i + lane] = pts[2 * i + lane];  // kept for the deferred apply (pipelined path)
   Line l = beam_line(g, pts, i);
   if (!l.valid) return;
   const uint32_t key = (g.epoch << kBeamBits) | (kBeamMask - (uint32_t)i);
@@ -129,11 +129,10 @@ k_logodds_mark(LevelGeom g, const float* __restrict__ pts, int n, uint32_t* __re
   if (lane == 0) atomicMax(&occ_key[(unsigned)(l.y1 * g.sx + l.x1)], key);
 }
 
-__global__ void __launch_bounds__(256)
-k_logodds_apply(LevelGeom g, const float* __restrict__ pts, int n, const uint32_t* __restrict__ free_key,
-                const uint32_t* __restrict__ occ_key, float* __restrict__ logodds) {
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+__device__ __forceinline__ void logodds_apply_wave(const LevelGeom& g, const float* __restrict__ pts, int n, int wave, int lane,
+                                                   const uint32_t* __restrict__ free_key, const uint32_t* __restrict__ occ_key,
+                                                   float* __restrict__ logodds) {
+  const int i = wave;
   if (i >= n) return;
   Line l = beam_line(g, pts, i);
   if (!l.valid) return;
@@ -184,98 +183,37 @@ k_logodds_apply(LevelGeom g, const float* __restrict__ pts, int n, const uint32_
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// ONE-LAUNCH single-scan update (containers of <= kOneMaxPoints points; BASELINE config 2 as stated: one 1081-beam
-// scan per call).  The two kernels above are two dependent ~10 us launches whose only link is "apply needs every mark".
-// Here the order-dependent part is confined to the scan's HIT cells, and those are few (<= n):
-//   phase 0  every block builds, in LDS, the complete set of the scan's end cells with the smallest beam index ending in
-//            each (open addressing, LDS atomics): n beam_line evaluations per block -- redundant, but ~1 us and it removes
-//            the grid-wide dependency;
-//   phase 1  wave per beam, closed-form Bresenham cells.  A crossed cell that is NOT an end cell gets +free from whichever
-//            beam ARRIVES first (returning atomicMax on the free-key plane: old epoch != this scan's -> first).  The value
-//            added is the same whoever wins, and the winner is the cell's only writer in this launch, so the float plane
-//            is bit-identical to the sequential walk.  A crossed END cell only records its key (min crossing beam index).
-//   phase 2  the LAST block to finish (agent-scope ticket) walks its own LDS set: for each end cell, "crossed by a beam
-//            with a smaller index than the first beam ending here" -> (v + free) - free, then +occ if v < 50
-//            (H/map/OccGridMapBase.h:316-330).  No spinning, no co-residency requirement.
-// ------------------------------------------------------------------------------------------
-constexpr int kOneMaxPoints = 2048;
-constexpr int kOneSlots = 4096;  // LDS hash: 2 x 16 KB
-constexpr int kOneThreads = 1024;
+__global__ void __launch_bounds__(256)
+k_logodds_mark(LevelGeom g, const float* __restrict__ pts, int n, uint32_t* __restrict__ free_key,
+               uint32_t* __restrict__ occ_key) {
+  logodds_mark_wave(g, pts, n, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), threadIdx.x & 63, free_key, occ_key, nullptr);
+}
 
-__global__ void __launch_bounds__(kOneThreads)
-k_logodds_one(LevelGeom g, const float* __restrict__ pts, int n, uint32_t* __restrict__ free_key,
-              float* __restrict__ logodds, unsigned* __restrict__ ticket) {
-  __shared__ uint32_t s_key[kOneSlots];   // end cell + 1 (0 = empty)
-  __shared__ uint32_t s_beam[kOneSlots];  // smallest beam index ending there
-  __shared__ unsigned s_last;
-  for (int t = threadIdx.x; t < kOneSlots; t += kOneThreads) {
-    s_key[t] = 0u;
-    s_beam[t] = 0xffffffffu;
-  }
-  __syncthreads();
-  // ---- phase 0: the scan's end cells ------------------------------------------------------------------------------
-  for (int b = threadIdx.x; b < n; b += kOneThreads) {
-    const Line l = beam_line(g, pts, b);
-    if (!l.valid) continue;
-    const uint32_t cell = (uint32_t)(l.y1 * g.sx + l.x1);
-    uint32_t slot = (cell * 2654435761u) >> 20;  // 12 bits
-    for (;;) {
-      const uint32_t old = atomicCAS(&s_key[slot], 0u, cell + 1u);
-      if (old == 0u || old == cell + 1u) break;
-      slot = (slot + 1u) & (kOneSlots - 1);
-    }
-    atomicMin(&s_beam[slot], (uint32_t)b);
-  }
-  __syncthreads();
-  // ---- phase 1: the rays ---------------------------------------------------------------------------------------------
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * (kOneThreads >> 6) + (threadIdx.x >> 6);
-  if (i < n) {
-    const Line l = beam_line(g, pts, i);
-    if (l.valid) {
-      const uint32_t key = (g.epoch << kBeamBits) | (kBeamMask - (uint32_t)i);
-      const Ray r = ray_of(l, g.sx);
-      for (unsigned c = lane; c < r.abs_da; c += 64) {
-        const unsigned cell = ray_cell(r, c);
-        bool is_end = false;
-        uint32_t slot = (cell * 2654435761u) >> 20;
-        for (;;) {
-          const uint32_t k = s_key[slot];
-          if (k == 0u) break;
-          if (k == cell + 1u) {
-            is_end = true;
-            break;
-          }
-          slot = (slot + 1u) & (kOneSlots - 1);
-        }
-        const uint32_t old = atomicMax(&free_key[cell], key);
-        if (!is_end && (old >> kBeamBits) != g.epoch) logodds[cell] = logodds[cell] + g.lo_free;  // first arrival: the one writer
-      }
-    }
-  }
-  // ---- phase 2: the last block applies the end cells ---------------------------------------------------------------
-  __threadfence();  // release: this block's keys and float stores are visible device-wide before its ticket
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();  // acquire
-  for (int t = threadIdx.x; t < kOneSlots; t += kOneThreads) {
-    const uint32_t k = s_key[t];
-    if (k == 0u) continue;
-    const unsigned cell = k - 1u;
-    const uint32_t me = kBeamMask - s_beam[t];
-    const uint32_t fk = __hip_atomic_load(&free_key[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float v = logodds[cell];  // nobody touched an end cell's float in this launch
-    if ((fk >> kBeamBits) == g.epoch && (fk & kBeamMask) > me) {  // crossed by an EARLIER beam: free then unset (:323-326)
-      v += g.lo_free;
-      v -= g.lo_free;
-    }
-    if (v < 50.0f) v += g.lo_occ;  // updateSetOccupied (H/map/GridMapLogOdds.h:108-114)
-    logodds[cell] = v;
-  }
-  if (threadIdx.x == 0) *ticket = 0u;  // ready for the next launch (stream order)
+__global__ void __launch_bounds__(256)
+k_logodds_apply(LevelGeom g, const float* __restrict__ pts, int n, const uint32_t* __restrict__ free_key,
+                const uint32_t* __restrict__ occ_key, float* __restrict__ logodds) {
+  logodds_apply_wave(g, pts, n, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), threadIdx.x & 63, free_key, occ_key, logodds);
+}
+
+// PIPELINED single-scan update: ONE launch per scan in steady state.  The two kernels above are two dependent ~10 us
+// launches whose only link is "apply needs every mark of its scan".  But the apply of scan t-1 and the mark of scan t are
+// independent once the two scans keep their keys in different planes: the mark of scan t goes into key-plane set t & 1,
+// while the apply of scan t-1 reads set (t-1) & 1 and is the launch's only writer of the float plane.  So each call
+// launches [apply blocks of the previous scan | mark blocks of this scan] together and leaves this scan's apply pending;
+// a reader (lslam_map_read_*, matchData, a batched update, lslam_synchronize, ...) first flushes the pending apply with the
+// stand-alone kernel.  Per cell the float operations and their order are exactly those of the sequential reference:
+// apply(t-1) completes in the launch before apply(t) starts (stream order).  The mark blocks also copy their points
+// aside (the caller's buffer may be reused before the deferred apply runs).
+__global__ void __launch_bounds__(256)
+k_logodds_pipe(LevelGeom g_prev, const float* __restrict__ pts_prev, int n_prev, const uint32_t* __restrict__ free_prev,
+               const uint32_t* __restrict__ occ_prev, float* __restrict__ logodds, int apply_blocks, LevelGeom g,
+               const float* __restrict__ pts, int n, uint32_t* __restrict__ free_key, uint32_t* __restrict__ occ_key,
+               float* __restrict__ pts_copy) {
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  if ((int)blockIdx.x < apply_blocks)
+    logodds_apply_wave(g_prev, pts_prev, n_prev, blockIdx.x * wpb + (threadIdx.x >> 6), lane, free_prev, occ_prev, logodds);
+  else
+    logodds_mark_wave(g, pts, n, ((int)blockIdx.x - apply_blocks) * wpb + (threadIdx.x >> 6), lane, free_key, occ_key, pts_copy);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -724,6 +662,13 @@ struct Level {
   uint32_t* d_free = nullptr;
   uint32_t* d_occ = nullptr;
   uint32_t epoch = 0;
+  // pipelined single-scan path: second key-plane set (scans alternate), the points of the scan whose apply is pending
+  uint32_t* d_free2 = nullptr;
+  uint32_t* d_occ2 = nullptr;
+  DevBuf<float> pipe_pts[2];
+  bool pending = false;  // marks of scan `pend_g.epoch` are in plane set (epoch & 1); its apply has not been launched
+  LevelGeom pend_g;
+  int pend_n = 0;
   // batched update (k_lo_batch_*): one byte plane per scan slot, allocated on first use
   uint8_t* d_planes = nullptr;  // [plane_slots][n_tiles][64] tiled byte planes
   uint8_t* d_flags = nullptr;   // [n_tiles][64]: tile touched by the scan in slot s
@@ -754,11 +699,10 @@ struct lslam_map {
   int cs_n = 0;
   int n_scan = 0;
   float scan_origo[2] = {0.f, 0.f};
-  DevBuf<unsigned> d_ticket;    // k_logodds_one's finished-block counter (returns to 0 at the end of every launch)
   DevBuf<uint32_t> d_hash;      // [3][K][slots]: key, first hit beam, first crossing beam
   DevBuf<ScanHdr> d_hdr;
   DevBuf<int8_t> d_i8;
-  bool force_two_kernels = false;  // LSLAM_MAP_TWO_KERNELS=1: the round-1/2 mark + apply pair (A/B measurements, tests)
+  bool force_two_kernels = false;  // LSLAM_MAP_TWO_KERNELS=1: mark + apply per call, nothing deferred (A/B measurements, tests)
   // host -> device staging of the per-scan points: a ring of pinned slots, so updateByScan only enqueues
   // (copy + two kernels per level) and returns; a slot is reused when its copy has completed
   static constexpr int kStageSlots = 8;
@@ -776,7 +720,25 @@ int clear_marks(lslam_map* map, Level& L) {
   size_t n = (size_t)L.sx * L.sy;
   LSLAM_HIP(ctx, hipMemsetAsync(L.d_free, 0, n * sizeof(uint32_t), ctx->stream));
   LSLAM_HIP(ctx, hipMemsetAsync(L.d_occ, 0, n * sizeof(uint32_t), ctx->stream));
+  if (L.d_free2) {
+    LSLAM_HIP(ctx, hipMemsetAsync(L.d_free2, 0, n * sizeof(uint32_t), ctx->stream));
+    LSLAM_HIP(ctx, hipMemsetAsync(L.d_occ2, 0, n * sizeof(uint32_t), ctx->stream));
+  }
   L.epoch = 0;
+  return LSLAM_OK;
+}
+
+// the deferred apply of the pipelined path, as a launch of its own: every reader of the float planes calls this first
+int flush_pending(lslam_map* map) {
+  lslam_context* ctx = map->ctx;
+  for (auto& L : map->levels) {
+    if (!L.pending) continue;
+    const int set = (int)(L.pend_g.epoch & 1u);
+    launch(ctx, "logodds_apply", k_logodds_apply, dim3((L.pend_n + 3) / 4), dim3(256), 0, L.pend_g, (const float*)L.pipe_pts[set].p,
+           L.pend_n, (const uint32_t*)(set ? L.d_free2 : L.d_free), (const uint32_t*)(set ? L.d_occ2 : L.d_occ), L.d_logodds);
+    L.pending = false;
+  }
+  LSLAM_HIP(ctx, hipGetLastError());
   return LSLAM_OK;
 }
 
@@ -786,6 +748,11 @@ int update_impl(lslam_map* map, const float* d_pts, int n, const float* origo, c
   if (n > kMaxBeams || (!just_once && map->levels.size() > 1 && map->n_cached > kMaxBeams))
     return ctx->fail(LSLAM_ERR_UNSUPPORTED, "at most %d points per scan are supported (got %d)", kMaxBeams, n);
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  const bool pipelined = !just_once && !map->force_two_kernels;
+  if (!pipelined) {
+    int rc = flush_pending(map);
+    if (rc) return rc;
+  }
   const int n_levels = just_once ? 1 : (int)map->levels.size();
   const float* const d_pts0 = d_pts;
   const int n0 = n;
@@ -798,7 +765,8 @@ int update_impl(lslam_map* map, const float* d_pts, int n, const float* origo, c
     n = li == 0 ? n0 : map->n_cached;
     origo = li == 0 ? origo0 : map->cached_origo;
     if (L.epoch >= kMaxEpoch) {
-      int rc = clear_marks(map, L);
+      int rc = flush_pending(map);  // the pending scan's keys are about to be cleared
+      if (rc == LSLAM_OK) rc = clear_marks(map, L);
       if (rc) return rc;
     }
     L.epoch++;
@@ -831,9 +799,33 @@ int update_impl(lslam_map* map, const float* d_pts, int n, const float* origo, c
     float byf = (g.s * ox + g.c * oy) + my;
     g.bx = (int)(bxf + 0.5f);                   // :135
     g.by = (int)(byf + 0.5f);
-    if (n > 0 && n <= kOneMaxPoints && !map->force_two_kernels) {
-      launch(ctx, "logodds_one", k_logodds_one, dim3((n + (kOneThreads >> 6) - 1) / (kOneThreads >> 6)), dim3(kOneThreads), 0,
-             g, d_pts, n, L.d_free, L.d_logodds, map->d_ticket.p);
+    if (pipelined) {
+      const size_t cells = (size_t)L.sx * L.sy;
+      if (!L.d_free2) {  // second key-plane set, on first use of the pipelined path
+        if (hipMalloc((void**)&L.d_free2, cells * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc((void**)&L.d_occ2, cells * sizeof(uint32_t)) != hipSuccess) {
+          (void)hipGetLastError();
+          if (L.d_free2) (void)hipFree(L.d_free2);
+          L.d_free2 = L.d_occ2 = nullptr;
+          return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the second key planes of map level %d", li);
+        }
+        LSLAM_HIP(ctx, hipMemsetAsync(L.d_free2, 0, cells * sizeof(uint32_t), ctx->stream));
+        LSLAM_HIP(ctx, hipMemsetAsync(L.d_occ2, 0, cells * sizeof(uint32_t), ctx->stream));
+      }
+      const int set = (int)(L.epoch & 1u);
+      LSLAM_HIP(ctx, L.pipe_pts[set].reserve((size_t)2 * std::max(n, 1)));  // nothing in flight reads THIS set's points
+      const int apply_blocks = L.pending ? (L.pend_n + 3) / 4 : 0;
+      const int mark_blocks = (n + 3) / 4;
+      if (apply_blocks + mark_blocks > 0) {
+        const int pset = L.pending ? (int)(L.pend_g.epoch & 1u) : 0;
+        launch(ctx, "logodds_pipe", k_logodds_pipe, dim3(apply_blocks + mark_blocks), dim3(256), 0, L.pending ? L.pend_g : g,
+               (const float*)L.pipe_pts[pset].p, L.pending ? L.pend_n : 0, (const uint32_t*)(pset ? L.d_free2 : L.d_free),
+               (const uint32_t*)(pset ? L.d_occ2 : L.d_occ), L.d_logodds, apply_blocks, g, d_pts, n, set ? L.d_free2 : L.d_free,
+               set ? L.d_occ2 : L.d_occ, L.pipe_pts[set].p);
+      }
+      L.pending = n > 0;
+      L.pend_g = g;
+      L.pend_n = n;
     } else if (n > 0) {
       dim3 grid((n + 3) / 4), block(256);  // 4 waves per block, one wave per beam
       launch(ctx, "logodds_mark", k_logodds_mark, grid, block, 0, g, d_pts, n, L.d_free, L.d_occ);
@@ -887,28 +879,33 @@ int lslam_map_create(lslam_context* ctx, int size_x, int size_y, float cell_leng
     sy /= 2;
     cl *= 2.0f;  // :84
   }
-  if (map->d_ticket.reserve(1) != hipSuccess) {
-    lslam_map_destroy(map);
-    return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the map's scratch in HBM");
-  }
-  (void)hipMemsetAsync(map->d_ticket.p, 0, sizeof(unsigned), ctx->stream);
   {
     const char* e = getenv("LSLAM_MAP_TWO_KERNELS");
     map->force_two_kernels = e && e[0] == '1';
   }
   (void)hipStreamSynchronize(ctx->stream);
+  ctx->pre_sync.emplace_back((void*)map, [](void* m) { return lslam_map_flush((lslam_map*)m); });  // lslam_synchronize flushes
   *out = map;
   return LSLAM_OK;
 }
 
 void lslam_map_destroy(lslam_map* map) {
   if (!map) return;
+  for (size_t i = 0; i < map->ctx->pre_sync.size(); i++)
+    if (map->ctx->pre_sync[i].first == (void*)map) {
+      map->ctx->pre_sync.erase(map->ctx->pre_sync.begin() + (long)i);
+      break;
+    }
   (void)hipSetDevice(map->ctx->device);
   (void)hipStreamSynchronize(map->ctx->stream);
   for (auto& L : map->levels) {
     if (L.d_logodds) (void)hipFree(L.d_logodds);
     if (L.d_free) (void)hipFree(L.d_free);
     if (L.d_occ) (void)hipFree(L.d_occ);
+    if (L.d_free2) (void)hipFree(L.d_free2);
+    if (L.d_occ2) (void)hipFree(L.d_occ2);
+    L.pipe_pts[0].release();
+    L.pipe_pts[1].release();
     if (L.d_planes) (void)hipFree(L.d_planes);
     if (L.d_flags) (void)hipFree(L.d_flags);
   }
@@ -916,7 +913,6 @@ void lslam_map_destroy(lslam_map* map) {
   map->d_cached.release();
   map->d_gn_out.release();
   map->d_hash.release();
-  map->d_ticket.release();
   map->d_hdr.release();
   map->d_scan.release();
   map->d_scan_ranges.release();
@@ -932,6 +928,7 @@ int lslam_map_reset(lslam_map* map) {
   if (!map) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_context* ctx = map->ctx;
   for (auto& L : map->levels) {
+    L.pending = false;  // a reset map has no use for the deferred apply
     LSLAM_HIP(ctx, hipMemsetAsync(L.d_logodds, 0, (size_t)L.sx * L.sy * sizeof(float), ctx->stream));
     int rc = clear_marks(map, L);
     if (rc) return rc;
@@ -1020,6 +1017,10 @@ constexpr int kBatchMaxScans = kBatchSlots;
 int update_batch_impl(lslam_map* map, int K, const float* d_pts, const int32_t* counts, const float* origos,
                       const float* poses) {
   lslam_context* ctx = map->ctx;
+  {
+    int rc = flush_pending(map);  // a single-scan update may still owe its apply
+    if (rc) return rc;
+  }
   int n_max = 0;
   for (int k = 0; k < K; k++) {
     if (counts[k] < 0 || counts[k] > kMaxBeams)
@@ -1250,6 +1251,10 @@ int match_data_impl(lslam_map* map, const float* pts, int n, bool pts_on_device,
   if ((size_t)n * 9 * sizeof(float) > 150 * 1024)
     return ctx->fail(LSLAM_ERR_UNSUPPORTED, "at most %d points per scan in matchData", (int)(150 * 1024 / 36));
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  {
+    int rc = flush_pending(map);  // the matcher reads the float planes
+    if (rc) return rc;
+  }
   LSLAM_HIP(ctx, map->d_cached.reserve((size_t)2 * (n > 0 ? n : 1)));
   LSLAM_HIP(ctx, map->d_gn_out.reserve(16));
   float* d_out = map->d_gn_out.p;
@@ -1302,6 +1307,11 @@ int lslam_map_read_logodds(lslam_map* map, int level, float* out) {
   if (!map || !out || level < 0 || level >= (int)map->levels.size()) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_context* ctx = map->ctx;
   Level& L = map->levels[level];
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  {
+    int rc = flush_pending(map);
+    if (rc) return rc;
+  }
   LSLAM_HIP(ctx, hipMemcpyAsync(out, L.d_logodds, (size_t)L.sx * L.sy * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return LSLAM_OK;
@@ -1312,6 +1322,11 @@ int lslam_map_read_occupancy_i8(lslam_map* map, int level, int8_t* out) {
   lslam_context* ctx = map->ctx;
   Level& L = map->levels[level];
   size_t n = (size_t)L.sx * L.sy;
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  {
+    int rc = flush_pending(map);
+    if (rc) return rc;
+  }
   LSLAM_HIP(ctx, map->d_i8.reserve(n));
   launch(ctx, "occupancy_i8", k_occupancy_i8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
          (const float*)L.d_logodds, map->d_i8.p, n);
@@ -1322,7 +1337,18 @@ int lslam_map_read_occupancy_i8(lslam_map* map, int level, int8_t* out) {
 
 void* lslam_map_cells_dev_ptr(lslam_map* map, int level) {
   if (!map || level < 0 || level >= (int)map->levels.size()) return nullptr;
+  (void)lslam_map_flush(map);
   return map->levels[level].d_logodds;
+}
+
+// Enqueue whatever a single-scan update still owes the float planes (the deferred apply of the pipelined path).
+// lslam_map_read_*, lslam_map_match_*, the batched update and lslam_synchronize do this themselves; a caller that reads
+// the plane behind lslam_map_cells_dev_ptr from its OWN stream calls it before recording its event on lslam_stream().
+int lslam_map_flush(lslam_map* map) {
+  if (!map) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = map->ctx;
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  return flush_pending(map);
 }
 
 }  // extern "C"

@@ -380,9 +380,9 @@ float lslam_map_scale_to_map(const lslam_map* map, int level); /* getScaleToMap 
  * Points whose end cell is not representable (NaN/Inf or beyond the int32 range) are dropped, as on
  * the reference's x86 build, where the float->int cast yields INT_MIN and the in-map test rejects it.
  * At most 65536 points per container (LSLAM_ERR_UNSUPPORTED beyond; the reference has no limit).
- * ASYNCHRONOUS: the update is enqueued on the context stream when the call returns (points_xy has
- * been copied and may be reused at once); lslam_map_read_*, lslam_map_match_data and
- * lslam_synchronize are ordered after it. */
+ * ASYNCHRONOUS and pipelined: when the call returns points_xy has been copied and may be reused at once, this scan's
+ * marks are enqueued on the context stream and its apply rides in the NEXT update's launch (or in the flush any reader
+ * issues: lslam_map_read_*, lslam_map_match_data, lslam_synchronize ... are ordered after the complete update). */
 int lslam_map_update_by_scan(lslam_map* map, const float* points_xy, int n,
                              const float origo_xy[2], const float pose_world[3]);
 int lslam_map_update_by_scan_dev(lslam_map* map, const float* points_xy_dev, int n,
@@ -443,7 +443,13 @@ int lslam_map_read_logodds(lslam_map* map, int level, float* out_host);
 /* nav_msgs/OccupancyGrid data as hector_slam.cc:287-304 / hector_mapping.cc:186-200 publish
  * it: free(<0) -> 0, occupied(>0) -> 100, else -1 */
 int lslam_map_read_occupancy_i8(lslam_map* map, int level, int8_t* out_host);
-void* lslam_map_cells_dev_ptr(lslam_map* map, int level); /* float log-odds plane in HBM */
+void* lslam_map_cells_dev_ptr(lslam_map* map, int level); /* float log-odds plane in HBM (flushes, see below) */
+/* lslam_map_update_by_scan[_dev] / _by_container are PIPELINED: a call launches [apply of the previous scan | mark of
+ * this scan] as ONE kernel and leaves this scan's apply pending (one launch per scan in steady state instead of two
+ * dependent ones; bit-identical planes).  Every reader in this library -- lslam_map_read_*, lslam_map_match_*, the batched
+ * update, lslam_map_cells_dev_ptr, lslam_synchronize -- enqueues the pending apply first.  A caller that consumes the raw
+ * plane from its OWN stream calls lslam_map_flush before recording its event on lslam_stream(). */
+int lslam_map_flush(lslam_map* map);
 
 /* ---------------------------------------------------------------------------------------- */
 /* lesson5 lidar motion de-skew (LidarUndistortion::CorrectLaserScan, lesson5/src/            */

@@ -318,11 +318,12 @@ def test_laserscan_to_container_on_device(ctx, oracle_lib):
     assert gpu_d.setScan(np.zeros(0, np.float32), sp) == 0  # an empty LaserScan is legal
 
 
-def test_one_launch_and_two_kernel_paths_agree(ctx, oracle_lib, monkeypatch):
-    """Containers of <= 2048 points take the ONE-launch kernel (k_logodds_one: LDS end-cell set, first-arrival frees,
-    last block applies the hits); LSLAM_MAP_TWO_KERNELS=1 (read at map creation) keeps the mark + apply pair.  Both must
-    reproduce the sequential reference bit for bit, incl. the order-dependent (v + free) - free cells, the clamp and a
-    3-level pyramid fed from cached containers."""
+def test_pipelined_and_two_kernel_paths_agree(ctx, oracle_lib, monkeypatch):
+    """updateByScan is PIPELINED (k_logodds_pipe: the apply of the previous scan and the mark of this one in one launch,
+    the last apply flushed by whoever reads); LSLAM_MAP_TWO_KERNELS=1 (read at map creation) keeps mark + apply per call.
+    Both must reproduce the sequential reference bit for bit, incl. the order-dependent (v + free) - free cells, the clamp
+    and a 3-level pyramid fed from cached containers -- with reads, matchData calls and batched updates interleaved so
+    that every flush point is crossed."""
     n, cell, LV = 512, 0.05, 3
     off = (n * cell * 0.5, n * cell * 0.5)
     one = api.OccGridMap(ctx, n, n, cell, off, levels=LV)
@@ -344,16 +345,49 @@ def test_one_launch_and_two_kernel_paths_agree(ctx, oracle_lib, monkeypatch):
         for m in (one, two):
             m.updateByScan(pts, (0.0, 0.0), pose)
         cpu.updateByScan(pts, (0.0, 0.0), pose)
+        if k == 4:  # a read in the middle of a run of updates
+            assert one.logodds(0).tobytes() == cpu.logodds(0).tobytes()
+        if k == 7:  # a batched update between single ones (every level is fed the same scan: match first on the CPU side)
+            for m in (one, two):
+                m.updateByScans([pts, pts], (0.0, 0.0), np.stack([pose, pose]))
+            for _ in range(2):
+                cpu.matchData(pts, pose)
+                cpu.updateByScan(pts, (0.0, 0.0), pose)
+            for m in (one, two):
+                m.matchData(pose, pts)
+            cpu.matchData(pts, pose)
     ctx.profile(True); ctx.profile_reset()
-    one.updateByScan(scans[0][0], (0.0, 0.0), scans[0][1])
-    two.updateByScan(scans[0][0], (0.0, 0.0), scans[0][1])
-    cpu.updateByScan(scans[0][0], (0.0, 0.0), scans[0][1])
-    ctx.synchronize()
+    for _ in range(2):
+        one.updateByScan(scans[0][0], (0.0, 0.0), scans[0][1])
+        two.updateByScan(scans[0][0], (0.0, 0.0), scans[0][1])
+        cpu.updateByScan(scans[0][0], (0.0, 0.0), scans[0][1])
+    ctx.synchronize()  # flushes the pending apply of `one`
     ctx.profile(False)
-    names = set(ctx.profile_read())
-    assert {"logodds_one", "logodds_mark", "logodds_apply"} <= names, names
+    prof = ctx.profile_read()
+    assert {"logodds_pipe", "logodds_mark", "logodds_apply"} <= set(prof), prof
+    # pipelined: 2 updates x 3 levels = 6 pipe launches + 3 flushed applies; two-kernel: 6 marks + 6 applies
+    assert prof["logodds_pipe"][0] == 6 and prof["logodds_mark"][0] == 6 and prof["logodds_apply"][0] == 9, prof
     for lv in range(LV):
         ref = cpu.logodds(lv)
         assert np.count_nonzero(ref) > 1000
         assert one.logodds(lv).tobytes() == ref.tobytes(), lv
         assert two.logodds(lv).tobytes() == ref.tobytes(), lv
+
+
+def test_pipelined_update_raw_plane_after_synchronize(ctx, oracle_lib):
+    """The raw float plane (lslam_map_cells_dev_ptr) is complete after lslam_synchronize: the context flushes the
+    pending apply of every map it owns before it waits."""
+    n, cell = 400, 0.05
+    off = (10.0, 10.0)
+    cpu = oracle_lib.PortHector(n, n, cell, off)
+    gpu = api.OccGridMap(ctx, n, n, cell, off)
+    ptr = gpu.cells_dev_ptr(0)
+    for pts, pose in scans_for_map(3, seed=5, map_cells=n):
+        pts = pts[(np.abs(pts) < 150).all(axis=1)]
+        pose = np.array([0.0, 0.0, float(pose[2])], np.float32)
+        cpu.updateByScan(pts, (0.0, 0.0), pose)
+        gpu.updateByScan(pts, (0.0, 0.0), pose)
+    ctx.synchronize()
+    raw = np.zeros((n, n), np.float32)
+    ctx.download(ptr, raw)
+    assert raw.tobytes() == cpu.logodds().tobytes()
