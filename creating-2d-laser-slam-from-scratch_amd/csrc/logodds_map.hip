@@ -109,9 +109,42 @@ __device__ __forceinline__ Ray ray_of(const Line& l, int sx) {
   }
   return r;
 }
+__device__ __forceinline__ unsigned ray_minor(const Ray& r, unsigned i) {  // minor-axis steps taken after i major steps
+  return (unsigned)(((unsigned long long)(r.abs_da / 2) + (unsigned long long)i * r.abs_db) / r.abs_da);
+}
 __device__ __forceinline__ unsigned ray_cell(const Ray& r, unsigned i) {
-  unsigned q = (unsigned)(((unsigned long long)(r.abs_da / 2) + (unsigned long long)i * r.abs_db) / r.abs_da);
-  return r.start + (unsigned)((int)i * r.offset_a) + (unsigned)((int)q * r.offset_b);
+  return r.start + (unsigned)((int)i * r.offset_a) + (unsigned)((int)ray_minor(r, i) * r.offset_b);
+}
+
+// "does the traversal of beam P (same origin) visit the cell at signed offset (ox, oy) from the origin?"  The visited
+// cells of a ray are exactly { A major steps, q_P(A) minor steps : 0 <= A < abs_da } (end point excluded), so membership
+// is one closed-form test.  Used by the mark pass: a beam whose PREDECESSOR also crosses a cell cannot be the smallest
+// beam index crossing it, so its atomicMax on that cell cannot change the result and is skipped.  Near the sensor every
+// cell is crossed by hundreds of beams; without this the same-address atomics of those cells serialise in L2 and set the
+// duration of the whole pass.
+struct RayShape {
+  unsigned abs_da, abs_db;
+  int sgn_x, sgn_y;  // util::sign: sign(0) = -1
+  bool x_major, valid;
+};
+__device__ __forceinline__ RayShape shape_of(const Line& l) {
+  RayShape p;
+  const int dx = l.x1 - l.x0, dy = l.y1 - l.y0;
+  const unsigned adx = (unsigned)abs(dx), ady = (unsigned)abs(dy);
+  p.sgn_x = dx > 0 ? 1 : -1;
+  p.sgn_y = dy > 0 ? 1 : -1;
+  p.x_major = adx >= ady;
+  p.abs_da = p.x_major ? adx : ady;
+  p.abs_db = p.x_major ? ady : adx;
+  p.valid = l.valid;
+  return p;
+}
+__device__ __forceinline__ bool ray_visits(const RayShape& p, int ox, int oy) {
+  const int A = p.x_major ? ox * p.sgn_x : oy * p.sgn_y;
+  const int M = p.x_major ? oy * p.sgn_y : ox * p.sgn_x;
+  if (A < 0 || (unsigned)A >= p.abs_da || M < 0) return false;
+  // A < abs_da <= 2^16 on any map this library allocates, so the product stays below 2^32
+  return (unsigned)M == (p.abs_da / 2u + (unsigned)A * p.abs_db) / p.abs_da;
 }
 
 // one wave per beam; `wave` = index of this wave among the kernel's mark (resp. apply) waves
@@ -125,7 +158,20 @@ __device__ __forceinline__ void logodds_mark_wave(const LevelGeom& g, const floa
   if (!l.valid) return;
   const uint32_t key = (g.epoch << kBeamBits) | (kBeamMask - (uint32_t)i);
   const Ray r = ray_of(l, g.sx);
-  for (unsigned c = lane; c < r.abs_da; c += 64) atomicMax(&free_key[ray_cell(r, c)], key);
+  const RayShape me = shape_of(l);
+  RayShape prev;
+  prev.valid = false;
+  if (i > 0 && me.abs_da < 65536u) prev = shape_of(beam_line(g, pts, i - 1));
+  prev.valid = prev.valid && prev.abs_da < 65536u;
+  for (unsigned c = lane; c < r.abs_da; c += 64) {
+    const unsigned q = ray_minor(r, c);
+    if (prev.valid) {
+      const int ox = me.x_major ? (int)c * me.sgn_x : (int)q * me.sgn_x;
+      const int oy = me.x_major ? (int)q * me.sgn_y : (int)c * me.sgn_y;
+      if (ray_visits(prev, ox, oy)) continue;  // beam i-1 marks this cell with a larger key
+    }
+    atomicMax(&free_key[r.start + (unsigned)((int)c * r.offset_a) + (unsigned)((int)q * r.offset_b)], key);
+  }
   if (lane == 0) atomicMax(&occ_key[(unsigned)(l.y1 * g.sx + l.x1)], key);
 }
 
