@@ -185,44 +185,28 @@ __device__ __forceinline__ void logodds_apply_wave(const LevelGeom& g, const flo
   const uint32_t me = kBeamMask - (uint32_t)i;
   const uint32_t ep = g.epoch;
   const Ray r = ray_of(l, g.sx);
-  // the owner of a crossed cell is the SMALLEST beam index crossing it: a beam whose predecessor also crosses the cell
-  // is not it and does not even look (ray_visits; the same rule the mark pass uses)
-  const RayShape mine = shape_of(l);
-  RayShape prev;
-  prev.valid = false;
-  if (i > 0 && mine.abs_da < 65536u) prev = shape_of(beam_line(g, pts, i - 1));
-  prev.valid = prev.valid && prev.abs_da < 65536u;
   // crossed cells: free once per scan unless some beam ends here (bresenhamCellFree, :302-313).
   // Four cells per lane and pass, their three reads issued together: the kernel is a chain of dependent
-  // L2 round trips, not bandwidth.
+  // L2 round trips, not bandwidth, so the reads of non-owners are the cheaper evil.
   constexpr int kIlp = 4;
   for (unsigned c0 = lane; c0 < r.abs_da; c0 += 64 * kIlp) {
     unsigned off[kIlp];
-    bool look[kIlp];
     uint32_t fk[kIlp], ok[kIlp];
     float lo[kIlp];
 #pragma unroll
     for (int u = 0; u < kIlp; u++) {
       const unsigned c = c0 + 64u * u;
-      look[u] = c < r.abs_da;
-      const unsigned cc = look[u] ? c : c0;
-      const unsigned q = ray_minor(r, cc);
-      off[u] = r.start + (unsigned)((int)cc * r.offset_a) + (unsigned)((int)q * r.offset_b);
-      if (look[u] && prev.valid) {
-        const int ox = mine.x_major ? (int)cc * mine.sgn_x : (int)q * mine.sgn_x;
-        const int oy = mine.x_major ? (int)q * mine.sgn_y : (int)cc * mine.sgn_y;
-        look[u] = !ray_visits(prev, ox, oy);
-      }
+      off[u] = ray_cell(r, c < r.abs_da ? c : c0);
     }
 #pragma unroll
     for (int u = 0; u < kIlp; u++) {
-      fk[u] = look[u] ? free_key[off[u]] : 0u;
-      ok[u] = look[u] ? occ_key[off[u]] : 0u;
-      lo[u] = look[u] ? logodds[off[u]] : 0.f;
+      fk[u] = free_key[off[u]];
+      ok[u] = occ_key[off[u]];
+      lo[u] = logodds[off[u]];
     }
 #pragma unroll
     for (int u = 0; u < kIlp; u++) {
-      if (!look[u]) continue;
+      if (c0 + 64u * u >= r.abs_da) continue;
       if ((fk[u] & kBeamMask) != me) continue;       // not the first beam crossing this cell
       if ((ok[u] >> kBeamBits) == ep) continue;      // a hit cell: handled by its occ owner
       logodds[off[u]] = lo[u] + g.lo_free;           // the owner is the only writer of this cell in this kernel
@@ -398,28 +382,16 @@ k_lo_batch_rays(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __res
   uint8_t* plane = planes + (size_t)sidx * g.n_tiles * 64;
   const uint32_t crossed = g.tag | kCodeCrossed, hit = g.tag | kCodeHit;
   const size_t hb = (size_t)sidx * (g.hash_mask + 1);
-  // A cell that beam i-1 of the same scan also crosses is left to beam i-1 (ray_visits): whatever this beam would do
-  // there -- set CROSSED, or record itself as a crossing beam of a hit cell -- beam i-1 does with the same byte / a
-  // smaller index.  By induction the first beam of every run of consecutive crossing beams does the work, and near the
-  // sensor such runs are hundreds of beams long: most of the traversal's loads and byte stores disappear.
-  RayShape prev;
-  prev.valid = false;
-  {
-    const int i0 = grp * kRayBeamsPerWave;
-    if (i0 > 0 && i0 < h.n) prev = shape_of(batch_line(g, h, pts, i0 - 1));
-  }
   for (int i = grp * kRayBeamsPerWave; i < min(h.n, (grp + 1) * kRayBeamsPerWave); i++) {
     const Line l = batch_line(g, h, pts, i);
-    const RayShape mine = shape_of(l);
-    const bool use_prev = prev.valid && prev.abs_da < 65536u && mine.abs_da < 65536u;
-    const RayShape pv = prev;
-    prev = mine;  // the next beam's predecessor (valid or not)
     if (!l.valid) continue;
     // the reference's traversal (H/map/OccGridMapBase.h:240-299) in closed form, here as (x, y): cell c of the ray is c
     // major steps and q(c) = floor((abs_da/2 + c*abs_db) / abs_da) minor steps from the begin cell (see ray_cell)
-    const int sgx = mine.sgn_x, sgy = mine.sgn_y;  // util::sign: sign(0) = -1
-    const bool xmajor = mine.x_major;
-    const unsigned abs_da = mine.abs_da, abs_db = mine.abs_db;
+    const int dx = l.x1 - l.x0, dy = l.y1 - l.y0;
+    const unsigned abs_dx = (unsigned)abs(dx), abs_dy = (unsigned)abs(dy);
+    const int sgx = dx > 0 ? 1 : -1, sgy = dy > 0 ? 1 : -1;  // util::sign: sign(0) = -1
+    const bool xmajor = abs_dx >= abs_dy;
+    const unsigned abs_da = xmajor ? abs_dx : abs_dy, abs_db = xmajor ? abs_dy : abs_dx;
     // q(c): the numerator stays below 2^31 (map sides <= 32768) and the quotient below 2^16, so a float estimate is
     // within +-1 of it and two integer corrections make it exact (a 64-bit integer division per cell otherwise)
     const float rcp_da = 1.0f / (float)abs_da;
@@ -431,11 +403,8 @@ k_lo_batch_rays(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __res
       if (rem < 0) { q -= 1; rem += (int)abs_da; }
       if (rem >= (int)abs_da) { q += 1; rem -= (int)abs_da; }
       if (rem >= (int)abs_da) { q += 1; }
-      const int ox = xmajor ? (int)c * sgx : (int)q * sgx;
-      const int oy = xmajor ? (int)q * sgy : (int)c * sgy;
-      if (use_prev && ray_visits(pv, ox, oy)) continue;
-      const int x = l.x0 + ox;
-      const int y = l.y0 + oy;
+      const int x = l.x0 + (xmajor ? (int)c * sgx : (int)q * sgx);
+      const int y = l.y0 + (xmajor ? (int)q * sgy : (int)c * sgy);
       const uint32_t t = tile_of(g, x, y);
       const size_t off = (size_t)t * 64 + in_tile(x, y);
       const uint32_t b = plane[off];
