@@ -426,6 +426,9 @@ def build_secondary(gpu, cpu, job, args):
                 "kernel_us_per_scan": {k: round(1e3 * v[1] / n, 2) for k, v in sorted(g["single_prof"].items())},
                 "launches_per_scan": round(sum(v[0] for v in g["single_prof"].values()) / n, 2),
                 "kernel_algorithmic_GBs": round(alg / k_single / 1e9, 2) if k_single else None,
+                "measured_hbm_bytes_per_scan": _traffic("logodds_pipe").get("hbm_bytes_per_launch"),
+                "measured_hbm_source": _traffic("logodds_pipe").get("source"),
+                "note": "pipelined: one launch per scan in steady state (apply of the previous scan + mark of this one)",
                 "bit_exact_vs_cpu": g["single_sha"] == c["map_sha"]},
             "batched_64_per_call": {
                 "scans_per_s": round(n / g["batch_s"], 1), "cell_updates_per_s": round(c["visits"] / g["batch_s"]),

@@ -2,7 +2,11 @@
 """profiles/traffic.json from a tools/pmc_summary.py result: the per-launch PMC figures bench.py quotes
 (HBM bytes, VALU wave-instructions, busy fractions) for the kernels of `python bench.py`.
 
-  python tools/make_traffic.py profiles/r02/pmc_per_launch.json 4096 > profiles/traffic.json
+  python tools/make_traffic.py profiles/r02/pmc_per_launch.json 4096 [pmc_cfg2_per_launch.json] > profiles/traffic.json
+
+The optional third argument is the same summary for `tools/bench_extra.py --only cfg2 --map-scans 256` (the log-odds
+kernels): `logodds_pipe` (one launch = one 1081-beam scan, apply of the previous scan + mark of this one) and
+`logodds_batched` (the four kernels of one 64-scan lslam_map_update_batch call, summed).
 
 FETCH_SIZE is doubled per the gfx950 note in MI355X_MICROARCH.md (the counter ticks in 64-B units but is
 reported as if 32-B); WRITE_SIZE is taken as reported.  Both are KiB.
@@ -21,7 +25,26 @@ NAMES = {  # rocprofv3 kernel name prefix -> the name bench.py's HIP-event timer
 }
 
 
-def main(path, scans):
+def hbm_bytes(c):
+    return int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024) if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None
+
+
+def logodds_entries(path):
+    pmc = json.load(open(path))
+    out = {}
+    pipe = next((c for k, c in pmc.items() if k.startswith("k_logodds_pipe")), None)
+    if pipe:
+        out["logodds_pipe"] = {"scans_per_launch": 1, "source": path, "hbm_bytes_per_launch": hbm_bytes(pipe),
+                               "valu_insts_per_launch": int(pipe.get("SQ_INSTS_VALU", 0)), "waves_per_launch": int(pipe.get("SQ_WAVES", 0))}
+    batch = [c for k, c in pmc.items() if k.startswith("k_lo_batch_")]
+    if batch and all(hbm_bytes(c) is not None for c in batch):
+        out["logodds_batched"] = {"scans_per_launch": 64, "source": path, "kernels": sorted(k for k in pmc if k.startswith("k_lo_batch_")),
+                                  "hbm_bytes_per_launch": sum(hbm_bytes(c) for c in batch),
+                                  "note": "sum over the kernels of one 64-scan call (per-launch averages), level 0 of a 1000x1000 map"}
+    return out
+
+
+def main(path, scans, cfg2_path=None):
     pmc = json.load(open(path))
     out = {}
     for kname, c in pmc.items():
@@ -55,6 +78,8 @@ def main(path, scans):
             rec["l2_hit"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3)
         rec = {k: v for k, v in rec.items() if v is not None}
         out[short] = rec
+    if cfg2_path:
+        out.update(logodds_entries(cfg2_path))
     # which kernel source these counters describe: bench.py flags `roofline` as stale when the file has changed since
     import hashlib
     import pathlib
@@ -68,4 +93,4 @@ def main(path, scans):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 4096)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 4096, sys.argv[3] if len(sys.argv) > 3 else None)

@@ -1,0 +1,25 @@
+#!/bin/bash
+# One gpurun call's worth of end-of-round evidence (run on the GPU box from the repo root):
+#   bash tools/measure_round.sh r03h
+# -> gpurun_out/<tag>/: bench.json (+ .err), kernel_stats_bench_default.csv (rocprofv3 --kernel-trace --stats of the same
+#    command), pmc_per_launch.json / pmc_cfg2_per_launch.json (separate --pmc passes, tools/pmc_passes.sh, summarised on the
+#    box: the raw counter CSVs are too big to travel), traffic.json (tools/make_traffic.py), extra_configs.jsonl
+#    (tools/bench_extra.py: cfg 2 / 3 / 5 at full size, loop-closure matcher, lesson4 loop, CreateFromScans), batch_sweep.txt,
+#    chain_profile.json
+TAG=${1:-rXX}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+(timeout 300 python bench.py > $O/bench.json 2> $O/bench.err); echo "bench rc=$?"
+(timeout 300 bash tools/prof_stats.sh > $O/prof_stats.log 2>&1); cp gpurun_out/prof_stats/kernel_stats.csv $O/kernel_stats_bench_default.csv
+(PMC_OUT=pmc_$TAG timeout 600 bash tools/pmc_passes.sh > $O/pmc_passes.log 2>&1)
+python tools/pmc_summary.py gpurun_out/pmc_$TAG > $O/pmc_per_launch.json
+(PMC_CMD="python tools/bench_extra.py --only cfg2 --map-scans 256" PMC_OUT=pmc_cfg2_$TAG timeout 600 bash tools/pmc_passes.sh > $O/pmc_cfg2_passes.log 2>&1)
+python tools/pmc_summary.py gpurun_out/pmc_cfg2_$TAG > $O/pmc_cfg2_per_launch.json
+rm -rf gpurun_out/pmc_$TAG gpurun_out/pmc_cfg2_$TAG gpurun_out/prof_stats
+python tools/make_traffic.py $O/pmc_per_launch.json 4096 $O/pmc_cfg2_per_launch.json > $O/traffic.json
+(timeout 600 python tools/bench_extra.py --stream-ref 0 2>/dev/null | grep "^{" > $O/extra_configs.jsonl)
+(timeout 200 python tools/batch_sweep.py > $O/batch_sweep.txt 2>&1)
+(timeout 120 python tools/chain_profile.py --scans 600 2>/dev/null | grep "^{" > $O/chain_profile.json)
+ls -la $O
