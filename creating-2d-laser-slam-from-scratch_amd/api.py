@@ -356,11 +356,11 @@ class Context:
     def __del__(self):
         # at interpreter shutdown the order of finalisers is arbitrary (a context may already be gone under a handle
         # that points into it) and the process is exiting anyway: release explicitly, or not at all
-        if sys.is_finalizing():
-            return
         try:
+            if sys.is_finalizing():
+                return
             self.close()
-        except Exception:
+        except Exception:  # incl. module globals already torn down (sys is None) late in shutdown
             pass
 
     def synchronize(self):
@@ -435,11 +435,11 @@ class ScanMatcher:
     def __del__(self):
         # at interpreter shutdown the order of finalisers is arbitrary (a context may already be gone under a handle
         # that points into it) and the process is exiting anyway: release explicitly, or not at all
-        if sys.is_finalizing():
-            return
         try:
+            if sys.is_finalizing():
+                return
             self.close()
-        except Exception:
+        except Exception:  # incl. module globals already torn down (sys is None) late in shutdown
             pass
 
     @property
@@ -479,7 +479,7 @@ class ScanMatcher:
         self.ctx.check(self.L.lslam_matcher_set_grid_u8_dev(self.h, ptr, o.ctypes.data))
 
     def set_option(self, name: str, value: int):
-        opt = {"row_occupancy": 1, "collect_stats": 2}[name]
+        opt = {"row_occupancy": 1, "collect_stats": 2, "pretest": 3}[name]
         self.ctx.check(self.L.lslam_matcher_set_option(self.h, opt, int(value)))
 
     def read_stats(self) -> dict:
@@ -596,11 +596,11 @@ class MatcherPool:
     def __del__(self):
         # at interpreter shutdown the order of finalisers is arbitrary (a context may already be gone under a handle
         # that points into it) and the process is exiting anyway: release explicitly, or not at all
-        if sys.is_finalizing():
-            return
         try:
+            if sys.is_finalizing():
+                return
             self.close()
-        except Exception:
+        except Exception:  # incl. module globals already torn down (sys is None) late in shutdown
             pass
 
     def _check(self, rc):
@@ -668,11 +668,11 @@ class FrontEnd:
     def __del__(self):
         # at interpreter shutdown the order of finalisers is arbitrary (a context may already be gone under a handle
         # that points into it) and the process is exiting anyway: release explicitly, or not at all
-        if sys.is_finalizing():
-            return
         try:
+            if sys.is_finalizing():
+                return
             self.close()
-        except Exception:
+        except Exception:  # incl. module globals already torn down (sys is None) late in shutdown
             pass
 
     def Process(self, ranges, odom_pose, time_s: float = 0.0):
@@ -787,11 +787,11 @@ class OccupancyGrid:
     def __del__(self):
         # at interpreter shutdown the order of finalisers is arbitrary (a context may already be gone under a handle
         # that points into it) and the process is exiting anyway: release explicitly, or not at all
-        if sys.is_finalizing():
-            return
         try:
+            if sys.is_finalizing():
+                return
             self.close()
-        except Exception:
+        except Exception:  # incl. module globals already torn down (sys is None) late in shutdown
             pass
 
     def info(self):
@@ -831,11 +831,11 @@ class OccGridMap:
     def __del__(self):
         # at interpreter shutdown the order of finalisers is arbitrary (a context may already be gone under a handle
         # that points into it) and the process is exiting anyway: release explicitly, or not at all
-        if sys.is_finalizing():
-            return
         try:
+            if sys.is_finalizing():
+                return
             self.close()
-        except Exception:
+        except Exception:  # incl. module globals already torn down (sys is None) late in shutdown
             pass
 
     def reset(self):
