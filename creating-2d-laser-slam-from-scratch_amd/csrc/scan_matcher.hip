@@ -371,97 +371,6 @@ k_occ_pairs(const uint32_t* __restrict__ occ_t, int stride, int words_per_half, 
   pairs[(size_t)ew * stride + x] = make_uint2(col[0], w + 1 < words_per_half ? col[1] : 0u);
 }
 
-// ------------------------------------------------------------------------------------------
-// Conservative fp32 PRE-TEST of the big-batch coarse pass, as a kernel of its own (round 3; the in-kernel form of round 2
-// died on the 128-VGPR wall of k_resp_rows).  65 % of the (beam, angle) pairs of the bench have no live lattice row, yet
-// each paid the full exact fp64 phase A.  Here:
-//   k_dilate_map  bit(X, Y) = any non-zero grid byte with x in [8X-1, 8X+28], y in [8Y-1, 8Y+28] (block 8, span
-//                 1 + 8 + 21): for a table cell known to within one cell, every byte any of the <= 11 x 11 coarse
-//                 candidates (2-cell steps) of the beam can read lies inside the region of the approximate cell's block;
-//   k_pretest     thread per (scan, beam), all angles: the rotation in fp32 (error ~1e-4 cell), one bit of the map; the
-//                 ballots of the passing beams are written as 64-bit words, mask[scan][angle][beam / 64];
-//   k_resp_rows<..., LIST> expands its (scan, angle)'s mask into a beam list in LDS and runs the exact phases on FULL
-//                 waves of listed beams only.
-// A clear bit proves that the beam sums zero for every candidate of that angle, so skipping it is exact (like the
-// row-occupancy pruning); beams near the border, where the flat index may wrap, always pass.
-// ------------------------------------------------------------------------------------------
-constexpr int kDilBlock = 8, kDilSpan = 30;
-constexpr int kListCap = 2048;  // beams per scan the LIST variant holds in LDS
-__global__ void __launch_bounds__(64)
-k_dilate_map(const uint32_t* __restrict__ nz, int nz_words, int stride, int height, uint32_t* __restrict__ dmap,
-             int words_per_row) {
-  const int X = blockIdx.x * 64 + threadIdx.x, Y = blockIdx.y;
-  const int x0 = max(kDilBlock * X - 1, 0), x1 = min(kDilBlock * X - 1 + kDilSpan - 1, stride - 1);
-  const int y0 = max(kDilBlock * Y - 1, 0), y1 = min(kDilBlock * Y - 1 + kDilSpan - 1, height - 1);
-  unsigned long long any = 0ull;
-  if (x1 >= x0) {
-    const unsigned long long span = (1ull << (x1 - x0 + 1)) - 1ull;
-    for (int y = y0; y <= y1; y++) {
-      const long long f0 = (long long)x0 + (long long)y * stride;
-      const int w = (int)(f0 >> 5), sh = (int)(f0 & 31);
-      const unsigned long long lo = nz[w], hi = w + 1 < nz_words ? nz[w + 1] : 0u;
-      any |= ((lo | (hi << 32)) >> sh) & span;
-    }
-  }
-  const unsigned long long bal = __ballot(any != 0ull);
-  if (threadIdx.x == 0) {
-    dmap[(size_t)Y * words_per_row + 2 * blockIdx.x] = (uint32_t)bal;
-    dmap[(size_t)Y * words_per_row + 2 * blockIdx.x + 1] = (uint32_t)(bal >> 32);
-  }
-}
-
-__global__ void __launch_bounds__(384)
-k_pretest(Geom g, PassCfg pc, const Lattice* __restrict__ lat, const double2* __restrict__ cossin,
-          const double2* __restrict__ local, const uint32_t* __restrict__ dmap, int dmap_wpr,
-          unsigned long long* __restrict__ mask, int mask_words, int S) {
-  __shared__ float2 cs[kMaxAngles];
-  const int s = blockIdx.y;
-  if (s >= S) return;
-  const Lattice& L = lat[s];
-  for (int a = threadIdx.x; a < pc.na; a += blockDim.x) {
-    const double2 c = cossin[(size_t)s * kMaxAngles + a];
-    cs[a] = make_float2((float)c.x, (float)c.y);
-  }
-  __syncthreads();
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int word = b >> 6;  // wave-uniform: blockDim is a multiple of 64
-  if (word >= mask_words) return;
-  // scans the exact kernel skips (inactive, failed set-up, non-uniform lattice) get all-ones: nobody reads them
-  const bool usable = L.active && L.status == 0;
-  float px = 0.f, py = 0.f;
-  bool readable = false;
-  if (b < g.n_beams) {
-    const double2 p = local[(size_t)s * g.n_beams + b];
-    readable = !isnan(p.x) && !isnan(p.y);  // NaN = INVALID_SCAN
-    px = (float)p.x;
-    py = (float)p.y;
-  }
-  const int X0 = L.gx[0], Y0 = L.gy[0];
-  const float scalef = (float)g.scale;
-  const uint32_t xlim = g.width > 2 * kDilBlock + kDilSpan ? (uint32_t)(g.width - 2 * kDilBlock - kDilSpan) : 0u;
-  const uint32_t ylim = g.height > 2 * kDilBlock + kDilSpan ? (uint32_t)(g.height - 2 * kDilBlock - kDilSpan) : 0u;
-  const int lane = threadIdx.x & 63;
-  unsigned long long* out = mask + (size_t)s * pc.na * mask_words + word;
-  for (int a = 0; a < pc.na; a++) {
-    bool pass = false;
-    if (readable) {
-      pass = true;
-      if (usable) {
-        const float2 c = cs[a];
-        const float ox = c.x * px - c.y * py, oy = c.y * px + c.x * py;
-        const float fx = floorf(ox * scalef + 0.5f), fy = floorf(oy * scalef + 0.5f);
-        if (fabsf(fx) < 1.0e6f && fabsf(fy) < 1.0e6f) {
-          const int x = X0 + (int)fx, y = Y0 + (int)fy;
-          if ((uint32_t)(x - kDilBlock) < xlim && (uint32_t)(y - kDilBlock) < ylim)
-            pass = (dmap[(size_t)(y >> 3) * dmap_wpr + (x >> 8)] >> ((x >> 3) & 31)) & 1u;
-        }
-      }
-    }
-    const unsigned long long v = __ballot(pass);
-    if (lane == 0) out[(size_t)a * mask_words] = v;
-  }
-}
-
 // wave64 sum, uniform result: four DPP adds give every lane its row-of-16 total, the four row totals
 // are read back as scalars
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -496,20 +405,16 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // STATS = true is the instrumented twin used for ONE untimed launch by lslam_matcher_read_stats (bench.py's
 // pruned_row_fraction): it counts, per launch, the lattice rows inside the reference's index range, the rows
 // still live after the exact row-occupancy pruning, the readable beams and the beams queued for phase B.
-// LIST = true: the beams of this (scan, angle) that passed k_pretest come as a bitmask; they are expanded into a list in
-// LDS and phase A runs on full waves of listed beams (beam_slices must be 1).
-template <int NXD, int NYC, bool TILED, bool STATS = false, bool LIST = false>
+template <int NXD, int NYC, bool TILED, bool STATS = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))  // <= 128 VGPRs
 k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int step, int limit, Geom g,
             PassCfg pc, const Lattice* __restrict__ lat, const double2* __restrict__ cossin,
             const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int beam_slices,
             int S, const uint2* __restrict__ occ_t, int occ_wpc, int tile_rows, uint32_t tile_class_bytes,
-            unsigned long long* __restrict__ stats, const unsigned long long* __restrict__ pre_mask, int mask_words) {
+            unsigned long long* __restrict__ stats) {
   constexpr int NW = NXD * NYC * 2;
   constexpr int kQueue = 128;
   static_assert(NYC <= 16 && 2 * (NYC - 1) < 32, "row mask / occupancy window width");
-  static_assert(!LIST || !STATS, "the instrumented twin runs without the pre-test");
-  __shared__ uint16_t blist[LIST ? kListCap : 1];
   __shared__ __align__(16) uint32_t red[NW][8];  // [packed word][group of 8 lanes]
   __shared__ int2 queue[kQueue];  // circular; .x = first row index m0, .y = row mask | parity << 31
   const int lane = threadIdx.x;
@@ -536,18 +441,6 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
   const uint32_t plane_delta = TILED ? 0u : (uint32_t)(src1 - src0);
   const uint32_t strip_bytes = (uint32_t)tile_rows * 32u;  // one 32-byte-wide strip, all class rows
   const int occ_wph = occ_wpc >> 1;  // words per (column, row parity)
-  int n_listed = 0;
-  if constexpr (LIST) {
-    const unsigned long long* mk = pre_mask + ((size_t)s * pc.na + a) * mask_words;
-    for (int w2 = 0; w2 < mask_words; w2++) {
-      const unsigned long long mw = mk[w2];  // wave-uniform
-      if ((mw >> lane) & 1ull)
-        blist[n_listed + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u))] =
-            (uint16_t)(64 * w2 + lane);
-      n_listed += __popcll(mw);
-    }
-    __syncthreads();
-  }
 
   for (int j0 = 0; j0 < pc.ny; j0 += NYC) {
     uint32_t acc[NYC][NXD][2];
@@ -611,23 +504,16 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
     const int Yb1 = Y0 + j0 * step + 1;
     const int m0_max = limit - ((rows_here - 1) * g.stride + 4 * NXD);  // whole neighbourhood in range
     const int y1_max = g.height + 1 - step * (NYC - 1);                 // y+1 range of the occupancy window
-    // the beams this wave looks at: every beam of its slice, or (LIST) the ones k_pretest passed for this angle
-    const int n_iter = LIST ? n_listed : g.n_beams;
-    const int first = LIST ? 0 : 64 * slice;
-    auto beam_at = [&](int k) -> int {  // k-th entry of the wave's work list (clamped: callers mask the overhang)
-      if constexpr (LIST) return (int)blist[min(k, max(n_listed - 1, 0))];
-      else return min(k, g.n_beams - 1);
-    };
-    double2 p_next = lp[beam_at(first + lane)];
-    for (int b0 = first; b0 < n_iter; b0 += (LIST ? 64 : bstride)) {
+    double2 p_next = lp[min(64 * slice + lane, g.n_beams - 1)];
+    for (int b0 = 64 * slice; b0 < g.n_beams; b0 += bstride) {
       const int b = b0 + lane;
-      const bool has = b < n_iter;
       const double2 p = p_next;  // fetched one block ahead: its latency hides behind this block's arithmetic
-      p_next = lp[beam_at(b + (LIST ? 64 : bstride))];      uint32_t mask = 0u, par = 0u, col = 0u, osh = 0u;
+      p_next = lp[min(b + bstride, g.n_beams - 1)];
+      uint32_t mask = 0u, par = 0u, col = 0u, osh = 0u;
       int m0i = 0;
       bool have_occ = false;
       // NaN = INVALID_SCAN (k_scan_prep writes both coordinates); testing both keeps the point ONE 16-byte load
-      if ((int)has & (int)!isnan(p.x) & (int)!isnan(p.y)) {
+      if ((int)(b < g.n_beams) & (int)!isnan(p.x) & (int)!isnan(p.y)) {
         // ComputeOffsets + WorldToGrid (Karto.h:6465-6494, 4237-4252): identical fp64 expression tree;
         // (int)math::Round(v) taken as trunc(copysign(|v| + 0.5, v))
         const double ox = cosine * p.x - sine * p.y, oy = sine * p.x + cosine * p.y;
@@ -684,7 +570,7 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       }
       if constexpr (STATS) {
         st_rows += (uint32_t)__popc(mask);
-        st_beams += (uint32_t)((int)has & (int)!isnan(p.x) & (int)!isnan(p.y));
+        st_beams += (uint32_t)((int)(b < g.n_beams) & (int)!isnan(p.x) & (int)!isnan(p.y));
       }
       if (occ_t) {
         const uint2 ow = occ_t[col];  // x-major: neighbouring beams read neighbouring words (k_occ_pairs)
@@ -2643,12 +2529,6 @@ struct lslam_matcher {
   // two-stream experiment.  The core entry points take this flag and refuse to overlap instead.
   std::atomic<bool> busy{false};
   bool use_row_occupancy = true;    // lslam_matcher_set_option(LSLAM_OPT_ROW_OCCUPANCY)
-  // conservative fp32 pre-test of the big-batch coarse pass (k_dilate_map + k_pretest + k_resp_rows<..., LIST>)
-  bool use_pretest = true;          // lslam_matcher_set_option(LSLAM_OPT_PRETEST)
-  uint32_t* d_dmap = nullptr;
-  int dmap_wpr = 0, dmap_rows = 0;
-  bool dmap_dirty = true, dmap_failed = false;
-  DevBuf<unsigned long long> d_premask;
   bool collect_stats = false;       // lslam_matcher_set_option(LSLAM_OPT_COLLECT_STATS): instrumented coarse kernel
   DevBuf<unsigned long long> d_stats;
   uint32_t* d_occ_t = nullptr;      // transposed row-occupancy bitmap (k_row_occupancy)
@@ -2890,38 +2770,8 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
 #define LSLAM_ROWS_ARGS(SRC0, SRC1)                                                                              \
   grid, dim3(64), 0, SRC0, SRC1, step, limit, g, p, (const Lattice*)m->d_lat.p, (const double2*)m->d_cossin.p, \
       (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc, m->ptile_rows, class_bytes, \
-      (unsigned long long*)(m->collect_stats ? m->d_stats.p : nullptr), pre_mask, mask_words
+      (unsigned long long*)(m->collect_stats ? m->d_stats.p : nullptr)
       const uint8_t* pt = m->d_ptiles;
-      // the conservative fp32 pre-test (its own kernel) + the exact kernel on the listed beams: big-batch coarse pass of
-      // the standard 11 x 11 lattice only
-      const unsigned long long* pre_mask = nullptr;
-      int mask_words = 0;
-      const bool pretest = m->use_pretest && occ && ptiled && variant == 2 && !m->collect_stats && !m->dmap_failed &&
-                           p.nx <= 11 && p.ny <= 11 && g.n_beams <= kListCap;
-      if (pretest) {
-        if (!m->d_dmap) {
-          m->dmap_wpr = 2 * ((g.stride / kDilBlock + 1 + 63) / 64);
-          m->dmap_rows = g.height / kDilBlock + 1;
-          if (hipMalloc((void**)&m->d_dmap, (size_t)m->dmap_wpr * m->dmap_rows * sizeof(uint32_t)) != hipSuccess) {
-            (void)hipGetLastError();
-            m->d_dmap = nullptr;
-            m->dmap_failed = true;
-          }
-        }
-        if (m->d_dmap) {
-          if (m->dmap_dirty) {  // d_nz is current: the row-occupancy refresh above rebuilt it for this grid
-            launch(ctx, "dilate_map", k_dilate_map, dim3(m->dmap_wpr / 2, m->dmap_rows), dim3(64), 0, (const uint32_t*)m->d_nz,
-                   m->nz_words, g.stride, g.height, m->d_dmap, m->dmap_wpr);
-            m->dmap_dirty = false;
-          }
-          mask_words = (g.n_beams + 63) / 64;
-          LSLAM_HIP(ctx, m->d_premask.reserve((size_t)S * p.na * mask_words));
-          launch(ctx, "pretest", k_pretest, dim3((unsigned)((mask_words * 64 + 383) / 384), S), dim3(384), 0, g, p,
-                 (const Lattice*)m->d_lat.p, (const double2*)m->d_cossin.p, (const double2*)m->d_local.p,
-                 (const uint32_t*)m->d_dmap, m->dmap_wpr, m->d_premask.p, mask_words, S);
-          pre_mask = m->d_premask.p;
-        }
-      }
       if (m->collect_stats && variant == 2 && step == 2) {  // instrumented twin (untimed diagnostics only)
         if (ptiled)
           launch(ctx, name, k_resp_rows<3, 11, true, true>, LSLAM_ROWS_ARGS(pt, pt));
@@ -2929,8 +2779,6 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
           launch(ctx, name, k_resp_rows<3, 11, false, true>, LSLAM_ROWS_ARGS(s0, s1));
       } else if (variant == 1)
         launch(ctx, name, k_resp_rows<1, 4, false>, LSLAM_ROWS_ARGS(s0, s1));
-      else if (variant == 2 && ptiled && pre_mask)
-        launch(ctx, name, k_resp_rows<3, 11, true, false, true>, LSLAM_ROWS_ARGS(pt, pt));
       else if (variant == 2 && ptiled)
         launch(ctx, name, k_resp_rows<3, 11, true>, LSLAM_ROWS_ARGS(pt, pt));
       else if (variant == 2)
@@ -3128,7 +2976,7 @@ int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, i
     launch(ctx, "grid_clear", k_rebuild_begin, dim3(blocks), dim3(256), 0, (uint4*)m->d_grid, n16, x);
   }
   m->resp_prezeroed = x.zero == m->d_resp.p && x.zero ? (size_t)x.zero_words : 0;
-  m->sub_dirty = m->occ_dirty = m->tile_dirty = m->ptile_dirty = m->dmap_dirty = true;
+  m->sub_dirty = m->occ_dirty = m->tile_dirty = m->ptile_dirty = true;
   if (B <= 0 || n <= 0) return LSLAM_OK;
   LSLAM_HIP(ctx, m->d_valid.reserve((size_t)B * n));
   if (!use_lds) LSLAM_HIP(ctx, m->d_fv_scratch.reserve((size_t)B * 2 * n));
@@ -3340,8 +3188,6 @@ void lslam_matcher_destroy(lslam_matcher* m) {
   (void)hipFree(m->d_nz);
   (void)hipFree(m->d_tiles);
   (void)hipFree(m->d_ptiles);
-  if (m->d_dmap) (void)hipFree(m->d_dmap);
-  m->d_premask.release();
   m->d_ranges64.release(); m->d_poses.release(); m->d_local.release(); m->d_world.release();
   m->d_valid.release(); m->d_fv_scratch.release(); m->d_centres.release(); m->d_lat.release(); m->d_cossin.release(); m->d_coarse.release(); m->d_resp.release();
   m->d_tbl.release(); m->d_part.release(); m->d_big.release(); m->d_results.release(); m->d_dbg.release();
@@ -3382,7 +3228,7 @@ int lslam_matcher_set_grid_u8(lslam_matcher* m, const uint8_t* grid, const doubl
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   m->g.off_x = offset_xy[0];
   m->g.off_y = offset_xy[1];
-  m->sub_dirty = m->occ_dirty = m->tile_dirty = m->ptile_dirty = m->dmap_dirty = true;
+  m->sub_dirty = m->occ_dirty = m->tile_dirty = m->ptile_dirty = true;
   return LSLAM_OK;
 }
 
@@ -3393,7 +3239,7 @@ int lslam_matcher_set_grid_u8_dev(lslam_matcher* m, const uint8_t* grid_dev, con
     LSLAM_HIP(ctx, hipMemcpyAsync(m->d_grid, grid_dev, (size_t)m->g.data_size, hipMemcpyDeviceToDevice, ctx->stream));
   m->g.off_x = offset_xy[0];
   m->g.off_y = offset_xy[1];
-  m->sub_dirty = m->occ_dirty = m->tile_dirty = m->ptile_dirty = m->dmap_dirty = true;
+  m->sub_dirty = m->occ_dirty = m->tile_dirty = m->ptile_dirty = true;
   return LSLAM_OK;
 }
 
@@ -3405,9 +3251,6 @@ int lslam_matcher_set_option(lslam_matcher* m, int option, int value) {
   switch (option) {
     case LSLAM_OPT_ROW_OCCUPANCY:
       m->use_row_occupancy = value != 0;
-      return LSLAM_OK;
-    case LSLAM_OPT_PRETEST:
-      m->use_pretest = value != 0;
       return LSLAM_OK;
     case LSLAM_OPT_COLLECT_STATS:
       if (value) {

@@ -151,11 +151,8 @@ void* lslam_matcher_grid_dev_ptr(lslam_matcher* m);
  *  LSLAM_OPT_COLLECT_STATS (default 0): 1 clears the counters and routes coarse passes through an instrumented twin of
  *    the hot kernel (slower: for an untimed diagnostic launch); lslam_matcher_read_stats then returns, summed over
  *    the passes since: [0] lattice rows inside the reference's index range (Mapper.cpp:841-845), [1] rows still live
- *    after pruning, [2] readable beam x angle pairs, [3] those with at least one live row.
- *  LSLAM_OPT_PRETEST (default 1): conservative fp32 pre-test of the big-batch coarse pass as a kernel of its own (a
- *    dilated occupancy map proves most (beam, angle) pairs dead before any fp64 arithmetic); the exact kernel then runs on
- *    full waves of the surviving beams.  0 = the exact kernel looks at every beam. */
-enum { LSLAM_OPT_ROW_OCCUPANCY = 1, LSLAM_OPT_COLLECT_STATS = 2, LSLAM_OPT_PRETEST = 3 };
+ *    after pruning, [2] readable beam x angle pairs, [3] those with at least one live row. */
+enum { LSLAM_OPT_ROW_OCCUPANCY = 1, LSLAM_OPT_COLLECT_STATS = 2 };
 int lslam_matcher_set_option(lslam_matcher* m, int option, int value);
 int lslam_matcher_read_stats(lslam_matcher* m, uint64_t out[4]);
 

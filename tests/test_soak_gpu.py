@@ -54,35 +54,3 @@ def test_random_world_batches_vs_reference(ctx, oracle_lib, seed, B):
     assert np.abs(res["response"] - c_resp).max() == 0.0
     assert np.abs(res["covariance"].reshape(B, 9) - c_covs).max() <= 1e-12
     assert res["response"].mean() > 0.3  # the matches are real ones
-
-
-@pytest.mark.parametrize("seed", [5, 6])
-def test_pretest_on_and_off_give_identical_records(ctx, seed):
-    """LSLAM_OPT_PRETEST only decides which beams the exact coarse kernel LOOKS at (k_pretest proves the others sum zero
-    for every candidate): result records byte-identical with the pre-test on and off -- queries near the grid border,
-    far outside the mapped area and with invalid readings included."""
-    rng = np.random.default_rng(500 + seed)
-    laser = synth.Laser()
-    world = synth.arena(size=rng.uniform(30, 90), n_axis=int(rng.integers(6, 30)), n_rot=int(rng.integers(2, 10)),
-                        seed=600 + seed)
-    wl = synth.make_match_workload(n_base=int(rng.integers(10, 70)), n_query=48, seed=700 + seed, laser=laser,
-                                   world=world, query_spread=rng.uniform(0.5, 6.0))
-    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
-    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
-    B = 384
-    idx = np.arange(B) % 48
-    poses = synth.perturb(wl.truth_poses[idx], rng.uniform(0.05, 0.45), math.radians(rng.uniform(2, 18)), 800 + seed)
-    poses[:16, :2] += rng.uniform(-45.0, 45.0, (16, 2))  # search windows far from the window's scans, some near the border
-    ranges = wl.query_ranges[idx].copy()
-    ranges[rng.random(ranges.shape) < 0.02] = np.inf
-    ranges[3, :] = np.nan
-    gm.set_option("pretest", 1)
-    ctx.profile(True); ctx.profile_reset()
-    on = gm.match_batch(ranges, poses)
-    ctx.profile(False)
-    assert "pretest" in ctx.profile_read()  # the two-kernel coarse pass really ran
-    gm.set_option("pretest", 0)
-    off = gm.match_batch(ranges, poses)
-    gm.set_option("pretest", 1)
-    assert on.tobytes() == off.tobytes()
-    assert (on["status"] == 0).sum() > B // 2
