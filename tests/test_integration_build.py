@@ -1,0 +1,50 @@
+"""CPU-side check of the drop-in sources under integration/: they compile against the reference's OWN headers
+(/root/reference: open_karto's Mapper.h, lesson4's hector_mapping headers), link against liblslam_gpu.so, and the
+link-time substitution really happened -- the one strong definition of karto::ScanMatcher::MatchScan in
+oracle/_ref_gpu/libkarto_ref_gpu.so is the one from integration/karto_scan_matcher_gpu.cpp (it calls the C ABI), while
+the reference's own definition is still the one inside oracle/_ref/libkarto_ref.so.  No GPU needed; skipped where the
+reference is absent (the GPU box: the prebuilt libraries travel, tests/test_ref_drives_gpu.py uses them there)."""
+import pathlib
+import subprocess
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+REF = pathlib.Path("/root/reference/lesson6/lib/open_karto/src/Mapper.cpp")
+SYM = "_ZN5karto11ScanMatcher9MatchScanEPNS_18LocalizedRangeScanERKSt6vectorIS2_SaIS2_EERNS_5Pose2ERNS_7Matrix3Ebb"
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not REF.exists():
+        pytest.skip("/root/reference absent")
+    from lslam_amd import build
+
+    build.build_library()
+    subprocess.run(["make", "-s", "-C", str(ROOT / "oracle"), "ref", "ref_gpu"], check=True)
+    return ROOT / "oracle"
+
+
+def _nm(path, *flags):
+    return subprocess.run(["nm", *flags, str(path)], check=True, capture_output=True, text=True).stdout
+
+
+def test_link_time_substitution_of_match_scan(built):
+    weak_obj = _nm(built / "_ref_gpu" / "Mapper_weak.o")
+    ours = _nm(built / "_ref_gpu" / "karto_scan_matcher_gpu.o")
+    assert any(l.endswith(" W " + SYM) or f" W {SYM}" in l for l in weak_obj.splitlines())  # the reference's definition, weakened
+    assert f" T {SYM}" in ours                                                                 # the strong one
+    assert " U lslam_matcher_match_scan" in ours                                               # ... which goes through the C ABI
+    lib = _nm(built / "_ref_gpu" / "libkarto_ref_gpu.so", "-D")
+    assert f" T {SYM}" in lib and " U lslam_matcher_match_scan" in lib
+    # Mapper::Process and the graph are the reference's compiled code in both libraries
+    for name in ("_ZN5karto6Mapper7ProcessEPNS_18LocalizedRangeScanE", "_ZN5karto11MapperGraph12TryCloseLoopEPNS_18LocalizedRangeScanERKNS_4NameE"):
+        assert name in lib and name in _nm(built / "_ref" / "libkarto_ref.so", "-D")
+    assert "lslam_matcher_match_scan" not in _nm(built / "_ref" / "libkarto_ref.so", "-D")      # the pure reference never sees the GPU
+
+
+def test_hector_map_rep_is_the_interface(built):
+    lib = _nm(built / "_ref_gpu" / "libhector_ref_gpu.so", "-D", "-C")
+    assert "lslam::HectorMapRepGpu" in lib and "lslam_map_match_data" in lib and "lslam_map_update_by_scan" in lib
+    assert "typeinfo for hectorslam::MapRepresentationInterface" in lib
+    assert "lslam_map_create" not in _nm(built / "_ref" / "libhector_ref.so", "-D")
