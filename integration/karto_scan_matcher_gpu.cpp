@@ -29,7 +29,7 @@
 
 #include "open_karto/Mapper.h"
 
-#include "lslam_gpu.h"
+#include "karto_occupancy_grid_gpu.hpp"  // lslam::LaserFrom (karto::LaserRangeFinder -> lslam_laser); includes lslam_gpu.h
 
 namespace lslam_karto {
 
@@ -44,21 +44,7 @@ static lslam_context* context() {
   return ctx;
 }
 
-// karto::LaserRangeFinder -> lslam_laser (Karto.h:3985-4137: the getters behind karto_slam.cc:384-395)
-static lslam_laser laser_from(karto::LaserRangeFinder* lrf) {
-  lslam_laser l;
-  l.minimum_angle = lrf->GetMinimumAngle();
-  l.maximum_angle = lrf->GetMaximumAngle();
-  l.angular_resolution = lrf->GetAngularResolution();
-  l.minimum_range = lrf->GetMinimumRange();
-  l.maximum_range = lrf->GetMaximumRange();
-  l.range_threshold = lrf->GetRangeThreshold();
-  const karto::Pose2 off = lrf->GetOffsetPose();
-  l.offset_x = off.GetX();
-  l.offset_y = off.GetY();
-  l.offset_heading = off.GetHeading();
-  return l;
-}
+static lslam_laser laser_from(karto::LaserRangeFinder* lrf) { return lslam::LaserFrom(lrf); }
 
 struct GpuMatcher {
   lslam_matcher* h = nullptr;

@@ -49,6 +49,22 @@
 #undef private
 #undef protected
 
+// -DKREF_GPU (oracle/Makefile target ref_gpu): the published-map build of this driver goes through
+// integration/karto_occupancy_grid_gpu.hpp -- the reference's LocalizedRangeScanVector in, a karto::OccupancyGrid* out,
+// the cells computed on the GPU -- instead of karto::OccupancyGrid::CreateFromScans (a header-inline static, so a call-site
+// change rather than a link-time substitution).  MatchScan is substituted at link time either way (see the Makefile).
+#ifdef KREF_GPU
+#include "karto_occupancy_grid_gpu.hpp"
+static lslam_context* kref_gpu_ctx() {
+  static lslam_context* ctx = nullptr;
+  if (!ctx && lslam_create(0, &ctx) != LSLAM_OK) throw std::runtime_error(lslam_last_error(nullptr));
+  return ctx;
+}
+#define KREF_CREATE_FROM_SCANS(scans, res) lslam::CreateOccupancyGridFromScans(kref_gpu_ctx(), scans, res)
+#else
+#define KREF_CREATE_FROM_SCANS(scans, res) karto::OccupancyGrid::CreateFromScans(scans, res)
+#endif
+
 using namespace karto;
 
 extern "C" {
@@ -434,8 +450,13 @@ int kref_running_scans(void* h) {
 int kref_occupancy_grid(void* h, double resolution, int* dims /* w,h */, double* offset_xy,
                         uint8_t* out) {
   KRef* k = (KRef*)h;
-  OccupancyGrid* g =
-      OccupancyGrid::CreateFromScans(k->mapper->GetAllProcessedScans(), resolution);
+  OccupancyGrid* g = nullptr;
+  try {
+    g = KREF_CREATE_FROM_SCANS(k->mapper->GetAllProcessedScans(), resolution);
+  } catch (std::exception& e) {
+    k->err = e.what();
+    return -2;
+  }
   if (!g) return -1;
   dims[0] = g->GetWidth();
   dims[1] = g->GetHeight();
@@ -542,7 +563,7 @@ int kref_occgrid_from_scans(void* h, int n_scans, const double* ranges, const do
   try {
     LocalizedRangeScanVector scans;
     for (int i = 0; i < n_scans; i++) scans.push_back(make_scan(k, ranges + (size_t)i * n_ranges, n_ranges, poses + 3 * i));
-    OccupancyGrid* g = OccupancyGrid::CreateFromScans(scans, resolution);
+    OccupancyGrid* g = KREF_CREATE_FROM_SCANS(scans, resolution);
     int rc = 0;
     if (!g) {
       rc = -1;

@@ -41,6 +41,7 @@ def test_link_time_substitution_of_match_scan(built):
     for name in ("_ZN5karto6Mapper7ProcessEPNS_18LocalizedRangeScanE", "_ZN5karto11MapperGraph12TryCloseLoopEPNS_18LocalizedRangeScanERKNS_4NameE"):
         assert name in lib and name in _nm(built / "_ref" / "libkarto_ref.so", "-D")
     assert "lslam_matcher_match_scan" not in _nm(built / "_ref" / "libkarto_ref.so", "-D")      # the pure reference never sees the GPU
+    assert " U lslam_occgrid_create_from_scans" in lib  # seam B2: integration/karto_occupancy_grid_gpu.hpp behind the driver
 
 
 def test_hector_map_rep_is_the_interface(built):

@@ -68,6 +68,13 @@ def test_reference_mapper_on_gpu_matcher_closed_loop(po):
     assert calls >= v - 1, (calls, v)
     print("reference Mapper + GPU MatchScan vs pure reference: max pose difference", worst, "device MatchScan calls", calls,
           "vertices/edges", (v, e))
+    # seam B2 with the reference's own types: the published map of ALL processed scans (karto_slam.cc:511-512), built from the
+    # Mapper's LocalizedRangeScanVector by integration/karto_occupancy_grid_gpu.hpp and returned as a karto::OccupancyGrid
+    g_c, off_c = cpu.occupancy_grid(0.05)
+    g_g, off_g = gpu.occupancy_grid(0.05)
+    assert g_c.shape == g_g.shape and np.array_equal(off_c, off_g)
+    assert np.array_equal(g_c, g_g)
+    assert (g_c == 100).sum() > 500 and (g_c == 255).sum() > 20000
 
 
 @pytest.mark.parametrize("variant", ["laser_offset", "response_expansion"])
@@ -153,3 +160,23 @@ def test_reference_hector_processor_on_gpu_map_rep_without_matching(po):
     for lv in range(LV):
         assert cpu.logodds(lv).tobytes() == gpu.logodds(lv).tobytes(), lv
     assert np.count_nonzero(cpu.logodds(0)) > 1000
+
+
+def test_reference_occupancy_grid_through_karto_types(po, workload):
+    """lslam::CreateOccupancyGridFromScans(LocalizedRangeScanVector, resolution) -> karto::OccupancyGrid*: cells, size and
+    CoordinateConverter offset equal to karto::OccupancyGrid::CreateFromScans on the same scans, incl. a laser mounted off
+    the base centre and ignored readings; an empty scan list is NULL on both sides."""
+    wl = workload
+    ranges = wl.base_ranges.copy()
+    ranges[0, 5] = np.nan
+    ranges[1, 7] = 0.05
+    ranges[2, 9] = 70.0
+    for offset, res in (((0.0, 0.0, 0.0), 0.05), ((0.2, -0.1, 0.05), 0.1)):
+        cpu = po.RefKarto(po.default_cfg(), po.laser_struct(wl.laser, 20.0, offset))
+        gpu = po.RefKarto(po.default_cfg(), po.laser_struct(wl.laser, 20.0, offset), gpu=True)
+        a, off_a = cpu.occgrid_from_scans(ranges, wl.base_poses, res)
+        b, off_b = gpu.occgrid_from_scans(ranges, wl.base_poses, res)
+        assert a.shape == b.shape and np.array_equal(off_a, off_b)
+        assert np.array_equal(a, b)
+        assert cpu.occgrid_from_scans(ranges[:0], wl.base_poses[:0], res) == (None, None)
+        assert gpu.occgrid_from_scans(ranges[:0], wl.base_poses[:0], res) == (None, None)
