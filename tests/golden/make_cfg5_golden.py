@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """tests/golden/karto_cfg5_golden.npz: the REFERENCE's own karto::Mapper::Process (oracle/_ref, compiled unmodified from
-/root/reference) over the first N scans of BASELINE config 5's 10 000-scan closed-loop trajectory -- the workload
-tools/bench_extra.py and bench.py use (synth.rings_trajectory(10000), 100 m arena seed 6, drifting odometry seed 6, ray
-casts seeded per scan [6, i]) -- with the pose graph and loop closing on.  N = 3600 reaches well into the second lap of
-the outermost ring: near-chain links and closed loops are part of the record.
+/root/reference) over the first N (default: all) scans of BASELINE config 5's 10 000-scan closed-loop trajectory -- the
+workload tools/bench_extra.py uses (synth.rings_trajectory(10000), 100 m arena seed 6, drifting odometry seed 6, ray
+casts seeded per scan [6, i]) -- with the pose graph and loop closing on: corrected pose of every scan when it was
+processed, edge count after every scan, final poses of all vertices.
 
-    python tests/golden/make_cfg5_golden.py [N]        # ~10 min of one CPU core
+    python tests/golden/make_cfg5_golden.py [N]        # N = 10000: ~39 min of one CPU core (3600: ~6 min)
 
 The ranges themselves (N x 1081 float32 = 15 MB) are NOT stored: the generator is deterministic, the test regenerates
 them and checks their SHA-256 against the one recorded here before comparing anything.
@@ -30,7 +30,7 @@ GRAPH = dict(scan_buffer_size=70, scan_buffer_max_scan_distance=20.0, do_loop_cl
              loop_search_maximum_distance=3.0, loop_match_minimum_chain_size=10)
 
 
-def workload(n_total=10000, n=3600):
+def workload(n_total=10000, n=10000):
     laser = synth.Laser()
     path = synth.rings_trajectory(n_total)
     world = synth.arena_around_path(path, size=100.0, n_axis=30, n_rot=10, seed=6)
@@ -40,7 +40,7 @@ def workload(n_total=10000, n=3600):
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 3600
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
     po.build("ref")
     assert po.have_ref(), "needs /root/reference to build oracle/_ref"
     laser, path, odom, scans32 = workload(n=n)
