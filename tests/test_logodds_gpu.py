@@ -391,3 +391,30 @@ def test_pipelined_update_raw_plane_after_synchronize(ctx, oracle_lib):
     raw = np.zeros((n, n), np.float32)
     ctx.download(ptr, raw)
     assert raw.tobytes() == cpu.logodds().tobytes()
+
+
+def test_pipelined_update_across_the_epoch_wrap(ctx, oracle_lib):
+    """The key planes carry a 16-bit scan epoch; when it wraps (every 65 535 single-scan updates) the planes are cleared --
+    after the pending apply of the pipelined path has been flushed, or the last scan before the wrap would lose its
+    update.  66 000 tiny updates (a handful of beams whose cells overlap from scan to scan) against the sequential oracle."""
+    n, cell = 64, 0.05
+    off = (1.6, 1.6)
+    cpu = oracle_lib.PortHector(n, n, cell, off)
+    gpu = api.OccGridMap(ctx, n, n, cell, off)
+    for m in (cpu, gpu):
+        m.setUpdateFreeFactor(0.49)      # tiny steps: 66 000 of them stay far from the +50 clamp and from float saturation
+        m.setUpdateOccupiedFactor(0.51)
+    rng = np.random.default_rng(9)
+    pts_all = (rng.uniform(-25.0, 25.0, (16, 5, 2))).astype(np.float32)
+    poses = np.zeros((16, 3), np.float32)
+    poses[:, 2] = rng.uniform(-3.0, 3.0, 16)
+    total = 66000
+    for k in range(total):
+        j = k & 15
+        cpu.updateByScan(pts_all[j], (0.0, 0.0), poses[j])
+        gpu.updateByScan(pts_all[j], (0.0, 0.0), poses[j])
+        if k in (65533, 65534, 65535, 65536, 65537):  # reads right around the wrap (each flushes the pending apply)
+            assert gpu.logodds().tobytes() == cpu.logodds().tobytes(), k
+    a = cpu.logodds()
+    assert np.count_nonzero(a) > 100
+    assert gpu.logodds().tobytes() == a.tobytes()
