@@ -96,23 +96,31 @@ namespace lslam {
                          __FILE__, __LINE__);                                                  \
   } while (0)
 
-// Growable device buffer (never shrinks; sized for 288 GB of HBM, so we keep everything resident).
+// Growable device buffer (never shrinks; sized for 288 GB of HBM, so we keep everything resident).  Growing does NOT
+// free the old allocation: kernels already on the stream may still read it, and hipFree would wait for the whole device
+// (a first big batch after small ones stalled the stream on it).  Outgrown allocations are kept until release(); growth
+// is geometric, so together they are smaller than the live one.  Contents are not carried over.
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t cap = 0;  // elements
+  std::vector<void*> outgrown;
   hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
+    T* fresh = nullptr;
     size_t want = n + n / 8 + 64;
-    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
-    if (e == hipSuccess) cap = want;
-    return e;
+    if (want < 2 * cap) want = 2 * cap;  // geometric: the outgrown allocations sum to less than the live one
+    hipError_t e = hipMalloc((void**)&fresh, want * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (p) outgrown.push_back((void*)p);
+    p = fresh;
+    cap = want;
+    return hipSuccess;
   }
   void release() {
     if (p) (void)hipFree(p);
+    for (void* q : outgrown) (void)hipFree(q);
+    outgrown.clear();
     p = nullptr;
     cap = 0;
   }
