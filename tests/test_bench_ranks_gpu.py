@@ -41,6 +41,16 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert two["gather_ms"] is not None
 
 
+def test_eight_ranks_equal_one_rank(tmp_path):
+    """The partition the driver's 8-GPU run uses -- 8 ranks x 128 of 1024 scans here, [r*B/8, (r+1)*B/8) -- on the one GPU
+    of the test box (gloo, all ranks on GPU 0): gathered records byte-equal to the single-rank run, one time per rank."""
+    one, r1 = run_bench(tmp_path, 1)
+    eight, r8 = run_bench(tmp_path, 8, backend="gloo")
+    assert eight["n_gpus"] == 8 and eight["config"]["scans_per_gpu_per_step"] == 128 and eight["results_ok"] == 1024
+    assert r1.tobytes() == r8.tobytes()
+    assert len(eight["per_rank_ms_per_step"]) == 8 and all(t > 0 for t in eight["per_rank_ms_per_step"])
+
+
 def test_broadcast_grid_equals_rebuild(tmp_path):
     """--broadcast-grid: rank 0 rasterises the window, shard.broadcast_grid replicates the 4 MB grid and every other
     rank installs it through lslam_matcher_set_grid_u8_dev (no AddScans there).  Gathered records byte-equal to the
