@@ -2561,6 +2561,10 @@ struct lslam_matcher {
   DevBuf<double> d_big;      // large lattices: reduce scratch
   DevBuf<lslam_match_result> d_results;
   DevBuf<int32_t> d_dbg;
+  // lslam_matcher_match_scan: the query scan's staging (pinned host) and its resident copy, the pinned result record
+  double* h_query = nullptr;
+  lslam_match_result* h_result = nullptr;
+  DevBuf<double> d_query, d_qpose;
 };
 
 namespace {
@@ -2650,7 +2654,11 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   LSLAM_HIP(ctx, m->d_lat.reserve(S));
   LSLAM_HIP(ctx, m->d_cossin.reserve((size_t)S * kMaxAngles));
   LSLAM_HIP(ctx, m->d_coarse.reserve(S));
-  LSLAM_HIP(ctx, m->d_resp.reserve((size_t)S * resp_stride));
+  {
+    const int32_t* resp_before = m->d_resp.p;
+    LSLAM_HIP(ctx, m->d_resp.reserve((size_t)S * resp_stride));
+    if (m->d_resp.p != resp_before) prezeroed = 0;  // the rebuild cleared the buffer this one has just replaced
+  }
 
   SearchCfg sc{m->cfg.distance_variance_penalty, m->cfg.angle_variance_penalty,
                m->cfg.minimum_distance_penalty, m->cfg.minimum_angle_penalty, do_penalize};
@@ -3191,6 +3199,9 @@ void lslam_matcher_destroy(lslam_matcher* m) {
   m->d_ranges64.release(); m->d_poses.release(); m->d_local.release(); m->d_world.release();
   m->d_valid.release(); m->d_fv_scratch.release(); m->d_centres.release(); m->d_lat.release(); m->d_cossin.release(); m->d_coarse.release(); m->d_resp.release();
   m->d_tbl.release(); m->d_part.release(); m->d_big.release(); m->d_results.release(); m->d_dbg.release();
+  m->d_query.release(); m->d_qpose.release();
+  if (m->h_query) (void)hipHostFree(m->h_query);
+  if (m->h_result) (void)hipHostFree(m->h_result);
   delete m;
 }
 
@@ -3338,12 +3349,52 @@ int lslam_matcher_match_batch_dev_f64(lslam_matcher* m, int S, const double* ran
 int lslam_matcher_match_scan(lslam_matcher* m, int n_base, const double* base_ranges, int stride,
                              const double* base_poses, const double* q_ranges, const double q_pose[3],
                              int do_penalize, int do_refine, lslam_match_result* out) {
-  if (!m || !q_ranges || !q_pose || !out) return LSLAM_ERR_INVALID_ARGUMENT;
-  if (m->g.n_beams != 0) {  // a scan without readings returns before AddScans (Mapper.cpp:199-209)
-    int rc = lslam_matcher_set_base_scans(m, n_base, base_ranges, stride, base_poses, q_pose);
-    if (rc) return rc;
+  if (!m || !q_ranges || !q_pose || !out || n_base < 0 || (n_base > 0 && (!base_ranges || !base_poses)))
+    return LSLAM_ERR_INVALID_ARGUMENT;
+  const int n = m->g.n_beams;
+  if (n == 0)  // a scan without readings returns before AddScans (Mapper.cpp:199-209)
+    return lslam_matcher_match_batch(m, 1, q_ranges, 1, q_pose, do_penalize, do_refine, out);
+  // ONE pass over the stream and one host synchronisation (round 3; it was AddScans + sync, then upload + match + download +
+  // sync): the window goes up and is rasterised as before; the query's readings are staged in pinned host memory and ride
+  // into HBM -- together with its pose, its scan_prep and the zeros for the first pass -- in the rebuild's first launch
+  // (RebuildExtras, what the streaming front-end does per scan); the last kernel of the match writes the 112-byte record
+  // straight into pinned host memory.
+  LSLAM_NOT_REENTRANT(m);
+  lslam_context* ctx = m->ctx;
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  if (!m->h_query) {
+    if (hipHostMalloc((void**)&m->h_query, sizeof(double) * (size_t)n, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&m->h_result, sizeof(lslam_match_result), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the pinned staging of MatchScan");
+    }
   }
-  return lslam_matcher_match_batch(m, 1, q_ranges, std::max(m->g.n_beams, 1), q_pose, do_penalize, do_refine, out);
+  LSLAM_HIP(ctx, m->d_query.reserve((size_t)n));
+  LSLAM_HIP(ctx, m->d_qpose.reserve(4));
+  if (n_base > 0) {
+    int rc = upload_scans(m, n_base, base_ranges, stride, base_poses);
+    if (rc) return rc;
+    LSLAM_HIP(ctx, m->d_world.reserve((size_t)n_base * n));
+    launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((n + 255) / 256, n_base), dim3(256), 0,
+           (const double*)m->d_ranges64.p, n, (const double*)m->d_poses.p, m->g, (double2*)nullptr, m->d_world.p, PassCfg{}, (Lattice*)nullptr, (double2*)nullptr, 0, PoseArg{});
+  }
+  memcpy(m->h_query, q_ranges, sizeof(double) * (size_t)n);
+  RebuildExtras x{};
+  for (int i = 0; i < 3; i++) x.pose[i] = q_pose[i];
+  x.pose_dst = m->d_qpose.p;
+  x.zero = m->d_resp.p;
+  x.zero_words = (int)std::min<size_t>(m->d_resp.cap, (size_t)1 << 16);
+  x.ranges_src = m->h_query;
+  x.ranges_dst = m->d_query.p;
+  x.n_ranges = n;
+  x.prep_ranges = m->h_query;  // the prep blocks read the staged copy (the device row is being written in the same launch)
+  int rc = rebuild_grid_dev(m, m->d_world.p, 0, n_base, n_base > 0 ? n_base : 1, q_pose, &x);
+  if (rc) return rc;
+  rc = match_batch_impl<double>(m, 1, m->d_query.p, n, m->d_qpose.p, do_penalize, do_refine, m->h_result, nullptr, 0);
+  if (rc) return rc;
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out = *m->h_result;
+  return LSLAM_OK;
 }
 
 int lslam_matcher_debug_lookup_table(lslam_matcher* m, const double* ranges, const double pose[3],
