@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Where the time of ONE complete host-API MatchScan goes (BASELINE config 3): the whole call, AddScans alone, the search alone,
+the 605 KB window upload alone."""
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lslam
 from lslam_amd import api, synth
 ctx = api.Context(0)
