@@ -96,3 +96,25 @@ def test_pool_without_gpu_fails_loudly():
     with pytest.raises(api.LslamError) as e:
         api.MatcherPool(api.baseline_config(), api.laser_params(synth.Laser()), 0)
     assert e.value.code == -2
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/lslam_gpu.h is the C ABI a cgo / JNI / ctypes binding would consume: it must compile as C99 on its own
+    (no C++, no HIP, no torch types) and link against the library."""
+    import subprocess
+
+    src = tmp_path / "abi.c"
+    src.write_text('#include "lslam_gpu.h"\n'
+                   'int main(void) {\n'
+                   '  lslam_matcher_config c; lslam_matcher_config_defaults(&c);\n'
+                   '  if (sizeof(lslam_match_result) != 112 || lslam_abi_version() != LSLAM_ABI_VERSION) return 1;\n'
+                   '  lslam_context* ctx = 0;\n'
+                   '  int rc = lslam_create(0, &ctx);            /* LSLAM_ERR_NO_DEVICE on a box without a GPU: never a fallback */\n'
+                   '  if (rc == LSLAM_OK) lslam_destroy(ctx);\n'
+                   '  return (rc == LSLAM_OK || rc == LSLAM_ERR_NO_DEVICE) ? 0 : 2;\n'
+                   '}\n')
+    lib = build.build_library()
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(exe),
+                    f"-L{lib.parent}", "-l:liblslam_gpu.so", f"-Wl,-rpath,{lib.parent}"], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
