@@ -479,7 +479,7 @@ class ScanMatcher:
         self.ctx.check(self.L.lslam_matcher_set_grid_u8_dev(self.h, ptr, o.ctypes.data))
 
     def set_option(self, name: str, value: int):
-        opt = {"row_occupancy": 1, "collect_stats": 2, "match_tail": 4}[name]
+        opt = {"row_occupancy": 1, "collect_stats": 2}[name]
         self.ctx.check(self.L.lslam_matcher_set_option(self.h, opt, int(value)))
 
     def read_stats(self) -> dict:

@@ -685,10 +685,15 @@ k_tile4(const uint8_t* __restrict__ grid, int stride, int data_size, uint4* __re
 
 // One wave64 per (scan, angle); lanes stride over the beams.  Same exact numerators as
 // k_resp_rows<1,4> at step 1 (Mapper.cpp:819-856), written resp[s][a][j*3+i].
-// the work of ONE wave: fine angle a of scan s (also called, wave by wave, from k_match_tail)
-__device__ __forceinline__ void resp_tile3_wave(int s, int a, int lane, const uint4* tiles, int tile_cols, const Geom& g,
-                                                const PassCfg& pc, const Lattice* lat, const double2* cossin, const double2* local,
-                                                int32_t* resp, size_t resp_stride) {
+__global__ void __launch_bounds__(64)
+k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc, const Lattice* __restrict__ lat,
+             const double2* __restrict__ cossin, const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int S) {
+  const int lane = threadIdx.x;
+  const int w = blockIdx.x;
+  const int xcd = w & 7, r = w >> 3;
+  const int s = (r / pc.na) * 8 + xcd;  // all angles of a scan on one XCD, like k_resp_rows
+  const int a = r % pc.na;
+  if (s >= S) return;
   const Lattice& L = lat[s];
   if (!L.active || L.status != 0 || L.step_x != 1 || L.step_y != 1) return;
 
@@ -756,17 +761,6 @@ __device__ __forceinline__ void resp_tile3_wave(int s, int a, int lane, const ui
   for (int c = 0; c < 9; c++)
     if (lane == c) mine = tot[c];
   if (lane < 9) resp[(size_t)s * resp_stride + (size_t)a * 9 + lane] = (int32_t)mine;
-}
-
-__global__ void __launch_bounds__(64)
-k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc, const Lattice* __restrict__ lat,
-             const double2* __restrict__ cossin, const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int S) {
-  const int w = blockIdx.x;
-  const int xcd = w & 7, r = w >> 3;
-  const int s = (r / pc.na) * 8 + xcd;  // all angles of a scan on one XCD, like k_resp_rows
-  const int a = r % pc.na;
-  if (s >= S) return;
-  resp_tile3_wave(s, a, (int)threadIdx.x, tiles, tile_cols, g, pc, lat, cossin, local, resp, resp_stride);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1082,14 +1076,14 @@ k_reduce_coarse(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ la
 // ------------------------------------------------------------------------------------------
 // NT threads per block: 128 when the batch fills the chip (a block is mostly single-thread ordered sums, so residency --
 // 32 waves per CU = 16 such blocks -- buys more than lanes), 256 for small batches (latency of the one block that runs).
-// body of the block of scan s (NT threads, `smem` = the block's dynamic LDS); a kernel of its own below, and the first
-// phase of k_match_tail
 template <int NT>
-__device__ __forceinline__ void reduce_coarse_lds_body(unsigned char* smem, const Geom& g, const PassCfg& pc, const SearchCfg& sc,
-                                                       Lattice* lat, int32_t* resp, size_t resp_stride, CoarseOut* out,
-                                                       int use_expansion, int pass_index, const uint8_t* grid, const double2* local,
-                                                       int fb_step, const PassCfg& fine_pc, double2* fine_cossin, int fine_step,
-                                                       int zero_fine_words, int parts) {
+__global__ void __launch_bounds__(NT)
+k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
+                    int32_t* resp, size_t resp_stride, CoarseOut* __restrict__ out,
+                    int use_expansion, int pass_index, const uint8_t* __restrict__ grid,
+                const double2* __restrict__ local, int fb_step, PassCfg fine_pc,
+                    double2* fine_cossin, int fine_step, int zero_fine_words, int parts) {
+  extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double sh[NT];
   __shared__ double s_ap[kMaxAngles];
   __shared__ unsigned long long s_nz[4];
@@ -1322,18 +1316,6 @@ __device__ __forceinline__ void reduce_coarse_lds_body(unsigned char* smem, cons
   // The fine pass follows at once and its beam-sliced form accumulates with atomics: clear its numerators here (every read
   // of this scan's coarse numerators is behind the barriers above) instead of a fill operation on the stream.
   for (int i = tid; i < zero_fine_words; i += NT) resp[(size_t)s * resp_stride + i] = 0;
-}
-
-template <int NT>
-__global__ void __launch_bounds__(NT)
-k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
-                    int32_t* resp, size_t resp_stride, CoarseOut* __restrict__ out,
-                    int use_expansion, int pass_index, const uint8_t* __restrict__ grid,
-                const double2* __restrict__ local, int fb_step, PassCfg fine_pc,
-                    double2* fine_cossin, int fine_step, int zero_fine_words, int parts) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  reduce_coarse_lds_body<NT>(smem, g, pc, sc, lat, resp, resp_stride, out, use_expansion, pass_index, grid, local, fb_step,
-                             fine_pc, fine_cossin, fine_step, zero_fine_words, parts);
 }
 
 
@@ -1888,10 +1870,12 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
 // gathered by the whole block; final result record.  Dynamic LDS: mask words.
 // ------------------------------------------------------------------------------------------
 template <int NT>  // threads per block: 128 for chip-filling batches (residency), 256 otherwise; see k_reduce_coarse_lds
-__device__ __forceinline__ void reduce_fine_body(unsigned char* smem, const uint8_t* grid, const Geom& g, const PassCfg& pc,
-                                                 const SearchCfg& sc, const Lattice* lat, int32_t* resp, size_t resp_stride,
-                                                 const double2* local, const CoarseOut* coarse, lslam_match_result* out,
-                                                 int do_refine, int fb_step) {
+__global__ void __launch_bounds__(NT)
+k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc,
+              const Lattice* __restrict__ lat, int32_t* resp, size_t resp_stride,
+              const double2* __restrict__ local, const CoarseOut* __restrict__ coarse,
+              lslam_match_result* __restrict__ out, int do_refine, int fb_step) {
+  extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double sh[NT];
   __shared__ int32_t asum[kMaxAngles];
   __shared__ double s_avg[3];
@@ -2036,44 +2020,6 @@ __device__ __forceinline__ void reduce_fine_body(unsigned char* smem, const uint
     res.response = s_best > 1.0 ? 1.0 : s_best;
   }
   out[s] = res;
-}
-
-template <int NT>
-__global__ void __launch_bounds__(NT)
-k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc,
-              const Lattice* __restrict__ lat, int32_t* resp, size_t resp_stride,
-              const double2* __restrict__ local, const CoarseOut* __restrict__ coarse,
-              lslam_match_result* __restrict__ out, int do_refine, int fb_step) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  reduce_fine_body<NT>(smem, grid, g, pc, sc, lat, resp, resp_stride, local, coarse, out, do_refine, fb_step);
-}
-
-// ------------------------------------------------------------------------------------------
-// k_match_tail: everything of a match that follows the coarse response pass, for batches too small to fill the chip with
-// it (a few hundred scans: the per-GPU share of a batch sharded over 8 GPUs).  There the three kernels k_reduce_coarse_lds ->
-// k_resp_tile3 -> k_reduce_fine are three launches whose blocks all fit the chip at once: each pays its launch, its ragged
-// end and -- the two reduces -- a chain of dependent ~1 us phases during which nothing else runs.  One block per scan does
-// all three, one after the other: coarse reduce with all NT threads, then wave w < nA takes fine angle w (the 4x4-block
-// kernel's wave, unchanged), then the fine reduce.  What one phase leaves in global memory for the next (the fine lattice,
-// CoarseOut, the fine numerators) is read by the SAME work-group after a barrier: work-group-scope visibility, no fence.
-// Same device functions as the three kernels, hence the same bits.
-// ------------------------------------------------------------------------------------------
-constexpr int kTailThreads = 768;  // 12 waves: >= the 11 fine angles of MatchScan (Mapper.cpp:279-280)
-constexpr int kTailMinScans = 192;  // from here on the fine pass has its 4x4 blocks (kTileMinWaves / 11 angles)
-template <int NT>
-__global__ void __launch_bounds__(NT)
-k_match_tail(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat, int32_t* resp, size_t resp_stride, CoarseOut* coarse, int pass_index,
-             const uint8_t* grid, const double2* local, int fb_step_coarse, PassCfg fine_pc, double2* cossin, int parts,
-             const uint4* tiles, int tile_cols, lslam_match_result* out, int do_refine) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  reduce_coarse_lds_body<NT>(smem, g, pc, sc, lat, resp, resp_stride, coarse, 0, pass_index, grid, local, fb_step_coarse, fine_pc,
-                             cossin, 1, 0, parts);
-  __syncthreads();
-  const int s = blockIdx.x, wave = threadIdx.x >> 6;
-  if (do_refine && wave < fine_pc.na && coarse[s].status == 0)
-    resp_tile3_wave(s, wave, threadIdx.x & 63, tiles, tile_cols, g, fine_pc, lat, cossin, local, resp, resp_stride);
-  __syncthreads();
-  reduce_fine_body<NT>(smem, grid, g, fine_pc, sc, lat, resp, resp_stride, local, coarse, out, do_refine, 1);
 }
 
 // result for a laser with zero beams (Mapper.cpp:199-209)
@@ -2583,7 +2529,6 @@ struct lslam_matcher {
   // two-stream experiment.  The core entry points take this flag and refuse to overlap instead.
   std::atomic<bool> busy{false};
   bool use_row_occupancy = true;    // lslam_matcher_set_option(LSLAM_OPT_ROW_OCCUPANCY)
-  bool use_match_tail = true;       // lslam_matcher_set_option(LSLAM_OPT_MATCH_TAIL): k_match_tail for mid-size batches
   bool collect_stats = false;       // lslam_matcher_set_option(LSLAM_OPT_COLLECT_STATS): instrumented coarse kernel
   DevBuf<unsigned long long> d_stats;
   uint32_t* d_occ_t = nullptr;      // transposed row-occupancy bitmap (k_row_occupancy)
@@ -2761,11 +2706,17 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   // the reduce kernels compute the numerators of scans with a different (non-uniform) lattice themselves
   int fb_step = 0;
   bool fine_prezeroed = false;
-  // the overlapping 4x4 blocks of the fine pass (k_tile4) exist and are current: allocates / rebuilds them when the batch
-  // is big enough to earn it.  False = the fine pass stays on the row kernel.
-  auto fine_tiles_ready = [&](const PassCfg& p) -> bool {
+  auto run_responses = [&](const PassCfg& p, int step, const char* name) -> int {
+    const int variant = force_generic ? 0 : (p.nx <= 4 && p.ny <= 4) ? 1 : (p.nx <= 12) ? 2 : (p.nx <= 16) ? 3 : 0;
+    fb_step = variant ? step : 0;
+    if (!setup_done)
+      launch(ctx, "pass_setup", k_pass_setup, dim3(S), dim3(64), 0, S, g, p, d_poses,
+             (const CoarseOut*)m->d_coarse.p, m->d_lat.p, m->d_cossin.p, step);
+    setup_done = false;
     const long long waves = (long long)((S + 7) / 8) * 8 * p.na;
-    bool tiled = !force_generic && p.nx == 3 && p.ny == 3 && waves >= kTileMinWaves && g.n_beams <= 16384 && !m->tile_failed &&
+    // fine pass of a batch big enough to fill the chip: one 16-byte load per beam from the 4x4 blocks
+    bool tiled = variant == 1 && step == 1 && p.nx == 3 && p.ny == 3 && waves >= kTileMinWaves &&
+                 g.n_beams <= 16384 && !m->tile_failed &&
                  (unsigned long long)g.data_size * 4ull + (1ull << 24) < (1ull << 32);  // k_resp_tile3 uses 32-bit offsets
     if (tiled && !m->d_tiles) {
       m->tile_cols = g.stride / 2;
@@ -2778,25 +2729,12 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
         tiled = false;
       }
     }
-    if (tiled && m->tile_dirty) {
-      launch(ctx, "tile4", k_tile4, dim3((m->tile_cols + 255) / 256, m->tile_rows), dim3(256), 0,
-             (const uint8_t*)m->d_grid, g.stride, g.data_size, m->d_tiles, m->tile_cols, m->tile_rows);
-      m->tile_dirty = false;
-    }
-    return tiled;
-  };
-  bool tail_done = false;  // k_match_tail has run: coarse reduce + fine pass + fine reduce are behind us
-  auto run_responses = [&](const PassCfg& p, int step, const char* name) -> int {
-    const int variant = force_generic ? 0 : (p.nx <= 4 && p.ny <= 4) ? 1 : (p.nx <= 12) ? 2 : (p.nx <= 16) ? 3 : 0;
-    fb_step = variant ? step : 0;
-    if (!setup_done)
-      launch(ctx, "pass_setup", k_pass_setup, dim3(S), dim3(64), 0, S, g, p, d_poses,
-             (const CoarseOut*)m->d_coarse.p, m->d_lat.p, m->d_cossin.p, step);
-    setup_done = false;
-    const long long waves = (long long)((S + 7) / 8) * 8 * p.na;
-    // fine pass of a batch big enough to fill the chip: one 16-byte load per beam from the 4x4 blocks
-    const bool tiled = variant == 1 && step == 1 && fine_tiles_ready(p);
     if (tiled) {
+      if (m->tile_dirty) {
+        launch(ctx, "tile4", k_tile4, dim3((m->tile_cols + 255) / 256, m->tile_rows), dim3(256), 0,
+               (const uint8_t*)m->d_grid, g.stride, g.data_size, m->d_tiles, m->tile_cols, m->tile_rows);
+        m->tile_dirty = false;
+      }
       launch(ctx, "resp_tile_fine", k_resp_tile3, dim3((unsigned)waves), dim3(64), 0, (const uint4*)m->d_tiles, m->tile_cols, g, p,
              (const Lattice*)m->d_lat.p, (const double2*)m->d_cossin.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S);
     } else if (variant) {
@@ -2932,19 +2870,6 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   g, p, sc, (const Lattice*)m->d_lat.p, m->d_resp.p, resp_stride, m->d_coarse.p,                              \
       (int)m->cfg.use_response_expansion, pass_index, (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, \
       fb_step
-    // A batch that leaves most of the chip idle in the three kernels after this pass (the per-GPU share of a batch sharded
-    // over 8 GPUs): one block per scan does coarse reduce, fine pass and fine reduce in ONE launch.
-    if (cache && ((size_t)p.nx * p.ny * p.na + 31) / 32 <= 256 && n_exp == 0 && do_refine && !dbg_coarse_sums && !force_generic &&
-        m->use_match_tail && S >= kTailMinScans && S < kReduceNarrowMinScans && pf.na <= kTailThreads / 64 && fb_step == 2 &&
-        fine_tiles_ready(pf)) {
-      const int parts = reduce_parts(p, kTailThreads);
-      const size_t lds = std::max(reduce_lds_nocache(p, parts), (size_t)(((size_t)pf.nx * pf.ny * pf.na + 31) / 32) * 4 + 16);
-      launch(ctx, "match_tail", k_match_tail<kTailThreads>, dim3(S), dim3(kTailThreads), lds, g, p, sc, m->d_lat.p, m->d_resp.p,
-             resp_stride, m->d_coarse.p, pass_index, (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step, pf,
-             m->d_cossin.p, parts, (const uint4*)m->d_tiles, m->tile_cols, d_out, do_refine);
-      tail_done = true;
-      return LSLAM_OK;
-    }
     if (cache && ((size_t)p.nx * p.ny * p.na + 31) / 32 <= 256) {
       const bool fuse_fine = n_exp == 0 && do_refine;  // nothing between this pass and the fine pass
 #define LSLAM_RC_LDS(NT)                                                                                                 \
@@ -2977,10 +2902,6 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   for (int e = 0; e < n_exp; e++) {
     rc = run_coarse(pe[e], e + 1);
     if (rc) return rc;
-  }
-  if (tail_done) {
-    LSLAM_HIP(ctx, hipGetLastError());
-    return LSLAM_OK;
   }
   if (do_refine) {
     rc = run_responses(pf, 1, "resp_rows_fine");
@@ -3341,9 +3262,6 @@ int lslam_matcher_set_option(lslam_matcher* m, int option, int value) {
   switch (option) {
     case LSLAM_OPT_ROW_OCCUPANCY:
       m->use_row_occupancy = value != 0;
-      return LSLAM_OK;
-    case LSLAM_OPT_MATCH_TAIL:
-      m->use_match_tail = value != 0;
       return LSLAM_OK;
     case LSLAM_OPT_COLLECT_STATS:
       if (value) {

@@ -151,10 +151,8 @@ void* lslam_matcher_grid_dev_ptr(lslam_matcher* m);
  *  LSLAM_OPT_COLLECT_STATS (default 0): 1 clears the counters and routes coarse passes through an instrumented twin of
  *    the hot kernel (slower: for an untimed diagnostic launch); lslam_matcher_read_stats then returns, summed over
  *    the passes since: [0] lattice rows inside the reference's index range (Mapper.cpp:841-845), [1] rows still live
- *    after pruning, [2] readable beam x angle pairs, [3] those with at least one live row.
- *  LSLAM_OPT_MATCH_TAIL (default 1): batches of 192 .. 2047 scans run everything after the coarse response pass (coarse
- *    reduce, fine pass, fine reduce) as ONE launch, one block per scan (k_match_tail); 0 = the three separate kernels. */
-enum { LSLAM_OPT_ROW_OCCUPANCY = 1, LSLAM_OPT_COLLECT_STATS = 2, LSLAM_OPT_MATCH_TAIL = 4 };
+ *    after pruning, [2] readable beam x angle pairs, [3] those with at least one live row. */
+enum { LSLAM_OPT_ROW_OCCUPANCY = 1, LSLAM_OPT_COLLECT_STATS = 2 };
 int lslam_matcher_set_option(lslam_matcher* m, int option, int value);
 int lslam_matcher_read_stats(lslam_matcher* m, uint64_t out[4]);
 

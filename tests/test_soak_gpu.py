@@ -54,41 +54,3 @@ def test_random_world_batches_vs_reference(ctx, oracle_lib, seed, B):
     assert np.abs(res["response"] - c_resp).max() == 0.0
     assert np.abs(res["covariance"].reshape(B, 9) - c_covs).max() <= 1e-12
     assert res["response"].mean() > 0.3  # the matches are real ones
-
-
-@pytest.mark.parametrize("B", [192, 320, 1000])
-def test_match_tail_on_and_off_give_identical_records(ctx, B):
-    """Batches of 192 .. 2047 scans run coarse reduce + fine pass + fine reduce as ONE launch (k_match_tail, one block per
-    scan); LSLAM_OPT_MATCH_TAIL = 0 keeps the three kernels.  Same device functions, so the result records must be
-    byte-identical -- with search windows outside the grid (status != 0), lattices on a cell boundary (non-uniform: the
-    reduce blocks compute those scans' numerators themselves), invalid readings, and without penalties."""
-    rng = np.random.default_rng(900 + B)
-    laser = synth.Laser()
-    world = synth.arena(size=60.0, n_axis=14, n_rot=5, seed=901)
-    wl = synth.make_match_workload(n_base=40, n_query=48, seed=902, laser=laser, world=world, query_spread=3.0)
-    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
-    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
-    idx = np.arange(B) % 48
-    poses = synth.perturb(wl.truth_poses[idx], 0.3, math.radians(10.0), 903)
-    poses[:6, :2] += 70.0                       # search window off the grid: Grid::GridIndex throws in the reference
-    gi = gm.grid_info()
-    res = 0.05
-    # exactly on a cell boundary of the lattice: coordinates round differently along the lattice -> non-uniform steps
-    poses[6:12, 0] = gi["offset"][0] + res * (np.round((poses[6:12, 0] - gi["offset"][0]) / res) + 0.5)
-    ranges = wl.query_ranges[idx].copy()
-    ranges[rng.random(ranges.shape) < 0.02] = np.inf
-    for pen in (True, False):
-        gm.set_option("match_tail", 1)
-        ctx.profile(True); ctx.profile_reset()
-        on = gm.match_batch(ranges, poses, doPenalize=pen)
-        ctx.profile(False)
-        names = set(ctx.profile_read())
-        assert "match_tail" in names and "reduce_fine" not in names, names
-        gm.set_option("match_tail", 0)
-        ctx.profile(True); ctx.profile_reset()
-        off = gm.match_batch(ranges, poses, doPenalize=pen)
-        ctx.profile(False)
-        assert "match_tail" not in set(ctx.profile_read())
-        gm.set_option("match_tail", 1)
-        assert on.tobytes() == off.tobytes(), pen
-    assert (on["status"][:6] != 0).all() and (on["status"][12:] == 0).all()
