@@ -382,6 +382,85 @@ def gpu_cfg5(ctx, api, d):
     return {"seconds": sec, "poses": poses, "updated": upd, "stats": st, "logodds": logodds, "prof": prof, "n": n, "cell": cell, "off": off}
 
 
+# ------------------------------------------------------------------------------------------------------
+# drop-in legs: the reference's OWN orchestrators (compiled from /root/reference by `make -C oracle ref_gpu`, test
+# infrastructure) driving the HIP path through the C ABI -- karto::Mapper::Process with MatchScan substituted at link time
+# (integration/karto_scan_matcher_gpu.cpp), HectorSlamProcessor with HectorMapRepGpu as its mapRep
+# (integration/hector_map_rep_gpu.hpp).  Labelled integration legs: never the headline.
+# ------------------------------------------------------------------------------------------------------
+def dropin_karto(d, repeat_reset=False):
+    """The cfg 5 slice through the reference's Mapper::Process + GPU MatchScan.  Returns scans/s, the integration layer's
+    counters and a host profile (share of the wall time spent inside MatchScan / inside the device call)."""
+    from oracle import pyoracle as po
+
+    if not po.have_ref_gpu():
+        return {"error": "oracle/_ref_gpu not built (needs /root/reference at build time)"}
+    ref = po.RefKarto(po.default_cfg(scan_buffer_max_scan_distance=20.0, **CFG5_GRAPH), po.laser_struct(d["laser"]), gpu=True)
+    r64, odom = d["r64"], d["odom"]
+    for i in range(3):  # device matcher + cache creation, first-use allocations
+        ref.process(r64[i], odom[i])
+    ref.reset()
+    s0 = ref.gpu_stats()
+    poses = np.zeros((len(r64), 3))
+    t0 = time.perf_counter()
+    for i, (r, o) in enumerate(zip(r64, odom)):
+        _, poses[i] = ref.process(r, o)
+    sec = time.perf_counter() - t0
+    s1 = ref.gpu_stats()
+    v, e = ref.graph_stats()
+    calls = s1["match_calls"] - s0["match_calls"]
+    in_match = (s1["ns_in_match_scan"] - s0["ns_in_match_scan"]) * 1e-9
+    in_dev = (s1["ns_in_device_call"] - s0["ns_in_device_call"]) * 1e-9
+    out = {"scans": len(r64), "seconds": sec, "scans_per_s": len(r64) / sec, "poses": poses, "vertices": int(v), "edges": int(e),
+           "device_match_calls": calls, "cached_calls": s1["cached_calls"] - s0["cached_calls"],
+           "scans_uploaded": s1["scans_uploaded"] - s0["scans_uploaded"], "refreshes_before_a_match": s1["refreshes"] - s0["refreshes"],
+           "us_per_match_call": 1e6 * in_dev / max(calls, 1),
+           "host_profile": {"wall_s": sec, "inside_MatchScan_s": in_match, "inside_device_call_s": in_dev,
+                            "reference_host_code_s": sec - in_match,
+                            "share_reference_host_code": (sec - in_match) / sec, "share_device_call": in_dev / sec}}
+    ref.close()
+    return out
+
+
+def dropin_hector(n_scans=300, update_every_scan=False):
+    """lesson4's loop through the reference's HectorSlamProcessor::update (H/slam_main/HectorSlamProcessor.h:84-110) with
+    mapRep = HectorMapRepGpu, beside the same processor on its own MapRepMultiMap (1 host core)."""
+    from lslam_amd import synth
+    from oracle import pyoracle as po
+
+    if not (po.have_ref_gpu() and po.have_ref_hector()):
+        return {"error": "oracle/_ref_gpu not built"}
+    laser = synth.Laser()
+    n, cell, levels = 1024, 0.05, 3
+    world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=3)
+    path = synth.trajectory(world, n_scans, step=0.05, seed=3, bounds=6.0)
+    rng = np.random.default_rng(1)
+    pts_all = [synth.hector_points(synth.cast_scan(world, t, laser, 0.01, 0.0, rng), laser, 1.0 / cell, use_max=20.0) for t in path]
+
+    def run(gpu):
+        proc = po.RefHectorProcessor(cell, n, n, (0.5, 0.5), levels, p_free=0.4, p_occ=0.9, gpu=gpu)
+        if update_every_scan:
+            proc.L.href_proc_set_update_thresholds(proc.h, 0.0, 0.0)
+        est = np.zeros(3, np.float32)  # the pose chain is fed back as the next start estimate (hector_slam.cc:200-204)
+        poses, upd = [], 0
+        t0 = time.perf_counter()
+        for pts in pts_all:
+            upd += bool(proc.update(pts, est))
+            est, _ = proc.last_pose()
+            poses.append(est.copy())
+        sec = time.perf_counter() - t0
+        lo = proc.logodds(0)
+        proc.close()
+        return sec, np.array(poses), upd, lo
+
+    g_s, g_p, g_u, g_lo = run(True)
+    c_s, c_p, c_u, c_lo = run(False)
+    return {"scans": n_scans, "gpu_scans_per_s": n_scans / g_s, "cpu_reference_scans_per_s": n_scans / c_s, "cpu_cores": 1,
+            "map_updates_gpu": g_u, "map_updates_reference": c_u, "max_pose_diff_vs_reference": float(np.abs(g_p - c_p).max()),
+            "map_cells_differing": int(np.count_nonzero(g_lo != c_lo)), "map_cells_touched": int(np.count_nonzero(c_lo)),
+            "update_every_scan": bool(update_every_scan)}
+
+
 def _source_sha(path):
     import hashlib
 

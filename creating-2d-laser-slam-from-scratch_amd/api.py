@@ -317,6 +317,16 @@ def lib() -> C.CDLL:
     L.lslam_pool_match_batch.argtypes = [vp, i32, vp, i32, vp, i32, i32, vp]
     L.lslam_deskew_scan.argtypes = [vp, vp, i32, C.POINTER(DeskewParams), vp, vp, vp, vp, i32, vp, vp]
     L.lslam_matcher_set_option.argtypes = [vp, i32, i32]
+    i64 = C.c_int64
+    L.lslam_scan_cache_create.argtypes = [vp, C.POINTER(LaserParams), C.POINTER(vp)]
+    L.lslam_scan_cache_destroy.argtypes = [vp]
+    L.lslam_scan_cache_destroy.restype = None
+    L.lslam_scan_cache_put.argtypes = [vp, i64, vp]
+    L.lslam_scan_cache_contains.argtypes = [vp, i64]
+    L.lslam_scan_cache_forget.argtypes = [vp, i64]
+    L.lslam_scan_cache_size.argtypes = [vp]
+    L.lslam_scan_cache_counters.argtypes = [vp, vp]
+    L.lslam_matcher_match_scan_cached.argtypes = [vp, vp, i32, vp, vp, i64, vp, vp, i32, vp]
     L.lslam_matcher_read_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     _LIB = L
     return L
@@ -570,6 +580,66 @@ class ScanMatcher:
         self.ctx.check(self.L.lslam_matcher_debug_valid_mask(self.h, r.ctypes.data, p.ctypes.data, v.ctypes.data,
                                                              out.ctypes.data))
         return out
+
+
+class ScanCache:
+    """lslam_scan_cache: the device-side scan cache behind seam B1 (readings, world points and FindValidPoints anchors of
+    every scan the caller has named, resident in HBM); MatchScan then names its base scans by id."""
+
+    PENALIZE, REFINE, QUERY_TAKES_RESULT_POSE = 1, 2, 4
+
+    def __init__(self, ctx: Context, laser: LaserParams):
+        self.ctx, self.L = ctx, ctx.L
+        h = C.c_void_p()
+        ctx.check(self.L.lslam_scan_cache_create(ctx.h, C.byref(laser), C.byref(h)))
+        self.h = h
+        ctx._adopt(self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lslam_scan_cache_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if sys.is_finalizing():
+                return
+            self.close()
+        except Exception:
+            pass
+
+    def put(self, scan_id: int, ranges):
+        r = _f64(ranges)
+        self.ctx.check(self.L.lslam_scan_cache_put(self.h, int(scan_id), r.ctypes.data))
+
+    def __contains__(self, scan_id: int) -> bool:
+        return bool(self.L.lslam_scan_cache_contains(self.h, int(scan_id)))
+
+    def forget(self, scan_id: int = -1):
+        self.ctx.check(self.L.lslam_scan_cache_forget(self.h, int(scan_id)))
+
+    def __len__(self) -> int:
+        return int(self.L.lslam_scan_cache_size(self.h))
+
+    def counters(self) -> dict:
+        out = np.zeros(5, dtype=np.int64)
+        self.ctx.check(self.L.lslam_scan_cache_counters(self.h, out.ctypes.data))
+        return dict(zip(("matches", "uploads", "refreshed", "speculated", "resident_bytes"), (int(v) for v in out)))
+
+    def MatchScan(self, matcher: "ScanMatcher", base_ids, base_sensor_poses, query_sensor_pose, query_id: int = -1,
+                  query_ranges=None, doPenalize: bool = True, doRefineMatch: bool = True, takes_result_pose: bool = False):
+        """ScanMatcher::MatchScan with the base scans named by id -> (response, mean pose, covariance 3x3)."""
+        ids = np.ascontiguousarray(base_ids, dtype=np.int64)
+        p, qp = _f64(base_sensor_poses), _f64(query_sensor_pose)
+        q = _f64(query_ranges) if query_ranges is not None else None
+        flags = (1 if doPenalize else 0) | (2 if doRefineMatch else 0) | (4 if takes_result_pose else 0)
+        res = np.zeros(1, dtype=RESULT_DTYPE)
+        self.ctx.check(self.L.lslam_matcher_match_scan_cached(matcher.h, self.h, len(ids), ids.ctypes.data, p.ctypes.data,
+                                                              int(query_id), q.ctypes.data if q is not None else None,
+                                                              qp.ctypes.data, flags, res.ctypes.data))
+        if res["status"][0] != 0:
+            raise LslamError(int(res["status"][0]), "the reference would have thrown here")
+        return float(res["response"][0]), res["pose"][0].copy(), res["covariance"][0].copy()
 
 
 class MatcherPool:

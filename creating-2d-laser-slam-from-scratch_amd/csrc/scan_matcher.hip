@@ -2048,6 +2048,8 @@ struct RebuildExtras {
   double* ranges_dst;        // ... and their resident row in HBM
   int n_ranges;
   const int* anchor_ring;    // nullptr, or k_anchor_chain's rows (n + 1 ints) of every resident scan, same ring as the world points
+  const int* slot_list;      // nullptr: window entry b lives in slot (ring_start + b) % cap; else in slot_list[b] (scan cache:
+                             // the base scans of a MatchScan are arbitrary resident scans; the list may be pinned host memory)
   // k_scan_prep of the ONE query scan of the match that follows (its pose is `pose`), run by extra blocks of the same
   // launch: the prep needs nothing of the grid, so it runs beside the clear instead of behind the whole rebuild
   const double* prep_ranges;  // nullptr: no prep
@@ -2150,7 +2152,8 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
     }
     return;
   }
-  const double2* gp = world + (size_t)((ring_start + b) % cap) * n;
+  const int slot = x.slot_list ? x.slot_list[b] : (ring_start + b) % cap;
+  const double2* gp = world + (size_t)slot * n;
   uint8_t* gv = valid + (size_t)b * n;
   const double2* p = gp;
   uint8_t* v = gv;
@@ -2186,7 +2189,7 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
   // The anchors depend on the scan's points only, not on the viewpoint: the streaming front-end lists them once per
   // (re)posed scan (k_anchor_chain: row = count, anchors in order) instead of once per rebuild of every window the scan
   // is part of; only the side tests and the marking are left here.
-  const int* ain = (anchor_ring && use_lds) ? anchor_ring + (size_t)((ring_start + b) % cap) * (n + 1) : nullptr;
+  const int* ain = (anchor_ring && use_lds) ? anchor_ring + (size_t)slot * (n + 1) : nullptr;
   if (ain) {
     const int cnt = ain[0];
     for (int k = tid; k + 1 < cnt; k += nt) keep_run(ain[1 + k], ain[2 + k], k == 0);
@@ -2245,9 +2248,8 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
 // by the streaming front-end when a scan's world points are (re)computed, off the per-scan critical path.
 // With `ranges` it first evaluates the world points themselves (k_scan_prep's world branch: LocalizedRangeScan::Update,
 // Karto.h:5384-5388, at the pose passed as a kernel argument) and stores them: one launch for both.
-__global__ void __launch_bounds__(1024)
-k_anchor_chain(int n, double2* __restrict__ world, int* __restrict__ row, const double* __restrict__ ranges, PoseArg pose,
-               Geom g) {
+__device__ __forceinline__ void anchor_chain_block(int n, double2* __restrict__ world, int* __restrict__ row,
+                                                   const double* __restrict__ ranges, const PoseArg& pose, const Geom& g) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int s_first, s_wc[16];
   double2* p = (double2*)smem;
@@ -2292,6 +2294,36 @@ k_anchor_chain(int n, double2* __restrict__ world, int* __restrict__ row, const 
     __syncthreads();
   }
   if (tid == 0) row[0] = base;
+}
+__global__ void __launch_bounds__(1024)
+k_anchor_chain(int n, double2* __restrict__ world, int* __restrict__ row, const double* __restrict__ ranges, PoseArg pose,
+               Geom g) {
+  anchor_chain_block(n, world, row, ranges, pose, g);
+}
+// The same for a LIST of resident scans of a scan cache (block e = entry e): slot and pose come from a small table the
+// host wrote into pinned memory (read over the bus: 32 bytes per block), or -- `from_result` -- the pose is the mean a
+// match has just written (the caller announced that its scan will take that pose: Mapper.cpp:2040-2044), so the refresh
+// needs no host round trip and runs behind the match, off the caller's critical path.
+struct CacheRefresh {
+  int slot, pad;
+  double pose[3];
+};
+__global__ void __launch_bounds__(1024)
+k_anchor_chain_list(int n, double2* __restrict__ world, int* __restrict__ rows, const double* __restrict__ ranges,
+                    const CacheRefresh* __restrict__ list, const lslam_match_result* __restrict__ from_result,
+                    int result_slot, Geom g) {
+  PoseArg pose;
+  int slot;
+  if (from_result) {
+    if (from_result->status != LSLAM_OK) return;
+    slot = result_slot;
+    for (int i = 0; i < 3; i++) pose.v[i] = from_result->pose[i];
+  } else {
+    const CacheRefresh e = list[blockIdx.x];
+    slot = e.slot;
+    for (int i = 0; i < 3; i++) pose.v[i] = e.pose[i];
+  }
+  anchor_chain_block(n, world + (size_t)slot * n, rows + (size_t)slot * (n + 1), ranges + (size_t)slot * n, pose, g);
 }
 
 // SmearPoint (Mapper.h:971-1005) of every centre k_find_valid marked, as a GATHER over the cleared-and-marked grid: one
@@ -2919,6 +2951,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   return LSLAM_OK;
 }
 
+constexpr int kRebuildNeedsContiguous = 1;  // internal return code of rebuild_grid_dev (never crosses the ABI)
 // AddScans on the device (Mapper.cpp:699-748) from world points already resident in HBM:
 // recentre, clear, FindValidPoints, mark + smear.  `world` is a ring of `cap` scans of n points.
 int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, int B, int cap, const double center[3],
@@ -2945,6 +2978,9 @@ int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, i
       m->mark_epoch = 0;
     }
   }
+  // a window named by a slot list (scan cache) exists only in the clear-free form: the caller gathers the scans into a
+  // contiguous workspace for the configurations it does not cover
+  if (extras && extras->slot_list && !fuse_mark && B > 0 && n > 0) return kRebuildNeedsContiguous;
   if (fuse_mark && (m->mark_epoch == 0 || m->mark_epoch >= 255)) {
     LSLAM_HIP(ctx, hipMemsetAsync(m->d_marks_alloc, 0, (size_t)g.data_size + 2 * kGuard, ctx->stream));
     m->mark_epoch = 0;
@@ -3478,3 +3514,4 @@ int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges, const
 }  // extern "C"
 
 #include "frontend_impl.hpp"
+#include "scan_cache_impl.hpp"

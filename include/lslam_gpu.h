@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LSLAM_ABI_VERSION 3
+#define LSLAM_ABI_VERSION 4
 
 typedef enum lslam_status {
   LSLAM_OK = 0,
@@ -192,6 +192,46 @@ int lslam_matcher_match_batch_dev_f64(lslam_matcher* m, int n_scans, const doubl
                                       int ranges_stride, const double* sensor_poses_dev,
                                       int do_penalize, int do_refine,
                                       lslam_match_result* out_dev);
+
+/* ---- device-side scan cache behind seam B1 -------------------------------------------------------------------------
+ * karto::ScanMatcher::MatchScan (Mapper.h:1155-1159) is handed its base scans as a LocalizedRangeScanVector on every
+ * call: the running window (Mapper.cpp:2040), near chains (:942, :1140), loop chains (:991, :1015).  A scan's readings
+ * never change and its pose changes about once in its life (when its own match is accepted, Mapper.cpp:2040-2044, or a
+ * closed loop re-poses it), so re-sending ~70 x 8.6 KB per call -- what lslam_matcher_match_scan's literal signature
+ * costs -- is avoidable: the cache keeps a scan's readings, its world points and the anchor chain of FindValidPoints
+ * (Mapper.cpp:756-811) resident in HBM under an id the CALLER chooses (integration/karto_scan_matcher_gpu.cpp numbers the
+ * LocalizedRangeScan objects it meets).  One cache serves every matcher of its context that was created for the same
+ * laser (the sequential and the loop matcher of one Mapper).  Not thread-safe, like the matcher. */
+typedef struct lslam_scan_cache lslam_scan_cache;
+int lslam_scan_cache_create(lslam_context* ctx, const lslam_laser* laser, lslam_scan_cache** out);
+void lslam_scan_cache_destroy(lslam_scan_cache* cache);
+/* readings of scan `scan_id` (>= 0; num_beams doubles, LocalizedRangeScan::GetRangeReadings) into HBM; an id that is
+ * already cached is overwritten.  The caller's buffer is free again on return. */
+int lslam_scan_cache_put(lslam_scan_cache* cache, int64_t scan_id, const double* ranges);
+int lslam_scan_cache_contains(const lslam_scan_cache* cache, int64_t scan_id); /* 1 / 0 */
+int lslam_scan_cache_forget(lslam_scan_cache* cache, int64_t scan_id);         /* scan_id < 0: every scan */
+int lslam_scan_cache_size(const lslam_scan_cache* cache);
+/* out[5] = matches served, scans uploaded, (scan, pose) refreshes (world points + anchors recomputed because the pose
+ * differed bitwise from the cached one), speculative refreshes (below), bytes of HBM held */
+int lslam_scan_cache_counters(const lslam_scan_cache* cache, int64_t out[5]);
+/* flags of lslam_matcher_match_scan_cached */
+enum {
+  LSLAM_MATCH_PENALIZE = 1, /* doPenalize */
+  LSLAM_MATCH_REFINE = 2,   /* doRefineMatch */
+  /* The caller will give the query scan the returned mean as its sensor pose (Mapper::Process: SetSensorPose(bestPose),
+   * Mapper.cpp:2040-2044): its world points + anchors at that pose are computed BEHIND the match on the stream, and the
+   * call returns as soon as the result record is on the host.  Purely a hint: a pose that turns out different is
+   * refreshed again when the scan is next named as a base scan. */
+  LSLAM_MATCH_QUERY_TAKES_RESULT_POSE = 4
+};
+/* ScanMatcher::MatchScan, complete (= lslam_matcher_match_scan, identical results), with the base scans named by id.
+ * base_sensor_poses: n_base*3, the scans' CURRENT sensor poses (24 bytes per scan are all that cross the bus).
+ * query_id >= 0 and cached: query_ranges may be NULL.  query_id >= 0 and not cached: query_ranges are uploaded INTO the
+ * cache under that id (the scan the caller is about to add to its running window).  query_id < 0: anonymous query
+ * (TryCloseLoop's temporary scan, Mapper.cpp:1008-1015), nothing is kept.  An unknown base id -> LSLAM_ERR_INVALID_ARGUMENT. */
+int lslam_matcher_match_scan_cached(lslam_matcher* m, lslam_scan_cache* cache, int n_base, const int64_t* base_ids,
+                                    const double* base_sensor_poses, int64_t query_id, const double* query_ranges,
+                                    const double query_sensor_pose[3], int flags, lslam_match_result* out);
 
 /* ---- inspection hooks used by the parity tests (intermediate state of the reference) ---- */
 /* GridIndexLookup::ComputeOffsets (Karto.h:6409-6501) for one scan: out = n_angles*num_beams

@@ -14,8 +14,17 @@
 //   getGridMap(l)  -> a HOST mirror hectorslam::GridMap per level, refreshed from HBM on demand (the publisher thread of
 //                     hector_slam.cc:263-311 reads cells through isFree / isOccupied; LogOddsCell::updateIndex is a
 //                     per-scan scratch mark of the CPU algorithm and is not mirrored)
+//
+// Threading (hector_slam.cc:263-311): the node's publisher thread calls getGridMap(i) and THEN takes the level's
+// MapLockerInterface to read the cells, while the main thread matches and updates.  An lslam_map is not thread-safe (its
+// pipelined update keeps a pending apply that every reader flushes), so every call into it -- and the stale_ flags -- sit
+// behind ONE internal mutex; the rewrite of a host mirror additionally holds that level's MapLockerInterface, the lock the
+// publisher holds while it reads the mirror (MapProcContainer::updateByScan takes the same lock around the CPU update,
+// H/slam_main/MapProcContainer.h:80-91).  getGridMap is called before the publisher locks (hector_slam.cc:263), so taking
+// the non-recursive lock inside it cannot deadlock in the reference's flow.
 #pragma once
 
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -58,6 +67,7 @@ class HectorMapRepGpu : public hectorslam::MapRepresentationInterface {
   HectorMapRepGpu& operator=(const HectorMapRepGpu&) = delete;
 
   virtual void reset() {
+    std::lock_guard<std::mutex> lock(mu_);
     check(lslam_map_reset(map_));
     for (size_t i = 0; i < mirrors_.size(); ++i) {
       mirrors_[i]->reset();
@@ -67,17 +77,22 @@ class HectorMapRepGpu : public hectorslam::MapRepresentationInterface {
   virtual float getScaleToMap() const { return lslam_map_scale_to_map(map_, 0); }
   virtual int getMapLevels() const { return static_cast<int>(mirrors_.size()); }
   virtual const hectorslam::GridMap& getGridMap(int mapLevel = 0) const {
+    std::lock_guard<std::mutex> lock(mu_);
     if (stale_[mapLevel]) {
       hectorslam::GridMap& g = *mirrors_[mapLevel];
       const int n = g.getSizeX() * g.getSizeY();
       scratch_.resize(static_cast<size_t>(n));
       check(lslam_map_read_logodds(map_, mapLevel, scratch_.data()));
+      MapLockerInterface* cells = mutexes_[mapLevel];  // a reader of the mirror holds this one
+      if (cells) cells->lockMap();
       for (int i = 0; i < n; ++i) g.getCell(i).logOddsVal = scratch_[static_cast<size_t>(i)];
+      if (cells) cells->unlockMap();
       stale_[mapLevel] = false;
     }
     return *mirrors_[mapLevel];
   }
   virtual void addMapMutex(int i, MapLockerInterface* mapMutex) {
+    std::lock_guard<std::mutex> lock(mu_);
     if (mutexes_[i]) delete mutexes_[i];
     mutexes_[i] = mapMutex;
   }
@@ -86,6 +101,7 @@ class HectorMapRepGpu : public hectorslam::MapRepresentationInterface {
 
   virtual Eigen::Vector3f matchData(const Eigen::Vector3f& beginEstimateWorld, const hectorslam::DataContainer& dataContainer,
                                     Eigen::Matrix3f& covMatrix) {
+    std::lock_guard<std::mutex> lock(mu_);
     flatten(dataContainer);
     const float begin[3] = {beginEstimateWorld[0], beginEstimateWorld[1], beginEstimateWorld[2]};
     float pose[3], cov[9];
@@ -96,6 +112,7 @@ class HectorMapRepGpu : public hectorslam::MapRepresentationInterface {
     return Eigen::Vector3f(pose[0], pose[1], pose[2]);
   }
   virtual void updateByScan(const hectorslam::DataContainer& dataContainer, const Eigen::Vector3f& robotPoseWorld) {
+    std::lock_guard<std::mutex> lock(mu_);
     flatten(dataContainer);
     const float pose[3] = {robotPoseWorld[0], robotPoseWorld[1], robotPoseWorld[2]};
     check(lslam_map_update_by_scan(map_, pts_.data(), dataContainer.getSize(), origo_, pose));
@@ -103,12 +120,21 @@ class HectorMapRepGpu : public hectorslam::MapRepresentationInterface {
       stale_[i] = true;
       mirrors_[i]->setUpdated();  // GridMapBase::setUpdated (H/map/GridMapBase.h:333): drives the node's re-publish
     }
+    ++updates_;
+  }
+  // number of updateByScan calls so far (what GridMapBase::getUpdateIndex tells a caller of the CPU map, without pulling
+  // the map out of HBM the way getGridMap() must)
+  long updateCount() const {
+    std::lock_guard<std::mutex> lock(mu_);
+    return updates_;
   }
   virtual void setUpdateFactorFree(float free_factor) {
+    std::lock_guard<std::mutex> lock(mu_);
     check(lslam_map_set_update_factor_free(map_, free_factor));
     for (size_t i = 0; i < mirrors_.size(); ++i) mirrors_[i]->setUpdateFreeFactor(free_factor);
   }
   virtual void setUpdateFactorOccupied(float occupied_factor) {
+    std::lock_guard<std::mutex> lock(mu_);
     check(lslam_map_set_update_factor_occupied(map_, occupied_factor));
     for (size_t i = 0; i < mirrors_.size(); ++i) mirrors_[i]->setUpdateOccupiedFactor(occupied_factor);
   }
@@ -131,7 +157,9 @@ class HectorMapRepGpu : public hectorslam::MapRepresentationInterface {
     origo_[1] = o[1];
   }
   lslam_context* ctx_;
+  mutable std::mutex mu_;  // every call into map_ and every access to stale_ / scratch_ / pts_
   lslam_map* map_ = nullptr;
+  long updates_ = 0;
   std::vector<hectorslam::GridMap*> mirrors_;
   mutable std::vector<bool> stale_;
   std::vector<MapLockerInterface*> mutexes_;

@@ -251,9 +251,18 @@ int href_proc_update(href_proc* p, const float* pts, int n, const float origo[2]
                      int map_without_matching) {
   CoutSilencer quiet;
   fill(p->dc, pts, n, origo);
+#ifdef HREF_GPU
+  // the device map rep counts its updates: getGridMap(0) would pull the whole level-0 map out of HBM twice per scan just
+  // to read one integer (this driver's instrumentation, not something HectorSlamProcessor does)
+  lslam::HectorMapRepGpu* rep = static_cast<lslam::HectorMapRepGpu*>(p->proc->mapRep);
+  const long before = rep->updateCount();
+  p->proc->update(p->dc, Eigen::Vector3f(pose_hint[0], pose_hint[1], pose_hint[2]), map_without_matching != 0);
+  return rep->updateCount() != before;
+#else
   const int before = p->proc->getGridMap(0).getUpdateIndex();
   p->proc->update(p->dc, Eigen::Vector3f(pose_hint[0], pose_hint[1], pose_hint[2]), map_without_matching != 0);
   return p->proc->getGridMap(0).getUpdateIndex() != before;
+#endif
 }
 void href_proc_last_pose(const href_proc* p, float out_pose[3], float out_cov[9]) {
   const Eigen::Vector3f& q = p->proc->getLastScanMatchPose();

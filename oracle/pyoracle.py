@@ -145,6 +145,10 @@ class RefKarto:
         self.gpu = gpu
         if gpu:
             L.lslam_karto_gpu_match_calls.restype = C.c_longlong
+            L.lslam_karto_gpu_stats.argtypes = [C.c_void_p]
+            L.lslam_karto_gpu_stats.restype = None
+        L.kref_reset.argtypes = [C.c_void_p]
+        L.kref_mapper_grid_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.kref_create.restype = C.c_void_p
         L.kref_create.argtypes = [C.POINTER(KrefCfg), C.POINTER(KrefLaser)]
         L.kref_destroy.argtypes = [C.c_void_p]
@@ -198,6 +202,30 @@ class RefKarto:
     def gpu_match_calls(self) -> int:
         """MatchScan calls that ran on the device so far (process-wide; gpu=True only)."""
         return int(self.L.lslam_karto_gpu_match_calls()) if self.gpu else 0
+
+    def gpu_stats(self) -> dict:
+        """integration/karto_scan_matcher_gpu.cpp's counters (process-wide; gpu=True only)."""
+        out = (C.c_longlong * 8)()
+        if self.gpu:
+            self.L.lslam_karto_gpu_stats(out)
+        return dict(zip(("match_calls", "cached_calls", "matchers_alive", "resident_scans", "scans_uploaded", "refreshes",
+                         "ns_in_match_scan", "ns_in_device_call"), (int(v) for v in out)))
+
+    def reset(self):
+        """Mapper::Reset (Mapper.cpp:1980-1992)."""
+        if self.L.kref_reset(self.h) != 0:
+            raise RuntimeError(self.L.kref_last_error(self.h).decode())
+
+    def mapper_grid(self):
+        """(bytes [h, stride], offset) of the Mapper's sequential matcher's correlation grid, or (None, None)."""
+        info = (C.c_int * 8)()
+        off = (C.c_double * 2)()
+        self.L.kref_grid_info(self.h, info, off)  # same geometry as the stand-alone matcher (same parameters)
+        g = np.zeros((info[1], info[2]), dtype=np.uint8)
+        o = np.zeros(2)
+        if not self.L.kref_mapper_grid_copy(self.h, g.ctypes.data, o.ctypes.data):
+            return None, None
+        return g, o
 
     @property
     def num_beams(self) -> int:

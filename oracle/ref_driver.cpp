@@ -417,6 +417,40 @@ int kref_process(void* h, int n_ranges, const double* ranges, const double* odom
   }
 }
 
+// Mapper::Reset (Mapper.cpp:1980-1992): deletes the sequential matcher, the graph (with its loop matcher) and the scan
+// manager; the next Process() re-initialises.  Scans already handed to the Dataset stay there (the Mapper never owned them).
+int kref_reset(void* h) {
+  KRef* k = (KRef*)h;
+  try {
+    k->mapper->Reset();
+    return 0;
+  } catch (std::exception& e) {
+    k->err = e.what();
+    return -1;
+  }
+}
+
+// GetCorrelationGrid() (Mapper.h:1226) of the Mapper's SEQUENTIAL matcher after the last Process(): the bytes and the grid
+// offset.  In the GPU-driven twin the host grid is only refreshed on request (integration/karto_scan_matcher_gpu.cpp:
+// lslam_karto::SyncCorrelationGrid); returns 0 when there is no matcher (or, GPU twin, nothing has been matched yet).
+#ifdef KREF_GPU
+namespace lslam_karto { bool SyncCorrelationGrid(karto::ScanMatcher* pMatcher); }
+#endif
+int kref_mapper_grid_copy(void* h, uint8_t* out, double* offset_xy) {
+  KRef* k = (KRef*)h;
+  ScanMatcher* sm = k->mapper->m_pSequentialScanMatcher;
+  if (!sm) return 0;
+#ifdef KREF_GPU
+  if (!lslam_karto::SyncCorrelationGrid(sm)) return 0;
+#endif
+  CorrelationGrid* g = sm->GetCorrelationGrid();
+  memcpy(out, g->GetDataPointer(), (size_t)g->GetDataSize());
+  const Vector2<kt_double> off = g->GetCoordinateConverter()->GetOffset();
+  offset_xy[0] = off.GetX();
+  offset_xy[1] = off.GetY();
+  return 1;
+}
+
 // pose-graph statistics after the scans processed so far: out[0] = vertices, out[1] = edges (Graph::GetEdges)
 void kref_graph_stats(void* h, int out[2]) {
   KRef* k = (KRef*)h;

@@ -77,6 +77,89 @@ def test_reference_mapper_on_gpu_matcher_closed_loop(po):
     assert (g_c == 100).sum() > 500 and (g_c == 255).sum() > 20000
 
 
+def test_reference_mapper_uses_the_scan_cache_and_survives_reset(po):
+    """Seam B1's device-side scan cache (round 4): the reference's Mapper::Process on the GPU MatchScan sends every scan's
+    readings ONCE (not its whole running window per call), the world points of the scan just matched are prepared behind
+    its own match, ~ScanMatcher releases the device matcher (Mapper::Reset, Mapper.cpp:1980-1992, deletes and re-creates
+    its matchers: no leak per cycle) and forgets the scans the old Mapper numbered; the host grid behind
+    GetCorrelationGrid() can be refreshed on request and equals the pure reference's."""
+    laser = synth.Laser()
+    world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=5)
+    path = synth.loop_trajectory(90, w=6.0, h=4.0, step=0.2, origin=(-3.0, -2.0))
+    odom = synth.drifting_odometry(path, scale=1.02, seed=13)
+    kw = dict(scan_buffer_size=20, scan_buffer_max_scan_distance=5.0, do_loop_closing=1, link_scan_maximum_distance=1.5,
+              loop_search_maximum_distance=3.0, loop_match_minimum_chain_size=6)
+    cfg = po.default_cfg(**kw)
+    cpu = po.RefKarto(cfg, po.laser_struct(laser, 20.0))
+    gpu = po.RefKarto(cfg, po.laser_struct(laser, 20.0), gpu=True)
+    scans = [synth.ranges_to_f64(synth.cast_scan(world, t, laser, 0.01, 0.01, np.random.default_rng([51, i]))) for i, t in enumerate(path)]
+    alive0 = gpu.gpu_stats()["matchers_alive"]
+    for cycle in range(3):
+        s0 = gpu.gpu_stats()
+        for i, (r, o) in enumerate(zip(scans, odom)):
+            ok_c, pose_c = cpu.process(r, o)
+            ok_g, pose_g = gpu.process(r, o)
+            assert ok_c == ok_g and np.abs(pose_c - pose_g).max() <= 1e-9, (cycle, i)
+            assert cpu.graph_stats() == gpu.graph_stats(), (cycle, i)
+        s1 = gpu.gpu_stats()
+        n = cpu.graph_stats()[0]
+        calls = s1["match_calls"] - s0["match_calls"]
+        assert calls >= n - 1 and s1["cached_calls"] - s0["cached_calls"] == calls  # every call of the Mapper went through the cache
+        # one upload per processed scan (the first scan of a Mapper is never a query: it goes up when first named as a base scan)
+        assert s1["scans_uploaded"] - s0["scans_uploaded"] == n, (s0, s1, n)
+        assert s1["resident_scans"] == n
+        # the scan a Process() call matches is prepared at its new pose behind that match: refreshes in front of a match are
+        # the exception (the first scan, scans a closed loop re-posed), not one per call
+        assert s1["refreshes"] - s0["refreshes"] <= 0.2 * calls + 2, (s0, s1)
+        assert s1["matchers_alive"] <= alive0 + 2  # sequential + loop matcher of THIS Mapper, whatever the cycle
+        g_c, off_c = cpu.mapper_grid()
+        g_g, off_g = gpu.mapper_grid()
+        assert g_c is not None and g_g is not None and g_c.any()
+        assert np.array_equal(off_c, off_g) and np.array_equal(g_c, g_g)
+        cpu.reset()
+        gpu.reset()
+        s2 = gpu.gpu_stats()
+        assert s2["matchers_alive"] == alive0 and s2["resident_scans"] == 0, s2
+    cpu.close()
+    gpu.close()
+
+
+def test_reference_mapper_literal_forwarding_switch(po):
+    """LSLAM_KARTO_NO_CACHE=1 (read once per process) selects round 3's literal forwarding; run in a child process and
+    compare its poses with the cached path of this process: same records either way."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import lslam
+        from lslam_amd import synth
+        from oracle import pyoracle as po
+        laser = synth.Laser()
+        world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=5)
+        path = synth.loop_trajectory(40, w=6.0, h=4.0, step=0.2, origin=(-3.0, -2.0))
+        odom = synth.drifting_odometry(path, scale=1.02, seed=13)
+        gpu = po.RefKarto(po.default_cfg(scan_buffer_size=20, scan_buffer_max_scan_distance=5.0), po.laser_struct(laser, 20.0), gpu=True)
+        out = []
+        for i, (t, o) in enumerate(zip(path, odom)):
+            r = synth.ranges_to_f64(synth.cast_scan(world, t, laser, 0.01, 0.01, np.random.default_rng([52, i])))
+            out.append(gpu.process(r, o)[1])
+        s = gpu.gpu_stats()
+        print("RESULT", s["cached_calls"], s["match_calls"], np.stack(out).tobytes().hex())
+    """) % str(__import__("pathlib").Path(__file__).resolve().parent.parent)
+    res = {}
+    for flag in ("0", "1"):
+        env = dict(__import__("os").environ, LSLAM_KARTO_NO_CACHE=flag)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+        res[flag] = (int(line[1]), int(line[2]), line[3])
+    assert res["0"][0] == res["0"][1] > 30 and res["1"][0] == 0 and res["1"][1] == res["0"][1]
+    assert res["0"][2] == res["1"][2]
+
+
 @pytest.mark.parametrize("variant", ["laser_offset", "response_expansion"])
 def test_reference_mapper_on_gpu_matcher_variants(po, variant):
     """The lslam_laser built from the reference's LaserRangeFinder carries the mounting offset (Sensor::SetOffsetPose,
