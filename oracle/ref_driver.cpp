@@ -61,6 +61,7 @@ static lslam_context* kref_gpu_ctx() {
   return ctx;
 }
 #define KREF_CREATE_FROM_SCANS(scans, res) lslam::CreateOccupancyGridFromScans(kref_gpu_ctx(), scans, res)
+namespace lslam_karto { bool SyncCorrelationGrid(karto::ScanMatcher* pMatcher); }  // integration/karto_scan_matcher_gpu.cpp
 #else
 #define KREF_CREATE_FROM_SCANS(scans, res) karto::OccupancyGrid::CreateFromScans(scans, res)
 #endif
@@ -433,9 +434,6 @@ int kref_reset(void* h) {
 // GetCorrelationGrid() (Mapper.h:1226) of the Mapper's SEQUENTIAL matcher after the last Process(): the bytes and the grid
 // offset.  In the GPU-driven twin the host grid is only refreshed on request (integration/karto_scan_matcher_gpu.cpp:
 // lslam_karto::SyncCorrelationGrid); returns 0 when there is no matcher (or, GPU twin, nothing has been matched yet).
-#ifdef KREF_GPU
-namespace lslam_karto { bool SyncCorrelationGrid(karto::ScanMatcher* pMatcher); }
-#endif
 int kref_mapper_grid_copy(void* h, uint8_t* out, double* offset_xy) {
   KRef* k = (KRef*)h;
   ScanMatcher* sm = k->mapper->m_pSequentialScanMatcher;

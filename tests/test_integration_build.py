@@ -49,3 +49,21 @@ def test_hector_map_rep_is_the_interface(built):
     assert "lslam::HectorMapRepGpu" in lib and "lslam_map_match_data" in lib and "lslam_map_update_by_scan" in lib
     assert "typeinfo for hectorslam::MapRepresentationInterface" in lib
     assert "lslam_map_create" not in _nm(built / "_ref" / "libhector_ref.so", "-D")
+
+
+def test_destructor_is_substituted_too_and_the_twins_load(built):
+    """~ScanMatcher (Mapper.cpp:119-124) is weakened in the copy of Mapper.o and defined by the integration file (it
+    releases the device matcher: Mapper::Reset deletes and re-creates its matchers); the scan-cache entry points are what
+    MatchScan goes through; and both GPU-driven twins resolve every symbol at load time (a C-linkage slip in the driver
+    once surfaced only on the GPU box)."""
+    import ctypes
+
+    weak_obj = _nm(built / "_ref_gpu" / "Mapper_weak.o")
+    ours = _nm(built / "_ref_gpu" / "karto_scan_matcher_gpu.o")
+    for d in ("_ZN5karto11ScanMatcherD0Ev", "_ZN5karto11ScanMatcherD1Ev", "_ZN5karto11ScanMatcherD2Ev"):
+        assert f" W {d}" in weak_obj and f" T {d}" in ours, d
+    for sym in ("lslam_matcher_match_scan_cached", "lslam_scan_cache_create", "lslam_scan_cache_put", "lslam_scan_cache_forget",
+                "lslam_matcher_destroy"):
+        assert f" U {sym}" in ours, sym
+    for name in ("libkarto_ref_gpu.so", "libhector_ref_gpu.so"):
+        ctypes.CDLL(str(built / "_ref_gpu" / name), mode=ctypes.RTLD_NOW)
