@@ -323,6 +323,7 @@ def lib() -> C.CDLL:
     L.lslam_scan_cache_destroy.restype = None
     L.lslam_scan_cache_put.argtypes = [vp, i64, vp]
     L.lslam_scan_cache_contains.argtypes = [vp, i64]
+    L.lslam_scan_cache_prepare.argtypes = [vp, i64, vp]
     L.lslam_scan_cache_forget.argtypes = [vp, i64]
     L.lslam_scan_cache_size.argtypes = [vp]
     L.lslam_scan_cache_counters.argtypes = [vp, vp]
@@ -611,6 +612,11 @@ class ScanCache:
     def put(self, scan_id: int, ranges):
         r = _f64(ranges)
         self.ctx.check(self.L.lslam_scan_cache_put(self.h, int(scan_id), r.ctypes.data))
+
+    def prepare(self, scan_id: int, sensor_pose):
+        """World points + anchors of a cached scan at this pose, enqueued (asynchronous)."""
+        p = _f64(sensor_pose)
+        self.ctx.check(self.L.lslam_scan_cache_prepare(self.h, int(scan_id), p.ctypes.data))
 
     def __contains__(self, scan_id: int) -> bool:
         return bool(self.L.lslam_scan_cache_contains(self.h, int(scan_id)))

@@ -206,6 +206,31 @@ int lslam_scan_cache_put(lslam_scan_cache* c, int64_t scan_id, const double* ran
   return LSLAM_OK;
 }
 
+int lslam_scan_cache_prepare(lslam_scan_cache* c, int64_t scan_id, const double sensor_pose[3]) {
+  if (!c || scan_id < 0 || !sensor_pose) return LSLAM_ERR_INVALID_ARGUMENT;
+  CacheBusy guard(c);
+  if (!guard.ok) return c->ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "scan cache used concurrently");
+  lslam_context* ctx = c->ctx;
+  auto it = c->slot_of.find(scan_id);
+  if (it == c->slot_of.end()) return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "scan %lld is not in the scan cache", (long long)scan_id);
+  const int n = c->g.n_beams;
+  lslam_scan_cache::Slot& s = c->slots[(size_t)it->second];
+  if (n <= 0 || (s.posed && sc_same_pose(s.pose, sensor_pose))) return LSLAM_OK;
+  if (sc_anchor_lds(n) > 60 * 1024) return LSLAM_OK;  // very long scans are refreshed in front of their match only
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  CacheRefresh one;
+  one.slot = it->second;
+  one.pad = 0;
+  for (int k = 0; k < 3; k++) one.pose[k] = sensor_pose[k];
+  launch(ctx, "cache_refresh", k_anchor_chain_list, dim3(1), dim3(n > 512 ? 1024 : 256), sc_anchor_lds(n), n, c->d_world,
+         c->d_anchor, (const double*)c->d_ranges, (const CacheRefresh*)nullptr, (const lslam_match_result*)nullptr, one, c->g);
+  LSLAM_HIP(ctx, hipGetLastError());
+  s.posed = true;
+  for (int k = 0; k < 3; k++) s.pose[k] = sensor_pose[k];
+  c->n_speculated++;
+  return LSLAM_OK;
+}
+
 int lslam_scan_cache_contains(const lslam_scan_cache* c, int64_t scan_id) {
   if (!c) return 0;
   return c->slot_of.count(scan_id) ? 1 : 0;
@@ -291,6 +316,10 @@ int lslam_matcher_match_scan_cached(lslam_matcher* m, lslam_scan_cache* c, int n
     }
     const lslam_scan_cache::Slot& s = c->slots[(size_t)slot];
     if (!s.posed || !sc_same_pose(s.pose, want)) {
+      if (getenv("LSLAM_CACHE_DEBUG"))
+        fprintf(stderr, "[cache] match %lld: base[%d] id %lld slot %d posed %d cached (%.17g %.17g %.17g) want (%.17g %.17g %.17g) query_id %lld flags %d\n",
+                (long long)c->n_matches, i, (long long)base_ids[i], slot, (int)s.posed, s.pose[0], s.pose[1], s.pose[2], want[0], want[1], want[2],
+                (long long)query_id, flags);
       CacheRefresh& r = c->h_refresh[n_refresh++];
       r.slot = slot;
       r.pad = 0;
@@ -323,7 +352,7 @@ int lslam_matcher_match_scan_cached(lslam_matcher* m, lslam_scan_cache* c, int n
     if (lds_ok) {
       launch(ctx, "cache_refresh", k_anchor_chain_list, dim3(n_refresh), dim3(n > 512 ? 1024 : 256), sc_anchor_lds(n), n,
              c->d_world, c->d_anchor, (const double*)c->d_ranges, (const CacheRefresh*)c->h_refresh,
-             (const lslam_match_result*)nullptr, 0, c->g);
+             (const lslam_match_result*)nullptr, CacheRefresh{}, c->g);
     } else {  // very long scans: world points only (k_find_valid walks the chain in global scratch)
       for (int k = 0; k < n_refresh; k++) {
         PoseArg pv;
@@ -382,7 +411,7 @@ int lslam_matcher_match_scan_cached(lslam_matcher* m, lslam_scan_cache* c, int n
     LSLAM_HIP(ctx, hipEventRecord(c->ev_result, ctx->stream));
     launch(ctx, "cache_refresh", k_anchor_chain_list, dim3(1), dim3(n > 512 ? 1024 : 256), sc_anchor_lds(n), n, c->d_world,
            c->d_anchor, (const double*)c->d_ranges, (const CacheRefresh*)nullptr, (const lslam_match_result*)c->h_result,
-           q_slot, c->g);
+           CacheRefresh{q_slot, 0, {0, 0, 0}}, c->g);
     LSLAM_HIP(ctx, hipEventSynchronize(c->ev_result));
   } else {
     LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -2311,15 +2311,15 @@ struct CacheRefresh {
 __global__ void __launch_bounds__(1024)
 k_anchor_chain_list(int n, double2* __restrict__ world, int* __restrict__ rows, const double* __restrict__ ranges,
                     const CacheRefresh* __restrict__ list, const lslam_match_result* __restrict__ from_result,
-                    int result_slot, Geom g) {
+                    CacheRefresh one, Geom g) {
   PoseArg pose;
   int slot;
   if (from_result) {
     if (from_result->status != LSLAM_OK) return;
-    slot = result_slot;
+    slot = one.slot;
     for (int i = 0; i < 3; i++) pose.v[i] = from_result->pose[i];
   } else {
-    const CacheRefresh e = list[blockIdx.x];
+    const CacheRefresh e = list ? list[blockIdx.x] : one;  // `one`: a single scan whose slot and pose are kernel arguments
     slot = e.slot;
     for (int i = 0; i < 3; i++) pose.v[i] = e.pose[i];
   }

@@ -211,6 +211,12 @@ int lslam_scan_cache_put(lslam_scan_cache* cache, int64_t scan_id, const double*
 int lslam_scan_cache_contains(const lslam_scan_cache* cache, int64_t scan_id); /* 1 / 0 */
 int lslam_scan_cache_forget(lslam_scan_cache* cache, int64_t scan_id);         /* scan_id < 0: every scan */
 int lslam_scan_cache_size(const lslam_scan_cache* cache);
+/* World points + FindValidPoints anchors of cached scan `scan_id` at `sensor_pose`, ENQUEUED on the context stream (returns
+ * at once): for a caller that knows -- or can guess -- the pose a scan will have when it is next named as a base scan
+ * (integration/karto_scan_matcher_gpu.cpp: the pose AddEdges gives the scan Mapper::Process has just matched, Mapper.cpp:
+ * 930-973), so that the preparation runs beside the caller's host code instead of in front of its next match.  A guess
+ * that turns out wrong costs nothing but the refresh it would have saved. */
+int lslam_scan_cache_prepare(lslam_scan_cache* cache, int64_t scan_id, const double sensor_pose[3]);
 /* out[5] = matches served, scans uploaded, (scan, pose) refreshes (world points + anchors recomputed because the pose
  * differed bitwise from the cached one), speculative refreshes (below), bytes of HBM held */
 int lslam_scan_cache_counters(const lslam_scan_cache* cache, int64_t out[5]);

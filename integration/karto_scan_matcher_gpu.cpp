@@ -145,21 +145,29 @@ static Residents& residents_for(const lslam_laser& laser) {
   return r;
 }
 
-// id of a MANAGED scan (unique id >= 0) in the cache, uploading its readings on a miss
-static int64_t resident_id(Residents& R, karto::LocalizedRangeScan* s, int nb) {
+// the resident entry of a MANAGED scan (unique id >= 0), or NULL: same object, same readings array, and either the same
+// unique id or a provisional entry (cached as the query of Mapper::Process, numbered by AddScan since) with equal contents
+static ResidentScan* find_resident(Residents& R, karto::LocalizedRangeScan* s, int nb) {
   const kt_double* rd = s->GetRangeReadings();
   const kt_int32s uid = s->GetUniqueId();
   auto it = R.scans.find(s);
-  if (it != R.scans.end() && it->second.readings == rd) {
-    if (it->second.unique_id == uid) return it->second.id;
-    if (it->second.unique_id < 0 && it->second.checksum == checksum(rd, nb)) {  // numbered by AddScan since its own match
-      it->second.unique_id = uid;
-      return it->second.id;
-    }
+  if (uid < 0 || it == R.scans.end() || it->second.readings != rd) return nullptr;
+  if (it->second.unique_id == uid) return &it->second;
+  if (it->second.unique_id < 0 && it->second.checksum == checksum(rd, nb)) {
+    it->second.unique_id = uid;
+    return &it->second;
   }
+  return nullptr;
+}
+
+// id of a MANAGED scan in the cache, uploading its readings on a miss
+static int64_t resident_id(Residents& R, karto::LocalizedRangeScan* s, int nb) {
+  if (ResidentScan* e = find_resident(R, s, nb)) return e->id;
+  const kt_double* rd = s->GetRangeReadings();
+  auto it = R.scans.find(s);
   ResidentScan e;
   e.id = it != R.scans.end() ? it->second.id : R.next_id++;
-  e.unique_id = uid;
+  e.unique_id = s->GetUniqueId();
   e.readings = rd;
   e.checksum = checksum(rd, nb);
   int rc = lslam_scan_cache_put(R.cache, e.id, rd);
@@ -187,6 +195,34 @@ void release_all() {
     if (kv.second.h) lslam_matcher_destroy(kv.second.h);
   registry().clear();
   drop_residents();
+}
+
+// What Mapper::Process does with the mean of its sequential match: AddEdges (Mapper.cpp:930-973) collects it with the
+// means of the near-chain matches and gives the scan ComputeWeightedMean(means, covariances) (Mapper.cpp:1288-1330) as its
+// sensor pose -- with ONE mean (no near chain linked: ~90 % of the scans) that is inverse(inverse(C)) * inverse(C) * mean,
+// the same pose up to a last-bit rounding, but not the same BITS.  The scan cache matches poses bitwise, so the pose the
+// scan is prepared at behind its own match is this function's, not the raw mean.  Same statements, same karto::Matrix3 /
+// Pose2 operations, same order as the reference for a single (mean, covariance); a wrong guess (near chains linked, a
+// closed loop) only costs the refresh in front of the next match that it was meant to save.
+karto::Pose2 PredictPoseAfterAddEdges(const karto::Pose2& rMean, const karto::Matrix3& rCovariance) {
+  using namespace karto;
+  Matrix3 sumOfInverses;
+  Matrix3 inverse = rCovariance.Inverse();
+  sumOfInverses += inverse;
+  Matrix3 inverseOfSumOfInverses = sumOfInverses.Inverse();
+  Pose2 accumulatedPose;
+  kt_double thetaX = 0.0;
+  kt_double thetaY = 0.0;
+  Pose2 pose = rMean;
+  kt_double angle = pose.GetHeading();
+  thetaX += cos(angle);
+  thetaY += sin(angle);
+  Matrix3 weight = inverseOfSumOfInverses * inverse;
+  accumulatedPose += weight * pose;
+  thetaX /= 1;
+  thetaY /= 1;
+  accumulatedPose.SetHeading(atan2(thetaY, thetaX));
+  return accumulatedPose;
 }
 
 // The host CorrelationGrid behind GetCorrelationGrid() (Mapper.h:1226) <- the device grid of this matcher's last match
@@ -376,14 +412,14 @@ kt_double ScanMatcher::MatchScan(LocalizedRangeScan* pScan, const LocalizedRange
     int flags = (doPenalize ? LSLAM_MATCH_PENALIZE : 0) | (doRefineMatch ? LSLAM_MATCH_REFINE : 0);
     int64_t qid = -1;
     const kt_double* qr = pScan->GetRangeReadings();
-    auto it = R.scans.find(pScan);
-    if (pScan->GetUniqueId() >= 0 && it != R.scans.end() && it->second.unique_id == pScan->GetUniqueId() &&
-        it->second.readings == qr) {
-      qid = it->second.id;  // a managed scan matched again (LinkNearChains, TryCloseLoop's coarse match): nothing to send
+    bool process_call = false;
+    if (ResidentScan* e = find_resident(R, pScan, nb)) {
+      qid = e->id;  // a managed scan matched again (LinkNearChains, TryCloseLoop's coarse match): nothing to send
       qr = nullptr;
     } else if (pScan->GetUniqueId() < 0 && sequential && doPenalize && doRefineMatch) {
-      // Mapper::Process (Mapper.cpp:2040-2044): the scan takes the returned mean and is added to the running window next;
-      // keep its readings (provisionally: AddScan numbers it after this call) and prepare it at that pose behind the match
+      // Mapper::Process (Mapper.cpp:2040-2044): the scan is added to the running window next; keep its readings
+      // (provisionally: AddScan numbers it after this call)
+      auto it = R.scans.find(pScan);
       ResidentScan e;
       e.id = it != R.scans.end() ? it->second.id : R.next_id++;
       e.unique_id = -1;
@@ -392,13 +428,31 @@ kt_double ScanMatcher::MatchScan(LocalizedRangeScan* pScan, const LocalizedRange
       R.scans[pScan] = e;
       qid = e.id;
       if (lslam_scan_cache_contains(R.cache, qid)) lslam_scan_cache_forget(R.cache, qid);  // stale provisional entry
-      flags |= LSLAM_MATCH_QUERY_TAKES_RESULT_POSE;
+      process_call = true;
     }  // else: a temporary (TryCloseLoop's stack scan) or an unmanaged scan: anonymous query, nothing kept
     t_dev = std::chrono::steady_clock::now();
     rc = lslam_matcher_match_scan_cached(g.h, R.cache, static_cast<int>(n_base), g.ids.data(), g.poses.data(), qid, qr, q,
                                          flags, &r);
     if (rc != LSLAM_OK) throw std::runtime_error(std::string("lslam_matcher_match_scan_cached: ") + lslam_last_error(context()));
     g.cached_calls++;
+    if (process_call && r.status == LSLAM_OK) {
+      // prepare the scan (world points + FindValidPoints anchors) at the pose AddEdges is about to give it, behind this
+      // call: the kernel runs while the reference's host code (AddScan, AddEdges, the graph search) does
+      Matrix3 cov = rCovariance;
+      cov(0, 0) = r.covariance[0];
+      cov(0, 1) = r.covariance[1];
+      cov(1, 0) = r.covariance[3];
+      cov(1, 1) = r.covariance[4];
+      cov(2, 2) = r.covariance[8];
+      const Pose2 next = PredictPoseAfterAddEdges(Pose2(r.pose[0], r.pose[1], r.pose[2]), cov);
+      // SetSensorPose(next) followed by GetSensorPose() (Karto.h:5280-5313): the identity for a laser at the robot's centre, a
+      // round trip through the robot pose otherwise
+      double robot[3], sensor[3];
+      const double np[3] = {next.GetX(), next.GetY(), next.GetHeading()};
+      lslam_robot_pose_from_sensor(&laser, np, robot);
+      lslam_sensor_pose_from_robot(&laser, robot, sensor);
+      (void)lslam_scan_cache_prepare(R.cache, qid, sensor);
+    }
   } else {
     // ---- literal forwarding: every base scan's readings cross the bus ------------------------------------------------
     g.ranges.resize(n_base * stride);

@@ -61,7 +61,10 @@ static lslam_context* kref_gpu_ctx() {
   return ctx;
 }
 #define KREF_CREATE_FROM_SCANS(scans, res) lslam::CreateOccupancyGridFromScans(kref_gpu_ctx(), scans, res)
-namespace lslam_karto { bool SyncCorrelationGrid(karto::ScanMatcher* pMatcher); }  // integration/karto_scan_matcher_gpu.cpp
+namespace lslam_karto {  // integration/karto_scan_matcher_gpu.cpp
+bool SyncCorrelationGrid(karto::ScanMatcher* pMatcher);
+karto::Pose2 PredictPoseAfterAddEdges(const karto::Pose2& rMean, const karto::Matrix3& rCovariance);
+}
 #else
 #define KREF_CREATE_FROM_SCANS(scans, res) karto::OccupancyGrid::CreateFromScans(scans, res)
 #endif
@@ -448,6 +451,31 @@ int kref_mapper_grid_copy(void* h, uint8_t* out, double* offset_xy) {
   offset_xy[1] = off.GetY();
   return 1;
 }
+
+#ifdef KREF_GPU
+// The integration file's statement of "the pose AddEdges gives a scan whose only mean is its sequential match" beside the
+// reference's own MapperGraph::ComputeWeightedMean (Mapper.cpp:1288-1330, private: this driver sees it through its
+// `#define private public`) on the same (mean, covariance): host arithmetic only, no GPU involved.
+int kref_weighted_mean_check(void* h, const double* mean, const double* cov9, double* out_ref, double* out_pred) {
+  KRef* k = (KRef*)h;
+  MapperGraph* g = k->mapper->GetGraph();
+  MapperGraph* tmp = nullptr;
+  if (!g) g = tmp = new MapperGraph(k->mapper, k->laser->GetRangeThreshold());
+  Matrix3 c;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) c(i, j) = cov9[3 * i + j];
+  Pose2Vector means;
+  means.push_back(Pose2(mean[0], mean[1], mean[2]));
+  std::vector<Matrix3> covs;
+  covs.push_back(c);
+  const Pose2 a = g->ComputeWeightedMean(means, covs);
+  const Pose2 b = lslam_karto::PredictPoseAfterAddEdges(means[0], c);
+  out_ref[0] = a.GetX(); out_ref[1] = a.GetY(); out_ref[2] = a.GetHeading();
+  out_pred[0] = b.GetX(); out_pred[1] = b.GetY(); out_pred[2] = b.GetHeading();
+  delete tmp;
+  return 0;
+}
+#endif
 
 // pose-graph statistics after the scans processed so far: out[0] = vertices, out[1] = edges (Graph::GetEdges)
 void kref_graph_stats(void* h, int out[2]) {

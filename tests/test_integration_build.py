@@ -4,6 +4,7 @@ link-time substitution really happened -- the one strong definition of karto::Sc
 oracle/_ref_gpu/libkarto_ref_gpu.so is the one from integration/karto_scan_matcher_gpu.cpp (it calls the C ABI), while
 the reference's own definition is still the one inside oracle/_ref/libkarto_ref.so.  No GPU needed; skipped where the
 reference is absent (the GPU box: the prebuilt libraries travel, tests/test_ref_drives_gpu.py uses them there)."""
+import os
 import pathlib
 import subprocess
 
@@ -66,4 +67,39 @@ def test_destructor_is_substituted_too_and_the_twins_load(built):
                 "lslam_matcher_destroy"):
         assert f" U {sym}" in ours, sym
     for name in ("libkarto_ref_gpu.so", "libhector_ref_gpu.so"):
-        ctypes.CDLL(str(built / "_ref_gpu" / name), mode=ctypes.RTLD_NOW)
+        ctypes.CDLL(str(built / "_ref_gpu" / name), mode=os.RTLD_NOW)
+
+
+def test_predicted_pose_equals_compute_weighted_mean(built):
+    """integration/karto_scan_matcher_gpu.cpp prepares the scan Mapper::Process has just matched at the pose AddEdges will
+    give it: its restatement of the single-mean case must equal the reference's own MapperGraph::ComputeWeightedMean BIT
+    for BIT (the scan cache compares poses bitwise) -- and that pose is, as a rule, NOT the raw mean."""
+    import ctypes
+
+    import numpy as np
+
+    from oracle import pyoracle as po
+
+    L = ctypes.CDLL(str(built / "_ref_gpu" / "libkarto_ref_gpu.so"))
+    L.kref_create.restype = ctypes.c_void_p
+    L.kref_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.kref_weighted_mean_check.argtypes = [ctypes.c_void_p] * 5
+    L.kref_destroy.argtypes = [ctypes.c_void_p]
+    from lslam_amd import synth
+
+    cfg, laser = po.default_cfg(), po.laser_struct(synth.Laser())
+    h = L.kref_create(ctypes.byref(cfg), ctypes.byref(laser))
+    assert h
+    rng = np.random.default_rng(3)
+    moved = 0
+    for _ in range(2000):
+        mean = np.array([rng.uniform(-50, 50), rng.uniform(-50, 50), rng.uniform(-3.14, 3.14)])
+        a, b, c = rng.uniform(1e-4, 2e-3), rng.uniform(1e-4, 2e-3), rng.uniform(-5e-5, 5e-5)
+        cov = np.array([[a, c, 0.0], [c, b, 0.0], [0.0, 0.0, rng.uniform(1e-6, 1e-4)]])  # what CorrelateScan fills (Mapper.cpp:535-692)
+        ref, pred = np.zeros(3), np.zeros(3)
+        L.kref_weighted_mean_check(h, mean.ctypes.data, cov.ctypes.data, ref.ctypes.data, pred.ctypes.data)
+        assert ref.tobytes() == pred.tobytes()
+        assert np.abs(ref - mean).max() < 1e-9
+        moved += ref.tobytes() != mean.tobytes()
+    assert moved > 200  # the weighted mean of ONE mean is that mean only up to rounding: why the raw mean is not the guess
+    L.kref_destroy(h)

@@ -163,3 +163,31 @@ def test_cache_grows_past_its_first_allocation(ctx):
     b = cache.MatchScan(cached, ids, base_p, odo[5], query_id=1000, query_ranges=ranges[5])
     assert _record(a) == _record(b)
     assert len(cache) == 301 and cache.counters()["resident_bytes"] >= 512 * 1081 * 24
+
+
+def test_prepare_moves_the_refresh_off_the_next_match(ctx):
+    """lslam_scan_cache_prepare: a scan's world points + anchors at the pose the caller EXPECTS it to have next (the drop-in
+    layer: the pose AddEdges gives the scan Mapper::Process has just matched), enqueued behind the match.  Right guess: the
+    next match needs no refresh; wrong guess: it refreshes again; either way the records equal lslam_matcher_match_scan's."""
+    plain, cached, cache = _pair(ctx)
+    ranges, odo = _trajectory(8, 16)
+    for i in range(6):
+        cache.put(i, ranges[i])
+    ids = np.arange(6)
+    cache.MatchScan(cached, ids, odo[:6], odo[6], query_id=6, query_ranges=ranges[6])
+    base = cache.counters()
+    assert base["refreshed"] == 6 and base["speculated"] == 0
+    moved = odo[:7].copy()
+    moved[6] += np.array([1e-3, -2e-3, 5e-4])
+    cache.prepare(6, moved[6])                       # right guess
+    cache.prepare(6, moved[6])                       # again: nothing to do
+    a = plain.MatchScan(ranges[7], odo[7], ranges[:7], moved)
+    b = cache.MatchScan(cached, np.arange(7), moved, odo[7], query_id=7, query_ranges=ranges[7])
+    c = cache.counters()
+    assert _record(a) == _record(b) and c["refreshed"] == 6 and c["speculated"] == 1
+    cache.prepare(3, moved[3] + 1e-6)                # wrong guess: scan 3 is still where it was
+    b = cache.MatchScan(cached, np.arange(7), moved, odo[7], query_id=7)
+    c = cache.counters()
+    assert _record(a) == _record(b) and c["refreshed"] == 7 and c["speculated"] == 2
+    with pytest.raises(api.LslamError):
+        cache.prepare(99, odo[0])
