@@ -295,6 +295,7 @@ def lib() -> C.CDLL:
     L.lslam_map_update_just_once.argtypes = [vp, vp, i32, vp, C.c_float, C.c_float, dbl]
     L.lslam_map_match_data.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     L.lslam_map_cached_points.argtypes = [vp]
+    L.lslam_map_set_option.argtypes = [vp, i32, i32]
     L.lslam_map_read_logodds.argtypes = [vp, i32, vp]
     L.lslam_map_read_occupancy_i8.argtypes = [vp, i32, vp]
     L.lslam_map_flush.argtypes = [vp]
@@ -1013,6 +1014,10 @@ class OccGridMap:
         self.ctx.check(self.L.lslam_map_match_data(self.h, p.ctypes.data, p.shape[0], o.ctypes.data, b.ctypes.data,
                                                    pose.ctypes.data, cov.ctypes.data))
         return pose, cov.reshape(3, 3)
+
+    def set_option(self, name: str, value: int):
+        """'ordered_sums': matchData adds its sums in point order (bit-equal to the CPU restatement) instead of in parallel."""
+        self.ctx.check(self.L.lslam_map_set_option(self.h, {"ordered_sums": 1}[name], int(value)))
 
     def cached_points(self) -> int:
         return self.L.lslam_map_cached_points(self.h)

@@ -696,6 +696,147 @@ k_gn_match(GnLevels lv, const float* __restrict__ pts, int n, float bx, float by
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_gn_match_fast -- the same Gauss-Newton matcher, summed in PARALLEL (round 4; the default).
+// k_gn_match above adds the nine H / dTr sums in point order on nine lanes so that they round like the reference's
+// sequential fp32 loop (it equals the CPU restatement bit for bit): 1081 dependent LDS adds per iteration, fourteen
+// iterations, on one CU.  The north star grants 1e-4 m / 1e-4 rad for floating point, device libm already differs from
+// glibc in the last bit, and a tree sum is -- if anything -- the more accurate one.  Here every thread keeps nine
+// partial sums of ITS points in registers, a wave adds them with DPP row operations (no LDS round trip), the waves'
+// partials meet in LDS and EVERY thread adds them up and solves the 3x3 system itself (same inputs, same operations:
+// bitwise the same estimate in every thread), so an iteration has ONE barrier and no single-thread phase.  exp / sin /
+// cos are the float32 ocml functions (<= 1 ulp; the ordered kernel evaluates them in double like the reference's host
+// code).  Points are staged once in LDS; the kernel also writes the cached container (MapRepMultiMap.h:161) when the
+// points come from pinned host memory, and its result lands in pinned host memory: no copy operation on the stream.
+// LSLAM_MAP_OPT_ORDERED_SUMS selects the ordered kernel (the bit comparison with the restatement).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gn_row16_sum(float v) {  // every lane of a 16-lane row ends up with the row's sum
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+__device__ __forceinline__ float gn_wave_sum(float v) {
+  v = gn_row16_sum(v);
+  const int b = __float_as_int(v);
+  return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
+}
+__device__ __forceinline__ float gn_prob_f(float lo) {  // getGridProbability (GridMapLogOdds.h:123-127), float32 exp
+  const float odds = expf(lo);
+  return odds / (odds + 1.0f);
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT)
+k_gn_match_fast(GnLevels lv, const float* __restrict__ pts, float* __restrict__ cache_dst, int n, int pts_in_lds, float bx,
+                float by, float bth, float* __restrict__ out /* pose[3] + H[9] */) {
+  extern __shared__ float s_pts[];  // [2n] when pts_in_lds
+  constexpr int NW = NT / 64;
+  __shared__ float s_part[2][NW][12];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int i = tid; i < 2 * n; i += NT) {
+    const float v = pts[i];
+    if (pts_in_lds) s_pts[i] = v;
+    if (cache_dst) cache_dst[i] = v;
+  }
+  const float* P = pts_in_lds ? s_pts : (cache_dst ? cache_dst : pts);
+  __syncthreads();  // (a thread reads points other threads staged; cache_dst is only re-read by its own writers' block)
+  float tmp0 = bx, tmp1 = by, tmp2 = bth;
+  float H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int flip = 0;
+  for (int L = lv.n_levels - 1; L >= 0; --L) {
+    if (n == 0) continue;
+    const float* lo = lv.logodds[L];
+    const int sx = lv.sx[L], sy = lv.sy[L];
+    const float sc = lv.scale[L];
+    const float factor = L == 0 ? 1.0f : 1.0f / (float)(1 << L);
+    const int iters = 1 + (L == 0 ? 5 : 3);
+    // getMapCoordsPose (GridMapBase.h:238-242)
+    float e0 = (sc * tmp0 + 0.0f * tmp1) + lv.t_x[L];
+    float e1 = (0.0f * tmp0 + sc * tmp1) + lv.t_y[L];
+    float e2 = tmp2;
+    const float lim_x = (float)sx - 2.0f, lim_y = (float)sy - 2.0f;  // MapDimensionProperties.h:66-70
+    for (int it = 0; it < iters; it++) {
+      float s, c;
+      sincosf(e2, &s, &c);
+      float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 2
+      for (int i = tid; i < n; i += NT) {
+        const float px = P[2 * i] * factor, py = P[2 * i + 1] * factor;
+        const float cx = (c * px + (-s) * py) + e0;
+        const float cy = (s * px + c * py) + e1;
+        float v = 0.0f, gxv = 0.0f, gyv = 0.0f;
+        if (!(cx < 0.0f || cx > lim_x || cy < 0.0f || cy > lim_y)) {  // pointOutOfMapBounds (:60-63)
+          const int ix = (int)cx, iy = (int)cy;
+          const float fx = cx - (float)ix, fy = cy - (float)iy;
+          const int index = iy * sx + ix;
+          const float l0 = lo[index], l1 = lo[index + 1], l2 = lo[index + sx], l3 = lo[index + sx + 1];
+          const float i0 = gn_prob_f(l0), i1 = gn_prob_f(l1), i2 = gn_prob_f(l2), i3 = gn_prob_f(l3);
+          const float dx1 = i0 - i1, dx2 = i2 - i3, dy1 = i0 - i2, dy2 = i1 - i3;
+          const float xi = 1.0f - fx, yi = 1.0f - fy;
+          v = ((i0 * xi + i1 * fx) * (yi)) + ((i2 * xi + i3 * fx) * (fy));
+          gxv = -((dx1 * yi) + (dx2 * fy));
+          gyv = -((dy1 * xi) + (dy2 * fx));
+        }
+        const float funVal = 1.0f - v;
+        const float rotDeriv = ((-s * px - c * py) * gxv + (c * px - s * py) * gyv);
+        acc[0] += gxv * funVal; acc[1] += gyv * funVal; acc[2] += rotDeriv * funVal;
+        acc[3] += gxv * gxv; acc[4] += gyv * gyv; acc[5] += rotDeriv * rotDeriv;
+        acc[6] += gxv * gyv; acc[7] += gxv * rotDeriv; acc[8] += gyv * rotDeriv;
+      }
+#pragma unroll
+      for (int q = 0; q < 9; q++) {
+        const float t = gn_wave_sum(acc[q]);
+        if (lane == 0) s_part[flip][wv][q] = t;
+      }
+      __syncthreads();
+      float sum[9];
+#pragma unroll
+      for (int q = 0; q < 9; q++) {
+        float t = s_part[flip][0][q];
+#pragma unroll
+        for (int w = 1; w < NW; w++) t += s_part[flip][w][q];
+        sum[q] = t;
+      }
+      flip ^= 1;  // the next iteration writes the other buffer: no second barrier needed
+      const float d0 = sum[0], d1 = sum[1], d2 = sum[2], h00 = sum[3], h11 = sum[4], h22 = sum[5], h01 = sum[6],
+                  h02 = sum[7], h12 = sum[8];
+      H[0] = h00; H[1] = h01; H[2] = h02; H[3] = h01; H[4] = h11; H[5] = h12; H[6] = h02; H[7] = h12; H[8] = h22;
+      if (h00 != 0.0f && h11 != 0.0f) {  // estimateTransformationLogLh (ScanMatcher.h:113-133)
+        const float c0 = gn_cof3(H, 0, 0), c1 = gn_cof3(H, 1, 0), c2 = gn_cof3(H, 2, 0);
+        const float det = c0 * H[0] + (c1 * H[3] + c2 * H[6]);
+        const float invdet = 1.0f / det;
+        const float Hi[9] = {c0 * invdet, c1 * invdet, c2 * invdet,
+                             gn_cof3(H, 0, 1) * invdet, gn_cof3(H, 1, 1) * invdet, gn_cof3(H, 2, 1) * invdet,
+                             gn_cof3(H, 0, 2) * invdet, gn_cof3(H, 1, 2) * invdet, gn_cof3(H, 2, 2) * invdet};
+        float sd[3];
+        for (int r = 0; r < 3; r++) sd[r] = Hi[3 * r] * d0 + (Hi[3 * r + 1] * d1 + Hi[3 * r + 2] * d2);
+        if (sd[2] > 0.2f) sd[2] = 0.2f; else if (sd[2] < -0.2f) sd[2] = -0.2f;
+        e0 += sd[0]; e1 += sd[1]; e2 += sd[2];
+      }
+    }
+    {
+      // util::normalize_angle (UtilFunctions.h:36-48), double arithmetic with M_PI
+      const double two_pi = 2.0f * 3.14159265358979323846;
+      float a = (float)fmod(fmod((double)e2, two_pi) + two_pi, two_pi);
+      if ((double)a > 3.14159265358979323846) a = (float)((double)a - two_pi);
+      // getWorldCoordsPose: worldTmap = mapTworld.inverse() (GridMapBase.h:229-233, 285)
+      const float invdet = 1.0f / (sc * sc - 0.0f * 0.0f);
+      const float l00 = sc * invdet, l01 = -0.0f * invdet, l10 = -0.0f * invdet, l11 = sc * invdet;
+      const float wt0 = -(l00 * lv.t_x[L] + l01 * lv.t_y[L]), wt1 = -(l10 * lv.t_x[L] + l11 * lv.t_y[L]);
+      tmp0 = (l00 * e0 + l01 * e1) + wt0;
+      tmp1 = (l10 * e0 + l11 * e1) + wt1;
+      tmp2 = a;
+    }
+  }
+  if (tid == 0) {
+    out[0] = tmp0; out[1] = tmp1; out[2] = tmp2;
+    for (int q = 0; q < 9; q++) out[3 + q] = H[q];
+  }
+}
+
 float prob_to_logodds(float prob) {  // H/map/GridMapLogOdds.h:151-155 (log() is the double overload)
   float odds = prob / (1.0f - prob);
   return (float)log((double)odds);
@@ -737,6 +878,13 @@ struct lslam_map {
   int n_cached = 0;
   float cached_origo[2] = {0.f, 0.f};
   DevBuf<float> d_gn_out;
+  // matchData, parallel-sum kernel (the default): the container goes up through pinned memory and is read -- and cached in
+  // d_cached -- by the kernel itself; its 12 result floats land in pinned memory.  ordered_sums: k_gn_match instead.
+  bool ordered_sums = false;  // lslam_map_set_option(LSLAM_MAP_OPT_ORDERED_SUMS) / LSLAM_GN_ORDERED=1
+  int gn_threads = 512;       // LSLAM_GN_THREADS = 256 | 512 | 1024
+  float* h_gn_pts = nullptr;
+  size_t h_gn_cap = 0;        // floats
+  float* h_gn_out = nullptr;  // 12 floats
   // resident container of lslam_map_set_scan (device-side LaserScan -> DataContainer)
   DevBuf<float> d_scan;         // projected points, then one int: their count
   DevBuf<float> d_scan_ranges;
@@ -928,6 +1076,10 @@ int lslam_map_create(lslam_context* ctx, int size_x, int size_y, float cell_leng
   {
     const char* e = getenv("LSLAM_MAP_TWO_KERNELS");
     map->force_two_kernels = e && e[0] == '1';
+    e = getenv("LSLAM_GN_ORDERED");
+    map->ordered_sums = e && e[0] == '1';
+    e = getenv("LSLAM_GN_THREADS");
+    if (e && atoi(e) >= 256) map->gn_threads = atoi(e);
   }
   (void)hipStreamSynchronize(ctx->stream);
   ctx->pre_sync.emplace_back((void*)map, [](void* m) { return lslam_map_flush((lslam_map*)m); });  // lslam_synchronize flushes
@@ -965,6 +1117,8 @@ void lslam_map_destroy(lslam_map* map) {
   map->d_cossin.release();
   map->d_i8.release();
   if (map->h_stage) (void)hipHostFree(map->h_stage);
+  if (map->h_gn_pts) (void)hipHostFree(map->h_gn_pts);
+  if (map->h_gn_out) (void)hipHostFree(map->h_gn_out);
   for (auto e : map->stage_ev)
     if (e) (void)hipEventDestroy(e);
   delete map;
@@ -1022,6 +1176,8 @@ int stage_points(lslam_map* map, const float* pts, int n) {
   if (floats > map->stage_cap) {  // (re)build the ring; drains whatever is in flight first
     LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (map->h_stage) (void)hipHostFree(map->h_stage);
+  if (map->h_gn_pts) (void)hipHostFree(map->h_gn_pts);
+  if (map->h_gn_out) (void)hipHostFree(map->h_gn_out);
     map->h_stage = nullptr;
     map->stage_cap = 0;
     const size_t cap = floats + floats / 4 + 64;
@@ -1294,7 +1450,7 @@ int match_data_impl(lslam_map* map, const float* pts, int n, bool pts_on_device,
   lslam_context* ctx = map->ctx;
   if ((int)map->levels.size() > kGnMaxLevels)
     return ctx->fail(LSLAM_ERR_UNSUPPORTED, "at most %d pyramid levels", kGnMaxLevels);
-  if ((size_t)n * 9 * sizeof(float) > 150 * 1024)
+  if (map->ordered_sums && (size_t)n * 9 * sizeof(float) > 150 * 1024)
     return ctx->fail(LSLAM_ERR_UNSUPPORTED, "at most %d points per scan in matchData", (int)(150 * 1024 / 36));
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
   {
@@ -1304,11 +1460,6 @@ int match_data_impl(lslam_map* map, const float* pts, int n, bool pts_on_device,
   LSLAM_HIP(ctx, map->d_cached.reserve((size_t)2 * (n > 0 ? n : 1)));
   LSLAM_HIP(ctx, map->d_gn_out.reserve(16));
   float* d_out = map->d_gn_out.p;
-  // dataContainers[index-1].setFrom(dataContainer, ...) (MapRepMultiMap.h:161): the container is cached for the
-  // next updateByScan -- also when it is empty
-  if (n > 0)
-    LSLAM_HIP(ctx, hipMemcpyAsync(map->d_cached.p, pts, (size_t)2 * n * sizeof(float),
-                                  pts_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
   if (map->levels.size() > 1) {
     map->n_cached = n;
     map->cached_origo[0] = origo ? origo[0] : 0.f;
@@ -1321,6 +1472,50 @@ int match_data_impl(lslam_map* map, const float* pts, int n, bool pts_on_device,
     lv.sx[i] = L.sx; lv.sy[i] = L.sy; lv.scale[i] = L.scale_to_map; lv.t_x[i] = L.t_x; lv.t_y[i] = L.t_y;
     lv.logodds[i] = L.d_logodds;
   }
+  if (!map->ordered_sums) {
+    // ---- parallel sums (default): one launch, no copy operation on the stream --------------------------------------------
+    if (!map->h_gn_out && hipHostMalloc((void**)&map->h_gn_out, 16 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the pinned result of matchData");
+    }
+    const float* src = pts;
+    if (!pts_on_device && n > 0) {
+      if ((size_t)2 * n > map->h_gn_cap) {
+        if (map->h_gn_pts) (void)hipHostFree(map->h_gn_pts);
+        map->h_gn_pts = nullptr;
+        map->h_gn_cap = 0;
+        const size_t want = (size_t)2 * n + 256;
+        if (hipHostMalloc((void**)&map->h_gn_pts, want * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+          (void)hipGetLastError();
+          return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the pinned staging of matchData");
+        }
+        map->h_gn_cap = want;
+      }
+      memcpy(map->h_gn_pts, pts, (size_t)2 * n * sizeof(float));
+      src = map->h_gn_pts;
+    }
+    const int in_lds = (size_t)2 * n * sizeof(float) <= 56 * 1024;
+    const size_t lds = in_lds ? (size_t)2 * std::max(n, 1) * sizeof(float) : 0;
+    float* cache_dst = n > 0 ? map->d_cached.p : (float*)nullptr;
+#define LSLAM_GN_FAST(NT)                                                                                                  \
+  launch(ctx, "gn_match", k_gn_match_fast<NT>, dim3(1), dim3(NT), lds, lv, src, cache_dst, n, in_lds, begin_world[0],      \
+         begin_world[1], begin_world[2], map->h_gn_out)
+    if (map->gn_threads >= 1024) LSLAM_GN_FAST(1024);
+    else if (map->gn_threads >= 512) LSLAM_GN_FAST(512);
+    else LSLAM_GN_FAST(256);
+#undef LSLAM_GN_FAST
+    LSLAM_HIP(ctx, hipGetLastError());
+    LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 3; i++) out_pose[i] = map->h_gn_out[i];
+    if (out_cov) for (int i = 0; i < 9; i++) out_cov[i] = map->h_gn_out[3 + i];
+    return LSLAM_OK;
+  }
+  // ---- ordered sums: the reference's sequential fp32 accumulation, bit for bit -----------------------------------------
+  // dataContainers[index-1].setFrom(dataContainer, ...) (MapRepMultiMap.h:161): the container is cached for the
+  // next updateByScan -- also when it is empty
+  if (n > 0)
+    LSLAM_HIP(ctx, hipMemcpyAsync(map->d_cached.p, pts, (size_t)2 * n * sizeof(float),
+                                  pts_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
   const size_t lds = (size_t)std::max(n, 1) * 9 * sizeof(float);
   if (lds > 64 * 1024)
     LSLAM_HIP(ctx, hipFuncSetAttribute((const void*)k_gn_match, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1345,6 +1540,15 @@ int lslam_map_match_data(lslam_map* map, const float* pts, int n, const float or
 int lslam_map_match_container(lslam_map* map, const float begin_world[3], float out_pose[3], float out_cov[9]) {
   if (!map || !begin_world || !out_pose) return LSLAM_ERR_INVALID_ARGUMENT;
   return match_data_impl(map, map->d_scan.p, map->n_scan, true, map->scan_origo, begin_world, out_pose, out_cov);
+}
+
+int lslam_map_set_option(lslam_map* map, int option, int value) {
+  if (!map) return LSLAM_ERR_INVALID_ARGUMENT;
+  if (option == LSLAM_MAP_OPT_ORDERED_SUMS) {
+    map->ordered_sums = value != 0;
+    return LSLAM_OK;
+  }
+  return map->ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "unknown map option %d", option);
 }
 
 int lslam_map_cached_points(const lslam_map* map) { return map ? map->n_cached : LSLAM_ERR_INVALID_ARGUMENT; }

@@ -461,6 +461,12 @@ int lslam_map_update_just_once(lslam_map* map, const float* points_xy, int n,
  * (the last Hessian, ScanMatcher.h:82-86).  n = 0 returns begin_world unchanged (ScanMatcher.h:96). */
 int lslam_map_match_data(lslam_map* map, const float* points_xy, int n, const float origo_xy[2],
                          const float begin_world[3], float out_pose[3], float out_cov[9]);
+/* matchData adds its nine Hessian / gradient sums over the points in PARALLEL (tree sums in fp32, float32 exp / sin / cos):
+ * within 1e-5 of the reference's poses on the test sequences, tolerance 1e-4 m / 1e-4 rad.  LSLAM_MAP_OPT_ORDERED_SUMS = 1
+ * selects the kernel that adds them in point order like the reference's sequential loop (H/matcher/ScanMatcher.h:94-126)
+ * and evaluates the libm calls in double like its host code: bit-equal to the CPU restatement, ~4x slower. */
+enum { LSLAM_MAP_OPT_ORDERED_SUMS = 1 };
+int lslam_map_set_option(lslam_map* map, int option, int value);
 /* LaserScan -> DataContainer ON THE DEVICE: HectorMappingRos::scanCallback's pre-processing (hector_slam.cc:186-205):
  * laser_geometry's projectLaser(scan, cloud, 30.0) and rosPointCloudToDataContainer (hector_slam.cc:320-362).  The
  * container stays resident in HBM; lslam_map_match_container / lslam_map_update_by_container are matchData /
