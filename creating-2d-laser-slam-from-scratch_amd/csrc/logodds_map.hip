@@ -1176,8 +1176,6 @@ int stage_points(lslam_map* map, const float* pts, int n) {
   if (floats > map->stage_cap) {  // (re)build the ring; drains whatever is in flight first
     LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (map->h_stage) (void)hipHostFree(map->h_stage);
-  if (map->h_gn_pts) (void)hipHostFree(map->h_gn_pts);
-  if (map->h_gn_out) (void)hipHostFree(map->h_gn_out);
     map->h_stage = nullptr;
     map->stage_cap = 0;
     const size_t cap = floats + floats / 4 + 64;
