@@ -250,16 +250,40 @@ k_logodds_apply(LevelGeom g, const float* __restrict__ pts, int n, const uint32_
 // stand-alone kernel.  Per cell the float operations and their order are exactly those of the sequential reference:
 // apply(t-1) completes in the launch before apply(t) starts (stream order).  The mark blocks also copy their points
 // aside (the caller's buffer may be reused before the deferred apply runs).
+// As ONE launch for EVERY pyramid level (round 4; a kernel per level until then): a 3-level MapRepMultiMap update was three pipe launches (and,
+// when a reader follows every scan -- matchData in lesson4's loop -- three more stand-alone applies), each a ~8 us
+// dependent step of a latency-bound chain.  A job = the apply of a level's pending scan or the mark of its new one; the
+// blocks of all jobs share the grid, a block finds its job by its index (a uniform select chain over the kernel
+// arguments: no dynamic indexing, no table in memory to keep alive behind an asynchronous call).  Within a level the
+// invariants of k_logodds_pipe hold unchanged; levels are independent planes.
+struct PipeJob {
+  LevelGeom g;
+  const float* pts;
+  int n, first_block, apply;
+  const uint32_t* free_r;
+  const uint32_t* occ_r;
+  uint32_t* free_w;
+  uint32_t* occ_w;
+  float* logodds;
+  float* pts_copy;
+};
+constexpr int kPipeMaxJobs = 12;
+struct PipeJobs {
+  int n_jobs;
+  PipeJob j[kPipeMaxJobs];
+};
 __global__ void __launch_bounds__(256)
-k_logodds_pipe(LevelGeom g_prev, const float* __restrict__ pts_prev, int n_prev, const uint32_t* __restrict__ free_prev,
-               const uint32_t* __restrict__ occ_prev, float* __restrict__ logodds, int apply_blocks, LevelGeom g,
-               const float* __restrict__ pts, int n, uint32_t* __restrict__ free_key, uint32_t* __restrict__ occ_key,
-               float* __restrict__ pts_copy) {
-  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-  if ((int)blockIdx.x < apply_blocks)
-    logodds_apply_wave(g_prev, pts_prev, n_prev, blockIdx.x * wpb + (threadIdx.x >> 6), lane, free_prev, occ_prev, logodds);
+k_logodds_pipe_ml(PipeJobs J) {
+  const int b = (int)blockIdx.x;
+  PipeJob cur = J.j[0];
+#pragma unroll
+  for (int k = 1; k < kPipeMaxJobs; k++)
+    if (k < J.n_jobs && b >= J.j[k].first_block) cur = J.j[k];
+  const int lane = threadIdx.x & 63, wave = (b - cur.first_block) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+  if (cur.apply)
+    logodds_apply_wave(cur.g, cur.pts, cur.n, wave, lane, cur.free_r, cur.occ_r, cur.logodds);
   else
-    logodds_mark_wave(g, pts, n, ((int)blockIdx.x - apply_blocks) * wpb + (threadIdx.x >> 6), lane, free_key, occ_key, pts_copy);
+    logodds_mark_wave(cur.g, cur.pts, cur.n, wave, lane, cur.free_w, cur.occ_w, cur.pts_copy);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -723,9 +747,12 @@ __device__ __forceinline__ float gn_wave_sum(float v) {
   return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
          (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
 }
-__device__ __forceinline__ float gn_prob_f(float lo) {  // getGridProbability (GridMapLogOdds.h:123-127), float32 exp
-  const float odds = expf(lo);
-  return odds / (odds + 1.0f);
+// getGridProbability (GridMapLogOdds.h:123-127) on the hardware's exp2 / reciprocal units (v_exp_f32, v_rcp_f32: ~1e-7
+// relative, far inside the 1e-4 the matcher's result is held to).  Log-odds stay below ~52 (the occupied clamp,
+// GridMapLogOdds.h:110), so odds + 1 neither overflows nor leaves __fdividef's range; -inf gives 0.
+__device__ __forceinline__ float gn_prob_f(float lo) {
+  const float odds = __expf(lo);
+  return __fdividef(odds, odds + 1.0f);
 }
 
 template <int NT>
@@ -792,14 +819,17 @@ k_gn_match_fast(GnLevels lv, const float* __restrict__ pts, float* __restrict__ 
         if (lane == 0) s_part[flip][wv][q] = t;
       }
       __syncthreads();
+      // lane q < 9 of every wave adds the NW partials of sum q (NW LDS reads instead of 9 NW per lane), readlane hands
+      // the nine totals to all lanes
+      float mine = 0.0f;
+      if (lane < 9) {
+        mine = s_part[flip][0][lane];
+#pragma unroll
+        for (int w = 1; w < NW; w++) mine += s_part[flip][w][lane];
+      }
       float sum[9];
 #pragma unroll
-      for (int q = 0; q < 9; q++) {
-        float t = s_part[flip][0][q];
-#pragma unroll
-        for (int w = 1; w < NW; w++) t += s_part[flip][w][q];
-        sum[q] = t;
-      }
+      for (int q = 0; q < 9; q++) sum[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), q));
       flip ^= 1;  // the next iteration writes the other buffer: no second barrier needed
       const float d0 = sum[0], d1 = sum[1], d2 = sum[2], h00 = sum[3], h11 = sum[4], h22 = sum[5], h01 = sum[6],
                   h02 = sum[7], h12 = sum[8];
@@ -922,16 +952,39 @@ int clear_marks(lslam_map* map, Level& L) {
   return LSLAM_OK;
 }
 
-// the deferred apply of the pipelined path, as a launch of its own: every reader of the float planes calls this first
+// apply job of level L's pending scan
+PipeJob apply_job(Level& L, int first_block) {
+  const int set = (int)(L.pend_g.epoch & 1u);
+  PipeJob j{};
+  j.g = L.pend_g;
+  j.pts = L.pipe_pts[set].p;
+  j.n = L.pend_n;
+  j.first_block = first_block;
+  j.apply = 1;
+  j.free_r = set ? L.d_free2 : L.d_free;
+  j.occ_r = set ? L.d_occ2 : L.d_occ;
+  j.logodds = L.d_logodds;
+  return j;
+}
+
+// the deferred apply of the pipelined path, as a launch of its own: every reader of the float planes calls this first.
+// ONE launch for all levels with a pending scan (k_logodds_pipe_ml); a pyramid deeper than the job table: per level.
 int flush_pending(lslam_map* map) {
   lslam_context* ctx = map->ctx;
+  PipeJobs J{};
+  int blocks = 0;
   for (auto& L : map->levels) {
     if (!L.pending) continue;
-    const int set = (int)(L.pend_g.epoch & 1u);
-    launch(ctx, "logodds_apply", k_logodds_apply, dim3((L.pend_n + 3) / 4), dim3(256), 0, L.pend_g, (const float*)L.pipe_pts[set].p,
-           L.pend_n, (const uint32_t*)(set ? L.d_free2 : L.d_free), (const uint32_t*)(set ? L.d_occ2 : L.d_occ), L.d_logodds);
+    if (J.n_jobs == kPipeMaxJobs) {
+      launch(ctx, "logodds_apply", k_logodds_pipe_ml, dim3(blocks), dim3(256), 0, J);
+      J = PipeJobs{};
+      blocks = 0;
+    }
+    J.j[J.n_jobs++] = apply_job(L, blocks);
+    blocks += (L.pend_n + 3) / 4;
     L.pending = false;
   }
+  if (blocks > 0) launch(ctx, "logodds_apply", k_logodds_pipe_ml, dim3(blocks), dim3(256), 0, J);
   LSLAM_HIP(ctx, hipGetLastError());
   return LSLAM_OK;
 }
@@ -951,6 +1004,41 @@ int update_impl(lslam_map* map, const float* d_pts, int n, const float* origo, c
   const float* const d_pts0 = d_pts;
   const int n0 = n;
   const float origo0[2] = {origo[0], origo[1]};
+  // ---- phase 1 (pipelined path): everything that can FAIL -- the second key-plane set, the point buffers of the set this
+  // scan will use, the mark reset when an epoch wraps -- for every level, before any epoch is bumped: an error return
+  // leaves every level's (epoch, pending) pair as it was
+  if (pipelined) {
+    for (int li = 0; li < n_levels; li++) {
+      Level& L = map->levels[li];
+      if (L.epoch >= kMaxEpoch) {
+        int rc = flush_pending(map);  // the pending scan's keys are about to be cleared
+        if (rc == LSLAM_OK) rc = clear_marks(map, L);
+        if (rc) return rc;
+      }
+      const size_t cells = (size_t)L.sx * L.sy;
+      if (!L.d_free2) {  // second key-plane set, on first use of the pipelined path
+        if (hipMalloc((void**)&L.d_free2, cells * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc((void**)&L.d_occ2, cells * sizeof(uint32_t)) != hipSuccess) {
+          (void)hipGetLastError();
+          if (L.d_free2) (void)hipFree(L.d_free2);
+          L.d_free2 = L.d_occ2 = nullptr;
+          return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the second key planes of map level %d", li);
+        }
+        LSLAM_HIP(ctx, hipMemsetAsync(L.d_free2, 0, cells * sizeof(uint32_t), ctx->stream));
+        LSLAM_HIP(ctx, hipMemsetAsync(L.d_occ2, 0, cells * sizeof(uint32_t), ctx->stream));
+      }
+      const int n_li = li == 0 ? n0 : map->n_cached;
+      const int set = (int)((L.epoch + 1u) & 1u);
+      LSLAM_HIP(ctx, L.pipe_pts[set].reserve((size_t)2 * std::max(n_li, 1)));  // nothing in flight reads THIS set's points
+    }
+  }
+  PipeJobs J{};
+  int blocks = 0;
+  auto submit = [&]() {
+    if (blocks > 0) launch(ctx, "logodds_pipe", k_logodds_pipe_ml, dim3(blocks), dim3(256), 0, J);
+    J = PipeJobs{};
+    blocks = 0;
+  };
   for (int li = 0; li < n_levels; li++) {
     Level& L = map->levels[li];
     // level 0 takes the container it is handed, level i > 0 takes dataContainers[i-1] = what the last matchData
@@ -958,9 +1046,8 @@ int update_impl(lslam_map* map, const float* d_pts, int n, const float* origo, c
     d_pts = li == 0 ? d_pts0 : map->d_cached.p;
     n = li == 0 ? n0 : map->n_cached;
     origo = li == 0 ? origo0 : map->cached_origo;
-    if (L.epoch >= kMaxEpoch) {
-      int rc = flush_pending(map);  // the pending scan's keys are about to be cleared
-      if (rc == LSLAM_OK) rc = clear_marks(map, L);
+    if (!pipelined && L.epoch >= kMaxEpoch) {
+      int rc = clear_marks(map, L);  // (nothing is pending on this path)
       if (rc) return rc;
     }
     L.epoch++;
@@ -994,28 +1081,25 @@ int update_impl(lslam_map* map, const float* d_pts, int n, const float* origo, c
     g.bx = (int)(bxf + 0.5f);                   // :135
     g.by = (int)(byf + 0.5f);
     if (pipelined) {
-      const size_t cells = (size_t)L.sx * L.sy;
-      if (!L.d_free2) {  // second key-plane set, on first use of the pipelined path
-        if (hipMalloc((void**)&L.d_free2, cells * sizeof(uint32_t)) != hipSuccess ||
-            hipMalloc((void**)&L.d_occ2, cells * sizeof(uint32_t)) != hipSuccess) {
-          (void)hipGetLastError();
-          if (L.d_free2) (void)hipFree(L.d_free2);
-          L.d_free2 = L.d_occ2 = nullptr;
-          return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the second key planes of map level %d", li);
-        }
-        LSLAM_HIP(ctx, hipMemsetAsync(L.d_free2, 0, cells * sizeof(uint32_t), ctx->stream));
-        LSLAM_HIP(ctx, hipMemsetAsync(L.d_occ2, 0, cells * sizeof(uint32_t), ctx->stream));
-      }
+      // [apply of this level's pending scan | mark of this one], the jobs of ALL levels in one launch
       const int set = (int)(L.epoch & 1u);
-      LSLAM_HIP(ctx, L.pipe_pts[set].reserve((size_t)2 * std::max(n, 1)));  // nothing in flight reads THIS set's points
-      const int apply_blocks = L.pending ? (L.pend_n + 3) / 4 : 0;
-      const int mark_blocks = (n + 3) / 4;
-      if (apply_blocks + mark_blocks > 0) {
-        const int pset = L.pending ? (int)(L.pend_g.epoch & 1u) : 0;
-        launch(ctx, "logodds_pipe", k_logodds_pipe, dim3(apply_blocks + mark_blocks), dim3(256), 0, L.pending ? L.pend_g : g,
-               (const float*)L.pipe_pts[pset].p, L.pending ? L.pend_n : 0, (const uint32_t*)(pset ? L.d_free2 : L.d_free),
-               (const uint32_t*)(pset ? L.d_occ2 : L.d_occ), L.d_logodds, apply_blocks, g, d_pts, n, set ? L.d_free2 : L.d_free,
-               set ? L.d_occ2 : L.d_occ, L.pipe_pts[set].p);
+      if (J.n_jobs + 2 > kPipeMaxJobs) submit();
+      if (L.pending) {
+        J.j[J.n_jobs++] = apply_job(L, blocks);
+        blocks += (L.pend_n + 3) / 4;
+      }
+      if (n > 0) {
+        PipeJob j{};
+        j.g = g;
+        j.pts = d_pts;
+        j.n = n;
+        j.first_block = blocks;
+        j.apply = 0;
+        j.free_w = set ? L.d_free2 : L.d_free;
+        j.occ_w = set ? L.d_occ2 : L.d_occ;
+        j.pts_copy = L.pipe_pts[set].p;
+        J.j[J.n_jobs++] = j;
+        blocks += (n + 3) / 4;
       }
       L.pending = n > 0;
       L.pend_g = g;
@@ -1027,6 +1111,7 @@ int update_impl(lslam_map* map, const float* d_pts, int n, const float* origo, c
              (const uint32_t*)L.d_occ, L.d_logodds);
     }
   }
+  if (pipelined) submit();
   LSLAM_HIP(ctx, hipGetLastError());
   return LSLAM_OK;
 }

@@ -212,7 +212,9 @@ def test_gauss_newton_match_data(ctx, oracle_lib, ordered):
             d = float(np.abs(pose_c - pose_g).max())
             worst = max(worst, d)
             assert d <= 1e-4, (k, pose_c, pose_g)
-            assert np.abs(H_c - H_g).max() <= 1e-3 * max(1.0, float(np.abs(H_c).max()))
+            # the last Hessian (what matchData returns as covMatrix) is summed over gradients that jump at cell borders: a
+            # 1e-5 pose difference moves it by a few 1e-3 relative
+            assert np.abs(H_c - H_g).max() <= (1e-3 if ordered else 1e-2) * max(1.0, float(np.abs(H_c).max()))
             assert np.hypot(*(pose_g[:2] - t[:2])) < 0.03  # it converges to the truth from an 10 cm / 1.7 deg hint
         for i, c in enumerate(cpus):  # keep both maps identical: update both with the ORACLE pose
             f = np.float32(oracle_lib.PortHector.level_factor(i))

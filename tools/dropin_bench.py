@@ -28,7 +28,7 @@ import lslam  # noqa: E402,F401
 
 
 def _slim(d):
-    return {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items() if k != "poses"}
+    return {k: (float("%.4g" % v) if isinstance(v, float) else v) for k, v in d.items() if k != "poses"}
 
 
 def main():
