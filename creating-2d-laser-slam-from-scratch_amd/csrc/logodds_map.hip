@@ -755,6 +755,7 @@ __device__ __forceinline__ float gn_prob_f(float lo) {
   return __fdividef(odds, odds + 1.0f);
 }
 
+__device__ __forceinline__ void gn_solve_step_fwd(const float* sum, float* H, float& e0, float& e1, float& e2);
 template <int NT>
 __global__ void __launch_bounds__(NT)
 k_gn_match_fast(GnLevels lv, const float* __restrict__ pts, float* __restrict__ cache_dst, int n, int pts_in_lds, float bx,
@@ -831,21 +832,153 @@ k_gn_match_fast(GnLevels lv, const float* __restrict__ pts, float* __restrict__ 
 #pragma unroll
       for (int q = 0; q < 9; q++) sum[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), q));
       flip ^= 1;  // the next iteration writes the other buffer: no second barrier needed
-      const float d0 = sum[0], d1 = sum[1], d2 = sum[2], h00 = sum[3], h11 = sum[4], h22 = sum[5], h01 = sum[6],
-                  h02 = sum[7], h12 = sum[8];
-      H[0] = h00; H[1] = h01; H[2] = h02; H[3] = h01; H[4] = h11; H[5] = h12; H[6] = h02; H[7] = h12; H[8] = h22;
-      if (h00 != 0.0f && h11 != 0.0f) {  // estimateTransformationLogLh (ScanMatcher.h:113-133)
-        const float c0 = gn_cof3(H, 0, 0), c1 = gn_cof3(H, 1, 0), c2 = gn_cof3(H, 2, 0);
-        const float det = c0 * H[0] + (c1 * H[3] + c2 * H[6]);
-        const float invdet = 1.0f / det;
-        const float Hi[9] = {c0 * invdet, c1 * invdet, c2 * invdet,
-                             gn_cof3(H, 0, 1) * invdet, gn_cof3(H, 1, 1) * invdet, gn_cof3(H, 2, 1) * invdet,
-                             gn_cof3(H, 0, 2) * invdet, gn_cof3(H, 1, 2) * invdet, gn_cof3(H, 2, 2) * invdet};
-        float sd[3];
-        for (int r = 0; r < 3; r++) sd[r] = Hi[3 * r] * d0 + (Hi[3 * r + 1] * d1 + Hi[3 * r + 2] * d2);
-        if (sd[2] > 0.2f) sd[2] = 0.2f; else if (sd[2] < -0.2f) sd[2] = -0.2f;
-        e0 += sd[0]; e1 += sd[1]; e2 += sd[2];
+      gn_solve_step_fwd(sum, H, e0, e1, e2);
+    }
+    {
+      // util::normalize_angle (UtilFunctions.h:36-48), double arithmetic with M_PI
+      const double two_pi = 2.0f * 3.14159265358979323846;
+      float a = (float)fmod(fmod((double)e2, two_pi) + two_pi, two_pi);
+      if ((double)a > 3.14159265358979323846) a = (float)((double)a - two_pi);
+      // getWorldCoordsPose: worldTmap = mapTworld.inverse() (GridMapBase.h:229-233, 285)
+      const float invdet = 1.0f / (sc * sc - 0.0f * 0.0f);
+      const float l00 = sc * invdet, l01 = -0.0f * invdet, l10 = -0.0f * invdet, l11 = sc * invdet;
+      const float wt0 = -(l00 * lv.t_x[L] + l01 * lv.t_y[L]), wt1 = -(l10 * lv.t_x[L] + l11 * lv.t_y[L]);
+      tmp0 = (l00 * e0 + l01 * e1) + wt0;
+      tmp1 = (l10 * e0 + l11 * e1) + wt1;
+      tmp2 = a;
+    }
+  }
+  if (tid == 0) {
+    out[0] = tmp0; out[1] = tmp1; out[2] = tmp2;
+    for (int q = 0; q < 9; q++) out[3 + q] = H[q];
+  }
+}
+
+// The solve + pose update every thread performs after the sums (estimateTransformationLogLh, ScanMatcher.h:113-133)
+__device__ __forceinline__ void gn_solve_step(const float* sum, float* H, float& e0, float& e1, float& e2);
+__device__ __forceinline__ void gn_solve_step_fwd(const float* sum, float* H, float& e0, float& e1, float& e2) { gn_solve_step(sum, H, e0, e1, e2); }
+__device__ __forceinline__ void gn_solve_step(const float* sum, float* H, float& e0, float& e1, float& e2) {
+  const float d0 = sum[0], d1 = sum[1], d2 = sum[2], h00 = sum[3], h11 = sum[4], h22 = sum[5], h01 = sum[6], h02 = sum[7],
+              h12 = sum[8];
+  H[0] = h00; H[1] = h01; H[2] = h02; H[3] = h01; H[4] = h11; H[5] = h12; H[6] = h02; H[7] = h12; H[8] = h22;
+  if (h00 != 0.0f && h11 != 0.0f) {
+    const float c0 = gn_cof3(H, 0, 0), c1 = gn_cof3(H, 1, 0), c2 = gn_cof3(H, 2, 0);
+    const float det = c0 * H[0] + (c1 * H[3] + c2 * H[6]);
+    const float invdet = 1.0f / det;
+    const float Hi[9] = {c0 * invdet, c1 * invdet, c2 * invdet,
+                         gn_cof3(H, 0, 1) * invdet, gn_cof3(H, 1, 1) * invdet, gn_cof3(H, 2, 1) * invdet,
+                         gn_cof3(H, 0, 2) * invdet, gn_cof3(H, 1, 2) * invdet, gn_cof3(H, 2, 2) * invdet};
+    float sd[3];
+    for (int r = 0; r < 3; r++) sd[r] = Hi[3 * r] * d0 + (Hi[3 * r + 1] * d1 + Hi[3 * r + 2] * d2);
+    if (sd[2] > 0.2f) sd[2] = 0.2f; else if (sd[2] < -0.2f) sd[2] = -0.2f;
+    e0 += sd[0]; e1 += sd[1]; e2 += sd[2];
+  }
+}
+
+// k_gn_match_reg<NT, PMAX> -- k_gn_match_fast for scans of at most NT * PMAX points (every real LaserScan: 1081 beams =
+// 512 x 3), the form that runs.  The generic kernel above walks its points one after the other, and each costs a
+// dependent LDS read, then a dependent round trip to L2 for the four map cells: ~3.4 us per Gauss-Newton iteration of
+// mostly waiting.  Here a thread's <= PMAX points live in REGISTERS for the whole match (no LDS, no barrier in front of
+// the first iteration), and an iteration is straight-line code: all cell addresses first -- an out-of-map point reads
+// cell 0 and is masked afterwards, so no load sits behind a branch --, then the 4 * PMAX loads back to back, then the
+// arithmetic.  One L2 round trip per iteration instead of PMAX.
+template <int NT, int PMAX>
+__global__ void __launch_bounds__(NT)
+k_gn_match_reg(GnLevels lv, const float* __restrict__ pts, float* __restrict__ cache_dst, int n, float bx, float by, float bth,
+               float* __restrict__ out /* pose[3] + H[9] */) {
+  constexpr int NW = NT / 64;
+  __shared__ float s_part[2][NW][12];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float px0[PMAX], py0[PMAX];
+  bool have[PMAX];
+#pragma unroll
+  for (int p = 0; p < PMAX; p++) {
+    const int i = tid + p * NT;
+    have[p] = i < n;
+    float2 v = make_float2(0.0f, 0.0f);
+    if (have[p]) {
+      v = reinterpret_cast<const float2*>(pts)[i];
+      if (cache_dst) reinterpret_cast<float2*>(cache_dst)[i] = v;
+    }
+    px0[p] = v.x;
+    py0[p] = v.y;
+  }
+  float tmp0 = bx, tmp1 = by, tmp2 = bth;
+  float H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int flip = 0;
+  for (int L = lv.n_levels - 1; L >= 0; --L) {
+    if (n == 0) continue;
+    const float* __restrict__ lo = lv.logodds[L];
+    const int sx = lv.sx[L], sy = lv.sy[L];
+    const float sc = lv.scale[L];
+    const float factor = L == 0 ? 1.0f : 1.0f / (float)(1 << L);
+    const int iters = 1 + (L == 0 ? 5 : 3);
+    float e0 = (sc * tmp0 + 0.0f * tmp1) + lv.t_x[L];  // getMapCoordsPose (GridMapBase.h:238-242)
+    float e1 = (0.0f * tmp0 + sc * tmp1) + lv.t_y[L];
+    float e2 = tmp2;
+    const float lim_x = (float)sx - 2.0f, lim_y = (float)sy - 2.0f;  // MapDimensionProperties.h:66-70
+    float px[PMAX], py[PMAX];
+#pragma unroll
+    for (int p = 0; p < PMAX; p++) {
+      px[p] = px0[p] * factor;
+      py[p] = py0[p] * factor;
+    }
+    for (int it = 0; it < iters; it++) {
+      float s, c;
+      sincosf(e2, &s, &c);
+      int idx[PMAX];
+      float fx[PMAX], fy[PMAX];
+      bool inb[PMAX];
+#pragma unroll
+      for (int p = 0; p < PMAX; p++) {
+        const float cx = (c * px[p] + (-s) * py[p]) + e0;
+        const float cy = (s * px[p] + c * py[p]) + e1;
+        inb[p] = have[p] && !(cx < 0.0f || cx > lim_x || cy < 0.0f || cy > lim_y);  // pointOutOfMapBounds (:60-63)
+        const int ix = inb[p] ? (int)cx : 0, iy = inb[p] ? (int)cy : 0;
+        fx[p] = cx - (float)ix;
+        fy[p] = cy - (float)iy;
+        idx[p] = iy * sx + ix;
       }
+      float l0[PMAX], l1[PMAX], l2[PMAX], l3[PMAX];
+#pragma unroll
+      for (int p = 0; p < PMAX; p++) {
+        l0[p] = lo[idx[p]];
+        l1[p] = lo[idx[p] + 1];
+        l2[p] = lo[idx[p] + sx];
+        l3[p] = lo[idx[p] + sx + 1];
+      }
+      float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int p = 0; p < PMAX; p++) {
+        const float i0 = gn_prob_f(l0[p]), i1 = gn_prob_f(l1[p]), i2 = gn_prob_f(l2[p]), i3 = gn_prob_f(l3[p]);
+        const float dx1 = i0 - i1, dx2 = i2 - i3, dy1 = i0 - i2, dy2 = i1 - i3;
+        const float xi = 1.0f - fx[p], yi = 1.0f - fy[p];
+        const float v = inb[p] ? ((i0 * xi + i1 * fx[p]) * (yi)) + ((i2 * xi + i3 * fx[p]) * (fy[p])) : 0.0f;
+        const float gxv = inb[p] ? -((dx1 * yi) + (dx2 * fy[p])) : 0.0f;
+        const float gyv = inb[p] ? -((dy1 * xi) + (dy2 * fx[p])) : 0.0f;
+        const float funVal = have[p] ? 1.0f - v : 0.0f;
+        const float rotDeriv = ((-s * px[p] - c * py[p]) * gxv + (c * px[p] - s * py[p]) * gyv);
+        acc[0] += gxv * funVal; acc[1] += gyv * funVal; acc[2] += rotDeriv * funVal;
+        acc[3] += gxv * gxv; acc[4] += gyv * gyv; acc[5] += rotDeriv * rotDeriv;
+        acc[6] += gxv * gyv; acc[7] += gxv * rotDeriv; acc[8] += gyv * rotDeriv;
+      }
+#pragma unroll
+      for (int q = 0; q < 9; q++) {
+        const float t = gn_wave_sum(acc[q]);
+        if (lane == 0) s_part[flip][wv][q] = t;
+      }
+      __syncthreads();
+      float mine = 0.0f;
+      if (lane < 9) {
+        mine = s_part[flip][0][lane];
+#pragma unroll
+        for (int w = 1; w < NW; w++) mine += s_part[flip][w][lane];
+      }
+      float sum[9];
+#pragma unroll
+      for (int q = 0; q < 9; q++) sum[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), q));
+      flip ^= 1;  // the next iteration writes the other buffer: one barrier per iteration
+      gn_solve_step(sum, H, e0, e1, e2);
     }
     {
       // util::normalize_angle (UtilFunctions.h:36-48), double arithmetic with M_PI
@@ -1583,9 +1716,17 @@ int match_data_impl(lslam_map* map, const float* pts, int n, bool pts_on_device,
 #define LSLAM_GN_FAST(NT)                                                                                                  \
   launch(ctx, "gn_match", k_gn_match_fast<NT>, dim3(1), dim3(NT), lds, lv, src, cache_dst, n, in_lds, begin_world[0],      \
          begin_world[1], begin_world[2], map->h_gn_out)
-    if (map->gn_threads >= 1024) LSLAM_GN_FAST(1024);
+#define LSLAM_GN_REG(NT, PMAX)                                                                                             \
+  launch(ctx, "gn_match", k_gn_match_reg<NT, PMAX>, dim3(1), dim3(NT), 0, lv, src, cache_dst, n, begin_world[0],           \
+         begin_world[1], begin_world[2], map->h_gn_out)
+    // the points of the scan in registers when they fit (3 per thread at 512 threads: a 1081-beam scan), else LDS / memory
+    if (map->gn_threads >= 1024 && n <= 1024 * 2) LSLAM_GN_REG(1024, 2);
+    else if (map->gn_threads >= 512 && map->gn_threads < 1024 && n <= 512 * 3) LSLAM_GN_REG(512, 3);
+    else if (map->gn_threads < 512 && n <= 256 * 5) LSLAM_GN_REG(256, 5);
+    else if (map->gn_threads >= 1024) LSLAM_GN_FAST(1024);
     else if (map->gn_threads >= 512) LSLAM_GN_FAST(512);
     else LSLAM_GN_FAST(256);
+#undef LSLAM_GN_REG
 #undef LSLAM_GN_FAST
     LSLAM_HIP(ctx, hipGetLastError());
     LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -223,7 +223,7 @@ def test_gauss_newton_match_data(ctx, oracle_lib, ordered):
     for i, c in enumerate(cpus):
         assert c.logodds().tobytes() == gpu.logodds(i).tobytes()
     print("ordered" if ordered else "parallel", "sums: max |pose_gpu - pose_oracle| =", worst)
-    assert worst <= (5e-6 if ordered else 2e-5)  # observed: ~2e-6 / ~5e-6 (what the 1e-4 tolerance is spent on)
+    assert worst <= (5e-6 if ordered else 5e-5)  # observed: ~2e-6 / ~2e-5 (what the 1e-4 tolerance is spent on)
     # empty scan: beginEstimateWorld comes back unchanged
     p, _ = gpu.matchData(np.array([1.0, 2.0, 0.3], np.float32), np.zeros((0, 2), np.float32))
     assert np.array_equal(p, np.array([1.0, 2.0, 0.3], np.float32))
@@ -371,8 +371,8 @@ def test_pipelined_and_two_kernel_paths_agree(ctx, oracle_lib, monkeypatch):
     ctx.profile(False)
     prof = ctx.profile_read()
     assert {"logodds_pipe", "logodds_mark", "logodds_apply"} <= set(prof), prof
-    # pipelined: 2 updates x 3 levels = 6 pipe launches + 3 flushed applies; two-kernel: 6 marks + 6 applies
-    assert prof["logodds_pipe"][0] == 6 and prof["logodds_mark"][0] == 6 and prof["logodds_apply"][0] == 9, prof
+    # pipelined (round 4: ONE launch for all 3 levels): 2 pipe launches + 1 flushed apply; two-kernel: 6 marks + 6 applies
+    assert prof["logodds_pipe"][0] == 2 and prof["logodds_mark"][0] == 6 and prof["logodds_apply"][0] == 7, prof
     for lv in range(LV):
         ref = cpu.logodds(lv)
         assert np.count_nonzero(ref) > 1000
