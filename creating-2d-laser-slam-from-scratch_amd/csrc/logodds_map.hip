@@ -752,7 +752,46 @@ __device__ __forceinline__ float gn_wave_sum(float v) {
 // GridMapLogOdds.h:110), so odds + 1 neither overflows nor leaves __fdividef's range; -inf gives 0.
 __device__ __forceinline__ float gn_prob_f(float lo) {
   const float odds = __expf(lo);
-  return __fdividef(odds, odds + 1.0f);
+  return odds * __builtin_amdgcn_rcpf(odds + 1.0f);  // (__fdividef compiles to the full IEEE division sequence here)
+}
+// Nine wave sums at once: the four row steps of all nine values interleaved (no DPP read-after-write stalls), then the two
+// cross-row broadcasts of GFX9's wave64 DPP; the totals are valid in LANE 63 only.
+__device__ __forceinline__ void gn_wave_sums9(float* v) {
+#define LSLAM_DPP_STEP(CTRL)                                                                                            \
+  _Pragma("unroll") for (int q = 0; q < 9; q++)                                                                         \
+      v[q] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[q]), CTRL, 0xF, 0xF, true));
+  LSLAM_DPP_STEP(0xB1)   // quad_perm [1,0,3,2]
+  LSLAM_DPP_STEP(0x4E)   // quad_perm [2,3,0,1]
+  LSLAM_DPP_STEP(0x141)  // row_half_mirror
+  LSLAM_DPP_STEP(0x140)  // row_mirror: every lane of a 16-lane row holds the row's sum
+#undef LSLAM_DPP_STEP
+#pragma unroll
+  for (int q = 0; q < 9; q++)  // row_bcast:15 into rows 1 and 3: row 1 = rows 0+1, row 3 = rows 2+3
+    v[q] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[q]), 0x142, 0xA, 0xF, false));
+#pragma unroll
+  for (int q = 0; q < 9; q++)  // row_bcast:31 into rows 2 and 3: row 3 = all four rows
+    v[q] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[q]), 0x143, 0xC, 0xF, false));
+}
+// sin / cos of the pose heading: |x| stays within a few radians (a normalised start estimate plus steps clamped to 0.2),
+// so the quadrant reduction is two fused steps of x - k * pi/2 with pi/2 split in two floats (exact to ~1e-8 for |k| <= 8)
+// and the rest the classic degree-7 / degree-8 kernels on [-pi/4, pi/4] (~1 ulp).  ocml's sincosf carries the
+// large-argument path along: four times the instructions, every thread, every iteration.
+__device__ __forceinline__ void gn_sincos(float x, float* sn, float* cs) {
+  const float k = rintf(x * 0.636619772367581343f);
+  const int q = (int)k;
+  float r = fmaf(-k, 1.57079601287841796875f, x);   // pi/2 hi (24 bits)
+  r = fmaf(-k, 3.1391647326017846e-7f, r);            // pi/2 lo
+  const float r2 = r * r;
+  float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = fmaf(ps, r2, -1.6666654611e-1f);
+  ps = fmaf(ps * r2, r, r);                           // sin r
+  float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = fmaf(pc, r2, 4.166664568298827e-2f);
+  pc = fmaf(pc, r2, -0.5f);
+  pc = fmaf(pc, r2, 1.0f);                            // cos r
+  const float s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
+  *sn = (q & 2) ? -s0 : s0;
+  *cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
 __device__ __forceinline__ void gn_solve_step_fwd(const float* sum, float* H, float& e0, float& e1, float& e2);
@@ -925,7 +964,7 @@ k_gn_match_reg(GnLevels lv, const float* __restrict__ pts, float* __restrict__ c
     }
     for (int it = 0; it < iters; it++) {
       float s, c;
-      sincosf(e2, &s, &c);
+      gn_sincos(e2, &s, &c);
       int idx[PMAX];
       float fx[PMAX], fy[PMAX];
       bool inb[PMAX];
@@ -962,10 +1001,10 @@ k_gn_match_reg(GnLevels lv, const float* __restrict__ pts, float* __restrict__ c
         acc[3] += gxv * gxv; acc[4] += gyv * gyv; acc[5] += rotDeriv * rotDeriv;
         acc[6] += gxv * gyv; acc[7] += gxv * rotDeriv; acc[8] += gyv * rotDeriv;
       }
+      gn_wave_sums9(acc);
+      if (lane == 63) {
 #pragma unroll
-      for (int q = 0; q < 9; q++) {
-        const float t = gn_wave_sum(acc[q]);
-        if (lane == 0) s_part[flip][wv][q] = t;
+        for (int q = 0; q < 9; q++) s_part[flip][wv][q] = acc[q];
       }
       __syncthreads();
       float mine = 0.0f;
