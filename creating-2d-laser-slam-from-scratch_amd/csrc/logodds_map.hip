@@ -1087,6 +1087,10 @@ struct lslam_map {
   float* h_gn_pts = nullptr;
   size_t h_gn_cap = 0;        // floats
   float* h_gn_out = nullptr;  // 12 floats
+  // h_gn_pts[0 .. 2 * gn_host_n) is a host copy of what d_cached holds (the last matchData's container, fed from the
+  // host): updateByScan with the SAME points -- HectorSlamProcessor::update always updates with the container it has just
+  // matched (HectorSlamProcessor.h:91-105) -- finds them already resident and skips its own staging copy
+  int gn_host_n = -1;
   // resident container of lslam_map_set_scan (device-side LaserScan -> DataContainer)
   DevBuf<float> d_scan;         // projected points, then one int: their count
   DevBuf<float> d_scan_ranges;
@@ -1461,6 +1465,8 @@ int lslam_map_update_by_scan(lslam_map* map, const float* pts, int n, const floa
   if (!map || n < 0 || (n > 0 && !pts) || !origo || !pose) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_context* ctx = map->ctx;
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  if (n > 0 && n == map->gn_host_n && map->levels.size() >= 1 && memcmp(pts, map->h_gn_pts, (size_t)2 * n * sizeof(float)) == 0)
+    return update_impl(map, map->d_cached.p, n, origo, pose, 0, 0.f, 0.f, 0.0);  // the container just matched: already in HBM
   int rc = stage_points(map, pts, n);
   if (rc) return rc;
   return update_impl(map, map->d_pts.p, n, origo, pose, 0, 0.f, 0.f, 0.0);
@@ -1592,6 +1598,7 @@ int lslam_map_update_batch_dev(lslam_map* map, int n_scans, const float* points_
   if (n_scans > 0 && map->levels.size() > 1) {  // dataContainers now hold the last scan (as after its matchData)
     const int last = n_scans - 1;
     const int n = n_points[last];
+    map->gn_host_n = -1;
     LSLAM_HIP(ctx, map->d_cached.reserve((size_t)2 * (n > 0 ? n : 1)));
     if (n > 0)
       LSLAM_HIP(ctx, hipMemcpyAsync(map->d_cached.p, points_xy_dev + 2 * (done_pts - (size_t)n), (size_t)2 * n * sizeof(float),
@@ -1715,6 +1722,7 @@ int match_data_impl(lslam_map* map, const float* pts, int n, bool pts_on_device,
   LSLAM_HIP(ctx, map->d_cached.reserve((size_t)2 * (n > 0 ? n : 1)));
   LSLAM_HIP(ctx, map->d_gn_out.reserve(16));
   float* d_out = map->d_gn_out.p;
+  map->gn_host_n = -1;  // d_cached is about to be rewritten; the fast host-fed path below re-validates its host copy
   if (map->levels.size() > 1) {
     map->n_cached = n;
     map->cached_origo[0] = origo ? origo[0] : 0.f;
@@ -1748,6 +1756,7 @@ int match_data_impl(lslam_map* map, const float* pts, int n, bool pts_on_device,
       }
       memcpy(map->h_gn_pts, pts, (size_t)2 * n * sizeof(float));
       src = map->h_gn_pts;
+      map->gn_host_n = n;
     }
     const int in_lds = (size_t)2 * n * sizeof(float) <= 56 * 1024;
     const size_t lds = in_lds ? (size_t)2 * std::max(n, 1) * sizeof(float) : 0;
