@@ -74,6 +74,8 @@ def main(path, scans, cfg2_path=None):
                 }
         if c.get("TA_TA_BUSY_sum") and c.get("GRBM_GUI_ACTIVE"):
             rec["gather_unit_busy"] = round(c["TA_TA_BUSY_sum"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 256), 3)  # 256 TAs, cycles per XCD
+        if c.get("TCP_TCC_READ_REQ_sum"):
+            rec["l2_read_requests_per_launch"] = int(c["TCP_TCC_READ_REQ_sum"])  # L1 -> L2 read requests, 128 B lines
         if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum") is not None and (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) > 0:
             rec["l2_hit"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3)
         rec = {k: v for k, v in rec.items() if v is not None}
@@ -86,7 +88,8 @@ def main(path, scans, cfg2_path=None):
 
     csrc = pathlib.Path(__file__).resolve().parent.parent / "creating-2d-laser-slam-from-scratch_amd" / "csrc"
     out["_meta"] = {"source_sha256": {f: hashlib.sha256((csrc / f).read_bytes()).hexdigest()[:16]
-                                      for f in ("scan_matcher.hip", "logodds_map.hip")},
+                                      for f in ("scan_matcher.hip", "logodds_map.hip", "common.hpp", "karto_math.hpp",
+                                                "scan_cache_impl.hpp", "frontend_impl.hpp")},
                     "note": "hash of the kernel sources at the time of the PMC passes (tools/pmc_passes.sh)"}
     json.dump(out, sys.stdout, indent=1)
     print()
