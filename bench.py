@@ -437,8 +437,11 @@ def dropin_hector(n_scans=300, update_every_scan=False):
         return {"error": "oracle/_ref_gpu not built"}
     laser = synth.Laser()
     n, cell, levels = 1024, 0.05, 3
-    world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=3)
-    path = synth.trajectory(world, n_scans, step=0.05, seed=3, bounds=6.0)
+    world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=5)
+    # a gentle arc (4 cm / 0.23 deg per scan) from the map origin: the processor feeds its own estimate back as the next
+    # start (hector_slam.cc:200-204), which the reference's matcher can only follow on a path without sharp turns
+    k = np.arange(n_scans)
+    path = np.stack([0.04 * k, 0.015 * k, 0.004 * k], axis=1)
     rng = np.random.default_rng(1)
     pts_all = [synth.hector_points(synth.cast_scan(world, t, laser, 0.01, 0.0, rng), laser, 1.0 / cell, use_max=20.0) for t in path]
 
@@ -466,14 +469,9 @@ def dropin_hector(n_scans=300, update_every_scan=False):
     # what happens up to the first differing decision.
     differ = np.nonzero(g_u != c_u)[0]
     k = int(differ[0]) if len(differ) else n_scans
-    # both against the TRUE motion (the processor's frame starts at the first pose): where the two runs differ by more
-    # than the matcher's tolerance, they are two answers of a matcher that is ill-conditioned there (a sparse map, updated
-    # every 0.4 m only), each as far from the truth as the other
-    c0, s0 = np.cos(path[0, 2]), np.sin(path[0, 2])
-    d = path[:, :2] - path[0, :2]
-    truth = np.stack([c0 * d[:, 0] + s0 * d[:, 1], -s0 * d[:, 0] + c0 * d[:, 1]], axis=1)
-    err_g = float(np.hypot(*(g_p[:, :2] - truth).T).max())
-    err_c = float(np.hypot(*(c_p[:, :2] - truth).T).max())
+    # both against the TRUE motion (the path starts at the map origin, the processor's frame)
+    err_g = float(np.hypot(*(g_p[:, :2] - path[:, :2]).T).max())
+    err_c = float(np.hypot(*(c_p[:, :2] - path[:, :2]).T).max())
     return {"scans": n_scans, "gpu_scans_per_s": n_scans / g_s, "cpu_reference_scans_per_s": n_scans / c_s, "cpu_cores": 1,
             "map_updates_gpu": int(g_u.sum()), "map_updates_reference": int(c_u.sum()),
             "scans_until_first_differing_update_decision": k,
