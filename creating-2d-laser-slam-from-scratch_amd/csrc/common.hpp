@@ -70,6 +70,7 @@ struct lslam_context {
   std::string last_error;
   lslam::KernelTimer timer;
   hipDeviceProp_t prop;
+  void* d_small = nullptr;  // 256 bytes of device memory that exist as long as the context does (collective staging)
   // work that objects of this context have deferred and that must be on the stream before a synchronise means
   // "everything is done" (the log-odds map's pipelined apply): (object, flush function)
   std::vector<std::pair<void*, int (*)(void*)>> pre_sync;

@@ -26,7 +26,8 @@ int lslam_create(int device, lslam_context** out) {
   lslam_context* ctx = new lslam_context();
   ctx->device = device;
   if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+      hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc(&ctx->d_small, 256) != hipSuccess) {
     lslam::g_last_error = "lslam_create: cannot initialise HIP device";
     delete ctx;
     return LSLAM_ERR_HIP;
@@ -41,6 +42,7 @@ void lslam_destroy(lslam_context* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   ctx->timer.drain();
   (void)hipStreamDestroy(ctx->stream);
+  if (ctx->d_small) (void)hipFree(ctx->d_small);
   delete ctx;
 }
 

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "karto_math.hpp"
 #include "rccl_dyn.hpp"
 
 struct lslam_pool {
@@ -168,6 +169,28 @@ int rccl_fail(lslam_context* ctx, const char* what, ncclResult_t r) {
 // the grid of ALL ranks' scans out.  nccl_comm is the caller's ncclComm_t for ctx's device.  Everything runs on the
 // context stream: box of the local scans -> all-reduce(max) of (-minx, -miny, maxx, maxy) -> local counters on the
 // merged box -> ONE all-reduce(sum) over both counter planes, in place in HBM.
+// Arguments every rank shares -- laser, resolution, the row stride -- are checked BEFORE the first collective,
+// independently of how many scans this rank holds (an empty shard must fail like a full one: a rank that returned early
+// would leave its peers waiting in ncclAllReduce for ever).  A failure that is genuinely local to one rank (its scans'
+// box, an allocation) does not return early either: the rank stays in the protocol with an error flag in the reduced
+// vector, so EVERY rank learns of it and all leave together -- after the box exchange, or after a one-word status
+// exchange in front of the counter all-reduce.
+namespace {
+int sharded_args_ok(lslam_context* ctx, const lslam_laser* laser, int n_scans, const double* ranges, int ranges_stride,
+                    const double* sensor_poses, double resolution) {
+  if (!laser || n_scans < 0 || (n_scans > 0 && (!ranges || !sensor_poses)))
+    return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "sharded map build: laser / scans");
+  if (!(laser->angular_resolution > 0.0) || !(laser->maximum_angle >= laser->minimum_angle))
+    return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "sharded map build: laser angles");
+  if (resolution == 0.0 || (resolution > -1e-6 && resolution < 1e-6) || !(resolution == resolution))
+    return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "Resolution cannot be 0");  // Karto.h:5627-5630
+  const int n = (int)(uint32_t)lslam::kround((laser->maximum_angle - laser->minimum_angle) / laser->angular_resolution);
+  if (ranges_stride < n)  // whatever n_scans is: every rank must come to the same verdict
+    return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "ranges_stride %d < num_beams %d", ranges_stride, n);
+  return LSLAM_OK;
+}
+}  // namespace
+
 int lslam_occgrid_create_sharded(lslam_context* ctx, const lslam_laser* laser, int n_scans, const double* ranges,
                                  int ranges_stride, const double* sensor_poses, double resolution, void* nccl_comm,
                                  lslam_occgrid** out) {
@@ -175,27 +198,62 @@ int lslam_occgrid_create_sharded(lslam_context* ctx, const lslam_laser* laser, i
   *out = nullptr;
   lslam::Rccl& R = lslam::Rccl::get();
   if (!R.ok()) return ctx->fail(LSLAM_ERR_UNSUPPORTED, "%s", R.error.c_str());
+  int rc = sharded_args_ok(ctx, laser, n_scans, ranges, ranges_stride, sensor_poses, resolution);
+  if (rc) return rc;  // the same on every rank: nobody enters a collective
   ncclComm_t comm = (ncclComm_t)nccl_comm;
-  double box[4];
-  int rc = lslam_occgrid_scan_bounds(ctx, laser, n_scans, ranges, ranges_stride, sensor_poses, box);
-  if (rc) return rc;
-  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
-  double* d_box = nullptr;
-  LSLAM_HIP(ctx, hipMalloc((void**)&d_box, 4 * sizeof(double)));
-  const double neg[4] = {-box[0], -box[1], box[2], box[3]};  // negation and max are exact: the union box bit for bit
-  hipError_t e = hipMemcpyAsync(d_box, neg, sizeof neg, hipMemcpyHostToDevice, ctx->stream);
-  ncclResult_t nr = ncclSuccess;
-  if (e == hipSuccess) nr = R.AllReduce(d_box, d_box, 4, ncclDouble, ncclMax, comm, ctx->stream);
-  double merged[4] = {0, 0, 0, 0};
-  if (e == hipSuccess && nr == ncclSuccess) e = hipMemcpyAsync(merged, d_box, sizeof merged, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess && nr == ncclSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_box);
+  // ---- exchange 1: union of the boxes + "some rank failed" -----------------------------------------------------------
+  std::string local_error;
+  double box[4] = {1e300, 1e300, -1e300, -1e300};  // the identity of the union: what a rank contributes when it failed
+  int local_rc = lslam_occgrid_scan_bounds(ctx, laser, n_scans, ranges, ranges_stride, sensor_poses, box);
+  if (local_rc) {
+    local_error = ctx->last_error;
+    box[0] = box[1] = 1e300;
+    box[2] = box[3] = -1e300;
+  }
+  if (hipSetDevice(ctx->device) != hipSuccess && !local_rc) {
+    local_rc = LSLAM_ERR_HIP;
+    local_error = "hipSetDevice failed";
+  }
+  double* d_x = (double*)ctx->d_small;  // allocated with the context: joining a collective never depends on a hipMalloc here
+  // negation and max are exact: the union box bit for bit; [4] = 1 where a rank failed locally
+  const double send[5] = {-box[0], -box[1], box[2], box[3], local_rc ? 1.0 : 0.0};
+  double merged[5] = {0, 0, 0, 0, 1.0};
+  hipError_t e = hipMemcpyAsync(d_x, send, sizeof send, hipMemcpyHostToDevice, ctx->stream);
+  ncclResult_t nr = R.AllReduce(d_x, d_x, 5, ncclDouble, ncclMax, comm, ctx->stream);  // joined even after a failed copy
+  if (e == hipSuccess && nr == ncclSuccess) e = hipMemcpyAsync(merged, d_x, sizeof merged, hipMemcpyDeviceToHost, ctx->stream);
+  if (nr == ncclSuccess) {
+    const hipError_t es = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = es;
+  }
   if (nr != ncclSuccess) return rccl_fail(ctx, "ncclAllReduce(box)", nr);
+  if (local_rc) return ctx->fail(local_rc, "%s", local_error.c_str());
   if (e != hipSuccess) return ctx->fail(LSLAM_ERR_HIP, "box exchange failed: %s", hipGetErrorString(e));
+  if (merged[4] != 0.0) return ctx->fail(LSLAM_ERR_HIP, "sharded map build: another rank failed before the box exchange");
   const double ubox[4] = {-merged[0], -merged[1], merged[2], merged[3]};
+  if (!(ubox[0] <= ubox[2] && ubox[1] <= ubox[3]))  // no scans on any rank: the reference's NULL -- on every rank alike
+    return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "empty bounding box (no scans on any shard: the reference returns NULL)");
+  // ---- local counters on the merged box, then exchange 2: one status word, so that a rank whose build failed (its
+  // counter planes did not fit) does not leave the others alone in the big all-reduce ----------------------------------
   lslam_occgrid* part = nullptr;
-  rc = lslam_occgrid_create_partial(ctx, laser, n_scans, ranges, ranges_stride, sensor_poses, resolution, ubox, &part);
-  if (rc) return rc;  // an empty union box (no scans on any rank) is the reference's NULL
+  local_rc = lslam_occgrid_create_partial(ctx, laser, n_scans, ranges, ranges_stride, sensor_poses, resolution, ubox, &part);
+  if (local_rc) local_error = ctx->last_error;
+  const double st = local_rc ? 1.0 : 0.0;
+  double st_all = 1.0;
+  e = hipMemcpyAsync(d_x, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream);
+  nr = R.AllReduce(d_x, d_x, 1, ncclDouble, ncclMax, comm, ctx->stream);
+  if (e == hipSuccess && nr == ncclSuccess) e = hipMemcpyAsync(&st_all, d_x, sizeof st_all, hipMemcpyDeviceToHost, ctx->stream);
+  if (nr == ncclSuccess) {
+    const hipError_t es = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = es;
+  }
+  if (nr != ncclSuccess || local_rc || e != hipSuccess || st_all != 0.0) {
+    if (part) lslam_occgrid_destroy(part);
+    if (nr != ncclSuccess) return rccl_fail(ctx, "ncclAllReduce(status)", nr);
+    if (local_rc) return ctx->fail(local_rc, "%s", local_error.c_str());
+    if (e != hipSuccess) return ctx->fail(LSLAM_ERR_HIP, "status exchange failed: %s", hipGetErrorString(e));
+    return ctx->fail(LSLAM_ERR_HIP, "sharded map build: another rank could not build its partial grid");
+  }
+  // ---- exchange 3: ONE all-reduce(sum) over both counter planes, in place in HBM ------------------------------------------
   size_t words = 0;
   lslam_occgrid_counter_words(part, &words);
   if (words) {
@@ -224,6 +282,13 @@ int lslam_pool_occgrid_from_scans(lslam_pool* p, const lslam_laser* laser, int n
   if (!p || p->ctx.empty() || !laser || !out || n_scans < 0 || (n_scans > 0 && (!ranges || !sensor_poses)))
     return LSLAM_ERR_INVALID_ARGUMENT;
   *out = nullptr;
+  {  // what every shard shares, checked ONCE before any thread (or collective) starts
+    int rc = sharded_args_ok(p->ctx[0], laser, n_scans, ranges, ranges_stride, sensor_poses, resolution);
+    if (rc) {
+      p->last_error = lslam_last_error(p->ctx[0]);
+      return rc;
+    }
+  }
   const int W = (int)p->ctx.size();
   std::set<int> distinct;
   for (auto* c : p->ctx) distinct.insert(c->device);

@@ -188,4 +188,16 @@ def test_create_sharded_with_a_callers_communicator(ctx, oracle_lib):
     # a rank without scans in a world of one: the union box is empty -> the reference's NULL
     with pytest.raises(api.LslamError):
         api.OccupancyGrid.CreateSharded(ctx, lp, np.zeros((0, 1081)), np.zeros((0, 3)), 0.05, comm.value)
+    # arguments every rank shares are refused BEFORE the first collective, also on a rank that holds no scans (ADVICE r03:
+    # an EMPTY shard used to pass a too-short row stride and wait in ncclAllReduce for peers that had returned) -- and
+    # the communicator is still usable afterwards, i.e. nobody entered a collective
+    for bad in (dict(ranges=np.zeros((0, 100)), res=0.05), dict(ranges=np.zeros((0, 1081)), res=0.0)):
+        with pytest.raises(api.LslamError) as e:
+            api.OccupancyGrid.CreateSharded(ctx, lp, bad["ranges"], np.zeros((0, 3)), bad["res"], comm.value)
+        assert e.value.code == -1
+    with pytest.raises(api.LslamError) as e:  # a failure LOCAL to this rank (a NaN pose) goes through the exchange as a flag
+        api.OccupancyGrid.CreateSharded(ctx, lp, wl.base_ranges[:2], np.full((2, 3), np.nan), 0.05, comm.value)
+    g = api.OccupancyGrid.CreateSharded(ctx, lp, wl.base_ranges, wl.base_poses, 0.05, comm.value)
+    assert np.array_equal(g.data(), exp)
+    g.close()
     rccl.ncclCommDestroy(comm)
