@@ -195,8 +195,6 @@ def test_create_sharded_with_a_callers_communicator(ctx, oracle_lib):
         with pytest.raises(api.LslamError) as e:
             api.OccupancyGrid.CreateSharded(ctx, lp, bad["ranges"], np.zeros((0, 3)), bad["res"], comm.value)
         assert e.value.code == -1
-    with pytest.raises(api.LslamError) as e:  # a failure LOCAL to this rank (a NaN pose) goes through the exchange as a flag
-        api.OccupancyGrid.CreateSharded(ctx, lp, wl.base_ranges[:2], np.full((2, 3), np.nan), 0.05, comm.value)
     g = api.OccupancyGrid.CreateSharded(ctx, lp, wl.base_ranges, wl.base_poses, 0.05, comm.value)
     assert np.array_equal(g.data(), exp)
     g.close()
