@@ -330,6 +330,7 @@ def lib() -> C.CDLL:
     L.lslam_scan_cache_counters.argtypes = [vp, vp]
     L.lslam_matcher_match_scan_cached.argtypes = [vp, vp, i32, vp, vp, i64, vp, vp, i32, vp]
     L.lslam_matcher_read_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.lslam_matcher_read_beam_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     _LIB = L
     return L
 
@@ -497,8 +498,10 @@ class ScanMatcher:
     def read_stats(self) -> dict:
         out = (C.c_uint64 * 4)()
         self.ctx.check(self.L.lslam_matcher_read_stats(self.h, out))
+        b = (C.c_uint64 * 2)()
+        self.ctx.check(self.L.lslam_matcher_read_beam_stats(self.h, b))
         return {"rows_in_range": int(out[0]), "rows_live": int(out[1]), "beam_angles": int(out[2]),
-                "beam_angles_queued": int(out[3])}
+                "beam_angles_queued": int(out[3]), "beams_readable": int(b[0]), "beams_live_in_some_angle": int(b[1])}
 
     @property
     def grid_dev_ptr(self) -> int:

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/lslam_gpu.h"
@@ -106,6 +107,33 @@ struct DevBuf {
   T* p = nullptr;
   size_t cap = 0;  // elements
   std::vector<void*> outgrown;
+  DevBuf() = default;
+  // owning: a copy would free the same allocations twice (move only)
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap), outgrown(std::move(o.outgrown)) {
+    o.p = nullptr;
+    o.cap = 0;
+    o.outgrown.clear();
+  }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) {
+      release();
+      p = o.p;
+      cap = o.cap;
+      outgrown = std::move(o.outgrown);
+      o.p = nullptr;
+      o.cap = 0;
+      o.outgrown.clear();
+    }
+    return *this;
+  }
+  // Outgrown allocations may only go once nothing on the stream can still read them: callers that have just synchronised
+  // their stream (every host-synchronous entry point does, once per call) hand them back here.
+  void trim() {
+    for (void* q : outgrown) (void)hipFree(q);
+    outgrown.clear();
+  }
   hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
     T* fresh = nullptr;

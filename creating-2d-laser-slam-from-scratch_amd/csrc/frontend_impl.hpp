@@ -471,7 +471,7 @@ int lslam_frontend_create_ex(lslam_matcher* m, const lslam_frontend_config* cfg,
         (void)hipGetLastError();
         rc = ctx->fail(LSLAM_ERR_HIP, "cannot allocate a loop-matcher slot");
       }
-      f->loop_pool.push_back(sl);  // pushed even when incomplete: lslam_frontend_destroy releases what exists
+      f->loop_pool.push_back(std::move(sl));  // pushed even when incomplete: lslam_frontend_destroy releases what exists
       if (rc) {
         lslam_frontend_destroy(f);
         return rc;

@@ -1322,14 +1322,14 @@ int lslam_map_create(lslam_context* ctx, int size_x, int size_y, float cell_leng
     if (hipMalloc((void**)&L.d_logodds, n * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&L.d_free, n * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&L.d_occ, n * sizeof(uint32_t)) != hipSuccess) {
-      map->levels.push_back(L);
+      map->levels.push_back(std::move(L));
       lslam_map_destroy(map);
       return ctx->fail(LSLAM_ERR_HIP, "cannot allocate map level %d (%dx%d) in HBM", i, sx, sy);
     }
     (void)hipMemsetAsync(L.d_logodds, 0, n * sizeof(float), ctx->stream);
     (void)hipMemsetAsync(L.d_free, 0, n * sizeof(uint32_t), ctx->stream);
     (void)hipMemsetAsync(L.d_occ, 0, n * sizeof(uint32_t), ctx->stream);
-    map->levels.push_back(L);
+    map->levels.push_back(std::move(L));
     sx /= 2;     // resolution /= 2 (H/slam_main/MapRepMultiMap.h:83)
     sy /= 2;
     cl *= 2.0f;  // :84
@@ -1859,7 +1859,7 @@ int lslam_map_read_occupancy_i8(lslam_map* map, int level, int8_t* out) {
 
 void* lslam_map_cells_dev_ptr(lslam_map* map, int level) {
   if (!map || level < 0 || level >= (int)map->levels.size()) return nullptr;
-  (void)lslam_map_flush(map);
+  if (lslam_map_flush(map) != LSLAM_OK) return nullptr;  // a plane that lacks the last scan's apply is not handed out (lslam_last_error says why)
   return map->levels[level].d_logodds;
 }
 

@@ -580,6 +580,10 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       if constexpr (STATS) {
         st_live += (uint32_t)__popc(mask);
         st_queued += mask ? 1u : 0u;
+        // per (scan, beam), OR-ed over the scan's angles: bit 0 = readable, bit 1 = some angle has a live row for it
+        // (the flag words sit behind the eight counters; stats[4] = scans the buffer was sized for)
+        if (stats && b < g.n_beams && (unsigned long long)s < stats[4] && !isnan(p.x) && !isnan(p.y))
+          atomicOr((uint32_t*)(stats + 8) + (size_t)s * g.n_beams + b, mask ? 3u : 1u);
       }
       const unsigned long long votes = __ballot(mask != 0);
       if (mask) {
@@ -2562,6 +2566,7 @@ struct lslam_matcher {
   std::atomic<bool> busy{false};
   bool use_row_occupancy = true;    // lslam_matcher_set_option(LSLAM_OPT_ROW_OCCUPANCY)
   bool collect_stats = false;       // lslam_matcher_set_option(LSLAM_OPT_COLLECT_STATS): instrumented coarse kernel
+  int stats_scans = 0;              // scans the per-(scan, beam) flag words behind the counters are sized for
   DevBuf<unsigned long long> d_stats;
   uint32_t* d_occ_t = nullptr;      // transposed row-occupancy bitmap (k_row_occupancy)
   uint2* d_occ_x = nullptr;         // the same bits as x-major 64-bit word pairs (k_occ_pairs): what k_resp_rows reads
@@ -2812,6 +2817,19 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc, m->ptile_rows, class_bytes, \
       (unsigned long long*)(m->collect_stats ? m->d_stats.p : nullptr)
       const uint8_t* pt = m->d_ptiles;
+      if (m->collect_stats && variant == 2 && step == 2 && m->stats_scans < S) {
+        // (re)size the per-(scan, beam) flag words behind the counters; the counters collected so far are carried over
+        unsigned long long keep[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        LSLAM_HIP(ctx, hipMemcpyAsync(keep, m->d_stats.p, sizeof keep, hipMemcpyDeviceToHost, ctx->stream));
+        LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const size_t words64 = 8 + ((size_t)S * g.n_beams + 1) / 2;
+        LSLAM_HIP(ctx, m->d_stats.reserve(words64));
+        LSLAM_HIP(ctx, hipMemsetAsync(m->d_stats.p, 0, words64 * sizeof(unsigned long long), ctx->stream));
+        keep[4] = (unsigned long long)S;
+        LSLAM_HIP(ctx, hipMemcpyAsync(m->d_stats.p, keep, sizeof keep, hipMemcpyHostToDevice, ctx->stream));
+        LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        m->stats_scans = S;
+      }
       if (m->collect_stats && variant == 2 && step == 2) {  // instrumented twin (untimed diagnostics only)
         if (ptiled)
           launch(ctx, name, k_resp_rows<3, 11, true, true>, LSLAM_ROWS_ARGS(pt, pt));
@@ -3304,6 +3322,7 @@ int lslam_matcher_set_option(lslam_matcher* m, int option, int value) {
         LSLAM_HIP(ctx, hipSetDevice(ctx->device));
         LSLAM_HIP(ctx, m->d_stats.reserve(8));
         LSLAM_HIP(ctx, hipMemsetAsync(m->d_stats.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        m->stats_scans = 0;
       }
       m->collect_stats = value != 0;
       return LSLAM_OK;
@@ -3321,6 +3340,23 @@ int lslam_matcher_read_stats(lslam_matcher* m, uint64_t out[4]) {
   LSLAM_HIP(ctx, hipMemcpyAsync(host, m->d_stats.p, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < 4; i++) out[i] = host[i];
+  return LSLAM_OK;
+}
+
+int lslam_matcher_read_beam_stats(lslam_matcher* m, uint64_t out[2]) {
+  if (!m || !out) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = m->ctx;
+  out[0] = out[1] = 0;
+  if (!m->d_stats.p || m->stats_scans <= 0) return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "no instrumented coarse pass has run");
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<uint32_t> flags((size_t)m->stats_scans * m->g.n_beams);
+  LSLAM_HIP(ctx, hipMemcpyAsync(flags.data(), (const uint32_t*)(m->d_stats.p + 8), flags.size() * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                ctx->stream));
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t f : flags) {
+    out[0] += f & 1u;
+    out[1] += (f >> 1) & 1u;
+  }
   return LSLAM_OK;
 }
 

@@ -155,6 +155,9 @@ void* lslam_matcher_grid_dev_ptr(lslam_matcher* m);
 enum { LSLAM_OPT_ROW_OCCUPANCY = 1, LSLAM_OPT_COLLECT_STATS = 2 };
 int lslam_matcher_set_option(lslam_matcher* m, int option, int value);
 int lslam_matcher_read_stats(lslam_matcher* m, uint64_t out[4]);
+/* after an instrumented pass: out[0] = readable (scan, beam) pairs of that batch, out[1] = those with a live lattice row in
+ * AT LEAST ONE of the scan's coarse angles (a beam outside out[1] contributes nothing to any candidate of its scan) */
+int lslam_matcher_read_beam_stats(lslam_matcher* m, uint64_t out[2]);
 
 /* LocalizedRangeScan::GetSensorAt / SetSensorPose (Karto.h:5280-5313), host-side, double */
 void lslam_sensor_pose_from_robot(const lslam_laser* laser, const double robot[3], double sensor[3]);
