@@ -22,10 +22,10 @@ from lslam_amd import api, synth  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 
 
-def cfg2_map_update(ctx, n_poses):
-    """lesson4 Hector-style log-odds update: 1081-beam scans into a 1000x1000 @ 0.05 m grid."""
+def cfg2_map_update(ctx, n_poses, n=1000, cell=0.05):
+    """lesson4 Hector-style log-odds update: 1081-beam scans into a 1000x1000 @ 0.05 m grid (BASELINE configs[1]); with
+    n = 4000, cell = 0.025 the same scans into config 5's map, whose planes (64 MB each) no longer fit the L2."""
     laser = synth.Laser()
-    n, cell = 1000, 0.05
     off = (n * cell * 0.5, n * cell * 0.5)
     world = synth.arena(size=44.0, n_axis=12, n_rot=4, seed=3)
     rng = np.random.default_rng(3)
@@ -100,7 +100,8 @@ def cfg2_map_update(ctx, n_poses):
     b_same = bmap.logodds().tobytes() == cmap.logodds().tobytes()
     ctx.free(d_all)
     bk_ms = sum(v[1] for v in bprof.values())
-    return {"config": "cfg2 log-odds update, 1081-beam scans into 1000x1000@0.05m", "scans": n_poses,
+    return {"config": "cfg2 log-odds update, 1081-beam scans into %dx%d@%gm" % (n, n, cell), "scans": n_poses,
+            "algorithmic_bytes_per_scan": round(alg_bytes / n_poses),
             "gpu_scans_per_s": round(n_poses / gpu_s, 1), "gpu_cell_updates_per_s": round(visits / gpu_s),
             "kernel_ms_total": round(k_ms, 3), "kernel_algorithmic_GBs": round(alg_bytes / (k_ms * 1e-3) / 1e9, 2),
             "batched": {"scans_per_call": 64, "gpu_scans_per_s": round(n_poses / b_s, 1),
@@ -317,12 +318,14 @@ def main():
     ap.add_argument("--loop", type=int, default=64)
     ap.add_argument("--hector", type=int, default=300)
     ap.add_argument("--occgrid", type=int, default=500)
+    ap.add_argument("--map-size", type=int, default=1000, help="cfg2: map side in cells")
+    ap.add_argument("--map-cell", type=float, default=0.05, help="cfg2: cell length [m]")
     ap.add_argument("--only", default="", help="comma list of: cfg2,cfg3,cfg5,loop,hector,occgrid")
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
     po.build("restate")
     ctx = api.Context(0)
-    jobs = [("cfg2", lambda: cfg2_map_update(ctx, args.map_scans)), ("cfg3", lambda: cfg3_single_scan(ctx, args.single)),
+    jobs = [("cfg2", lambda: cfg2_map_update(ctx, args.map_scans, args.map_size, args.map_cell)), ("cfg3", lambda: cfg3_single_scan(ctx, args.single)),
             ("cfg5", lambda: cfg5_streaming(ctx, args.stream, args.stream_ref)), ("loop", lambda: loop_closure(ctx, args.loop)),
             ("hector", lambda: hector_front_end(ctx, args.hector)), ("occgrid", lambda: occgrid_from_scans(ctx, args.occgrid))]
     for name, fn in jobs:

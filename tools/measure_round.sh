@@ -1,11 +1,12 @@
 #!/bin/bash
 # One gpurun call's worth of end-of-round evidence (run on the GPU box from the repo root):
-#   bash tools/measure_round.sh r03h
-# -> gpurun_out/<tag>/: bench.json (+ .err), kernel_stats_bench_default.csv (rocprofv3 --kernel-trace --stats of the same
-#    command), pmc_per_launch.json / pmc_cfg2_per_launch.json (separate --pmc passes, tools/pmc_passes.sh, summarised on the
-#    box: the raw counter CSVs are too big to travel), traffic.json (tools/make_traffic.py), extra_configs.jsonl
-#    (tools/bench_extra.py: cfg 2 / 3 / 5 at full size, loop-closure matcher, lesson4 loop, CreateFromScans), batch_sweep.txt,
-#    chain_profile.json
+#   bash tools/measure_round.sh r04z
+# -> gpurun_out/<tag>/: bench.json (+ .err) = the driver's command; kernel_stats_bench_default.csv (rocprofv3 --kernel-trace
+#    --stats of the same step); pmc_per_launch.json / pmc_cfg2_per_launch.json / pmc_cfg2_4000_per_launch.json (separate --pmc
+#    passes, tools/pmc_passes.sh, summarised on the box: the raw counter CSVs are too big to travel); traffic.json
+#    (tools/make_traffic.py); extra_configs.jsonl (tools/bench_extra.py: cfg 2 / 3 / 5 at full size, loop-closure matcher,
+#    lesson4 loop, CreateFromScans; cfg 2 on the 4000x4000@0.025 map); dropin.jsonl (tools/dropin_bench.py); batch_sweep.txt;
+#    chain_profile.json; bench_batch512.json + kernel_stats_bench_batch512.csv (the small-batch step, plain and pipelined)
 TAG=${1:-rXX}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
@@ -17,9 +18,16 @@ cd $R
 python tools/pmc_summary.py gpurun_out/pmc_$TAG > $O/pmc_per_launch.json
 (PMC_CMD="python tools/bench_extra.py --only cfg2 --map-scans 256" PMC_OUT=pmc_cfg2_$TAG timeout 600 bash tools/pmc_passes.sh > $O/pmc_cfg2_passes.log 2>&1)
 python tools/pmc_summary.py gpurun_out/pmc_cfg2_$TAG > $O/pmc_cfg2_per_launch.json
-rm -rf gpurun_out/pmc_$TAG gpurun_out/pmc_cfg2_$TAG gpurun_out/prof_stats
+(PMC_CMD="python tools/bench_extra.py --only cfg2 --map-scans 256 --map-size 4000 --map-cell 0.025" PMC_OUT=pmc_cfg2_4000_$TAG timeout 600 bash tools/pmc_passes.sh > $O/pmc_cfg2_4000_passes.log 2>&1)
+python tools/pmc_summary.py gpurun_out/pmc_cfg2_4000_$TAG > $O/pmc_cfg2_4000_per_launch.json
+rm -rf gpurun_out/pmc_$TAG gpurun_out/pmc_cfg2_$TAG gpurun_out/pmc_cfg2_4000_$TAG gpurun_out/prof_stats
 python tools/make_traffic.py $O/pmc_per_launch.json 4096 $O/pmc_cfg2_per_launch.json > $O/traffic.json
 (timeout 600 python tools/bench_extra.py --stream-ref 0 2>/dev/null | grep "^{" > $O/extra_configs.jsonl)
+(timeout 200 python tools/bench_extra.py --only cfg2 --map-size 4000 --map-cell 0.025 2>/dev/null | grep "^{" > $O/extra_cfg2_4000.jsonl)
+(timeout 300 python tools/dropin_bench.py 2>/dev/null | grep "^{" > $O/dropin.jsonl)
 (timeout 200 python tools/batch_sweep.py > $O/batch_sweep.txt 2>&1)
 (timeout 120 python tools/chain_profile.py --scans 600 2>/dev/null | grep "^{" > $O/chain_profile.json)
+mkdir -p gpurun_out/prof512 && (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof512 -o s -- python $R/bench.py --batch 512 --no-cpu --sustained-s 0 > $O/bench_batch512.json 2> $O/bench_batch512.err)
+find gpurun_out/prof512 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_bench_batch512.csv
+rm -rf gpurun_out/prof512
 ls -la $O
