@@ -1044,6 +1044,40 @@ def main():
                     "pruning-off step time is the worst case over world sparsity",
         }
 
+    # ---- untimed-by-contract: the LDS-staged variant of the hot kernel (north star: "pyramid staged in LDS tiles"; built as
+    # an experiment, measured here, not used): phase B of the coarse pass reads its rows from per-drain patches of the
+    # linear parity planes staged in LDS instead of gathering from the L2-resident tiled planes
+    lds_experiment = None
+    if not args.no_diagnostics and n_mine >= 2048:
+        try:
+            gm.set_option("lds_staged", 1)
+            gm.set_option("collect_stats", 1)
+            step(); ctx.synchronize()
+            st_l = gm.read_stats()
+            gm.set_option("collect_stats", 0)
+            step()
+            n_l = max(2, min(100, args.steps // 5))
+            ctx.profile(True); ctx.profile_only("resp_rows_coarse"); ctx.profile_reset()
+            el_l = timed(n_l)
+            ctx.profile(False)
+            pl = ctx.profile_read().get("resp_rows_coarse", (0, 0.0))
+            ctx.profile_only(None)
+            l_np = results[:n_mine].cpu().numpy().view(api.RESULT_DTYPE).reshape(-1)
+            gm.set_option("lds_staged", 0)
+            step(); ctx.synchronize()
+            lds_experiment = {
+                "ms_per_step": round(1e3 * el_l / n_l, 4), "resp_rows_coarse_ms_per_launch": round(pl[1] / max(pl[0], 1), 4),
+                "drains_staged_in_lds": st_l["lds_drains_staged"], "drains_on_the_global_path": st_l["lds_drains_global"],
+                "results_identical": bool(np.array_equal(l_np["pose"], res_np["pose"]) and np.array_equal(l_np["response"], res_np["response"])),
+                "note": "k_resp_rows<3,11,false,false,true>: 6 KB LDS patch per parity plane per drain of 64 queued beams "
+                        "(LSLAM_OPT_LDS_STAGED); compare ms_per_step / roofline.avg_launch_ms of the shipped kernel"}
+        except Exception as e:  # pragma: no cover
+            lds_experiment = {"error": f"{type(e).__name__}: {e}"[:200]}
+            try:
+                gm.set_option("lds_staged", 0); gm.set_option("collect_stats", 0)
+            except Exception:
+                pass
+
     # ---- untimed-by-contract: whole steps pipelined over TWO matcher instances on two HIP streams (alternate steps, not
     # halves of one step), so that one step's latency-bound reduce kernels run under the other's response kernels: what
     # the small per-GPU batches of an 8-GPU strong-scaling run can recover.  Results must be byte-identical.
@@ -1260,6 +1294,7 @@ def main():
         "kernel_ms_per_step": {k: round(v[1], 4) for k, v in sorted(prof_all.items())},
         "pruning": pruning,
         "pipelined": pipelined,
+        "lds_staged_experiment": lds_experiment,
         "value_leg": "the %d timed steps of the contract (barrier + synchronize on both sides); `sustained` is reported beside it" % args.steps,
         "sustained": sustained,
         "roofline": roofline,

@@ -492,16 +492,17 @@ class ScanMatcher:
         self.ctx.check(self.L.lslam_matcher_set_grid_u8_dev(self.h, ptr, o.ctypes.data))
 
     def set_option(self, name: str, value: int):
-        opt = {"row_occupancy": 1, "collect_stats": 2}[name]
+        opt = {"row_occupancy": 1, "collect_stats": 2, "lds_staged": 3}[name]
         self.ctx.check(self.L.lslam_matcher_set_option(self.h, opt, int(value)))
 
     def read_stats(self) -> dict:
         out = (C.c_uint64 * 4)()
         self.ctx.check(self.L.lslam_matcher_read_stats(self.h, out))
-        b = (C.c_uint64 * 2)()
+        b = (C.c_uint64 * 4)()
         self.ctx.check(self.L.lslam_matcher_read_beam_stats(self.h, b))
         return {"rows_in_range": int(out[0]), "rows_live": int(out[1]), "beam_angles": int(out[2]),
-                "beam_angles_queued": int(out[3]), "beams_readable": int(b[0]), "beams_live_in_some_angle": int(b[1])}
+                "beam_angles_queued": int(out[3]), "beams_readable": int(b[0]), "beams_live_in_some_angle": int(b[1]),
+                "lds_drains_staged": int(b[2]), "lds_drains_global": int(b[3])}
 
     @property
     def grid_dev_ptr(self) -> int:

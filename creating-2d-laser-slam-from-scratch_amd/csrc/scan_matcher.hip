@@ -405,7 +405,22 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // STATS = true is the instrumented twin used for ONE untimed launch by lslam_matcher_read_stats (bench.py's
 // pruned_row_fraction): it counts, per launch, the lattice rows inside the reference's index range, the rows
 // still live after the exact row-occupancy pruning, the readable beams and the beams queued for phase B.
-template <int NXD, int NYC, bool TILED, bool STATS = false>
+// LDSB = true is the MEASURED-AND-DROPPED variant the north star's wording asks about ("grid pyramid staged in LDS
+// tiles"): phase B stages, per drain of 64 queued beams, the bounding patch of their rows from the
+// linear parity planes in LDS (one patch per parity) and reads the row words with ds_read instead of global gathers;
+// drains whose patch does not fit 6 KB per parity take the global path.  Same bytes, same sums.  DESIGN 5.0 has the numbers.
+constexpr int kPatchDw = 1536;  // dwords per parity patch
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  v = min(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true));
+  v = min(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true));
+  v = min(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true));
+  v = min(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true));
+  return min(min((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+             min((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }
+
+template <int NXD, int NYC, bool TILED, bool STATS = false, bool LDSB = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))  // <= 128 VGPRs
 k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int step, int limit, Geom g,
             PassCfg pc, const Lattice* __restrict__ lat, const double2* __restrict__ cossin,
@@ -417,6 +432,7 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
   static_assert(NYC <= 16 && 2 * (NYC - 1) < 32, "row mask / occupancy window width");
   __shared__ __align__(16) uint32_t red[NW][8];  // [packed word][group of 8 lanes]
   __shared__ int2 queue[kQueue];  // circular; .x = first row index m0, .y = row mask | parity << 31
+  __shared__ uint32_t patch[LDSB ? 2 : 1][LDSB ? kPatchDw : 1];  // LDSB: the drain's bounding patch of each parity plane
   const int lane = threadIdx.x;
   int w = blockIdx.x;
   const int slice = w % beam_slices;
@@ -474,13 +490,66 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
           __builtin_memcpy(wv[j], __builtin_assume_aligned(zbase + (size_t)off + 32 * j, 4), 4 * (NXD + 1));
         }
       } else {
-        uint32_t cur = ((uint32_t)e.x & ~3u) + (uint32_t)kRowZero + (e.y < 0 ? plane_delta : 0u);
+        bool staged = false;
+        if constexpr (LDSB) {
+          // plane coordinates of the beam's first row word: pitch g.stride (one lattice row = one pitch)
+          const uint32_t rowmask = (uint32_t)e.y & ((1u << NYC) - 1u);
+          const bool on = lane < cnt && rowmask != 0u && e.x >= 0;
+          const uint32_t cur0 = ((uint32_t)e.x & ~3u) + (uint32_t)kRowZero;
+          const uint32_t ry = cur0 / (uint32_t)g.stride, cx = cur0 - ry * (uint32_t)g.stride;
+          const bool p1 = e.y < 0;
+          const bool bad = lane < cnt && rowmask != 0u && e.x < 0;  // a beam hanging over the plane's start: global path
+          uint32_t W[2], Hh[2], cmin[2], rmin[2];
+          bool fit = !__any(bad);
 #pragma unroll
-        for (int j = 0; j < NYC; j++) {
-          // a masked row reads the zeros at offset 0 instead: straight-line loads beat exec-masked ones
-          const uint32_t off = cur & (uint32_t)__builtin_amdgcn_sbfe(e.y, j, 1);
-          __builtin_memcpy(wv[j], __builtin_assume_aligned(zbase + off, 4), 4 * (NXD + 1));
-          cur += (uint32_t)g.stride;
+          for (int q = 0; q < 2; q++) {
+            const bool mine = on && (p1 == (q == 1));
+            cmin[q] = wave_min_u32(mine ? cx : 0xFFFFFFFFu);
+            rmin[q] = wave_min_u32(mine ? ry : 0xFFFFFFFFu);
+            const uint32_t cmax = wave_max_u32(mine ? cx + 4u * (NXD + 1) : 0u), rmax = wave_max_u32(mine ? ry + NYC : 0u);
+            W[q] = cmax > cmin[q] ? (cmax - cmin[q]) >> 2 : 0u;
+            Hh[q] = rmax > rmin[q] ? rmax - rmin[q] : 0u;
+            fit = fit && W[q] * Hh[q] <= (uint32_t)kPatchDw && W[q] < 65536u && Hh[q] < 65536u;
+          }
+          if constexpr (STATS)
+            if (lane == 0 && stats) atomicAdd(&stats[fit ? 5 : 6], 1ull);
+          if (fit) {
+            staged = true;
+            const uint32_t limit_bytes = (uint32_t)limit + (uint32_t)kRowZero;  // rows past the plane's end are zeros
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+              const uint32_t total = W[q] * Hh[q];
+              if (total == 0u) continue;
+              const uint32_t inv = 0xFFFFFFFFu / W[q] + 1u;  // idx / W for idx < 2^16 by one multiply
+              for (uint32_t idx = (uint32_t)lane; idx < total; idx += 64u) {
+                const uint32_t r = __umulhi(idx, inv), c = idx - r * W[q];
+                const uint32_t off = (rmin[q] + r) * (uint32_t)g.stride + cmin[q] + 4u * c;
+                uint32_t v = 0u;
+                if (off + 4u <= limit_bytes + 64u) v = *(const uint32_t*)(zbase + (size_t)off + (q ? plane_delta : 0u));
+                patch[q][idx] = v;
+              }
+            }
+            __syncthreads();
+            const int q = p1 ? 1 : 0;
+            const uint32_t base = on ? (ry - rmin[q]) * W[q] + ((cx - cmin[q]) >> 2) : 0u;
+#pragma unroll
+            for (int j = 0; j < NYC; j++) {
+              const bool live = on && ((rowmask >> j) & 1u);
+#pragma unroll
+              for (int k = 0; k <= NXD; k++) wv[j][k] = live ? patch[q][base + (uint32_t)j * W[q] + (uint32_t)k] : 0u;
+            }
+            __syncthreads();  // the next drain restages the patches
+          }
+        }
+        if (!staged) {
+          uint32_t cur = ((uint32_t)e.x & ~3u) + (uint32_t)kRowZero + (e.y < 0 ? plane_delta : 0u);
+#pragma unroll
+          for (int j = 0; j < NYC; j++) {
+            // a masked row reads the zeros at offset 0 instead: straight-line loads beat exec-masked ones
+            const uint32_t off = cur & (uint32_t)__builtin_amdgcn_sbfe(e.y, j, 1);
+            __builtin_memcpy(wv[j], __builtin_assume_aligned(zbase + off, 4), 4 * (NXD + 1));
+            cur += (uint32_t)g.stride;
+          }
         }
       }
 #pragma unroll
@@ -2566,6 +2635,7 @@ struct lslam_matcher {
   std::atomic<bool> busy{false};
   bool use_row_occupancy = true;    // lslam_matcher_set_option(LSLAM_OPT_ROW_OCCUPANCY)
   bool collect_stats = false;       // lslam_matcher_set_option(LSLAM_OPT_COLLECT_STATS): instrumented coarse kernel
+  bool lds_staged = false;          // lslam_matcher_set_option(LSLAM_OPT_LDS_STAGED): the measured-and-dropped LDS-staged phase B
   int stats_scans = 0;              // scans the per-(scan, beam) flag words behind the counters are sized for
   DevBuf<unsigned long long> d_stats;
   uint32_t* d_occ_t = nullptr;      // transposed row-occupancy bitmap (k_row_occupancy)
@@ -2791,7 +2861,8 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       // the bitmap covers row spans of kOccWin grid bytes: step*(nX-1)+1 must fit
       const uint2* occ = (want_occ && step == 2 && step * (p.nx - 1) + 1 <= m->occ_win) ? m->d_occ_x : (const uint2*)nullptr;
       // coarse pass of a batch that fills the chip on its own: gather from the TILED parity planes
-      bool ptiled = step == 2 && slices == 1 && waves >= kTileMinWaves && !m->ptile_failed;
+      bool ptiled = step == 2 && slices == 1 && waves >= kTileMinWaves && !m->ptile_failed &&
+                    !(m->lds_staged && variant == 2);  // the LDS-staged experiment reads the LINEAR planes
       if (ptiled && !m->d_ptiles) {
         m->ptile_tx = (g.stride / 2 + 15) / 16;
         m->ptile_rows = (((g.height - 1 + kTileYOff) / 2 + 1) + 3) & ~3;  // class rows, whole 4-row lines
@@ -2830,7 +2901,12 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
         LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         m->stats_scans = S;
       }
-      if (m->collect_stats && variant == 2 && step == 2) {  // instrumented twin (untimed diagnostics only)
+      if (m->lds_staged && variant == 2 && step == 2) {  // experiment: phase B through LDS patches
+        if (m->collect_stats)
+          launch(ctx, name, k_resp_rows<3, 11, false, true, true>, LSLAM_ROWS_ARGS(s0, s1));
+        else
+          launch(ctx, name, k_resp_rows<3, 11, false, false, true>, LSLAM_ROWS_ARGS(s0, s1));
+      } else if (m->collect_stats && variant == 2 && step == 2) {  // instrumented twin (untimed diagnostics only)
         if (ptiled)
           launch(ctx, name, k_resp_rows<3, 11, true, true>, LSLAM_ROWS_ARGS(pt, pt));
         else
@@ -3317,6 +3393,9 @@ int lslam_matcher_set_option(lslam_matcher* m, int option, int value) {
     case LSLAM_OPT_ROW_OCCUPANCY:
       m->use_row_occupancy = value != 0;
       return LSLAM_OK;
+    case LSLAM_OPT_LDS_STAGED:
+      m->lds_staged = value != 0;
+      return LSLAM_OK;
     case LSLAM_OPT_COLLECT_STATS:
       if (value) {
         LSLAM_HIP(ctx, hipSetDevice(ctx->device));
@@ -3343,10 +3422,10 @@ int lslam_matcher_read_stats(lslam_matcher* m, uint64_t out[4]) {
   return LSLAM_OK;
 }
 
-int lslam_matcher_read_beam_stats(lslam_matcher* m, uint64_t out[2]) {
+int lslam_matcher_read_beam_stats(lslam_matcher* m, uint64_t out[4]) {
   if (!m || !out) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_context* ctx = m->ctx;
-  out[0] = out[1] = 0;
+  out[0] = out[1] = out[2] = out[3] = 0;
   if (!m->d_stats.p || m->stats_scans <= 0) return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "no instrumented coarse pass has run");
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
   std::vector<uint32_t> flags((size_t)m->stats_scans * m->g.n_beams);
@@ -3357,6 +3436,11 @@ int lslam_matcher_read_beam_stats(lslam_matcher* m, uint64_t out[2]) {
     out[0] += f & 1u;
     out[1] += (f >> 1) & 1u;
   }
+  unsigned long long fits[2] = {0, 0};  // LSLAM_OPT_LDS_STAGED: drains whose patches fit LDS / took the global path
+  LSLAM_HIP(ctx, hipMemcpyAsync(fits, m->d_stats.p + 5, sizeof fits, hipMemcpyDeviceToHost, ctx->stream));
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  out[2] = fits[0];
+  out[3] = fits[1];
   return LSLAM_OK;
 }
 

@@ -152,12 +152,16 @@ void* lslam_matcher_grid_dev_ptr(lslam_matcher* m);
  *    the hot kernel (slower: for an untimed diagnostic launch); lslam_matcher_read_stats then returns, summed over
  *    the passes since: [0] lattice rows inside the reference's index range (Mapper.cpp:841-845), [1] rows still live
  *    after pruning, [2] readable beam x angle pairs, [3] those with at least one live row. */
-enum { LSLAM_OPT_ROW_OCCUPANCY = 1, LSLAM_OPT_COLLECT_STATS = 2 };
+/*  LSLAM_OPT_LDS_STAGED (default 0): 1 routes the coarse pass of chip-filling batches through the LDS-staged variant of
+ *    the hot kernel (phase B reads its rows from per-drain patches of the parity planes staged in LDS): an experiment that
+ *    was measured and dropped, kept selectable so the measurement can be repeated. */
+enum { LSLAM_OPT_ROW_OCCUPANCY = 1, LSLAM_OPT_COLLECT_STATS = 2, LSLAM_OPT_LDS_STAGED = 3 };
 int lslam_matcher_set_option(lslam_matcher* m, int option, int value);
 int lslam_matcher_read_stats(lslam_matcher* m, uint64_t out[4]);
 /* after an instrumented pass: out[0] = readable (scan, beam) pairs of that batch, out[1] = those with a live lattice row in
- * AT LEAST ONE of the scan's coarse angles (a beam outside out[1] contributes nothing to any candidate of its scan) */
-int lslam_matcher_read_beam_stats(lslam_matcher* m, uint64_t out[2]);
+ * AT LEAST ONE of the scan's coarse angles (a beam outside out[1] contributes nothing to any candidate of its scan);
+ * out[2], out[3] = with LSLAM_OPT_LDS_STAGED: drains of 64 queued beams whose patches fit LDS / that took the global path */
+int lslam_matcher_read_beam_stats(lslam_matcher* m, uint64_t out[4]);
 
 /* LocalizedRangeScan::GetSensorAt / SetSensorPose (Karto.h:5280-5313), host-side, double */
 void lslam_sensor_pose_from_robot(const lslam_laser* laser, const double robot[3], double sensor[3]);
