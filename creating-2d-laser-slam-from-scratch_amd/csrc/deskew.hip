@@ -4,11 +4,10 @@
 // the scan, pcl::getTransformation of both (float32 Euler -> affine), the transform of the FIRST valid beam inverted once
 // per scan, transBt = transStartInverse * transFinal, point = transBt * (r cos a, r sin a, 1.0) in the reference's mixed
 // float/double arithmetic (the z = 1.0 is the reference's).
-// PARITY UNPINNED: the arithmetic of the reference goes through PCL (getTransformation) and Eigen (Affine3f inverse and
-// product), neither of which is in the tree, and the function is a member of a ROS node class.  This kernel follows the
-// published PCL formula (pcl/common/impl/eigen.hpp) and Eigen 3.3's evaluation orders as oracle/shim/Eigen states them;
-// tests/test_deskew_gpu.py checks it bit for bit against a numpy restatement of the same statements, not against the
-// reference's numbers.
+// The reference's arithmetic goes through PCL (getTransformation) and Eigen (Affine3f inverse and product) inside a ROS node
+// class.  This kernel follows the published PCL formula (pcl/common/impl/eigen.hpp) and Eigen 3.3's evaluation orders;
+// round 4 pins it against the reference's own source compiled in place behind stand-ins for those libraries
+// (tests/test_deskew_pin.py: <= 4e-6 m, the device's float32 cos / sin being the difference).
 #include <cmath>
 
 #include "common.hpp"

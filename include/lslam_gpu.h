@@ -512,9 +512,10 @@ int lslam_map_flush(lslam_map* map);
 
 /* ---------------------------------------------------------------------------------------- */
 /* lesson5 lidar motion de-skew (LidarUndistortion::CorrectLaserScan, lesson5/src/            */
-/* lidar_undistortion.cc:339-447) -- SURVEY 8(f) #4.  PARITY UNPINNED: the reference's        */
-/* arithmetic goes through PCL and Eigen inside a ROS node class, none of which is in the     */
-/* tree; the kernel follows the published PCL formula and Eigen 3.3's evaluation orders.      */
+/* lidar_undistortion.cc:339-447) -- SURVEY 8(f) #4.  Pinned (round 4) against the reference's */
+/* own source compiled in place behind ROS / tf / PCL / Eigen stand-ins (oracle/shim, which    */
+/* define PCL's getTransformation formula and Eigen 3.3's evaluation orders; tests/            */
+/* test_deskew_pin.py): <= 4e-6 m (float32 cos / sin of the Euler angles from the device libm).*/
 /* ---------------------------------------------------------------------------------------- */
 typedef struct lslam_deskew_params {
   float angle_min, angle_increment, range_min, range_max; /* sensor_msgs/LaserScan header */

@@ -1131,3 +1131,66 @@ def href_pose_difference_larger_than(a, b, dist, ang) -> bool:
     L = _HrefLib.lib()
     a32, b32 = _f32(a), _f32(b)  # keep the temporaries alive across the call
     return bool(L.href_pose_difference_larger_than(a32.ctypes.data, b32.ctypes.data, dist, ang))
+
+
+def have_ref_lesson5() -> bool:
+    return (HERE / "_ref" / "liblesson5_ref.so").exists()
+
+
+class RefLesson5:
+    """The reference's own lesson5 LidarUndistortion (lesson5/src/lidar_undistortion.cc compiled unmodified behind
+    oracle/lesson5_ref_driver.cpp, against the ROS / tf / PCL / Eigen stand-ins under oracle/shim): IMU and odometry
+    messages in, LaserScans in, the de-skewed point cloud of the PREVIOUS scan out -- plus the state CorrectLaserScan read
+    (the integrated gyro samples and the odometry increment of PruneImuDeque / PruneOdomDeque), which is what
+    lslam_deskew_scan takes as its inputs."""
+
+    CAP = 2000
+
+    def __init__(self, use_imu=True, use_odom=True):
+        path = HERE / "_ref" / "liblesson5_ref.so"
+        if not path.exists():
+            raise FileNotFoundError(f"{path} (build it here with `make -C oracle ref_lesson5`)")
+        L = C.CDLL(str(path))
+        L.l5_create.restype = C.c_void_p
+        L.l5_create.argtypes = [C.c_int, C.c_int]
+        L.l5_destroy.argtypes = [C.c_void_p]
+        L.l5_add_imu.argtypes = [C.c_void_p] + [C.c_double] * 4
+        L.l5_add_odom.argtypes = [C.c_void_p] + [C.c_double] * 8
+        L.l5_scan.argtypes = [C.c_void_p, C.c_double] + [C.c_float] * 5 + [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 2
+        self.L = L
+        self.h = L.l5_create(int(use_imu), int(use_odom))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.l5_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_imu(self, stamp, w):
+        self.L.l5_add_imu(self.h, float(stamp), float(w[0]), float(w[1]), float(w[2]))
+
+    def add_odom(self, stamp, xyz, quat_xyzw):
+        self.L.l5_add_odom(self.h, float(stamp), *[float(v) for v in xyz], *[float(v) for v in quat_xyzw])
+
+    def scan(self, stamp, angle_min, angle_increment, time_increment, range_min, range_max, ranges):
+        """-> None while the first scan is queued / the node waits for data, else a dict for the scan that WAS corrected."""
+        r = np.ascontiguousarray(ranges, dtype=np.float32)
+        n = len(r)
+        xyz, valid = np.zeros((n, 3), np.float32), np.zeros(n, np.uint8)
+        state, imu = np.zeros(8), np.zeros((4, self.CAP))
+        hdr, cr = np.zeros(4, np.float32), np.zeros(n, np.float32)
+        rc = self.L.l5_scan(self.h, float(stamp), float(angle_min), float(angle_increment), float(time_increment), float(range_min),
+                            float(range_max), r.ctypes.data, n, xyz.ctypes.data, valid.ctypes.data, state.ctypes.data,
+                            imu.ctypes.data, self.CAP, hdr.ctypes.data, cr.ctypes.data)
+        if rc != 1:
+            return None
+        k = int(state[7]) + 1
+        return {"xyz": xyz, "valid": valid.astype(bool), "ranges": cr, "scan_time_start": float(state[0]), "time_increment": float(state[1]),
+                "start_odom_time": float(state[2]), "end_odom_time": float(state[3]), "odom_incre": state[4:7].astype(np.float32),
+                "imu_time": imu[0, :k].copy(), "imu_rot": imu[1:4, :k].T.copy(),
+                "angle_min": float(hdr[0]), "angle_increment": float(hdr[1]), "range_min": float(hdr[2]), "range_max": float(hdr[3])}

@@ -1,0 +1,2 @@
+// TEST INFRASTRUCTURE ONLY: see lslam_ros_pcl_shim.hpp
+#include "lslam_ros_pcl_shim.hpp"
