@@ -316,10 +316,6 @@ int lslam_matcher_match_scan_cached(lslam_matcher* m, lslam_scan_cache* c, int n
     }
     const lslam_scan_cache::Slot& s = c->slots[(size_t)slot];
     if (!s.posed || !sc_same_pose(s.pose, want)) {
-      if (getenv("LSLAM_CACHE_DEBUG"))
-        fprintf(stderr, "[cache] match %lld: base[%d] id %lld slot %d posed %d cached (%.17g %.17g %.17g) want (%.17g %.17g %.17g) query_id %lld flags %d\n",
-                (long long)c->n_matches, i, (long long)base_ids[i], slot, (int)s.posed, s.pose[0], s.pose[1], s.pose[2], want[0], want[1], want[2],
-                (long long)query_id, flags);
       CacheRefresh& r = c->h_refresh[n_refresh++];
       r.slot = slot;
       r.pad = 0;
@@ -342,11 +338,6 @@ int lslam_matcher_match_scan_cached(lslam_matcher* m, lslam_scan_cache* c, int n
     if (rc) return rc;
     c->n_uploads++;
   }
-  for (int k = 0; k < n_refresh; k++) {
-    lslam_scan_cache::Slot& s = c->slots[(size_t)c->h_refresh[k].slot];
-    s.posed = true;
-    for (int j = 0; j < 3; j++) s.pose[j] = c->h_refresh[k].pose[j];
-  }
   const bool lds_ok = sc_anchor_lds(n) <= 60 * 1024;
   if (n_refresh > 0) {
     if (lds_ok) {
@@ -362,6 +353,15 @@ int lslam_matcher_match_scan_cached(lslam_matcher* m, lslam_scan_cache* c, int n
                (double2*)nullptr, c->d_world + (size_t)c->h_refresh[k].slot * n, PassCfg{}, (Lattice*)nullptr,
                (double2*)nullptr, 0, pv);
       }
+    }
+    if (hipGetLastError() != hipSuccess) {  // the refresh is not on the stream: the slots stay as they were
+      for (int k = 0; k < n_refresh; k++) c->slots[(size_t)c->h_refresh[k].slot].posed = false;
+      return ctx->fail(LSLAM_ERR_HIP, "scan cache: the refresh launch failed");
+    }
+    for (int k = 0; k < n_refresh; k++) {
+      lslam_scan_cache::Slot& s = c->slots[(size_t)c->h_refresh[k].slot];
+      s.posed = true;
+      for (int j = 0; j < 3; j++) s.pose[j] = c->h_refresh[k].pose[j];
     }
     c->n_refreshed += n_refresh;
   }

@@ -2676,6 +2676,14 @@ struct lslam_matcher {
 
 namespace {
 
+// Hand back the allocations the workspaces have outgrown.  Only from entry points that have JUST synchronised the
+// context stream: nothing in flight can still read them (DevBuf::reserve keeps them until then, see common.hpp).
+void trim_workspaces(lslam_matcher* m) {
+  m->d_stats.trim(); m->d_ranges64.trim(); m->d_poses.trim(); m->d_local.trim(); m->d_world.trim(); m->d_valid.trim();
+  m->d_fv_scratch.trim(); m->d_centres.trim(); m->d_lat.trim(); m->d_cossin.trim(); m->d_coarse.trim(); m->d_resp.trim();
+  m->d_tbl.trim(); m->d_part.trim(); m->d_big.trim(); m->d_results.trim(); m->d_dbg.trim(); m->d_query.trim(); m->d_qpose.trim();
+}
+
 struct BusyGuard {
   lslam_matcher* m;
   bool ok;
@@ -3462,6 +3470,7 @@ int lslam_matcher_set_base_scans(lslam_matcher* m, int B, const double* ranges, 
   int rc = rebuild_grid_dev(m, m->d_world.p, 0, B, B > 0 ? B : 1, center);
   if (rc) return rc;
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  trim_workspaces(m);
   return LSLAM_OK;
 }
 
@@ -3481,6 +3490,7 @@ int lslam_matcher_match_batch(lslam_matcher* m, int S, const double* ranges, int
   LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_results.p, (size_t)S * sizeof(lslam_match_result), hipMemcpyDeviceToHost,
                                 ctx->stream));
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  trim_workspaces(m);
   return LSLAM_OK;
 }
 
@@ -3550,6 +3560,7 @@ int lslam_matcher_match_scan(lslam_matcher* m, int n_base, const double* base_ra
   if (rc) return rc;
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *out = *m->h_result;
+  trim_workspaces(m);
   return LSLAM_OK;
 }
 

@@ -1,5 +1,8 @@
+"""Where the lesson4 loop (matchData + updateByScan per scan, 3-level 1024^2 pyramid) spends its time: loop / match-only
+microseconds per scan and the HIP-event time of every kernel.  LSLAM_GN_THREADS=256|512|1024, LSLAM_GN_ORDERED=1 select the
+Gauss-Newton kernel variant.  Usage (GPU box): python tools/gn_profile.py"""
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent.parent))
 import lslam
 from lslam_amd import api, synth
 ctx = api.Context(0)

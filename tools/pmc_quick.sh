@@ -1,4 +1,4 @@
-# quick FETCH/WRITE passes of a command: bash tools/_pmc_quick.sh <tag> <cmd...>
+# quick FETCH/WRITE passes of a command: bash tools/pmc_quick.sh <tag> <cmd...>
 R=$GRAFT_REPO_ROOT; TAG=$1; shift
 mkdir -p $R/gpurun_out/pq_$TAG && cd /tmp && export TMPDIR=/tmp
 (cd $R && rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum --output-format csv -d $R/gpurun_out/pq_$TAG/fetch -o p -- "$@" > /dev/null 2>&1)
