@@ -399,9 +399,20 @@ int lslam_matcher_match_scan_cached(lslam_matcher* m, lslam_scan_cache* c, int n
     x.slot_list = nullptr;
     rc = rebuild_grid_dev(m, m->d_world.p, 0, n_base, n_base > 0 ? n_base : 1, q_pose, &x);
   }
-  if (rc) return rc;
-  rc = match_batch_impl<double>(m, 1, q_row, n, c->d_qpose.p, do_penalize, do_refine, c->h_result, nullptr, 0);
-  if (rc) return rc;
+  if (rc == LSLAM_OK)
+    rc = match_batch_impl<double>(m, 1, q_row, n, c->d_qpose.p, do_penalize, do_refine, c->h_result, nullptr, 0);
+  if (rc) {
+    // the query's readings may never have reached the slot this call handed out for them: an id that names garbage must
+    // not stay behind
+    if (q_slot >= 0 && !q_cached) {
+      c->slot_of.erase(query_id);
+      c->slots[(size_t)q_slot].id = -1;
+      c->slots[(size_t)q_slot].posed = false;
+      c->free_slots.push_back(q_slot);
+      c->n_uploads--;
+    }
+    return rc;
+  }
   // The caller announced that the query scan will take the match's mean as its sensor pose (Mapper::Process does:
   // Mapper.cpp:2040-2044) and, as the newest scan of the running window, be a base scan of the very next call: refresh
   // its world points + anchors at that pose BEHIND the match.  The host waits for the record only (an event in front of

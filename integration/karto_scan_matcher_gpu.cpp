@@ -90,6 +90,7 @@ struct GpuMatcher {
   std::vector<int64_t> ids;
   long long calls = 0, cached_calls = 0;
   long long ns_total = 0, ns_device = 0;  // wall time inside MatchScan / inside the lslam call of it (host profile)
+  bool sequential = false;                // this instance is its Mapper's m_pSequentialScanMatcher (noted by MatchScan)
 };
 
 // keyed by the karto::ScanMatcher instance (a library that adopts this file would hold the handle as a member)
@@ -153,8 +154,8 @@ static ResidentScan* find_resident(Residents& R, karto::LocalizedRangeScan* s, i
   auto it = R.scans.find(s);
   if (uid < 0 || it == R.scans.end() || it->second.readings != rd) return nullptr;
   if (it->second.unique_id == uid) return &it->second;
-  if (it->second.unique_id < 0 && it->second.checksum == checksum(rd, nb)) {
-    it->second.unique_id = uid;
+  if (it->second.unique_id < 0 && it->second.checksum == checksum(rd, nb) && lslam_scan_cache_contains(R.cache, it->second.id)) {
+    it->second.unique_id = uid;  // (contains: a match that threw may have left the provisional entry without its readings)
     return &it->second;
   }
   return nullptr;
@@ -284,9 +285,9 @@ ScanMatcher::~ScanMatcher() {
     std::lock_guard<std::mutex> lock(lslam_karto::mutex());
     auto it = registry().find(this);
     if (it != registry().end()) {
-      const bool sequential = m_pMapper && this == m_pMapper->m_pSequentialScanMatcher;
+      // (the role was noted by MatchScan: the destructor does not look at m_pMapper, which a caller may already have deleted)
       if (it->second.h) {
-        if (sequential)
+        if (it->second.sequential)
           for (Residents& r : residents())
             if (same_laser(r.laser, it->second.laser)) {
               if (r.cache) lslam_scan_cache_forget(r.cache, -1);
@@ -381,6 +382,7 @@ kt_double ScanMatcher::MatchScan(LocalizedRangeScan* pScan, const LocalizedRange
     g.grid_h = info[1];
   }
 
+  g.sequential = sequential;
   const int nb = lslam_matcher_num_beams(g.h);
   const size_t stride = static_cast<size_t>(nb > 0 ? nb : 1);
   const size_t n_base = rBaseScans.size();
