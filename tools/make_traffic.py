@@ -15,6 +15,7 @@ import json
 import sys
 
 NAMES = {  # rocprofv3 kernel name prefix -> the name bench.py's HIP-event timer uses
+    "k_resp_rows<3, 11, true, false, false>": "resp_rows_coarse",
     "k_resp_rows<3, 11, true, false>": "resp_rows_coarse",
     "k_resp_rows<3, 11, true>": "resp_rows_coarse",
     "k_resp_tile3": "resp_tile_fine",
@@ -23,6 +24,15 @@ NAMES = {  # rocprofv3 kernel name prefix -> the name bench.py's HIP-event timer
     "k_scan_prep<float>": "scan_prep",
     "k_match_fused": "match_fused",
 }
+
+
+def _rel(path):
+    """the summary's path as it will be cited: inside the repository when it lies there"""
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ap = os.path.abspath(path)
+    return os.path.relpath(ap, root) if ap.startswith(root + os.sep) else path
 
 
 def hbm_bytes(c):
@@ -34,11 +44,11 @@ def logodds_entries(path):
     out = {}
     pipe = next((c for k, c in pmc.items() if k.startswith("k_logodds_pipe")), None)
     if pipe:
-        out["logodds_pipe"] = {"scans_per_launch": 1, "source": path, "hbm_bytes_per_launch": hbm_bytes(pipe),
+        out["logodds_pipe"] = {"scans_per_launch": 1, "source": _rel(path), "hbm_bytes_per_launch": hbm_bytes(pipe),
                                "valu_insts_per_launch": int(pipe.get("SQ_INSTS_VALU", 0)), "waves_per_launch": int(pipe.get("SQ_WAVES", 0))}
     batch = [c for k, c in pmc.items() if k.startswith("k_lo_batch_")]
     if batch and all(hbm_bytes(c) is not None for c in batch):
-        out["logodds_batched"] = {"scans_per_launch": 64, "source": path, "kernels": sorted(k for k in pmc if k.startswith("k_lo_batch_")),
+        out["logodds_batched"] = {"scans_per_launch": 64, "source": _rel(path), "kernels": sorted(k for k in pmc if k.startswith("k_lo_batch_")),
                                   "hbm_bytes_per_launch": sum(hbm_bytes(c) for c in batch),
                                   "note": "sum over the kernels of one 64-scan call (per-launch averages), level 0 of a 1000x1000 map"}
     return out
@@ -51,7 +61,7 @@ def main(path, scans, cfg2_path=None):
         short = next((v for k, v in NAMES.items() if kname.startswith(k)), None)
         if short is None or short in out:
             continue
-        rec = {"scans_per_launch": scans, "source": path}
+        rec = {"scans_per_launch": scans, "source": _rel(path)}
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             rec["FETCH_SIZE_KiB"], rec["WRITE_SIZE_KiB"] = c["FETCH_SIZE"], c["WRITE_SIZE"]
             rec["hbm_bytes_per_launch"] = int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
