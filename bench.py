@@ -341,8 +341,21 @@ def gpu_cfg3(ctx, api, d):
     t0 = time.perf_counter()
     out = [gm.MatchScan(wl.query_ranges[i], wl.query_poses[i], wl.base_ranges, wl.base_poses) for i in idx]
     sec = (time.perf_counter() - t0) / len(idx)
+    # the same calls with the window named by id in a device-side scan cache (seam B1, round 4): 24 bytes of pose per base
+    # scan instead of its 8.6 KB of readings; records must be identical
+    cache = api.ScanCache(ctx, api.laser_params(wl.laser))
+    for k in range(len(wl.base_ranges)):
+        cache.put(k, wl.base_ranges[k])
+    ids = np.arange(len(wl.base_ranges))
+    cache.MatchScan(gm, ids, wl.base_poses, wl.query_poses[0], query_id=-1, query_ranges=wl.query_ranges[0])
+    t0 = time.perf_counter()
+    out_c = [cache.MatchScan(gm, ids, wl.base_poses, wl.query_poses[i], query_id=-1, query_ranges=wl.query_ranges[i]) for i in idx]
+    sec_c = (time.perf_counter() - t0) / len(idx)
+    same = all(a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) for a, b in zip(out, out_c))
+    cache.close()
     gm.close()
-    return {"ms_per_match": 1e3 * sec, "poses": np.stack([o[1] for o in out]), "resp": np.array([o[0] for o in out])}
+    return {"ms_per_match": 1e3 * sec, "poses": np.stack([o[1] for o in out]), "resp": np.array([o[0] for o in out]),
+            "ms_per_match_cached": 1e3 * sec_c, "cached_identical": bool(same)}
 
 
 def gpu_cfg5(ctx, api, d):
@@ -662,7 +675,9 @@ def build_secondary(gpu, cpu, job, args):
     else:
         out["cfg3"] = {"config": "BASELINE configs[2]: single-scan MatchScan (AddScans of the 70-scan window + coarse/fine search, "
                                  "Mapper.cpp:184-291), host entry point incl. the PCIe upload of the window",
-                       "calls": len(job["cfg3"]["idx"]), "gpu_ms_per_match": round(g["ms_per_match"], 4)}
+                       "calls": len(job["cfg3"]["idx"]), "gpu_ms_per_match": round(g["ms_per_match"], 4),
+                       "gpu_ms_per_match_window_in_scan_cache": round(g["ms_per_match_cached"], 4),
+                       "scan_cache_records_identical": g["cached_identical"]}
         if c:
             out["cfg3"].update({"cpu_reference_ms_per_match": round(c["ms_per_match"], 4), "cpu_cores": 1,
                                 "max_pose_err_vs_reference": float(np.abs(g["poses"] - c["poses"]).max()),
@@ -670,6 +685,7 @@ def build_secondary(gpu, cpu, job, args):
             cpus["cfg3_ms_per_match"] = out["cfg3"]["cpu_reference_ms_per_match"]
             roof["cfg3_max_pose_err"] = out["cfg3"]["max_pose_err_vs_reference"]
         roof["cfg3_ms_per_match"] = out["cfg3"]["gpu_ms_per_match"]
+        roof["cfg3_ms_per_match_scan_cache"] = out["cfg3"]["gpu_ms_per_match_window_in_scan_cache"]
     # ---- cfg 5: streaming front-end slice ------------------------------------------------------------------------
     g, c = gpu.get("cfg5", {}), cpu.get("cfg5")
     if "error" in g:
