@@ -229,6 +229,49 @@ def test_gauss_newton_match_data(ctx, oracle_lib, ordered):
     assert np.array_equal(p, np.array([1.0, 2.0, 0.3], np.float32))
 
 
+@pytest.mark.parametrize("n_points,threads", [(900, "256"), (900, "1024"), (2000, "512"), (9000, "512")])
+def test_gauss_newton_kernel_variants_agree(ctx, monkeypatch, n_points, threads):
+    """The parallel-sum matcher has three forms -- points in registers (<= 3 per thread at 512 threads: every real scan),
+    points in LDS (longer containers), points in memory (beyond 56 KB of LDS) -- and three block sizes (LSLAM_GN_THREADS);
+    all must land within the matcher's tolerance of the ORDERED kernel (which equals the CPU restatement bit for bit,
+    test_gauss_newton_match_data[True]) on the same map and container, and the cached container must feed the update of
+    the levels above 0 identically."""
+    laser = synth.Laser()
+    n, cell, levels = 1024, 0.05, 3
+    off = (n * cell * 0.5, n * cell * 0.5)
+    world = synth.arena(size=40.0, n_axis=10, n_rot=4, seed=3)
+    rng = np.random.default_rng(7)
+    base = synth.hector_points(synth.cast_scan(world, (0.5, 0.2, 0.3), laser, 0.01, 0.0, rng), laser, 1.0 / cell, use_max=20.0)
+    reps = -(-n_points // len(base))
+    pts = np.concatenate([base + rng.normal(0.0, 0.05, base.shape).astype(np.float32) for _ in range(reps)])[:n_points].astype(np.float32)
+    monkeypatch.setenv("LSLAM_GN_THREADS", threads)
+    fast = api.OccGridMap(ctx, n, n, cell, off, levels=levels)
+    monkeypatch.delenv("LSLAM_GN_THREADS")
+    slow = api.OccGridMap(ctx, n, n, cell, off, levels=levels)
+    slow.set_option("ordered_sums", 1)
+    pose0 = np.array([0.5, 0.2, 0.3], np.float32)
+    for m in (fast, slow):
+        m.setUpdateOccupiedFactor(0.9)
+        m.matchData(pose0, base)               # caches the container for the levels above 0
+        m.updateByScan(base, (0.0, 0.0), pose0)
+    if n_points > 4266:  # the ordered kernel keeps nine terms per point in LDS: it refuses containers this long
+        with pytest.raises(api.LslamError):
+            slow.matchData(pose0, pts)
+        p_f, H_f = fast.matchData(pose0 + np.array([0.06, -0.05, 0.02], np.float32), pts)
+        assert np.abs(p_f - pose0).max() < 0.03 and np.isfinite(H_f).all()
+        return
+    hint = pose0 + np.array([0.06, -0.05, 0.02], np.float32)
+    p_f, H_f = fast.matchData(hint, pts)
+    p_s, H_s = slow.matchData(hint, pts)
+    assert np.abs(p_f - p_s).max() <= 5e-5, (p_f, p_s)
+    assert np.abs(H_f - H_s).max() <= 1e-2 * max(1.0, float(np.abs(H_s).max()))
+    assert np.abs(p_f - pose0).max() < 0.03     # and both converge back to the pose the map was built at
+    for m in (fast, slow):                      # the cached container (n_points of them) feeds levels 1 and 2
+        m.updateByScan(pts, (0.0, 0.0), pose0)
+    for lv in range(levels):
+        assert fast.logodds(lv).tobytes() == slow.logodds(lv).tobytes(), lv
+
+
 def test_batched_update_equals_sequential(ctx, oracle_lib):
     """lslam_map_update_batch: K scans marked in parallel + one apply pass == K successive updateByScan calls, bit for
     bit, on every pyramid level -- including repeats that reach the occupied clamp, an empty scan, uneven point counts,

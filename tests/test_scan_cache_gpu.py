@@ -191,3 +191,21 @@ def test_prepare_moves_the_refresh_off_the_next_match(ctx):
     assert _record(a) == _record(b) and c["refreshed"] == 7 and c["speculated"] == 2
     with pytest.raises(api.LslamError):
         cache.prepare(99, odo[0])
+
+
+def test_long_scans_take_the_fallback_paths(ctx):
+    """2400 beams per scan: the anchor chains no longer fit LDS, so the cache refreshes world points only
+    (k_scan_prep), the clear-free rebuild refuses the window and the cache gathers it into a contiguous workspace for the
+    listed path -- still byte-identical to lslam_matcher_match_scan."""
+    laser = synth.Laser(n_ranges=2400, angle_min=-np.pi * 0.75, angle_increment=1.5 * np.pi / 2400)
+    plain, cached, cache = _pair(ctx, laser=laser, range_threshold=20.0)
+    assert plain.num_beams == 2400
+    wl = synth.make_match_workload(n_base=7, n_query=1, seed=17, laser=laser)
+    odo = wl.base_poses + np.array([0.05, -0.03, 0.01])
+    for i in range(5):
+        cache.put(i, wl.base_ranges[i])
+    for q in (5, 6):
+        a = plain.MatchScan(wl.base_ranges[q], odo[q], wl.base_ranges[:5], odo[:5])
+        b = cache.MatchScan(cached, np.arange(5), odo[:5], odo[q], query_id=q, query_ranges=wl.base_ranges[q], takes_result_pose=True)
+        assert _record(a) == _record(b)
+    assert np.array_equal(plain.GetCorrelationGrid(), cached.GetCorrelationGrid())
