@@ -176,12 +176,15 @@ int fe_match_enqueue(lslam_frontend* f, lslam_matcher* m, double* d_q, lslam_mat
   }
   int rc = rebuild_grid_dev(m, f->d_world, first, count, f->cap, sensor, &x);
   if (rc) return rc;
-  // the last kernel of the match writes the 112-byte record straight into pinned host memory: no copy operation
+  // the last kernel of the match writes the 112-byte record straight into pinned host memory -- no copy operation -- and
+  // posts a ticket behind it, on which fe_match_finish spins (arm_done_ticket / wait_record)
+  arm_done_ticket(m);
   return match_batch_impl<double>(m, 1, f->d_ranges + (size_t)id * n, n, d_q, do_penalize, do_refine, h_res, nullptr, 0);
 }
 int fe_match_finish(lslam_matcher* m, const lslam_match_result* h_res, lslam_match_result* out) {
   lslam_context* ctx = m->ctx;
-  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int rcw = wait_record(m);
+  if (rcw) return rcw;
   *out = *h_res;
   if (out->status != LSLAM_OK) return ctx->fail(out->status, "scan matcher: the reference throws here");
   return LSLAM_OK;

@@ -38,7 +38,6 @@ struct lslam_scan_cache {
   double* h_query = nullptr;
   lslam_match_result* h_result = nullptr;
   DevBuf<double> d_qpose;
-  hipEvent_t ev_result = nullptr;
   int64_t n_uploads = 0, n_refreshed = 0, n_speculated = 0, n_matches = 0;
   std::atomic<bool> busy{false};
 };
@@ -87,8 +86,7 @@ int sc_staging(lslam_scan_cache* c, int n_base) {
   if (!c->h_query) {
     const size_t n = (size_t)std::max(c->g.n_beams, 1);
     if (hipHostMalloc((void**)&c->h_query, sizeof(double) * n, hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_result, sizeof(lslam_match_result), hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_result, hipEventDisableTiming) != hipSuccess) {
+        hipHostMalloc((void**)&c->h_result, sizeof(lslam_match_result), hipHostMallocDefault) != hipSuccess) {
       (void)hipGetLastError();
       return ctx->fail(LSLAM_ERR_HIP, "scan cache: cannot allocate the pinned staging");
     }
@@ -176,7 +174,6 @@ void lslam_scan_cache_destroy(lslam_scan_cache* c) {
   if (c->h_refresh) (void)hipHostFree(c->h_refresh);
   if (c->h_query) (void)hipHostFree(c->h_query);
   if (c->h_result) (void)hipHostFree(c->h_result);
-  if (c->ev_result) (void)hipEventDestroy(c->ev_result);
   c->d_qpose.release();
   delete c;
 }
@@ -399,8 +396,10 @@ int lslam_matcher_match_scan_cached(lslam_matcher* m, lslam_scan_cache* c, int n
     x.slot_list = nullptr;
     rc = rebuild_grid_dev(m, m->d_world.p, 0, n_base, n_base > 0 ? n_base : 1, q_pose, &x);
   }
-  if (rc == LSLAM_OK)
+  if (rc == LSLAM_OK) {
+    arm_done_ticket(m);  // the last kernel posts a ticket behind the record: the host spins on it, not on the stream
     rc = match_batch_impl<double>(m, 1, q_row, n, c->d_qpose.p, do_penalize, do_refine, c->h_result, nullptr, 0);
+  }
   if (rc) {
     // the query's readings may never have reached the slot this call handed out for them: an id that names garbage must
     // not stay behind
@@ -415,18 +414,15 @@ int lslam_matcher_match_scan_cached(lslam_matcher* m, lslam_scan_cache* c, int n
   }
   // The caller announced that the query scan will take the match's mean as its sensor pose (Mapper::Process does:
   // Mapper.cpp:2040-2044) and, as the newest scan of the running window, be a base scan of the very next call: refresh
-  // its world points + anchors at that pose BEHIND the match.  The host waits for the record only (an event in front of
-  // the refresh), so the refresh overlaps the caller's own bookkeeping.
+  // its world points + anchors at that pose BEHIND the match.  The host waits for the record only (the ticket the match's
+  // last kernel posts), so the refresh overlaps the caller's own bookkeeping.
   const bool speculate = (flags & LSLAM_MATCH_QUERY_TAKES_RESULT_POSE) && q_slot >= 0 && lds_ok;
-  if (speculate) {
-    LSLAM_HIP(ctx, hipEventRecord(c->ev_result, ctx->stream));
+  if (speculate)
     launch(ctx, "cache_refresh", k_anchor_chain_list, dim3(1), dim3(n > 512 ? 1024 : 256), sc_anchor_lds(n), n, c->d_world,
            c->d_anchor, (const double*)c->d_ranges, (const CacheRefresh*)nullptr, (const lslam_match_result*)c->h_result,
            CacheRefresh{q_slot, 0, {0, 0, 0}}, c->g);
-    LSLAM_HIP(ctx, hipEventSynchronize(c->ev_result));
-  } else {
-    LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
+  rc = wait_record(m);
+  if (rc) return rc;
   *out = *c->h_result;
   c->n_matches++;
   if (speculate && out->status == LSLAM_OK) {

@@ -24,6 +24,7 @@
 // the reference's expression order (built with -ffp-contract=off).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -1947,10 +1948,19 @@ __global__ void __launch_bounds__(NT)
 k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc,
               const Lattice* __restrict__ lat, int32_t* resp, size_t resp_stride,
               const double2* __restrict__ local, const CoarseOut* __restrict__ coarse,
-              lslam_match_result* __restrict__ out, int do_refine, int fb_step) {
+              lslam_match_result* __restrict__ out, int do_refine, int fb_step, int* done_flag, int done_ticket) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double sh[NT];
   __shared__ int32_t asum[kMaxAngles];
+  // done_flag (single-scan matches whose record goes to pinned host memory): after the record, a system-scope fence and the
+  // caller's ticket -- the host spins on the ticket instead of waiting for the stream (the kernel-completion signal and the
+  // runtime's wake-up cost more than the last kernel itself)
+  auto signal_done = [&]() {
+    if (done_flag) {
+      __threadfence_system();
+      *(volatile int*)done_flag = done_ticket;
+    }
+  };
   __shared__ double s_avg[3];
   __shared__ double s_best;
   __shared__ int s_status, s_pos;
@@ -1966,6 +1976,7 @@ k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc
       res.status = co.status;
       res.flags = co.flags;
       out[s] = res;
+      signal_done();
     }
     return;
   }
@@ -1977,6 +1988,7 @@ k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc
       res.status = L.status;
       res.flags = co.flags;
       out[s] = res;
+      signal_done();
     }
     return;
   }
@@ -2093,6 +2105,7 @@ k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc
     res.response = s_best > 1.0 ? 1.0 : s_best;
   }
   out[s] = res;
+  signal_done();
 }
 
 // result for a laser with zero beams (Mapper.cpp:199-209)
@@ -2668,6 +2681,11 @@ struct lslam_matcher {
   DevBuf<double> d_big;      // large lattices: reduce scratch
   DevBuf<lslam_match_result> d_results;
   DevBuf<int32_t> d_dbg;
+  // single-scan matches: the last kernel posts a ticket in pinned memory behind its record and the host spins on it
+  int* h_done = nullptr;   // pinned
+  int done_ticket = 0;
+  bool arm_next = false;   // set by arm_done_ticket, consumed by the next match_batch_impl
+  bool done_armed = false; // the match just enqueued will post done_ticket
   // lslam_matcher_match_scan: the query scan's staging (pinned host) and its resident copy, the pinned result record
   double* h_query = nullptr;
   lslam_match_result* h_result = nullptr;
@@ -2698,6 +2716,39 @@ struct BusyGuard {
     return (m)->ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "matcher used concurrently: a ScanMatcher instance is not " \
                                                       "re-entrant (one grid + one set of workspaces, Mapper.h:1273-1278)")
 
+// Ask the next single-scan match to post a ticket behind its record (see k_reduce_fine) ...
+void arm_done_ticket(lslam_matcher* m) {
+  if (!m->h_done) {
+    if (hipHostMalloc((void**)&m->h_done, sizeof(int), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      m->h_done = nullptr;
+      return;  // no ticket: wait_record falls back to the stream
+    }
+    *m->h_done = 0;
+  }
+  m->arm_next = true;
+}
+// ... and wait for it: a bounded spin on the pinned word (acquire), the stream itself when no ticket was armed or it does
+// not show up in time (a failed launch, a device fault: hipStreamSynchronize reports those).  On return the record in
+// pinned memory is complete; kernels behind the match on the stream (a speculative refresh) may still be running.
+int wait_record(lslam_matcher* m) {
+  lslam_context* ctx = m->ctx;
+  if (m->done_armed) {
+    m->done_armed = false;
+    const int want = m->done_ticket;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+      if (__atomic_load_n(m->h_done, __ATOMIC_ACQUIRE) == want) return LSLAM_OK;
+      __builtin_ia32_pause();
+      if ((spins & 1023u) == 1023u &&
+          std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= 20)
+        break;
+    }
+  }
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return LSLAM_OK;
+}
+
 int n_angles_of(double off, double res) { return lattice_count(off, res); }
 
 // coarse pass geometry (Mapper.cpp:228-240)
@@ -2727,6 +2778,16 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   size_t prezeroed = m->resp_prezeroed;
   m->prep_done = false;
   m->resp_prezeroed = 0;
+  // a caller that will wait for ONE record in pinned memory arms the done ticket (arm_done_ticket); consumed here
+  int* done_flag = nullptr;
+  int done_ticket = 0;
+  m->done_armed = false;
+  if (m->arm_next && S == 1 && S < kReduceNarrowMinScans && m->h_done) {
+    done_flag = m->h_done;
+    done_ticket = ++m->done_ticket;
+    m->done_armed = true;
+  }
+  m->arm_next = false;
   if (S <= 0) return LSLAM_OK;
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
   if (g.n_beams == 0) {
@@ -3044,11 +3105,13 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   if (S >= kReduceNarrowMinScans)
     launch(ctx, "reduce_fine", k_reduce_fine<64>, dim3(S), dim3(64), (size_t)(((size_t)pf.nx * pf.ny * pf.na + 31) / 32) * 4 + 16,
            (const uint8_t*)m->d_grid, g, pf, sc, (const Lattice*)m->d_lat.p, m->d_resp.p, resp_stride,
-           (const double2*)m->d_local.p, (const CoarseOut*)m->d_coarse.p, d_out, do_refine, do_refine ? fb_step : 0);
+           (const double2*)m->d_local.p, (const CoarseOut*)m->d_coarse.p, d_out, do_refine, do_refine ? fb_step : 0,
+           (int*)nullptr, 0);
   else
     launch(ctx, "reduce_fine", k_reduce_fine<256>, dim3(S), dim3(256), (size_t)(((size_t)pf.nx * pf.ny * pf.na + 31) / 32) * 4 + 16,
            (const uint8_t*)m->d_grid, g, pf, sc, (const Lattice*)m->d_lat.p, m->d_resp.p, resp_stride,
-           (const double2*)m->d_local.p, (const CoarseOut*)m->d_coarse.p, d_out, do_refine, do_refine ? fb_step : 0);
+           (const double2*)m->d_local.p, (const CoarseOut*)m->d_coarse.p, d_out, do_refine, do_refine ? fb_step : 0,
+           done_flag, done_ticket);
   LSLAM_HIP(ctx, hipGetLastError());
   return LSLAM_OK;
 }
@@ -3338,6 +3401,7 @@ void lslam_matcher_destroy(lslam_matcher* m) {
   m->d_valid.release(); m->d_fv_scratch.release(); m->d_centres.release(); m->d_lat.release(); m->d_cossin.release(); m->d_coarse.release(); m->d_resp.release();
   m->d_tbl.release(); m->d_part.release(); m->d_big.release(); m->d_results.release(); m->d_dbg.release();
   m->d_query.release(); m->d_qpose.release();
+  if (m->h_done) (void)hipHostFree(m->h_done);
   if (m->h_query) (void)hipHostFree(m->h_query);
   if (m->h_result) (void)hipHostFree(m->h_result);
   delete m;
@@ -3556,11 +3620,12 @@ int lslam_matcher_match_scan(lslam_matcher* m, int n_base, const double* base_ra
   x.prep_ranges = m->h_query;  // the prep blocks read the staged copy (the device row is being written in the same launch)
   int rc = rebuild_grid_dev(m, m->d_world.p, 0, n_base, n_base > 0 ? n_base : 1, q_pose, &x);
   if (rc) return rc;
+  arm_done_ticket(m);
   rc = match_batch_impl<double>(m, 1, m->d_query.p, n, m->d_qpose.p, do_penalize, do_refine, m->h_result, nullptr, 0);
   if (rc) return rc;
-  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  rc = wait_record(m);
+  if (rc) return rc;
   *out = *m->h_result;
-  trim_workspaces(m);
   return LSLAM_OK;
 }
 
