@@ -21,6 +21,7 @@
 // HBM-bound integer/byte work: coalescing comes from neighbouring beams crossing neighbouring
 // cells; nothing here is GEMM-shaped.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -804,7 +805,7 @@ __device__ __forceinline__ void gn_solve_step_fwd(const float* sum, float* H, fl
 template <int NT>
 __global__ void __launch_bounds__(NT)
 k_gn_match_fast(GnLevels lv, const float* __restrict__ pts, float* __restrict__ cache_dst, int n, int pts_in_lds, float bx,
-                float by, float bth, float* __restrict__ out /* pose[3] + H[9] */) {
+                float by, float bth, float* __restrict__ out /* pose[3] + H[9], [15] = ticket */, int ticket) {
   extern __shared__ float s_pts[];  // [2n] when pts_in_lds
   constexpr int NW = NT / 64;
   __shared__ float s_part[2][NW][12];
@@ -896,6 +897,10 @@ k_gn_match_fast(GnLevels lv, const float* __restrict__ pts, float* __restrict__ 
   if (tid == 0) {
     out[0] = tmp0; out[1] = tmp1; out[2] = tmp2;
     for (int q = 0; q < 9; q++) out[3 + q] = H[q];
+    // `out` is pinned host memory: a system-scope fence, then the caller's ticket -- the host spins on it instead of waiting
+    // for the stream (the completion signal + wake-up cost several microseconds of a 34 us match)
+    __threadfence_system();
+    ((volatile int*)out)[15] = ticket;
   }
 }
 
@@ -930,7 +935,7 @@ __device__ __forceinline__ void gn_solve_step(const float* sum, float* H, float&
 template <int NT, int PMAX>
 __global__ void __launch_bounds__(NT)
 k_gn_match_reg(GnLevels lv, const float* __restrict__ pts, float* __restrict__ cache_dst, int n, float bx, float by, float bth,
-               float* __restrict__ out /* pose[3] + H[9] */) {
+               float* __restrict__ out /* pose[3] + H[9], [15] = ticket */, int ticket) {
   constexpr int NW = NT / 64;
   __shared__ float s_part[2][NW][12];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1042,6 +1047,10 @@ k_gn_match_reg(GnLevels lv, const float* __restrict__ pts, float* __restrict__ c
   if (tid == 0) {
     out[0] = tmp0; out[1] = tmp1; out[2] = tmp2;
     for (int q = 0; q < 9; q++) out[3 + q] = H[q];
+    // `out` is pinned host memory: a system-scope fence, then the caller's ticket -- the host spins on it instead of waiting
+    // for the stream (the completion signal + wake-up cost several microseconds of a 34 us match)
+    __threadfence_system();
+    ((volatile int*)out)[15] = ticket;
   }
 }
 
@@ -1092,7 +1101,8 @@ struct lslam_map {
   int gn_threads = 512;       // LSLAM_GN_THREADS = 256 | 512 | 1024
   float* h_gn_pts = nullptr;
   size_t h_gn_cap = 0;        // floats
-  float* h_gn_out = nullptr;  // 12 floats
+  float* h_gn_out = nullptr;  // 12 floats + the ticket word [15] the kernel posts behind them
+  int gn_ticket = 0;
   // h_gn_pts[0 .. 2 * gn_host_n) is a host copy of what d_cached holds (the last matchData's container, fed from the
   // host): updateByScan with the SAME points -- HectorSlamProcessor::update always updates with the container it has just
   // matched (HectorSlamProcessor.h:91-105) -- finds them already resident and skips its own staging copy
@@ -1750,6 +1760,7 @@ int match_data_impl(lslam_map* map, const float* pts, int n, bool pts_on_device,
       (void)hipGetLastError();
       return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the pinned result of matchData");
     }
+    if (map->gn_ticket == 0) ((int*)map->h_gn_out)[15] = 0;  // fresh allocation: no stale word may look like ticket 1
     const float* src = pts;
     if (!pts_on_device && n > 0) {
       if ((size_t)2 * n > map->h_gn_cap) {
@@ -1770,12 +1781,13 @@ int match_data_impl(lslam_map* map, const float* pts, int n, bool pts_on_device,
     const int in_lds = (size_t)2 * n * sizeof(float) <= 56 * 1024;
     const size_t lds = in_lds ? (size_t)2 * std::max(n, 1) * sizeof(float) : 0;
     float* cache_dst = n > 0 ? map->d_cached.p : (float*)nullptr;
+    const int ticket = ++map->gn_ticket;
 #define LSLAM_GN_FAST(NT)                                                                                                  \
   launch(ctx, "gn_match", k_gn_match_fast<NT>, dim3(1), dim3(NT), lds, lv, src, cache_dst, n, in_lds, begin_world[0],      \
-         begin_world[1], begin_world[2], map->h_gn_out)
+         begin_world[1], begin_world[2], map->h_gn_out, ticket)
 #define LSLAM_GN_REG(NT, PMAX)                                                                                             \
   launch(ctx, "gn_match", k_gn_match_reg<NT, PMAX>, dim3(1), dim3(NT), 0, lv, src, cache_dst, n, begin_world[0],           \
-         begin_world[1], begin_world[2], map->h_gn_out)
+         begin_world[1], begin_world[2], map->h_gn_out, ticket)
     // the points of the scan in registers when they fit (3 per thread at 512 threads: a 1081-beam scan), else LDS / memory
     if (map->gn_threads >= 1024 && n <= 1024 * 2) LSLAM_GN_REG(1024, 2);
     else if (map->gn_threads >= 512 && map->gn_threads < 1024 && n <= 512 * 3) LSLAM_GN_REG(512, 3);
@@ -1786,7 +1798,20 @@ int match_data_impl(lslam_map* map, const float* pts, int n, bool pts_on_device,
 #undef LSLAM_GN_REG
 #undef LSLAM_GN_FAST
     LSLAM_HIP(ctx, hipGetLastError());
-    LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {  // bounded spin on the ticket (acquire); the stream itself if it does not show up (a failed launch, a device fault)
+      const volatile int* tk = (const volatile int*)map->h_gn_out + 15;
+      const auto t0 = std::chrono::steady_clock::now();
+      bool seen = false;
+      for (unsigned spins = 0; !seen; spins++) {
+        seen = __atomic_load_n((const int*)tk, __ATOMIC_ACQUIRE) == ticket;
+        if (seen) break;
+        __builtin_ia32_pause();
+        if ((spins & 1023u) == 1023u &&
+            std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= 20)
+          break;
+      }
+      if (!seen) LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     for (int i = 0; i < 3; i++) out_pose[i] = map->h_gn_out[i];
     if (out_cov) for (int i = 0; i < 9; i++) out_cov[i] = map->h_gn_out[3 + i];
     return LSLAM_OK;
