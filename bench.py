@@ -1205,6 +1205,12 @@ def main():
                 "l2_read_frac": (round(rec["l2_read_requests_per_launch"] * 128.0 * n_mine / scans_ref / (avg_ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4)
                                  if rec.get("l2_read_requests_per_launch") else None),
                 "l2_read_frac_definition": "TCP_TCC_READ_REQ x 128 B / launch time / 34.5 TB/s",
+                # the gather rate itself: L1 tag lookups (one per distinct 128-B line an instruction touches) against one
+                # lookup per CU per clock -- the unit `gather_unit_busy` says is the busiest besides the VALUs
+                "l1_lookup_frac": (round(rec["l1_line_lookups_per_launch"] * n_mine / scans_ref / (avg_ms * 1e-3) / (256 * 2.4e9), 4)
+                                   if rec.get("l1_line_lookups_per_launch") else None),
+                "l1_lookup_frac_definition": "TCP_TOTAL_CACHE_ACCESSES / launch time / (256 CUs x 2.4 GHz)",
+                "l1_line_lookups_per_vmem_read": rec.get("l1_line_lookups_per_vmem_read"),
                 # world sparsity: the exact zero-row pruning makes the headline depend on how empty the grid is; with pruning
                 # off every in-range row is gathered -- the worst case over worlds, measured in this run (`pruning`)
                 "worst_case_value": (round(n_total / (pruning["ms_per_step_pruning_off"] * 1e-3), 1) if pruning else None),

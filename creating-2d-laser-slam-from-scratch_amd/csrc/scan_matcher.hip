@@ -390,8 +390,10 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 //   STEP 2 (coarse pass): sources are the parity planes F_0/F_1 of the grid, a lattice row is nX
 //                         contiguous bytes of F_(base&1) starting at base>>1;
 //   STEP 1 (fine pass)  : the source is the grid itself.
-// Phase A (every beam; lane = beam): the lookup-table cell on the fly in fp64 (no table round trip
-// through HBM; cos/sin of the angle come from k_pass_setup), the flat index in int32, the rows
+// Phase A (every beam; lane = beam, two blocks of 64 beams in flight per iteration): the lookup-table
+// cell on the fly (no table round trip through HBM; cos/sin of the angle come from k_pass_setup) --
+// decided on an fp32 estimate with a proven error band, the few beams inside the band of a rounding
+// boundary re-done on the reference's own fp64 expression tree --, the flat index in int32, the rows
 // inside the reference's 1-D index range, and -- coarse pass -- the exact row-occupancy bits; a beam
 // with at least one live row is pushed on a circular LDS queue (wave ballot compaction).
 // Phase B (every 64 queued beams; lane = beam): one dword-aligned 16-byte load per lattice row
@@ -429,10 +431,11 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
             int S, const uint2* __restrict__ occ_t, int occ_wpc, int tile_rows, uint32_t tile_class_bytes,
             unsigned long long* __restrict__ stats) {
   constexpr int NW = NXD * NYC * 2;
-  constexpr int kQueue = 128;
+  constexpr int kQueue = 256;  // >= 63 waiting + two blocks of 64 coming in
   static_assert(NYC <= 16 && 2 * (NYC - 1) < 32, "row mask / occupancy window width");
   __shared__ __align__(16) uint32_t red[NW][8];  // [packed word][group of 8 lanes]
   __shared__ int2 queue[kQueue];  // circular; .x = first row index m0, .y = row mask | parity << 31
+  __shared__ uint16_t ambq[64 * kMaxBeamsPerLane];  // beams whose fp32 estimate could not decide the rounding (phase A)
   __shared__ uint32_t patch[LDSB ? 2 : 1][LDSB ? kPatchDw : 1];  // LDSB: the drain's bounding patch of each parity plane
   const int lane = threadIdx.x;
   int w = blockIdx.x;
@@ -447,6 +450,10 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
 
   const double2 cs = cossin[(size_t)s * kMaxAngles + a];  // of (center - ang_off) + a * ang_res (k_pass_setup)
   const double cosine = cs.x, sine = cs.y;
+  // cos * scale and sin * scale of the fp32 estimate of phase A, pinned to SGPRs: the packed-fp32 forms the vectoriser
+  // prefers would keep them in VGPRs, which this kernel (66 accumulators in a 128-VGPR budget) does not have
+  auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+  const float cos_sc = uniform((float)cosine * (float)g.scale), sin_sc = uniform((float)sine * (float)g.scale);
   const int X0 = L.gx[0], Y0 = L.gy[0];
   const double2* lp = local + (size_t)s * g.n_beams;
   const int ncand = pc.nx * pc.ny;
@@ -574,99 +581,182 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
     const int Yb1 = Y0 + j0 * step + 1;
     const int m0_max = limit - ((rows_here - 1) * g.stride + 4 * NXD);  // whole neighbourhood in range
     const int y1_max = g.height + 1 - step * (NYC - 1);                 // y+1 range of the occupancy window
-    double2 p_next = lp[min(64 * slice + lane, g.n_beams - 1)];
-    for (int b0 = 64 * slice; b0 < g.n_beams; b0 += bstride) {
-      const int b = b0 + lane;
-      const double2 p = p_next;  // fetched one block ahead: its latency hides behind this block's arithmetic
-      p_next = lp[min(b + bstride, g.n_beams - 1)];
-      uint32_t mask = 0u, par = 0u, col = 0u, osh = 0u;
-      int m0i = 0;
-      bool have_occ = false;
-      // NaN = INVALID_SCAN (k_scan_prep writes both coordinates); testing both keeps the point ONE 16-byte load
-      if ((int)(b < g.n_beams) & (int)!isnan(p.x) & (int)!isnan(p.y)) {
-        // ComputeOffsets + WorldToGrid (Karto.h:6465-6494, 4237-4252): identical fp64 expression tree;
-        // (int)math::Round(v) taken as trunc(copysign(|v| + 0.5, v))
-        const double ox = cosine * p.x - sine * p.y, oy = sine * p.x + cosine * p.y;
-        const double vx = ((ox + g.off_x) - g.off_x) * g.scale, vy = ((oy + g.off_y) - g.off_y) * g.scale;
-        const double ax = fabs(vx) + 0.5, ay = fabs(vy) + 0.5;
-        const int gx = (int)copysign(ax, vx), gy = (int)copysign(ay, vy);
-        if (fmax(ax, ay) < 32768.0) {  // |gx|, |gy| < 2^15
-          const int base = B0 + gx + __mul24(gy, g.stride);  // Karto.h:6494 + Mapper.cpp:838
-          par = (uint32_t)(base & shift);
-          const int m0 = base >> shift;  // arithmetic shift = floor
-          // rows inside the valid index range (the reference's 1-D check, Mapper.cpp:841-845)
-          if (m0_max >= 0 && (uint32_t)m0 <= (uint32_t)m0_max) {
-            mask = all_rows;
-          } else {
-            for (int j = 0; j < rows_here; j++) {
-              const int rs = m0 + j * g.stride;
-              if (rs >= -(4 * NXD) && rs < limit) mask |= 1u << j;
-            }
-          }
-          int x = X0 + gx, y1 = Yb1 + gy;
-          if (occ_t || TILED) {
-            if ((uint32_t)x >= (uint32_t)g.stride) {  // flat index wrapped into a neighbouring row
-              const int y = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
-              x = base - y * g.stride;
-              y1 = y + 1;
-            }
-          }
-          if (occ_t) {  // exact row occupancy (step 2): lattice rows are consecutive bits of one parity
-            if ((uint32_t)y1 <= (uint32_t)y1_max) {
-              have_occ = true;
-              col = (uint32_t)__mul24(__mul24(y1 & 1, occ_wph) + (y1 >> 6), g.stride) + (uint32_t)x;
-              osh = ((uint32_t)y1 >> 1) & 31u;
-            }
-          }
-          // a live row has y + 2j >= -1, so y >= -(2 NYC - 1) > -kTileYOff whenever the mask is not empty
-          m0i = TILED ? (int)(((uint32_t)x >> 1) | (par << 15) | ((uint32_t)(y1 + kTileYOff - 1) << 16)) : m0;
-        } else {
-          const int t = gx + gy * g.stride;  // int32 like the reference
-          const long long base = (long long)B0 + t;
-          par = (uint32_t)((int)(base & 1) & shift);
-          const long long m0 = base >> shift;
-          for (int j = 0; j < rows_here; j++) {
-            long long rs = m0 + (long long)j * g.stride;
-            if (rs >= -(long long)(4 * NXD) && rs < (long long)limit) mask |= 1u << j;
-          }
-          if constexpr (TILED) {
-            const long long yl = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
-            const long long xl = base - yl * g.stride;
-            m0i = mask ? (int)(((uint32_t)xl >> 1) | (par << 15) | ((uint32_t)(yl + kTileYOff) << 16)) : 0;
-          } else {
-            m0i = (int)m0;
-          }  // no occupancy pruning on this path
+    // The table cell of a beam -- ComputeOffsets + WorldToGrid (Karto.h:6465-6494, 4237-4252) -- is decided in two steps:
+    //  * every beam on an fp32 ESTIMATE (x, y) -> (cos*scale x - sin*scale y, sin*scale x + cos*scale y).  With u = 2^-24,
+    //    the roundings of cos*scale and sin*scale (three each), of the point, the product and the fma leave the estimate
+    //    within 6 u scale (|x| + |y|) cells of the exact value of the reference's expression, whose own fp64 roundings stay
+    //    below 1e-9 cells; a coordinate farther than 10 u scale (|x| + |y|) + 1e-6 from a half-integer therefore rounds
+    //    the way the reference's does.  A beam with a coordinate inside the band (a few in 10^4), or beyond +-32000 cells
+    //    (the int32 form of the flat index does not cover it), is parked in `ambq`;
+    //  * the parked beams, 64 at a time, on the reference's own fp64 expression tree.
+    // The sums are integer, so the order in which beams reach the accumulators does not matter.
+    // `emit`: flat index, rows in range, exact row occupancy, queue push, drain -- the part both steps share.  It takes TWO
+    // blocks of 64 beams at a time: a block is a chain of dependent latencies (point -> cell -> occupancy word -> ballot ->
+    // queue), and two chains in flight per wave keep the SIMD fed where four waves of one chain each did not.
+    struct Cell {
+      uint32_t mask, par, col, osh;
+      int m0i;
+      bool have_occ;
+    };
+    auto cell_of = [&](bool valid, bool small, int gx, int gy) {
+      // Straight-line for the common case (every lane, also the ones without a beam: their (gx, gy) is harmless and their
+      // mask is cleared at the end); only the rare cases branch.
+      Cell c;
+      const int base = B0 + gx + __mul24(gy, g.stride);  // Karto.h:6494 + Mapper.cpp:838; |gx|, |gy| < 2^15 (`small`)
+      c.par = (uint32_t)(base & shift);
+      const int m0 = base >> shift;  // arithmetic shift = floor
+      // rows inside the valid index range (the reference's 1-D check, Mapper.cpp:841-845)
+      uint32_t mask = all_rows;
+      if (!(m0_max >= 0 && (uint32_t)m0 <= (uint32_t)m0_max)) {
+        mask = 0u;
+        for (int j = 0; j < rows_here; j++) {
+          const int rs = m0 + j * g.stride;
+          if (rs >= -(4 * NXD) && rs < limit) mask |= 1u << j;
         }
       }
-      if constexpr (STATS) {
-        st_rows += (uint32_t)__popc(mask);
-        st_beams += (uint32_t)((int)(b < g.n_beams) & (int)!isnan(p.x) & (int)!isnan(p.y));
+      int x = X0 + gx, y1 = Yb1 + gy;
+      if (occ_t || TILED) {
+        if ((uint32_t)x >= (uint32_t)g.stride) {  // flat index wrapped into a neighbouring row
+          const int y = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
+          x = base - y * g.stride;
+          y1 = y + 1;
+        }
       }
+      // exact row occupancy (step 2): lattice rows are consecutive bits of one parity
+      c.have_occ = occ_t != nullptr && (uint32_t)y1 <= (uint32_t)y1_max;
+      c.col = c.have_occ ? (uint32_t)__mul24(__mul24(y1 & 1, occ_wph) + (y1 >> 6), g.stride) + (uint32_t)x : 0u;
+      c.osh = ((uint32_t)y1 >> 1) & 31u;
+      // a live row has y + 2j >= -1, so y >= -(2 NYC - 1) > -kTileYOff whenever the mask is not empty
+      c.m0i = TILED ? (int)(((uint32_t)x >> 1) | (c.par << 15) | ((uint32_t)(y1 + kTileYOff - 1) << 16)) : m0;
+      c.mask = valid ? mask : 0u;
+      if (valid && !small) {  // a table cell beyond +-2^15: 64-bit flat index, no occupancy pruning
+        const int t = gx + gy * g.stride;  // int32 like the reference
+        const long long base64 = (long long)B0 + t;
+        c.par = (uint32_t)((int)(base64 & 1) & shift);
+        const long long m064 = base64 >> shift;
+        c.mask = 0u;
+        for (int j = 0; j < rows_here; j++) {
+          long long rs = m064 + (long long)j * g.stride;
+          if (rs >= -(long long)(4 * NXD) && rs < (long long)limit) c.mask |= 1u << j;
+        }
+        if constexpr (TILED) {
+          const long long yl = base64 >= 0 ? base64 / g.stride : -((-base64 + g.stride - 1) / g.stride);
+          const long long xl = base64 - yl * g.stride;
+          c.m0i = c.mask ? (int)(((uint32_t)xl >> 1) | (c.par << 15) | ((uint32_t)(yl + kTileYOff) << 16)) : 0;
+        } else {
+          c.m0i = (int)m064;
+        }
+        c.have_occ = false;
+        c.col = 0u;
+      }
+      return c;
+    };
+    auto emit = [&](int bA, bool validA, bool smallA, int gxA, int gyA, int bB, bool validB, bool smallB, int gxB, int gyB) {
+      Cell cA = cell_of(validA, smallA, gxA, gyA), cB = cell_of(validB, smallB, gxB, gyB);
+      if constexpr (STATS) st_rows += (uint32_t)__popc(cA.mask) + (uint32_t)__popc(cB.mask);
       if (occ_t) {
-        const uint2 ow = occ_t[col];  // x-major: neighbouring beams read neighbouring words (k_occ_pairs)
-        const uint32_t keep = __builtin_amdgcn_alignbit(ow.y, ow.x, osh);  // bit j <-> lattice row j0 + j
-        mask &= have_occ ? keep : 0xFFFFFFFFu;
+        // x-major: neighbouring beams read neighbouring words (k_occ_pairs); both words are in flight together
+        // (32-bit byte offsets from a uniform base: the scalar-base form of the load, no 64-bit address pairs in VGPRs)
+        uint32_t offA = cA.col << 3, offB = cB.col << 3;
+        asm("" : "+v"(offA));  // (keeps the compiler from widening the offsets to 64 bits inside cell_of's branches, which
+        asm("" : "+v"(offB));  //  costs a register pair this kernel has to spill)
+        const uint2 owA = *(const uint2*)((const char*)occ_t + offA), owB = *(const uint2*)((const char*)occ_t + offB);
+        const uint32_t keepA = __builtin_amdgcn_alignbit(owA.y, owA.x, cA.osh);  // bit j <-> lattice row j0 + j
+        const uint32_t keepB = __builtin_amdgcn_alignbit(owB.y, owB.x, cB.osh);
+        cA.mask &= cA.have_occ ? keepA : 0xFFFFFFFFu;
+        cB.mask &= cB.have_occ ? keepB : 0xFFFFFFFFu;
       }
       if constexpr (STATS) {
-        st_live += (uint32_t)__popc(mask);
-        st_queued += mask ? 1u : 0u;
+        st_live += (uint32_t)__popc(cA.mask) + (uint32_t)__popc(cB.mask);
+        st_queued += (cA.mask ? 1u : 0u) + (cB.mask ? 1u : 0u);
         // per (scan, beam), OR-ed over the scan's angles: bit 0 = readable, bit 1 = some angle has a live row for it
         // (the flag words sit behind the eight counters; stats[4] = scans the buffer was sized for)
-        if (stats && b < g.n_beams && (unsigned long long)s < stats[4] && !isnan(p.x) && !isnan(p.y))
-          atomicOr((uint32_t*)(stats + 8) + (size_t)s * g.n_beams + b, mask ? 3u : 1u);
+        if (stats && (unsigned long long)s < stats[4]) {
+          if (validA) atomicOr((uint32_t*)(stats + 8) + (size_t)s * g.n_beams + bA, cA.mask ? 3u : 1u);
+          if (validB) atomicOr((uint32_t*)(stats + 8) + (size_t)s * g.n_beams + bB, cB.mask ? 3u : 1u);
+        }
       }
-      const unsigned long long votes = __ballot(mask != 0);
-      if (mask) {
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(votes >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)votes, 0u));
-        queue[(qhead + qcount + rank) & (kQueue - 1)] = make_int2(m0i, (int)(mask | (par << 31)));
+      const unsigned long long votesA = __ballot(cA.mask != 0), votesB = __ballot(cB.mask != 0);
+      if (cA.mask) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(votesA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)votesA, 0u));
+        queue[(qhead + qcount + rank) & (kQueue - 1)] = make_int2(cA.m0i, (int)(cA.mask | (cA.par << 31)));
       }
-      qcount += __popcll(votes);
+      qcount += __popcll(votesA);
+      if (cB.mask) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(votesB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)votesB, 0u));
+        queue[(qhead + qcount + rank) & (kQueue - 1)] = make_int2(cB.m0i, (int)(cB.mask | (cB.par << 31)));
+      }
+      qcount += __popcll(votesB);
       __syncthreads();
-      if (qcount >= 64) {
+      while (qcount >= 64) {  // at most 63 were waiting and at most 128 came in
         drain(qhead, 64);
         qhead = (qhead + 64) & (kQueue - 1);
         qcount -= 64;
       }
+    };
+    // one block of beams on the estimate: cell, and whether the estimate decides it -- otherwise the beam is parked
+    int acount = 0;
+    auto estimate = [&](int it, float2 p, bool in_scan, bool& valid, int& gx, int& gy) {
+      float t1, t2, fx, fy;
+      asm("v_mul_f32 %0, %1, %2" : "=v"(t1) : "s"(sin_sc), "v"(p.y));
+      asm("v_mul_f32 %0, %1, %2" : "=v"(t2) : "s"(cos_sc), "v"(p.y));
+      asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(fx) : "s"(cos_sc), "v"(p.x), "v"(t1));
+      asm("v_fma_f32 %0, %1, %2, %3" : "=v"(fy) : "s"(sin_sc), "v"(p.x), "v"(t2));
+      const float rx = __builtin_rintf(fx), ry = __builtin_rintf(fy);
+      // the band in cells: scale (|x| + |y|) <= sqrt(2) (|fx| + |fy|), so 10 u sqrt(2) (|fx| + |fy|) + 1e-6 covers E
+      const float reach = fabsf(fx) + fabsf(fy);
+      const float lim = (0.5f - 1e-6f) - reach * (14.2f / 16777216.0f);
+      // NaN = INVALID_SCAN (k_scan_prep writes both coordinates): every comparison below is false for it
+      valid = (int)in_scan & (int)(fabsf(fx - rx) < lim) & (int)(fabsf(fy - ry) < lim) & (int)(reach < 32000.0f);
+      const unsigned long long unsure = __ballot(!valid);
+      if (unsure) {
+        const bool park = !valid && in_scan && reach == reach;  // a beam the estimate does not decide
+        if constexpr (STATS) st_beams += (valid || park) ? 1u : 0u;
+        const unsigned long long parked = __ballot(park);
+        if (park) {
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(parked >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)parked, 0u));
+          ambq[acount + rank] = (uint16_t)(it * 64 + lane);  // (block of the slice, lane): < 64 kMaxBeamsPerLane
+        }
+        acount += __popcll(parked);
+      } else {
+        if constexpr (STATS) st_beams += 1u;
+      }
+      gx = (int)rx;
+      gy = (int)ry;
+    };
+    auto point_f = [&](int bb) {  // converted as it arrives: two registers in flight per block, not four
+      const double2 t = *(const double2*)((const char*)lp + ((uint32_t)min(bb, g.n_beams - 1) << 4));
+      return make_float2((float)t.x, (float)t.y);
+    };
+    float2 pA_next = point_f(64 * slice + lane), pB_next = point_f(64 * slice + bstride + lane);
+    for (int b0 = 64 * slice, it = 0; b0 < g.n_beams; b0 += 2 * bstride, it += 2) {
+      const int bA = b0 + lane, bB = bA + bstride;
+      const float2 pA = pA_next, pB = pB_next;  // fetched an iteration ahead: the latency hides behind this one's arithmetic
+      pA_next = point_f(bA + 2 * bstride);
+      pB_next = point_f(bB + 2 * bstride);
+      bool validA, validB;
+      int gxA, gyA, gxB, gyB;
+      estimate(it, pA, bA < g.n_beams, validA, gxA, gyA);
+      estimate(it + 1, pB, bB < g.n_beams, validB, gxB, gyB);
+      emit(bA, validA, true, gxA, gyA, bB, validB, true, gxB, gyB);
+    }
+    for (int a0 = 0; a0 < acount; a0 += 64) {
+      const bool valid = a0 + lane < acount;
+      const int parked_at = valid ? (int)ambq[a0 + lane] : 0;
+      const int b = 64 * slice + (parked_at >> 6) * bstride + (parked_at & 63);
+      int gx = 0, gy = 0;
+      bool small = true;
+      if (valid) {
+        // identical fp64 expression tree; (int)math::Round(v) taken as trunc(copysign(|v| + 0.5, v))
+        const double2 p = lp[b];
+        const double ox = cosine * p.x - sine * p.y, oy = sine * p.x + cosine * p.y;
+        const double vx = ((ox + g.off_x) - g.off_x) * g.scale, vy = ((oy + g.off_y) - g.off_y) * g.scale;
+        const double ax = fabs(vx) + 0.5, ay = fabs(vy) + 0.5;
+        gx = (int)copysign(ax, vx);
+        gy = (int)copysign(ay, vy);
+        small = fmax(ax, ay) < 32768.0;
+      }
+      emit(b, valid, small, gx, gy, 0, false, true, 0, 0);
     }
     if (qcount > 0) drain(qhead, qcount);
     __syncthreads();
@@ -773,6 +863,7 @@ k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc,
 
   const double2 cs = cossin[(size_t)s * kMaxAngles + a];  // of (center - ang_off) + a * ang_res (k_pass_setup)
   const double cosine = cs.x, sine = cs.y;
+  const float cos_sc = (float)cosine * (float)g.scale, sin_sc = (float)sine * (float)g.scale;  // of the fp32 estimate
   const int X0 = L.gx[0], Y0 = L.gy[0];
   const int B0 = X0 + Y0 * g.stride;
   const int cols4 = (tile_cols + 3) / 4;
@@ -783,15 +874,28 @@ k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc,
   for (int b = lane; b < g.n_beams; b += 64) {
     const double2 pn = lp[min(b + 64, g.n_beams - 1)];  // next point in flight while this one is used
     if (!isnan(p.x)) {  // NaN = INVALID_SCAN
-      // the table cell exactly as k_resp_rows evaluates it (same fp64 expression tree as lookup_cell_i32;
-      // (int)math::Round(v) taken as trunc(copysign(|v| + 0.5, v)))
-      const double ox = cosine * p.x - sine * p.y, oy = sine * p.x + cosine * p.y;
-      const double vx = ((ox + g.off_x) - g.off_x) * g.scale, vy = ((oy + g.off_y) - g.off_y) * g.scale;
-      const double ax = fabs(vx) + 0.5, ay = fabs(vy) + 0.5;
+      // The table cell as k_resp_rows evaluates it: decided on the fp32 estimate wherever the estimate's error band
+      // (10 u sqrt(2) (|fx| + |fy|) + 1e-6 cells, derived in k_resp_rows' phase A) leaves no doubt about the rounding;
+      // the few beams inside the band take the reference's own fp64 expression tree (lookup_cell_i32's;
+      // (int)math::Round(v) taken as trunc(copysign(|v| + 0.5, v))).
+      const float x32 = (float)p.x, y32 = (float)p.y;
+      const float fx = __builtin_fmaf(cos_sc, x32, -(sin_sc * y32)), fy = __builtin_fmaf(sin_sc, x32, cos_sc * y32);
+      const float rx = __builtin_rintf(fx), ry = __builtin_rintf(fy);
+      const float reach = fabsf(fx) + fabsf(fy);
+      const float lim = (0.5f - 1e-6f) - reach * (14.2f / 16777216.0f);
+      int gx = (int)rx, gy = (int)ry;
+      bool small = true;
+      double vx = 0.0, vy = 0.0;
+      if (!((int)(fabsf(fx - rx) < lim) & (int)(fabsf(fy - ry) < lim) & (int)(reach < 32000.0f))) {
+        const double ox = cosine * p.x - sine * p.y, oy = sine * p.x + cosine * p.y;
+        vx = ((ox + g.off_x) - g.off_x) * g.scale, vy = ((oy + g.off_y) - g.off_y) * g.scale;
+        const double ax = fabs(vx) + 0.5, ay = fabs(vy) + 0.5;
+        gx = (int)copysign(ax, vx), gy = (int)copysign(ay, vy);
+        small = fmax(ax, ay) < 32768.0;
+      }
       int x, y;
       bool ok;
-      if (fmax(ax, ay) < 32768.0) {  // |gx|, |gy| < 2^15: all int32-exact, see k_resp_rows
-        const int gx = (int)copysign(ax, vx), gy = (int)copysign(ay, vy);
+      if (small) {  // |gx|, |gy| < 2^15: all int32-exact, see k_resp_rows
         x = X0 + gx, y = Y0 + gy;
         if ((uint32_t)x >= (uint32_t)g.stride) {  // flat index wrapped into a neighbouring row
           const int base = B0 + gx + __mul24(gy, g.stride);
@@ -800,8 +904,8 @@ k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc,
         }
         ok = y >= -3 && y < g.height;
       } else {
-        const int gx = kround_i32(vx), gy = kround_i32(vy);
-        const long long base = (long long)B0 + (int)(gx + gy * g.stride);  // int32 table offset like the reference
+        const int gxl = kround_i32(vx), gyl = kround_i32(vy);
+        const long long base = (long long)B0 + (int)(gxl + gyl * g.stride);  // int32 table offset like the reference
         const long long yl = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
         ok = yl >= -3 && yl < g.height;
         y = ok ? (int)yl : 0;

@@ -118,6 +118,41 @@ def test_coarse_response_sums_bit_exact(ctx, oracle_lib, workload):
         assert np.array_equal(slow, sums_cpu)  # generic per-candidate kernel
 
 
+@pytest.mark.parametrize("heading", [0.0, math.pi / 2])
+def test_beams_on_half_cell_boundaries(ctx, oracle_lib, heading):
+    """Phase A of k_resp_rows decides a beam's table cell on an fp32 estimate and parks the beams whose coordinate lies
+    within the estimate's error band of a half-integer for the reference's own fp64 expression.  Here EVERY beam sits on
+    such a boundary for one candidate heading (scan-frame x or y = (k + 0.5 +- 3e-7) cells: where the reference rounds is
+    beyond doubt in fp64 -- it does not hinge on the last ulp of the device's and glibc's sin/cos -- and undecidable in
+    fp32), so whole waves of beams take the parked path; the numerators must still be the reference's bit for bit."""
+    laser = synth.Laser()
+    port, gm = make_pair(ctx, oracle_lib, laser)
+    n = laser.n_ranges
+    phi = laser.angle_min + np.arange(n) * laser.angle_increment
+    b = np.arange(n)
+    on_x = np.abs(np.cos(phi)) > 0.6
+    off = np.where(b % 2 == 0, 3e-7, -3e-7)  # cells: far inside the fp32 band (~1e-4), far outside libm's last-ulp noise
+    r = np.where(on_x, ((100 + b % 40) + 0.5 + off) / 20.0 / np.abs(np.cos(phi)),
+                 ((60 + b % 30) + 0.5 + off) / 20.0 / np.maximum(np.abs(np.sin(phi)), 1e-3))
+    r[::97] = np.nan  # a few INVALID_SCAN readings among them
+    base_poses = np.array([[1.0, 2.0, heading], [1.05, 2.0, heading], [1.0, 1.95, heading]])
+    base_ranges = np.stack([r, r, r])
+    center = np.array([1.03, 1.98, heading])  # candidate 10 of 21: (heading - 0.349) + 10 * 0.0349 = heading (+- 1 ulp)
+    port.set_base_scans(base_ranges, base_poses, center)
+    gm.AddScans(base_ranges, base_poses, center)
+    _, _, _, st, sums_cpu = port.correlate_scan(r, center, center, 0.5, 0.1, 0.349, 0.0349, True, False, want_sums=True)
+    assert st == 0 and sums_cpu.any()
+    assert np.array_equal(gm.coarse_sums(r, center, force_generic=False), sums_cpu)
+    assert np.array_equal(gm.coarse_sums(r, center, force_generic=True), sums_cpu)
+    # the same through the batched kernels (tiled planes, beam slices) and the whole match
+    S = 2304
+    res = gm.match_batch(np.tile(r, (S, 1)), np.tile(center, (S, 1)))
+    mean, cov, resp = port.match(r, center)
+    for i in (0, 1, S - 1):
+        _assert_result(res[i], mean, cov, resp)
+    assert np.ptp(res["response"]) == 0.0
+
+
 def _assert_result(res, mean, cov, resp):
     assert res["status"] == 0
     assert np.abs(res["pose"][:2] - mean[:2]).max() <= POSE_TOL

@@ -84,6 +84,12 @@ def main(path, scans, cfg2_path=None):
                 }
         if c.get("TA_TA_BUSY_sum") and c.get("GRBM_GUI_ACTIVE"):
             rec["gather_unit_busy"] = round(c["TA_TA_BUSY_sum"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 256), 3)  # 256 TAs, cycles per XCD
+        if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+            # L1 (TCP) tag lookups: one per distinct 128-byte line a vector-memory instruction touches -- what a gather costs
+            # (tools/micro/ta_rate.hip: ~1 cycle each)
+            rec["l1_line_lookups_per_launch"] = int(c["TCP_TOTAL_CACHE_ACCESSES_sum"])
+            if c.get("TA_FLAT_READ_WAVEFRONTS_sum"):
+                rec["l1_line_lookups_per_vmem_read"] = round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / c["TA_FLAT_READ_WAVEFRONTS_sum"], 1)
         if c.get("TCP_TCC_READ_REQ_sum"):
             rec["l2_read_requests_per_launch"] = int(c["TCP_TCC_READ_REQ_sum"])  # L1 -> L2 read requests, 128 B lines
         if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum") is not None and (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) > 0:
