@@ -27,6 +27,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -431,11 +432,12 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
             int S, const uint2* __restrict__ occ_t, int occ_wpc, int tile_rows, uint32_t tile_class_bytes,
             unsigned long long* __restrict__ stats) {
   constexpr int NW = NXD * NYC * 2;
+  constexpr bool EST = TILED;  // phase A on the fp32 estimate, two blocks in flight: the chip-filling batches (see phase A)
   constexpr int kQueue = 256;  // >= 63 waiting + two blocks of 64 coming in
   static_assert(NYC <= 16 && 2 * (NYC - 1) < 32, "row mask / occupancy window width");
   __shared__ __align__(16) uint32_t red[NW][8];  // [packed word][group of 8 lanes]
   __shared__ int2 queue[kQueue];  // circular; .x = first row index m0, .y = row mask | parity << 31
-  __shared__ uint16_t ambq[64 * kMaxBeamsPerLane];  // beams whose fp32 estimate could not decide the rounding (phase A)
+  __shared__ uint16_t ambq[TILED ? 64 * kMaxBeamsPerLane : 1];  // beams whose fp32 estimate could not decide the rounding (phase A)
   __shared__ uint32_t patch[LDSB ? 2 : 1][LDSB ? kPatchDw : 1];  // LDSB: the drain's bounding patch of each parity plane
   const int lane = threadIdx.x;
   int w = blockIdx.x;
@@ -651,20 +653,26 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       }
       return c;
     };
-    auto emit = [&](int bA, bool validA, bool smallA, int gxA, int gyA, int bB, bool validB, bool smallB, int gxB, int gyB) {
-      Cell cA = cell_of(validA, smallA, gxA, gyA), cB = cell_of(validB, smallB, gxB, gyB);
+    auto emit = [&](auto two_blocks, int bA, bool validA, bool smallA, int gxA, int gyA, int bB, bool validB, bool smallB,
+                    int gxB, int gyB) {
+      constexpr bool TWO = decltype(two_blocks)::value;  // false: block B does not exist (single-block callers)
+      Cell cA = cell_of(validA, smallA, gxA, gyA), cB{0u, 0u, 0u, 0u, 0, false};
+      if constexpr (TWO) cB = cell_of(validB, smallB, gxB, gyB);
       if constexpr (STATS) st_rows += (uint32_t)__popc(cA.mask) + (uint32_t)__popc(cB.mask);
       if (occ_t) {
         // x-major: neighbouring beams read neighbouring words (k_occ_pairs); both words are in flight together
         // (32-bit byte offsets from a uniform base: the scalar-base form of the load, no 64-bit address pairs in VGPRs)
         uint32_t offA = cA.col << 3, offB = cB.col << 3;
         asm("" : "+v"(offA));  // (keeps the compiler from widening the offsets to 64 bits inside cell_of's branches, which
-        asm("" : "+v"(offB));  //  costs a register pair this kernel has to spill)
-        const uint2 owA = *(const uint2*)((const char*)occ_t + offA), owB = *(const uint2*)((const char*)occ_t + offB);
+        if constexpr (TWO) asm("" : "+v"(offB));  //  costs a register pair this kernel has to spill)
+        const uint2 owA = *(const uint2*)((const char*)occ_t + offA);
         const uint32_t keepA = __builtin_amdgcn_alignbit(owA.y, owA.x, cA.osh);  // bit j <-> lattice row j0 + j
-        const uint32_t keepB = __builtin_amdgcn_alignbit(owB.y, owB.x, cB.osh);
         cA.mask &= cA.have_occ ? keepA : 0xFFFFFFFFu;
-        cB.mask &= cB.have_occ ? keepB : 0xFFFFFFFFu;
+        if constexpr (TWO) {
+          const uint2 owB = *(const uint2*)((const char*)occ_t + offB);
+          const uint32_t keepB = __builtin_amdgcn_alignbit(owB.y, owB.x, cB.osh);
+          cB.mask &= cB.have_occ ? keepB : 0xFFFFFFFFu;
+        }
       }
       if constexpr (STATS) {
         st_live += (uint32_t)__popc(cA.mask) + (uint32_t)__popc(cB.mask);
@@ -673,25 +681,35 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
         // (the flag words sit behind the eight counters; stats[4] = scans the buffer was sized for)
         if (stats && (unsigned long long)s < stats[4]) {
           if (validA) atomicOr((uint32_t*)(stats + 8) + (size_t)s * g.n_beams + bA, cA.mask ? 3u : 1u);
-          if (validB) atomicOr((uint32_t*)(stats + 8) + (size_t)s * g.n_beams + bB, cB.mask ? 3u : 1u);
+          if (TWO && validB) atomicOr((uint32_t*)(stats + 8) + (size_t)s * g.n_beams + bB, cB.mask ? 3u : 1u);
         }
       }
-      const unsigned long long votesA = __ballot(cA.mask != 0), votesB = __ballot(cB.mask != 0);
+      const unsigned long long votesA = __ballot(cA.mask != 0);
       if (cA.mask) {
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(votesA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)votesA, 0u));
         queue[(qhead + qcount + rank) & (kQueue - 1)] = make_int2(cA.m0i, (int)(cA.mask | (cA.par << 31)));
       }
       qcount += __popcll(votesA);
-      if (cB.mask) {
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(votesB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)votesB, 0u));
-        queue[(qhead + qcount + rank) & (kQueue - 1)] = make_int2(cB.m0i, (int)(cB.mask | (cB.par << 31)));
+      if constexpr (TWO) {
+        const unsigned long long votesB = __ballot(cB.mask != 0);
+        if (cB.mask) {
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(votesB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)votesB, 0u));
+          queue[(qhead + qcount + rank) & (kQueue - 1)] = make_int2(cB.m0i, (int)(cB.mask | (cB.par << 31)));
+        }
+        qcount += __popcll(votesB);
       }
-      qcount += __popcll(votesB);
       __syncthreads();
-      while (qcount >= 64) {  // at most 63 were waiting and at most 128 came in
+      if (qcount >= 64) {
         drain(qhead, 64);
         qhead = (qhead + 64) & (kQueue - 1);
         qcount -= 64;
+      }
+      if constexpr (TWO) {  // at most 63 were waiting and at most 128 came in
+        if (qcount >= 64) {
+          drain(qhead, 64);
+          qhead = (qhead + 64) & (kQueue - 1);
+          qcount -= 64;
+        }
       }
     };
     // one block of beams on the estimate: cell, and whether the estimate decides it -- otherwise the beam is parked
@@ -728,35 +746,55 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       const double2 t = *(const double2*)((const char*)lp + ((uint32_t)min(bb, g.n_beams - 1) << 4));
       return make_float2((float)t.x, (float)t.y);
     };
-    float2 pA_next = point_f(64 * slice + lane), pB_next = point_f(64 * slice + bstride + lane);
-    for (int b0 = 64 * slice, it = 0; b0 < g.n_beams; b0 += 2 * bstride, it += 2) {
-      const int bA = b0 + lane, bB = bA + bstride;
-      const float2 pA = pA_next, pB = pB_next;  // fetched an iteration ahead: the latency hides behind this one's arithmetic
-      pA_next = point_f(bA + 2 * bstride);
-      pB_next = point_f(bB + 2 * bstride);
-      bool validA, validB;
-      int gxA, gyA, gxB, gyB;
-      estimate(it, pA, bA < g.n_beams, validA, gxA, gyA);
-      estimate(it + 1, pB, bB < g.n_beams, validB, gxB, gyB);
-      emit(bA, validA, true, gxA, gyA, bB, validB, true, gxB, gyB);
-    }
-    for (int a0 = 0; a0 < acount; a0 += 64) {
-      const bool valid = a0 + lane < acount;
-      const int parked_at = valid ? (int)ambq[a0 + lane] : 0;
-      const int b = 64 * slice + (parked_at >> 6) * bstride + (parked_at & 63);
-      int gx = 0, gy = 0;
-      bool small = true;
-      if (valid) {
-        // identical fp64 expression tree; (int)math::Round(v) taken as trunc(copysign(|v| + 0.5, v))
-        const double2 p = lp[b];
-        const double ox = cosine * p.x - sine * p.y, oy = sine * p.x + cosine * p.y;
-        const double vx = ((ox + g.off_x) - g.off_x) * g.scale, vy = ((oy + g.off_y) - g.off_y) * g.scale;
-        const double ax = fabs(vx) + 0.5, ay = fabs(vy) + 0.5;
-        gx = (int)copysign(ax, vx);
-        gy = (int)copysign(ay, vy);
-        small = fmax(ax, ay) < 32768.0;
+    // the reference's own expression tree: identical fp64 operations; (int)math::Round(v) taken as trunc(copysign(|v| + 0.5, v))
+    auto exact_cell = [&](double2 p, int& gx, int& gy, bool& small) {
+      const double ox = cosine * p.x - sine * p.y, oy = sine * p.x + cosine * p.y;
+      const double vx = ((ox + g.off_x) - g.off_x) * g.scale, vy = ((oy + g.off_y) - g.off_y) * g.scale;
+      const double ax = fabs(vx) + 0.5, ay = fabs(vy) + 0.5;
+      gx = (int)copysign(ax, vx);
+      gy = (int)copysign(ay, vy);
+      small = fmax(ax, ay) < 32768.0;  // |gx|, |gy| < 2^15
+    };
+    if constexpr (EST) {
+      float2 pA_next = point_f(64 * slice + lane), pB_next = point_f(64 * slice + bstride + lane);
+      for (int b0 = 64 * slice, it = 0; b0 < g.n_beams; b0 += 2 * bstride, it += 2) {
+        const int bA = b0 + lane, bB = bA + bstride;
+        const float2 pA = pA_next, pB = pB_next;  // fetched an iteration ahead: the latency hides behind this one's arithmetic
+        pA_next = point_f(bA + 2 * bstride);
+        pB_next = point_f(bB + 2 * bstride);
+        bool validA, validB;
+        int gxA, gyA, gxB, gyB;
+        estimate(it, pA, bA < g.n_beams, validA, gxA, gyA);
+        estimate(it + 1, pB, bB < g.n_beams, validB, gxB, gyB);
+        emit(std::true_type{}, bA, validA, true, gxA, gyA, bB, validB, true, gxB, gyB);
       }
-      emit(b, valid, small, gx, gy, 0, false, true, 0, 0);
+      for (int a0 = 0; a0 < acount; a0 += 64) {
+        const bool valid = a0 + lane < acount;
+        const int parked_at = valid ? (int)ambq[a0 + lane] : 0;
+        const int b = 64 * slice + (parked_at >> 6) * bstride + (parked_at & 63);
+        int gx = 0, gy = 0;
+        bool small = true;
+        if (valid) exact_cell(lp[b], gx, gy, small);
+        emit(std::false_type{}, b, valid, small, gx, gy, 0, false, true, 0, 0);
+      }
+    } else {
+      // Launches that do not fill the chip (a lone MatchScan is 21 x 8 waves) end when their SLOWEST wave does: a parked
+      // beam -- a dependent load and one more pass through `emit` on some wave of nearly every launch -- costs them more
+      // than the estimate saves (measured: 11.9 -> 13.8 us for the coarse pass of one scan), so they evaluate every beam
+      // on the fp64 tree, one block per iteration.
+      double2 p_next = lp[min(64 * slice + lane, g.n_beams - 1)];
+      for (int b0 = 64 * slice; b0 < g.n_beams; b0 += bstride) {
+        const int b = b0 + lane;
+        const double2 p = p_next;  // fetched one block ahead
+        p_next = lp[min(b + bstride, g.n_beams - 1)];
+        // NaN = INVALID_SCAN (k_scan_prep writes both coordinates); testing both keeps the point ONE 16-byte load
+        const bool valid = (int)(b < g.n_beams) & (int)!isnan(p.x) & (int)!isnan(p.y);
+        if constexpr (STATS) st_beams += valid ? 1u : 0u;
+        int gx = 0, gy = 0;
+        bool small = true;
+        if (valid) exact_cell(p, gx, gy, small);
+        emit(std::false_type{}, b, valid, small, gx, gy, 0, false, true, 0, 0);
+      }
     }
     if (qcount > 0) drain(qhead, qcount);
     __syncthreads();
