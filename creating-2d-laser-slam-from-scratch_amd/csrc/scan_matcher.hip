@@ -474,6 +474,14 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
     for (int j = 0; j < NYC; j++)
 #pragma unroll
       for (int k = 0; k < NXD; k++) acc[j][k][0] = acc[j][k][1] = 0u;
+    // The lane index as this iteration sees it, opaque to the optimiser: everything derived from it (offsets of the first
+    // point loads, LDS addresses of the epilogue) is then computed where it is used instead of being hoisted out of this
+    // loop into registers that the kernel -- 66 accumulators in a 128-VGPR budget -- would have to spill to scratch.
+    // (re-read from the hardware -- mbcnt over a full mask = the lane's index, the block being one wave -- so that not even
+    //  the index itself has to stay in a register across the iteration)
+    uint32_t all_lanes = ~0u;
+    asm volatile("" : "+s"(all_lanes));  // (pins the re-read inside the iteration)
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(all_lanes, __builtin_amdgcn_mbcnt_lo(all_lanes, 0u));
 
     // Phase B: one queued beam per lane -- load the rows its mask names, accumulate 4 candidates per dword
     auto drain = [&](int head, int cnt) {
@@ -743,7 +751,10 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       gy = (int)ry;
     };
     auto point_f = [&](int bb) {  // converted as it arrives: two registers in flight per block, not four
-      const double2 t = *(const double2*)((const char*)lp + ((uint32_t)min(bb, g.n_beams - 1) << 4));
+      uint32_t off = (uint32_t)min(bb, g.n_beams - 1) << 4;
+      asm volatile("" : "+v"(off));  // (a 32-bit offset from the scalar base, computed where it is used -- not an address
+                                     //  pair, or an offset, hoisted out of the j0 loop into registers this kernel has to spill)
+      const double2 t = *(const double2*)((const char*)lp + off);
       return make_float2((float)t.x, (float)t.y);
     };
     // the reference's own expression tree: identical fp64 operations; (int)math::Round(v) taken as trunc(copysign(|v| + 0.5, v))
@@ -774,7 +785,7 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
         const int b = 64 * slice + (parked_at >> 6) * bstride + (parked_at & 63);
         int gx = 0, gy = 0;
         bool small = true;
-        if (valid) exact_cell(lp[b], gx, gy, small);
+        if (valid) exact_cell(*(const double2*)((const char*)lp + ((uint32_t)b << 4)), gx, gy, small);
         emit(std::false_type{}, b, valid, small, gx, gy, 0, false, true, 0, 0);
       }
     } else {
