@@ -1558,9 +1558,12 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_table_big(int S, Geom g, PassCfg pc, const Lattice* __restrict__ lat, const double2* __restrict__ local,
-            int32_t* __restrict__ tbl) {
+            int32_t* __restrict__ tbl, unsigned long long* __restrict__ best_bits) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int a = blockIdx.y, s = blockIdx.z;
+  // k_big_latmax's atomicMax target starts from zero: cleared here (two launches ahead of its first use) instead of by a
+  // fill operation on the stream -- a 5 us kernel of its own in a lone loop-closure match
+  if (b == 0 && a == 0) best_bits[s] = 0ull;
   if (b >= g.n_beams) return;
   const Lattice& L = lat[s];
   int32_t v = kInvalidScan;
@@ -1785,7 +1788,25 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
                     int32_t* resp, size_t resp_stride, CoarseOut* __restrict__ out,
                     int use_expansion, int pass_index, double* __restrict__ scratch, size_t scratch_stride,
                     const uint8_t* __restrict__ grid, const double2* __restrict__ local, int fb_step,
-                    const unsigned long long* __restrict__ best_bits) {
+                    const unsigned long long* __restrict__ best_bits, lslam_match_result* __restrict__ final_out,
+                    int* done_flag, int done_ticket) {
+  // final_out != nullptr: nothing follows this pass (no refinement, no response expansion -- the coarse match of a
+  // loop-closure candidate, Mapper.cpp:991): the block writes the match record itself, and posts the caller's ticket behind
+  // it, instead of leaving both to a k_reduce_fine launch that would only copy them
+  auto publish = [&](const CoarseOut& co) {
+    if (!final_out) return;
+    lslam_match_result res;
+    for (int i = 0; i < 3; i++) res.pose[i] = co.status ? 0.0 : co.mean[i];
+    for (int i = 0; i < 9; i++) res.covariance[i] = co.status ? 0.0 : co.cov[i];
+    res.response = co.status ? 0.0 : co.best;
+    res.status = co.status;
+    res.flags = co.flags;
+    final_out[blockIdx.x] = res;
+    if (done_flag) {
+      __threadfence_system();
+      *(volatile int*)done_flag = done_ticket;
+    }
+  };
   constexpr int kList = 2048;
   __shared__ double sh[NT];
   __shared__ double chunk[4 * NT];
@@ -1800,7 +1821,13 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
   const Lattice& L = lat[s];
   if (!L.active) return;
   if (L.status != 0) {
-    if (tid == 0) { out[s].status = L.status; out[s].expand = 0; out[s].best = 0.0; }
+    if (tid == 0) {
+      out[s].status = L.status; out[s].expand = 0; out[s].best = 0.0;
+      CoarseOut co{};
+      co.status = L.status;
+      co.flags = pass_index > 0 ? 1 : 0;
+      publish(co);
+    }
     return;
   }
   block_generic_fallback(grid, g, pc, L, local + (size_t)s * g.n_beams, resp + (size_t)s * resp_stride, fb_step, tid, NT);
@@ -2089,6 +2116,7 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
   o.best = best > 1.0 ? 1.0 : best;
   o.expand = (use_expansion && o.status == 0 && pass_index < 3 && double_equal(o.best, 0.0)) ? 1 : 0;
   out[s] = o;
+  publish(o);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3153,6 +3181,9 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     }
     return LSLAM_OK;
   };
+  // a coarse-only match on a loop-closure-size lattice: k_reduce_coarse_big writes the record (and posts the ticket) itself
+  lslam_match_result* const big_final_out = (!do_refine && n_exp == 0) ? d_out : (lslam_match_result*)nullptr;
+  bool record_written = false;
   auto run_coarse_big = [&](const PassCfg& p, int pass_index) -> int {
     // dense kernel for uniform lattices; scans with a non-uniform lattice fall to the generic kernel
     fb_step = 2;
@@ -3161,8 +3192,13 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
              (const CoarseOut*)m->d_coarse.p, m->d_lat.p, m->d_cossin.p, 2);
     setup_done = false;
     LSLAM_HIP(ctx, m->d_tbl.reserve((size_t)S * p.na * g.n_beams));
+    const size_t ncand = (size_t)p.nx * p.ny, total = ncand * p.na;
+    const size_t stride = ncand + (size_t)g.probs_side * g.probs_side + 4 * ncand + (total + 63) / 64 + 8;  // doubles
+    LSLAM_HIP(ctx, m->d_big.reserve((size_t)S * stride + S + 1));
+    // per-scan best response (bit pattern of a non-negative double), behind the scratch of the last scan
+    unsigned long long* best_bits = (unsigned long long*)(m->d_big.p + (size_t)S * stride);
     launch(ctx, "table_big", k_table_big, dim3((g.n_beams + 255) / 256, p.na, S), dim3(256), 0, S, g, p,
-           (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_tbl.p);
+           (const Lattice*)m->d_lat.p, (const double2*)m->d_local.p, m->d_tbl.p, best_bits);
     const int lpr = (p.nx + 15) / 16, rpw = 64 / lpr;
     const bool lone = (long long)S * p.na * ((p.ny + rpw * kDenseT - 1) / (rpw * kDenseT)) * 8 < 4096;  // few waves even with 8 slices
     const int dense_t = lone ? 1 : kDenseT;
@@ -3182,13 +3218,8 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       launch(ctx, "resp_dense", k_resp_dense<kDenseT>, dim3((unsigned)((long long)S * p.na * n_tiles * slices)), dim3(64), 0,
              (const uint8_t*)m->d_sub[0], (const uint8_t*)m->d_sub[1], g.data_size / 2, g, p, (const Lattice*)m->d_lat.p,
              (const int32_t*)m->d_tbl.p, slices > 1 ? m->d_part.p : m->d_resp.p, resp_stride, n_tiles, slices);
-    const size_t ncand = (size_t)p.nx * p.ny, total = ncand * p.na;
-    const size_t stride = ncand + (size_t)g.probs_side * g.probs_side + 4 * ncand + (total + 63) / 64 + 8;  // doubles
-    LSLAM_HIP(ctx, m->d_big.reserve((size_t)S * stride + S + 1));
     // per-cell maxima + best response of every scan on (ncand / 256) x S blocks; the reduce block then only does the
-    // order-dependent parts.  best_bits lives behind the scratch of the last scan.
-    unsigned long long* best_bits = (unsigned long long*)(m->d_big.p + (size_t)S * stride);
-    LSLAM_HIP(ctx, hipMemsetAsync(best_bits, 0, (size_t)S * sizeof(unsigned long long), ctx->stream));
+    // order-dependent parts (best_bits was cleared by k_table_big)
     launch(ctx, "big_latmax", k_big_latmax, dim3((unsigned)((ncand + 63) / 64), S), dim3(256), 0, g, p, sc,
            (const Lattice*)m->d_lat.p, m->d_resp.p, resp_stride, m->d_big.p, stride, best_bits, fb_step,
            (const int32_t*)m->d_part.p, slices);
@@ -3196,12 +3227,13 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       launch(ctx, "reduce_coarse_big", k_reduce_coarse_big<1024>, dim3(S), dim3(1024), 0, g, p, sc, (const Lattice*)m->d_lat.p,
              m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
              m->d_big.p, stride, (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step,
-             (const unsigned long long*)best_bits);
+             (const unsigned long long*)best_bits, big_final_out, big_final_out ? done_flag : (int*)nullptr, done_ticket);
     else
       launch(ctx, "reduce_coarse_big", k_reduce_coarse_big<256>, dim3(S), dim3(256), 0, g, p, sc, (const Lattice*)m->d_lat.p,
              m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,
              m->d_big.p, stride, (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step,
-             (const unsigned long long*)best_bits);
+             (const unsigned long long*)best_bits, big_final_out, big_final_out ? done_flag : (int*)nullptr, done_ticket);
+    if (big_final_out) record_written = true;
     if (dbg_coarse_sums && pass_index == 0)  // after the reduce: it fills in scans the packed kernel skipped
       LSLAM_HIP(ctx, hipMemcpyAsync(dbg_coarse_sums, m->d_resp.p, (size_t)p.nx * p.ny * p.na * sizeof(int32_t),
                                     hipMemcpyDeviceToDevice, ctx->stream));
@@ -3254,6 +3286,10 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   if (do_refine) {
     rc = run_responses(pf, 1, "resp_rows_fine");
     if (rc) return rc;
+  }
+  if (record_written) {
+    LSLAM_HIP(ctx, hipGetLastError());
+    return LSLAM_OK;
   }
   if (S >= kReduceNarrowMinScans)
     launch(ctx, "reduce_fine", k_reduce_fine<64>, dim3(S), dim3(64), (size_t)(((size_t)pf.nx * pf.ny * pf.na + 31) / 32) * 4 + 16,
