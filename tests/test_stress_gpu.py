@@ -12,7 +12,10 @@ from lslam_amd import api, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n_ranges,inc_deg,seed", [(360, 1.0, 1), (1081, 0.25, 2), (721, 0.5, 3), (1080, 0.3333, 4)])
+# (2500 beams: more than 64 x 32 per wave, so the chip-filling coarse kernel runs with two beam slices per (scan, angle) --
+# the parked-beam bookkeeping of its phase A is per slice -- and the rebuild leaves its LDS-resident form)
+@pytest.mark.parametrize("n_ranges,inc_deg,seed", [(360, 1.0, 1), (1081, 0.25, 2), (721, 0.5, 3), (1080, 0.3333, 4),
+                                                    (2500, 0.1, 5)])
 def test_random_sweep(ctx, oracle_lib, n_ranges, inc_deg, seed):
     rng = np.random.default_rng(seed)
     laser = synth.Laser(n_ranges=n_ranges, angle_min=math.radians(-0.5 * (n_ranges - 1) * inc_deg),
