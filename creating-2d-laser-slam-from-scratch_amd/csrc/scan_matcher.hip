@@ -1606,6 +1606,17 @@ k_resp_dense(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1,
   for (int t = 0; t < T; t++)
 #pragma unroll
     for (int c = 0; c < 16; c++) acc[t][c] = 0u;
+  // the planes are addressed like k_resp_rows addresses them: 32-bit offsets from the 64 zero bytes in front of plane 0
+  const uint8_t* zbase = src0 - kRowZero;
+  const uint32_t plane_delta = (uint32_t)(src1 - src0);
+  int lane_off[T];   // of the lane's 16 candidates in row slot t, relative to the window's first half-index
+  bool slot_on[T];
+#pragma unroll
+  for (int t = 0; t < T; t++) {
+    const int j = j_base + t * rpw + r;
+    slot_on[t] = lane_on && j < pc.ny;
+    lane_off[t] = 16 * k + (slot_on[t] ? j : 0) * g.stride;
+  }
 
   for (int b0 = b_lo; b0 < b_hi; b0 += 256) {
     uint32_t pe[T][4], po[T][4];
@@ -1614,45 +1625,82 @@ k_resp_dense(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1,
 #pragma unroll
       for (int q = 0; q < 4; q++) pe[t][q] = po[t][q] = 0u;
     const int b1 = min(b_hi, b0 + 256);
-    // kGroup beams per iteration: their table entries (wave-uniform) and all kGroup * T row loads are issued before the
-    // first byte is used -- one beam per iteration was a chain of dependent loads (135 round trips for a single match)
+    // The table entries of 64 beams arrive as ONE coalesced vector load (lane = beam; the next 64 are requested while these
+    // are used) and are handed out with v_readlane: a scalar load per beam group sat in front of every group's row loads
+    // as a second dependent round trip.  kGroup beams per iteration: all kGroup * T row loads are issued before the first
+    // byte is used -- one beam per iteration was a chain of dependent loads (135 round trips for a single match).
     constexpr int kGroup = 4;
-    int32_t tv_next[kGroup];
+    int32_t tvec_next = b0 + lane < b1 ? trow[b0 + lane] : kInvalidScan;
+    for (int c0 = b0; c0 < b1; c0 += 64) {
+      const int32_t tvec = tvec_next;
+      tvec_next = c0 + 64 + lane < b1 ? trow[c0 + 64 + lane] : kInvalidScan;
+      const int cn = min(64, b1 - c0);
+      for (int u0 = 0; u0 < cn; u0 += kGroup) {
+        // Five dword-ALIGNED words per lane (a byte-aligned 16-byte access is split into single dwords by the address unit:
+        // four times the cycles -- that, not latency or arithmetic, was this kernel's time), shifted into place below.  The
+        // byte phase is wave-uniform: the planes, widthStep and the lanes' 16 k + j * widthStep are multiples of 4.
+        uint32_t w5[kGroup][T][5];
+        uint32_t phase[kGroup];
 #pragma unroll
-    for (int u = 0; u < kGroup; u++) tv_next[u] = b0 + u < b1 ? trow[b0 + u] : kInvalidScan;
-    for (int b = b0; b < b1; b += kGroup) {
-      int32_t tv[kGroup];
+        for (int u = 0; u < kGroup; u++) {
+          // per beam, on the scalar unit: flat index of the window's first cell, its parity plane, half index
+          const int32_t tv = u0 + u < cn ? __builtin_amdgcn_readlane(tvec, u0 + u) : kInvalidScan;
+          const long long base = pos00 + tv;  // the lattice lies inside the grid and the grid has <= 2^30 cells: |base| < 2^31
+          const int half = (int)(base >> 1);
+          const uint32_t poff = (uint32_t)kRowZero + ((base & 1) ? plane_delta : 0u);
+          const bool beam_on = tv != kInvalidScan;
+          phase[u] = ((uint32_t)half + poff) & 3u;
 #pragma unroll
-      for (int u = 0; u < kGroup; u++) tv[u] = tv_next[u];
-      // the next group's table entries are requested before this group's rows: one round trip per iteration, not two
-#pragma unroll
-      for (int u = 0; u < kGroup; u++) tv_next[u] = b + kGroup + u < b1 ? trow[b + kGroup + u] : kInvalidScan;
-      uint4 d[kGroup][T];
-#pragma unroll
-      for (int u = 0; u < kGroup; u++) {
-        const long long base = pos00 + tv[u];
-        const uint8_t* src = (base & 1) ? src1 : src0;
-        const long long m0 = (base >> 1) + 16 * k;
-#pragma unroll
-        for (int t = 0; t < T; t++) {
-          const int j = j_base + t * rpw + r;
-          const long long m = m0 + (long long)j * g.stride;
-          d[u][t] = make_uint4(0u, 0u, 0u, 0u);
-          if (tv[u] != kInvalidScan && lane_on && j < pc.ny && m + 16 > 0 && m < (long long)limit)
-            __builtin_memcpy(&d[u][t], src + m, 16);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < kGroup; u++)
-#pragma unroll
-        for (int t = 0; t < T; t++) {
-          const uint32_t dw[4] = {d[u][t].x, d[u][t].y, d[u][t].z, d[u][t].w};
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            pe[t][q] += dw[q] & 0x00FF00FFu;
-            po[t][q] += (dw[q] >> 8) & 0x00FF00FFu;
+          for (int t = 0; t < T; t++) {
+            // per lane: 32-bit offset from the zero guard in front of plane 0; a segment outside (-16, limit) -- and every
+            // lane of a beam without a reading -- reads the guard instead: straight-line loads, no 64-bit address arithmetic
+            const int mm = half + lane_off[t];
+            const bool in = beam_on && slot_on[t] && (uint32_t)(mm + 15) < (uint32_t)(limit + 15);
+            const uint32_t off = in ? (((uint32_t)mm + poff) & ~3u) : 0u;
+            __builtin_memcpy(w5[u][t], __builtin_assume_aligned(zbase + off, 4), 20);
           }
         }
+        uint4 d[kGroup][T];
+#pragma unroll
+        for (int u = 0; u < kGroup; u++)
+#pragma unroll
+          for (int t = 0; t < T; t++) {
+            d[u][t].x = __builtin_amdgcn_alignbyte(w5[u][t][1], w5[u][t][0], phase[u]);
+            d[u][t].y = __builtin_amdgcn_alignbyte(w5[u][t][2], w5[u][t][1], phase[u]);
+            d[u][t].z = __builtin_amdgcn_alignbyte(w5[u][t][3], w5[u][t][2], phase[u]);
+            d[u][t].w = __builtin_amdgcn_alignbyte(w5[u][t][4], w5[u][t][3], phase[u]);
+          }
+        if constexpr (T == 1) {
+          // a lone match is a handful of waves per SIMD, each a serial instruction stream: one byte-select add (SDWA) per
+          // candidate straight into its 32-bit sum is 16 instructions per beam where mask / shift / packed add / flush are 22
+#pragma unroll
+          for (int u = 0; u < kGroup; u++) {
+            const uint32_t dw[4] = {d[u][0].x, d[u][0].y, d[u][0].z, d[u][0].w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+#define LSLAM_ADD_BYTE(A, W, B) \
+  asm("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #B : "+v"(A) : "v"(W))
+              LSLAM_ADD_BYTE(acc[0][4 * q + 0], dw[q], 0);
+              LSLAM_ADD_BYTE(acc[0][4 * q + 1], dw[q], 1);
+              LSLAM_ADD_BYTE(acc[0][4 * q + 2], dw[q], 2);
+              LSLAM_ADD_BYTE(acc[0][4 * q + 3], dw[q], 3);
+#undef LSLAM_ADD_BYTE
+            }
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < kGroup; u++)
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+              const uint32_t dw[4] = {d[u][t].x, d[u][t].y, d[u][t].z, d[u][t].w};
+#pragma unroll
+              for (int q = 0; q < 4; q++) {
+                pe[t][q] += dw[q] & 0x00FF00FFu;
+                po[t][q] += (dw[q] >> 8) & 0x00FF00FFu;
+              }
+            }
+        }
+      }
     }
 #pragma unroll
     for (int t = 0; t < T; t++)
