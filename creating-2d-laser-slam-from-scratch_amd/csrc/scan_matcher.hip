@@ -896,98 +896,130 @@ k_tile4(const uint8_t* __restrict__ grid, int stride, int data_size, uint4* __re
   tiles[tile4_slot(ux, uy, (tile_cols + 3) / 4)] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// One wave64 per (scan, angle); lanes stride over the beams.  Same exact numerators as
-// k_resp_rows<1,4> at step 1 (Mapper.cpp:819-856), written resp[s][a][j*3+i].
+// One wave64 per (scan, kTile3Angles angles); lanes stride over the beams.  Same exact numerators as
+// k_resp_rows<1,4> at step 1 (Mapper.cpp:819-856), written resp[s][a][j*3+i].  Several angles per wave in the chip-filling
+// batches because the kernel runs at the lookup rate of the L1s (PMC: 29 tag lookups per vector-memory instruction, gather
+// unit 85 % busy): a coalesced 16-byte-per-lane point load is 16 of the ~58 lookups a (block of beams, angle) costs, and
+// the angles' block gathers are independent loads in flight together.  Measured per 4096-scan launch: 1 angle per wave
+// 119 us, 2: 96, 3: 92, 4: 95; below ~1000 scans one angle per wave (more waves) is the faster form (256 scans: 14 vs 22 us).
+constexpr int kTile3ManyAngles = 3, kTile3ManyMinScans = 1536;
+template <int kTile3Angles>
 __global__ void __launch_bounds__(64)
 k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc, const Lattice* __restrict__ lat,
              const double2* __restrict__ cossin, const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int S) {
   const int lane = threadIdx.x;
   const int w = blockIdx.x;
   const int xcd = w & 7, r = w >> 3;
-  const int s = (r / pc.na) * 8 + xcd;  // all angles of a scan on one XCD, like k_resp_rows
-  const int a = r % pc.na;
+  const int pairs = (pc.na + kTile3Angles - 1) / kTile3Angles;
+  const int s = (r / pairs) * 8 + xcd;  // all angles of a scan on one XCD, like k_resp_rows
+  const int a0 = (r % pairs) * kTile3Angles;
   if (s >= S) return;
   const Lattice& L = lat[s];
   if (!L.active || L.status != 0 || L.step_x != 1 || L.step_y != 1) return;
 
-  const double2 cs = cossin[(size_t)s * kMaxAngles + a];  // of (center - ang_off) + a * ang_res (k_pass_setup)
-  const double cosine = cs.x, sine = cs.y;
-  const float cos_sc = (float)cosine * (float)g.scale, sin_sc = (float)sine * (float)g.scale;  // of the fp32 estimate
+  double cosine[kTile3Angles], sine[kTile3Angles];
+  float cos_sc[kTile3Angles], sin_sc[kTile3Angles];  // of the fp32 estimate
+  bool angle_on[kTile3Angles];
+#pragma unroll
+  for (int q = 0; q < kTile3Angles; q++) {
+    angle_on[q] = a0 + q < pc.na;
+    const double2 cs = cossin[(size_t)s * kMaxAngles + min(a0 + q, pc.na - 1)];  // of (center - ang_off) + a * ang_res (k_pass_setup)
+    cosine[q] = cs.x, sine[q] = cs.y;
+    cos_sc[q] = (float)cs.x * (float)g.scale, sin_sc[q] = (float)cs.y * (float)g.scale;
+  }
   const int X0 = L.gx[0], Y0 = L.gy[0];
   const int B0 = X0 + Y0 * g.stride;
   const int cols4 = (tile_cols + 3) / 4;
   const double2* lp = local + (size_t)s * g.n_beams;
   // packed 16-bit fields: e[j] = candidates (0,j) | (2,j) << 16; o01 = (1,0) | (1,1) << 16; o2 = (1,2)
-  uint32_t e0 = 0, e1 = 0, e2 = 0, o01 = 0, o2 = 0;
+  uint32_t e0[kTile3Angles], e1[kTile3Angles], e2[kTile3Angles], o01[kTile3Angles], o2[kTile3Angles];
+#pragma unroll
+  for (int q = 0; q < kTile3Angles; q++) e0[q] = e1[q] = e2[q] = o01[q] = o2[q] = 0u;
+  // the 4x4 block of one beam at one angle: byte offset of its 12 bytes (0 = nothing to read: the buffer starts with
+  // block rows of the pad, which hold zeros) and the column parity inside the block
+  auto block_of = [&](const double2& p, float x32, float y32, int q, uint32_t& off, uint32_t& dx) {
+    // The table cell as k_resp_rows evaluates it: decided on the fp32 estimate wherever the estimate's error band
+    // (10 u sqrt(2) (|fx| + |fy|) + 1e-6 cells, derived in k_resp_rows' phase A) leaves no doubt about the rounding;
+    // the few beams inside the band take the reference's own fp64 expression tree (lookup_cell_i32's;
+    // (int)math::Round(v) taken as trunc(copysign(|v| + 0.5, v))).
+    const float fx = __builtin_fmaf(cos_sc[q], x32, -(sin_sc[q] * y32)), fy = __builtin_fmaf(sin_sc[q], x32, cos_sc[q] * y32);
+    const float rx = __builtin_rintf(fx), ry = __builtin_rintf(fy);
+    const float reach = fabsf(fx) + fabsf(fy);
+    const float lim = (0.5f - 1e-6f) - reach * (14.2f / 16777216.0f);
+    int gx = (int)rx, gy = (int)ry;
+    bool small = true;
+    double vx = 0.0, vy = 0.0;
+    if (!((int)(fabsf(fx - rx) < lim) & (int)(fabsf(fy - ry) < lim) & (int)(reach < 32000.0f))) {
+      const double ox = cosine[q] * p.x - sine[q] * p.y, oy = sine[q] * p.x + cosine[q] * p.y;
+      vx = ((ox + g.off_x) - g.off_x) * g.scale, vy = ((oy + g.off_y) - g.off_y) * g.scale;
+      const double ax = fabs(vx) + 0.5, ay = fabs(vy) + 0.5;
+      gx = (int)copysign(ax, vx), gy = (int)copysign(ay, vy);
+      small = fmax(ax, ay) < 32768.0;
+    }
+    int x, y;
+    bool ok;
+    if (small) {  // |gx|, |gy| < 2^15: all int32-exact, see k_resp_rows
+      x = X0 + gx, y = Y0 + gy;
+      if ((uint32_t)x >= (uint32_t)g.stride) {  // flat index wrapped into a neighbouring row
+        const int base = B0 + gx + __mul24(gy, g.stride);
+        y = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
+        x = base - y * g.stride;
+      }
+      ok = y >= -3 && y < g.height;
+    } else {
+      const int gxl = kround_i32(vx), gyl = kround_i32(vy);
+      const long long base = (long long)B0 + (int)(gxl + gyl * g.stride);  // int32 table offset like the reference
+      const long long yl = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
+      ok = yl >= -3 && yl < g.height;
+      y = ok ? (int)yl : 0;
+      x = ok ? (int)(base - yl * g.stride) : 0;
+    }
+    // rows y .. y+2 of the patch are 12 contiguous bytes of the block, 4 bytes in when y is odd: one 12-byte load
+    // (32-bit offset from the buffer base: the host keeps the tiled copy below 4 GB)
+    off = (uint32_t)tile4_slot(x >> 1, (y + kTileYPad) >> 1, cols4) * 16u + ((uint32_t)y & 1u) * 4u;
+    dx = (uint32_t)x & 1u;
+    return ok;
+  };
   double2 p = lp[min(lane, g.n_beams - 1)];
   for (int b = lane; b < g.n_beams; b += 64) {
     const double2 pn = lp[min(b + 64, g.n_beams - 1)];  // next point in flight while this one is used
     if (!isnan(p.x)) {  // NaN = INVALID_SCAN
-      // The table cell as k_resp_rows evaluates it: decided on the fp32 estimate wherever the estimate's error band
-      // (10 u sqrt(2) (|fx| + |fy|) + 1e-6 cells, derived in k_resp_rows' phase A) leaves no doubt about the rounding;
-      // the few beams inside the band take the reference's own fp64 expression tree (lookup_cell_i32's;
-      // (int)math::Round(v) taken as trunc(copysign(|v| + 0.5, v))).
       const float x32 = (float)p.x, y32 = (float)p.y;
-      const float fx = __builtin_fmaf(cos_sc, x32, -(sin_sc * y32)), fy = __builtin_fmaf(sin_sc, x32, cos_sc * y32);
-      const float rx = __builtin_rintf(fx), ry = __builtin_rintf(fy);
-      const float reach = fabsf(fx) + fabsf(fy);
-      const float lim = (0.5f - 1e-6f) - reach * (14.2f / 16777216.0f);
-      int gx = (int)rx, gy = (int)ry;
-      bool small = true;
-      double vx = 0.0, vy = 0.0;
-      if (!((int)(fabsf(fx - rx) < lim) & (int)(fabsf(fy - ry) < lim) & (int)(reach < 32000.0f))) {
-        const double ox = cosine * p.x - sine * p.y, oy = sine * p.x + cosine * p.y;
-        vx = ((ox + g.off_x) - g.off_x) * g.scale, vy = ((oy + g.off_y) - g.off_y) * g.scale;
-        const double ax = fabs(vx) + 0.5, ay = fabs(vy) + 0.5;
-        gx = (int)copysign(ax, vx), gy = (int)copysign(ay, vy);
-        small = fmax(ax, ay) < 32768.0;
+      uint32_t off[kTile3Angles], dx[kTile3Angles], rr[kTile3Angles][3];
+      bool ok[kTile3Angles];
+#pragma unroll
+      for (int q = 0; q < kTile3Angles; q++) ok[q] = block_of(p, x32, y32, q, off[q], dx[q]) && angle_on[q];
+#pragma unroll
+      for (int q = 0; q < kTile3Angles; q++) {
+        rr[q][0] = rr[q][1] = rr[q][2] = 0u;
+        if (ok[q]) __builtin_memcpy(rr[q], __builtin_assume_aligned((const uint8_t*)tiles + off[q], 4), 12);
       }
-      int x, y;
-      bool ok;
-      if (small) {  // |gx|, |gy| < 2^15: all int32-exact, see k_resp_rows
-        x = X0 + gx, y = Y0 + gy;
-        if ((uint32_t)x >= (uint32_t)g.stride) {  // flat index wrapped into a neighbouring row
-          const int base = B0 + gx + __mul24(gy, g.stride);
-          y = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
-          x = base - y * g.stride;
-        }
-        ok = y >= -3 && y < g.height;
-      } else {
-        const int gxl = kround_i32(vx), gyl = kround_i32(vy);
-        const long long base = (long long)B0 + (int)(gxl + gyl * g.stride);  // int32 table offset like the reference
-        const long long yl = base >= 0 ? base / g.stride : -((-base + g.stride - 1) / g.stride);
-        ok = yl >= -3 && yl < g.height;
-        y = ok ? (int)yl : 0;
-        x = ok ? (int)(base - yl * g.stride) : 0;
-      }
-      if (ok) {
-        // rows y .. y+2 of the patch are 12 contiguous bytes of the block, 4 bytes in when y is odd: one 12-byte load
-        // (32-bit offset from the buffer base: the host keeps the tiled copy below 4 GB)
-        const uint32_t off = (uint32_t)tile4_slot(x >> 1, (y + kTileYPad) >> 1, cols4) * 16u + ((uint32_t)y & 1u) * 4u;
-        uint32_t rr[3];
-        __builtin_memcpy(rr, __builtin_assume_aligned((const uint8_t*)tiles + off, 4), 12);
-        const uint32_t dx = (uint32_t)x & 1u;
-        const uint32_t r0 = rr[0], r1 = rr[1], r2 = rr[2];
-        const uint32_t sel_e = 0x0C020C00u + dx * 0x00010001u;  // bytes dx, dx+2 of one row
-        const uint32_t sel_o = 0x0C050C01u + dx * 0x00010001u;  // byte dx+1 of src1 (low) and of src0 (high)
-        e0 += __builtin_amdgcn_perm(r0, r0, sel_e);
-        e1 += __builtin_amdgcn_perm(r1, r1, sel_e);
-        e2 += __builtin_amdgcn_perm(r2, r2, sel_e);
-        o01 += __builtin_amdgcn_perm(r1, r0, sel_o);
-        o2 += __builtin_amdgcn_perm(r2, r2, 0x0C0C0C01u + dx);
+#pragma unroll
+      for (int q = 0; q < kTile3Angles; q++) {
+        const uint32_t r0 = rr[q][0], r1 = rr[q][1], r2 = rr[q][2];
+        const uint32_t sel_e = 0x0C020C00u + dx[q] * 0x00010001u;  // bytes dx, dx+2 of one row
+        const uint32_t sel_o = 0x0C050C01u + dx[q] * 0x00010001u;  // byte dx+1 of src1 (low) and of src0 (high)
+        e0[q] += __builtin_amdgcn_perm(r0, r0, sel_e);
+        e1[q] += __builtin_amdgcn_perm(r1, r1, sel_e);
+        e2[q] += __builtin_amdgcn_perm(r2, r2, sel_e);
+        o01[q] += __builtin_amdgcn_perm(r1, r0, sel_o);
+        o2[q] += __builtin_amdgcn_perm(r2, r2, 0x0C0C0C01u + dx[q]);
       }
     }
     p = pn;
   }
-  uint32_t tot[9];
-  tot[0] = wave_sum(e0 & 0xFFFFu), tot[1] = wave_sum(o01 & 0xFFFFu), tot[2] = wave_sum(e0 >> 16);
-  tot[3] = wave_sum(e1 & 0xFFFFu), tot[4] = wave_sum(o01 >> 16), tot[5] = wave_sum(e1 >> 16);
-  tot[6] = wave_sum(e2 & 0xFFFFu), tot[7] = wave_sum(o2), tot[8] = wave_sum(e2 >> 16);
-  uint32_t mine = 0;
 #pragma unroll
-  for (int c = 0; c < 9; c++)
-    if (lane == c) mine = tot[c];
-  if (lane < 9) resp[(size_t)s * resp_stride + (size_t)a * 9 + lane] = (int32_t)mine;
+  for (int q = 0; q < kTile3Angles; q++) {
+    uint32_t tot[9];
+    tot[0] = wave_sum(e0[q] & 0xFFFFu), tot[1] = wave_sum(o01[q] & 0xFFFFu), tot[2] = wave_sum(e0[q] >> 16);
+    tot[3] = wave_sum(e1[q] & 0xFFFFu), tot[4] = wave_sum(o01[q] >> 16), tot[5] = wave_sum(e1[q] >> 16);
+    tot[6] = wave_sum(e2[q] & 0xFFFFu), tot[7] = wave_sum(o2[q]), tot[8] = wave_sum(e2[q] >> 16);
+    uint32_t mine = 0;
+#pragma unroll
+    for (int c = 0; c < 9; c++)
+      if (lane == c) mine = tot[c];
+    if (lane < 9 && angle_on[q]) resp[(size_t)s * resp_stride + (size_t)(a0 + q) * 9 + lane] = (int32_t)mine;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3140,8 +3172,16 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
                (const uint8_t*)m->d_grid, g.stride, g.data_size, m->d_tiles, m->tile_cols, m->tile_rows);
         m->tile_dirty = false;
       }
-      launch(ctx, "resp_tile_fine", k_resp_tile3, dim3((unsigned)waves), dim3(64), 0, (const uint4*)m->d_tiles, m->tile_cols, g, p,
-             (const Lattice*)m->d_lat.p, (const double2*)m->d_cossin.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S);
+#define LSLAM_TILE3_ARGS                                                                                                \
+  (const uint4*)m->d_tiles, m->tile_cols, g, p, (const Lattice*)m->d_lat.p, (const double2*)m->d_cossin.p,              \
+      (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S
+      if (S >= kTile3ManyMinScans)
+        launch(ctx, "resp_tile_fine", k_resp_tile3<kTile3ManyAngles>,
+               dim3((unsigned)((long long)((S + 7) / 8) * 8 * ((p.na + kTile3ManyAngles - 1) / kTile3ManyAngles))), dim3(64), 0,
+               LSLAM_TILE3_ARGS);
+      else
+        launch(ctx, "resp_tile_fine", k_resp_tile3<1>, dim3((unsigned)waves), dim3(64), 0, LSLAM_TILE3_ARGS);
+#undef LSLAM_TILE3_ARGS
     } else if (variant) {
       // small batches: split the beams of one (scan, angle) over several waves to fill the chip
       int slices = 1;
