@@ -359,18 +359,21 @@ k_row_occupancy(const uint32_t* __restrict__ nz, int n_words, int stride, int he
   occ_t[(size_t)x * (2 * words_per_half) + wq] = bits;
 }
 
-// pass C: the same bits regrouped for the gather unit: P[E][w][x] = words (w, w+1) of column x's
+// pass C: the same bits regrouped for the gather unit: P[w][x][E] = words (w, w+1) of column x's
 // parity-E bitmap as one 64-bit value.  Column-major words put the 64 beams of a wave on 64 different
 // 128-byte lines (one line = 1024 rows of ONE column); x-major pairs put neighbouring beams --
-// neighbouring columns -- on the same line, and the (w, w+1) overlap keeps it one 8-byte load.
+// neighbouring columns, either row parity -- on the same line, and the (w, w+1) overlap keeps it one 8-byte load.
 __global__ void __launch_bounds__(256)
 k_occ_pairs(const uint32_t* __restrict__ occ_t, int stride, int words_per_half, uint2* __restrict__ pairs) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ew = blockIdx.y;  // E * words_per_half + w
+  const int ew = blockIdx.y;  // E * words_per_half + w (the layout of occ_t's columns)
   if (x >= stride) return;
-  const int w = ew % words_per_half;
+  const int w = ew % words_per_half, E = ew / words_per_half;
   const uint32_t* col = occ_t + (size_t)x * (2 * words_per_half) + ew;
-  pairs[(size_t)ew * stride + x] = make_uint2(col[0], w + 1 < words_per_half ? col[1] : 0u);
+  // [w][x][E]: the two row parities of a column side by side, columns next to each other -- the four beams of a lane quad
+  // (neighbouring columns, either parity) find their words in ONE 128-byte line; a gather costs one L1 lookup per distinct
+  // line per QUAD, and with the parities in separate planes this load was ~49 lookups per wave instruction
+  pairs[((size_t)w * stride + x) * 2 + E] = make_uint2(col[0], w + 1 < words_per_half ? col[1] : 0u);
 }
 
 // wave64 sum, uniform result: four DPP adds give every lane its row-of-16 total, the four row totals
@@ -634,7 +637,7 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       }
       // exact row occupancy (step 2): lattice rows are consecutive bits of one parity
       c.have_occ = occ_t != nullptr && (uint32_t)y1 <= (uint32_t)y1_max;
-      c.col = c.have_occ ? (uint32_t)__mul24(__mul24(y1 & 1, occ_wph) + (y1 >> 6), g.stride) + (uint32_t)x : 0u;
+      c.col = c.have_occ ? (((uint32_t)__mul24(y1 >> 6, g.stride) + (uint32_t)x) << 1) + ((uint32_t)y1 & 1u) : 0u;  // k_occ_pairs
       c.osh = ((uint32_t)y1 >> 1) & 31u;
       // a live row has y + 2j >= -1, so y >= -(2 NYC - 1) > -kTileYOff whenever the mask is not empty
       c.m0i = TILED ? (int)(((uint32_t)x >> 1) | (c.par << 15) | ((uint32_t)(y1 + kTileYOff - 1) << 16)) : m0;
