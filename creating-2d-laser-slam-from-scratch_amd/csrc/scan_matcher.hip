@@ -370,9 +370,9 @@ k_occ_pairs(const uint32_t* __restrict__ occ_t, int stride, int words_per_half, 
   if (x >= stride) return;
   const int w = ew % words_per_half, E = ew / words_per_half;
   const uint32_t* col = occ_t + (size_t)x * (2 * words_per_half) + ew;
-  // [w][x][E]: the two row parities of a column side by side, columns next to each other -- the four beams of a lane quad
-  // (neighbouring columns, either parity) find their words in ONE 128-byte line; a gather costs one L1 lookup per distinct
-  // line per QUAD, and with the parities in separate planes this load was ~49 lookups per wave instruction
+  // [w][x][E]: the two row parities of a column side by side, columns next to each other -- neighbouring beams (neighbouring
+  // columns, either parity) find their words in ONE 128-byte line; with the parities in separate planes they sat in two
+  // (measured: 288 M -> 276 M L1 accesses per 4096-scan launch of k_resp_rows)
   pairs[((size_t)w * stride + x) * 2 + E] = make_uint2(col[0], w + 1 < words_per_half ? col[1] : 0u);
 }
 
@@ -901,9 +901,9 @@ k_tile4(const uint8_t* __restrict__ grid, int stride, int data_size, uint4* __re
 
 // One wave64 per (scan, kTile3Angles angles); lanes stride over the beams.  Same exact numerators as
 // k_resp_rows<1,4> at step 1 (Mapper.cpp:819-856), written resp[s][a][j*3+i].  Several angles per wave in the chip-filling
-// batches because the kernel runs at the lookup rate of the L1s (PMC: 29 tag lookups per vector-memory instruction, gather
-// unit 85 % busy): a coalesced 16-byte-per-lane point load is 16 of the ~58 lookups a (block of beams, angle) costs, and
-// the angles' block gathers are independent loads in flight together.  Measured per 4096-scan launch: 1 angle per wave
+// batches because the one-angle form runs at the access rate of the L1s (PMC: 29 accesses per vector-memory instruction,
+// gather unit 85 % busy; the coalesced 16-byte-per-lane point load is charged about as much as the block gather): the
+// angles share the point load, and their block gathers are independent loads in flight together.  Measured per 4096-scan launch: 1 angle per wave
 // 119 us, 2: 96, 3: 92, 4: 95; below ~1000 scans one angle per wave (more waves) is the faster form (256 scans: 14 vs 22 us).
 constexpr int kTile3ManyAngles = 3, kTile3ManyMinScans = 1536;
 template <int kTile3Angles>
