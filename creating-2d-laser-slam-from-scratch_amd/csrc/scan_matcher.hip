@@ -27,6 +27,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <vector>
 
@@ -63,7 +64,22 @@ struct PassCfg {
 struct SearchCfg {
   double dvp, avp, min_dp, min_ap;
   int do_penalize;
+  // GetResponse's normalisation (Mapper.cpp:852) is response = sum / (nBeams * 100) in fp64.  The numerator is an integer in
+  // [0, nBeams * 100], so whether q = sum * inv, q' = fma(fma(-q, d, sum), inv, q) (inv = RN(1/d); Markstein's correction
+  // step) returns the correctly rounded quotient can be -- and is, at lslam_matcher_create -- checked for EVERY possible
+  // numerator: fast_div is set only if all of them agree with the division bit for bit (three instructions instead of the
+  // dozen, one of them a quarter-rate v_rcp_f64, of an IEEE division; 2 541 of them per scan in the coarse reduce).
+  int fast_div;
+  double inv_denom;
 };
+__device__ __forceinline__ double response_of_sum(int32_t sum, int n_beams, const SearchCfg& sc) {
+  const double d = (double)((uint32_t)n_beams * (uint32_t)kOccupied), a = (double)sum;
+  if (sc.fast_div) {
+    const double q = a * sc.inv_denom;
+    return __builtin_fma(__builtin_fma(-q, d, a), sc.inv_denom, q);
+  }
+  return a / d;
+}
 
 constexpr int kTilePad = 512;  // zero bytes in front of the tiled parity planes (a dead row j reads offset 32 j)
 constexpr int kTileYOff = 32;  // tiled planes: class rows start at grid row y = -kTileYOff (>= 2*16 - 1 + 1)
@@ -1118,7 +1134,7 @@ __device__ __forceinline__ Cand cand_of(int k, const PassCfg& pc, const double* 
 // GetResponse normalisation + odometry penalty (Mapper.cpp:852, 399-414)
 __device__ __forceinline__ double penalized(int32_t sum, const Cand& cd, const double* center, int n_beams,
                                             const SearchCfg& sc) {
-  double r = (double)sum / (double)((uint32_t)n_beams * (uint32_t)kOccupied);
+  double r = response_of_sum(sum, n_beams, sc);
   if (sc.do_penalize && !double_equal(r, 0.0)) {
     double sd = ksq(cd.x) + ksq(cd.y);
     double dp = 1.0 - (kDistPenaltyGain * sd / sc.dvp);
@@ -1402,9 +1418,8 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
   __syncthreads();
 
   // penalised response of candidate (c, a): GetResponse normalisation (:852) and r *= (dp * ap) (:399-414)
-  const double denom = (double)((uint32_t)g.n_beams * (uint32_t)kOccupied);
   auto value_of = [&](int32_t sum, int c, int a) -> double {
-    double v = (double)sum / denom;
+    double v = response_of_sum(sum, g.n_beams, sc);
     if (sc.do_penalize && !double_equal(v, 0.0)) v *= (dpen[c] * s_ap[a]);
     return v;
   };
@@ -1811,7 +1826,6 @@ k_big_latmax(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ lat, 
   if (c < ncand) {
     int32_t* r = resp + (size_t)s * resp_stride;
     const int32_t* ps = part + (size_t)s * slices * resp_stride;
-    const double denom = (double)((uint32_t)g.n_beams * (uint32_t)kOccupied);
     double dp = 1.0;
     if (sc.do_penalize) {
       const int xi = c % pc.nx, yi = c / pc.nx;
@@ -1845,7 +1859,7 @@ k_big_latmax(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ lat, 
 #pragma unroll
       for (int i = 0; i < kBatch; i++)
         if (a0 + i < a_hi) {
-          double v = (double)rv[i] / denom;  // GetResponse normalisation (:852)
+          double v = response_of_sum(rv[i], g.n_beams, sc);  // GetResponse normalisation (:852)
           if (sc.do_penalize && !double_equal(v, 0.0)) v *= (dp * s_ap[a0 + i]);
           m = m > v ? m : v;
         }
@@ -1933,7 +1947,6 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
     s_ap[a] = ap > sc.min_ap ? ap : sc.min_ap;
   }
   __syncthreads();
-  const double denom = (double)((uint32_t)g.n_beams * (uint32_t)kOccupied);
   auto cell_dp = [&](int c) -> double {
     const int xi = c % pc.nx, yi = c / pc.nx;
     const double x = -pc.off_x + (uint32_t)xi * pc.res_x;  // Mapper.cpp:342-345
@@ -1943,7 +1956,7 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
     return dp > sc.min_dp ? dp : sc.min_dp;
   };
   auto value_of = [&](int32_t sum, double dp, int a) -> double {
-    double v = (double)sum / denom;
+    double v = response_of_sum(sum, g.n_beams, sc);
     if (sc.do_penalize && !double_equal(v, 0.0)) v *= (dp * s_ap[a]);
     return v;
   };
@@ -2351,7 +2364,7 @@ k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc
     double start = center[2] - pc.ang_off;
     for (int a = 0; a < pc.na; a++) {
       double angle = start + (uint32_t)a * pc.ang_res;
-      double rr = (double)asum[a] / (double)((uint32_t)g.n_beams * (uint32_t)kOccupied);
+      double rr = response_of_sum(asum[a], g.n_beams, sc);
       if (rr >= (s_best - 0.1)) {
         norm += rr;
         acc += (ksq(angle - bestAngle) * rr);
@@ -2939,6 +2952,8 @@ struct lslam_matcher {
   DevBuf<CoarseOut> d_coarse;
   DevBuf<int32_t> d_resp;
   size_t resp_prezeroed = 0;  // words at the start of d_resp the last grid rebuild cleared for the NEXT match
+  int fast_div = 0;           // SearchCfg::fast_div / inv_denom: set at creation after the exhaustive check
+  double inv_denom = 0.0;
   bool prep_done = false;     // the last grid rebuild also ran k_scan_prep for the ONE scan of the next match
   DevBuf<int32_t> d_tbl;     // large lattices: materialised lookup tables [S][nA][N]
   DevBuf<int32_t> d_part;    // large lattices, few scans: per-beam-slice partial numerators [S][slices][resp_stride]
@@ -3101,7 +3116,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   }
 
   SearchCfg sc{m->cfg.distance_variance_penalty, m->cfg.angle_variance_penalty,
-               m->cfg.minimum_distance_penalty, m->cfg.minimum_angle_penalty, do_penalize};
+               m->cfg.minimum_distance_penalty, m->cfg.minimum_angle_penalty, do_penalize, m->fast_div, m->inv_denom};
 
   // scan_prep also lays out the coarse lattice of pass 0 (mode 0 needs only the pose): one launch fewer
   if (prep_was_done && S == 1) {  // k_rebuild_begin's extra blocks did it (streaming front-end)
@@ -3639,6 +3654,17 @@ int lslam_matcher_create(lslam_context* ctx, const lslam_matcher_config* cfg, co
     const double res = 1.0 / g.scale;
     const int nx = lattice_count(0.5 * ((double)g.probs_side - 1) * res, 2 * res);
     m->occ_win = std::min(kOccWinMax, std::max(3, 2 * (nx - 1) + 1));
+  }
+  {  // SearchCfg::fast_div: the reciprocal form of the response normalisation, checked against the division for every
+     // numerator a response sum can take (0 .. nBeams * 100; a beam adds at most GridStates_Occupied = 100)
+    const double d = (double)((uint32_t)g.n_beams * (uint32_t)kOccupied), inv = 1.0 / d;
+    bool same = g.n_beams > 0 && (long long)g.n_beams * kOccupied <= (1 << 26);
+    for (long long sum = 0; same && sum <= (long long)g.n_beams * kOccupied; sum++) {
+      const double a = (double)sum, q = a * inv, fast = std::fma(std::fma(-q, d, a), inv, q), exact = a / d;
+      same = memcmp(&fast, &exact, sizeof fast) == 0;
+    }
+    m->fast_div = same ? 1 : 0;
+    m->inv_denom = inv;
   }
   m->occ_wpc = 2 * (((g.height + 2) / 2 + 1 + 31) / 32 + 1);  // two row-parity bitmaps per column, +1 word each for the 64-bit read
   m->nz_words = (g.data_size + 31) / 32;
