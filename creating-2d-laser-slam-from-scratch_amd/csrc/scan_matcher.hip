@@ -15,13 +15,17 @@
 //                                  the 2-D tiled parity planes (k_tile_planes)
 //   k_reduce_coarse  S blocks      penalties, max, tie average, positional covariance; then the fine
 //                                  lattice of the scan
-//   k_resp_tile3     S*nA waves    fine pass: one 16-byte load per beam from overlapping 4x4 blocks
-//                                  (k_tile4); k_resp_rows<1,4> for small batches
+//   k_resp_tile3     S*nA/3 waves  fine pass: one 12-byte load per (beam, angle) from overlapping 4x4 blocks
+//                                  (k_tile4), three angles per wave from 1536 scans up (one below);
+//                                  k_resp_rows<1,4> for small batches
 //   k_reduce_fine    S blocks      same reductions + angular covariance (Mapper.cpp:431-506, 535-692)
 //   k_resp_generic                 the same sums for arbitrary lattices; as block_generic_fallback it
 //                                  runs inside the reduce kernels for scans with a non-uniform lattice
 // Response numerators stay integers end to end (sum of uint8 <= 255*N); the fp64 part follows
-// the reference's expression order (built with -ffp-contract=off).
+// the reference's expression order (built with -ffp-contract=off).  Where a cheaper evaluation is
+// used -- the fp32 estimate of a beam's table cell, the reciprocal form of the response
+// normalisation -- it is one whose result is PROVEN (error band, exhaustive check) to be the
+// reference's, with the reference's own expression as the fallback.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
