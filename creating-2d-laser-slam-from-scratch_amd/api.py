@@ -318,6 +318,9 @@ def lib() -> C.CDLL:
     L.lslam_pool_match_batch.argtypes = [vp, i32, vp, i32, vp, i32, i32, vp]
     L.lslam_deskew_scan.argtypes = [vp, vp, i32, C.POINTER(DeskewParams), vp, vp, vp, vp, i32, vp, vp]
     L.lslam_matcher_set_option.argtypes = [vp, i32, i32]
+    L.lslam_matcher_flush.argtypes = [vp]
+    L.lslam_matcher_pipelined_steps.argtypes = [vp]
+    L.lslam_matcher_pipelined_steps.restype = C.c_int64
     i64 = C.c_int64
     L.lslam_scan_cache_create.argtypes = [vp, C.POINTER(LaserParams), C.POINTER(vp)]
     L.lslam_scan_cache_destroy.argtypes = [vp]
@@ -492,8 +495,16 @@ class ScanMatcher:
         self.ctx.check(self.L.lslam_matcher_set_grid_u8_dev(self.h, ptr, o.ctypes.data))
 
     def set_option(self, name: str, value: int):
-        opt = {"row_occupancy": 1, "collect_stats": 2, "lds_staged": 3}[name]
+        opt = {"row_occupancy": 1, "collect_stats": 2, "lds_staged": 3, "pipeline_depth": 4}[name]
         self.ctx.check(self.L.lslam_matcher_set_option(self.h, opt, int(value)))
+
+    def flush(self):
+        """Order the context stream behind every pipelined step in flight (set_option('pipeline_depth', D > 1))."""
+        self.ctx.check(self.L.lslam_matcher_flush(self.h))
+
+    @property
+    def pipelined_steps(self) -> int:
+        return int(self.L.lslam_matcher_pipelined_steps(self.h))
 
     def read_stats(self) -> dict:
         out = (C.c_uint64 * 4)()
@@ -553,7 +564,9 @@ class ScanMatcher:
 
     def match_batch_dev(self, n_scans: int, ranges_ptr: int, stride: int, poses_ptr: int, out_ptr: int,
                         dtype="f32", doPenalize: bool = True, doRefineMatch: bool = True):
-        """Same with float32/float64 ranges, poses and results resident in HBM; asynchronous."""
+        """Same with float32/float64 ranges, poses and results resident in HBM; asynchronous.  With
+        set_option('pipeline_depth', D > 1) consecutive calls are pipelined steps: up to D in flight at once, so give D
+        consecutive calls their own result buffers and read them after ctx.synchronize()."""
         fn = self.L.lslam_matcher_match_batch_dev_f32 if dtype == "f32" else self.L.lslam_matcher_match_batch_dev_f64
         self.ctx.check(fn(self.h, n_scans, ranges_ptr, stride, poses_ptr, int(doPenalize), int(doRefineMatch), out_ptr))
 

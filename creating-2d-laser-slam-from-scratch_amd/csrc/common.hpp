@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -154,6 +155,33 @@ struct DevBuf {
     cap = 0;
   }
 };
+
+// One polite iteration of a host spin loop (the host side of this library builds for x86-64 and AArch64 hosts).
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#else
+  asm volatile("" ::: "memory");
+#endif
+}
+
+// Wait for a ticket a kernel posts in pinned host memory behind its record (single-scan calls: the kernel-completion
+// signal and the runtime's wake-up cost more than the last kernel itself).  A bounded busy spin -- it occupies the
+// calling host thread's core for the length of the device call, at most `budget_ms` -- with acquire loads; false when
+// the ticket did not show up in time (a failed launch, a device fault, a path that posts none): the caller then waits
+// for the stream, which also reports the error.
+inline bool spin_for_ticket(const int* word, int want, int budget_ms = 20) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; spins++) {
+    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) return true;
+    cpu_relax();
+    if ((spins & 1023u) == 1023u &&
+        std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= budget_ms)
+      return false;
+  }
+}
 
 // Launch with optional HIP-event timing on the context stream.
 template <typename K, typename... Args>

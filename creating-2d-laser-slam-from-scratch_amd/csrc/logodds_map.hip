@@ -1798,20 +1798,8 @@ int match_data_impl(lslam_map* map, const float* pts, int n, bool pts_on_device,
 #undef LSLAM_GN_REG
 #undef LSLAM_GN_FAST
     LSLAM_HIP(ctx, hipGetLastError());
-    {  // bounded spin on the ticket (acquire); the stream itself if it does not show up (a failed launch, a device fault)
-      const volatile int* tk = (const volatile int*)map->h_gn_out + 15;
-      const auto t0 = std::chrono::steady_clock::now();
-      bool seen = false;
-      for (unsigned spins = 0; !seen; spins++) {
-        seen = __atomic_load_n((const int*)tk, __ATOMIC_ACQUIRE) == ticket;
-        if (seen) break;
-        __builtin_ia32_pause();
-        if ((spins & 1023u) == 1023u &&
-            std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= 20)
-          break;
-      }
-      if (!seen) LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
+    // bounded spin on the ticket (acquire); the stream itself if it does not show up (a failed launch, a device fault)
+    if (!spin_for_ticket((const int*)map->h_gn_out + 15, ticket)) LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 3; i++) out_pose[i] = map->h_gn_out[i];
     if (out_cov) for (int i = 0; i < 9; i++) out_cov[i] = map->h_gn_out[3 + i];
     return LSLAM_OK;

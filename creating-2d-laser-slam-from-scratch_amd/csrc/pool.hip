@@ -43,6 +43,9 @@ int lslam_pool_create_on(const int* devices, int n_devices, const lslam_matcher_
       return rc;
     }
     p->m.push_back(mm);
+    // every device's share of a batch goes through as two pipelined sub-batches (upload of one under the kernels of the
+    // other, reduce chains overlapped): lslam_matcher_match_batch does the splitting
+    (void)lslam_matcher_set_option(mm, LSLAM_OPT_PIPELINE_DEPTH, 2);
   }
   *out = p;
   return LSLAM_OK;
@@ -176,10 +179,10 @@ int rccl_fail(lslam_context* ctx, const char* what, ncclResult_t r) {
 // vector, so EVERY rank learns of it and all leave together -- after the box exchange, or after a one-word status
 // exchange in front of the counter all-reduce.
 namespace {
-int sharded_args_ok(lslam_context* ctx, const lslam_laser* laser, int n_scans, const double* ranges, int ranges_stride,
-                    const double* sensor_poses, double resolution) {
-  if (!laser || n_scans < 0 || (n_scans > 0 && (!ranges || !sensor_poses)))
-    return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "sharded map build: laser / scans");
+// what every rank passes alike -- the laser, the resolution, the row stride: a rank-independent verdict, so checking it
+// BEFORE the first collective cannot strand a peer
+int sharded_args_ok(lslam_context* ctx, const lslam_laser* laser, int ranges_stride, double resolution) {
+  if (!laser) return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "sharded map build: laser");
   if (!(laser->angular_resolution > 0.0) || !(laser->maximum_angle >= laser->minimum_angle))
     return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "sharded map build: laser angles");
   if (resolution == 0.0 || (resolution > -1e-6 && resolution < 1e-6) || !(resolution == resolution))
@@ -187,6 +190,14 @@ int sharded_args_ok(lslam_context* ctx, const lslam_laser* laser, int n_scans, c
   const int n = (int)(uint32_t)lslam::kround((laser->maximum_angle - laser->minimum_angle) / laser->angular_resolution);
   if (ranges_stride < n)  // whatever n_scans is: every rank must come to the same verdict
     return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "ranges_stride %d < num_beams %d", ranges_stride, n);
+  return LSLAM_OK;
+}
+// what only THIS rank can see -- its own shard's pointers and count: never a reason to return before a collective
+// (the rank joins exchange 1 with its error flag set, like any other local failure)
+int shard_args_local(lslam_context* ctx, int n_scans, const double* ranges, const double* sensor_poses) {
+  if (n_scans < 0 || (n_scans > 0 && (!ranges || !sensor_poses)))
+    return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "sharded map build: this rank's scans (count %d, ranges %p, poses %p)", n_scans,
+                     (const void*)ranges, (const void*)sensor_poses);
   return LSLAM_OK;
 }
 }  // namespace
@@ -198,13 +209,14 @@ int lslam_occgrid_create_sharded(lslam_context* ctx, const lslam_laser* laser, i
   *out = nullptr;
   lslam::Rccl& R = lslam::Rccl::get();
   if (!R.ok()) return ctx->fail(LSLAM_ERR_UNSUPPORTED, "%s", R.error.c_str());
-  int rc = sharded_args_ok(ctx, laser, n_scans, ranges, ranges_stride, sensor_poses, resolution);
-  if (rc) return rc;  // the same on every rank: nobody enters a collective
+  int rc = sharded_args_ok(ctx, laser, ranges_stride, resolution);
+  if (rc) return rc;  // arguments every rank shares: the same verdict everywhere, nobody enters a collective
   ncclComm_t comm = (ncclComm_t)nccl_comm;
   // ---- exchange 1: union of the boxes + "some rank failed" -----------------------------------------------------------
   std::string local_error;
   double box[4] = {1e300, 1e300, -1e300, -1e300};  // the identity of the union: what a rank contributes when it failed
-  int local_rc = lslam_occgrid_scan_bounds(ctx, laser, n_scans, ranges, ranges_stride, sensor_poses, box);
+  int local_rc = shard_args_local(ctx, n_scans, ranges, sensor_poses);
+  if (!local_rc) local_rc = lslam_occgrid_scan_bounds(ctx, laser, n_scans, ranges, ranges_stride, sensor_poses, box);
   if (local_rc) {
     local_error = ctx->last_error;
     box[0] = box[1] = 1e300;
@@ -283,7 +295,7 @@ int lslam_pool_occgrid_from_scans(lslam_pool* p, const lslam_laser* laser, int n
     return LSLAM_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   {  // what every shard shares, checked ONCE before any thread (or collective) starts
-    int rc = sharded_args_ok(p->ctx[0], laser, n_scans, ranges, ranges_stride, sensor_poses, resolution);
+    int rc = sharded_args_ok(p->ctx[0], laser, ranges_stride, resolution);
     if (rc) {
       p->last_error = lslam_last_error(p->ctx[0]);
       return rc;

@@ -416,13 +416,20 @@ int lslam_matcher_match_scan_cached(lslam_matcher* m, lslam_scan_cache* c, int n
   // Mapper.cpp:2040-2044) and, as the newest scan of the running window, be a base scan of the very next call: refresh
   // its world points + anchors at that pose BEHIND the match.  The host waits for the record only (the ticket the match's
   // last kernel posts), so the refresh overlaps the caller's own bookkeeping.
-  const bool speculate = (flags & LSLAM_MATCH_QUERY_TAKES_RESULT_POSE) && q_slot >= 0 && lds_ok;
-  if (speculate)
+  bool speculate = (flags & LSLAM_MATCH_QUERY_TAKES_RESULT_POSE) && q_slot >= 0 && lds_ok;
+  if (speculate) {
     launch(ctx, "cache_refresh", k_anchor_chain_list, dim3(1), dim3(n > 512 ? 1024 : 256), sc_anchor_lds(n), n, c->d_world,
            c->d_anchor, (const double*)c->d_ranges, (const CacheRefresh*)nullptr, (const lslam_match_result*)c->h_result,
            CacheRefresh{q_slot, 0, {0, 0, 0}}, c->g);
+    // a refresh that was never enqueued must not leave the slot marked as posed at the result: the next call would
+    // rasterise stale world points and anchors.  (The match itself is fine: its record is still delivered below.)
+    if (hipGetLastError() != hipSuccess) speculate = false;
+  }
   rc = wait_record(m);
-  if (rc) return rc;
+  if (rc) {  // the stream reported an error: nothing about the slot's pose can be trusted any more
+    if (q_slot >= 0) c->slots[(size_t)q_slot].posed = false;
+    return rc;
+  }
   *out = *c->h_result;
   c->n_matches++;
   if (speculate && out->status == LSLAM_OK) {
@@ -430,7 +437,8 @@ int lslam_matcher_match_scan_cached(lslam_matcher* m, lslam_scan_cache* c, int n
     s.posed = true;
     for (int k = 0; k < 3; k++) s.pose[k] = out->pose[k];
     c->n_speculated++;
-  } else if (q_slot >= 0 && !q_cached) {
+  } else if (q_slot >= 0 && ((flags & LSLAM_MATCH_QUERY_TAKES_RESULT_POSE) || !q_cached)) {
+    // a refresh that failed to launch (or a failed match) may have left the slot half-way: recomputed on next use
     c->slots[(size_t)q_slot].posed = false;
   }
   return LSLAM_OK;

@@ -91,6 +91,7 @@ constexpr int kRowZero = 64;  // k_resp_rows: row-load offset 0 = 64 zero guard 
 constexpr int kMaxBeamsPerLane = 32;  // k_resp_rows: 8 lanes x 32 beams x 255 < 2^16 (packed DPP reduce)
 constexpr int kOccMinScans = 8;      // smaller batches do not rebuild the row-occupancy bitmap for themselves
 constexpr int kTileMinWaves = 2048;  // below this the fine pass stays on k_resp_rows (beam slices fill the chip)
+constexpr int kPipeMinChunk = 256;   // lslam_matcher_match_batch, pipelined: no sub-batch smaller than this
 constexpr int kMaxGridSide = 32768;  // widthStep and height: dataSize <= 2^30, flat indices stay int32
 
 struct Lattice {  // per scan, per pass
@@ -1920,6 +1921,9 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
   __shared__ unsigned long long s_bal[NT / 64];
   const int s = blockIdx.x, tid = threadIdx.x;
   const Lattice& L = lat[s];
+  // (an inactive lattice belongs to an expansion pass that is not needed or to a fine pass behind a failed coarse one;
+  // final_out is only ever set for pass 0 of a match without either, whose lattice is always active -- so no record
+  // and no ticket is skipped here)
   if (!L.active) return;
   if (L.status != 0) {
     if (tid == 0) {
@@ -2973,6 +2977,31 @@ struct lslam_matcher {
   double* h_query = nullptr;
   lslam_match_result* h_result = nullptr;
   DevBuf<double> d_query, d_qpose;
+  // ---- pipelined steps (LSLAM_OPT_PIPELINE_DEPTH > 1) ----------------------------------------------------------------
+  // Consecutive batched matches take turns on `pipe_depth` internal streams, each with its OWN set of the workspaces a
+  // step writes between its first and its last kernel (StepWork), so that one step's latency-bound reduce kernels run
+  // under the next step's response kernels.  The grid and everything derived from it are shared and read-only while
+  // steps are in flight: whoever changes them joins the internal streams into the context stream first (pipe_join).
+  struct StepWork {
+    DevBuf<double2> d_local, d_cossin;
+    DevBuf<Lattice> d_lat;
+    DevBuf<CoarseOut> d_coarse;
+    DevBuf<int32_t> d_resp, d_tbl, d_part;
+    DevBuf<double> d_big;
+  };
+  static constexpr int kMaxPipe = 4;
+  int pipe_depth = 1;
+  int pipe_next = 0;                 // slot of the next pipelined step
+  bool pipe_in_step = false;         // match_batch_impl is running for a pipelined step (on a swapped-in stream)
+  bool pipe_registered = false;      // pipe_join is in the context's pre_sync list
+  hipStream_t pipe_stream[kMaxPipe] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t pipe_done[kMaxPipe] = {nullptr, nullptr, nullptr, nullptr};
+  bool pipe_pending[kMaxPipe] = {false, false, false, false};
+  hipEvent_t pipe_in = nullptr;      // the context stream at the moment a step was enqueued (inputs, grid changes)
+  hipEvent_t view_ready = nullptr;   // behind the last refresh of a grid view (parity planes, bitmap, tiles) by a step
+  int view_owner = -1;               // slot whose stream recorded view_ready (-1: none since the last join)
+  StepWork pipe_work[kMaxPipe];      // slot 0 is unused: it works in the members above
+  uint64_t pipe_steps = 0;           // pipelined steps enqueued so far (diagnostics)
 };
 
 namespace {
@@ -2983,6 +3012,29 @@ void trim_workspaces(lslam_matcher* m) {
   m->d_stats.trim(); m->d_ranges64.trim(); m->d_poses.trim(); m->d_local.trim(); m->d_world.trim(); m->d_valid.trim();
   m->d_fv_scratch.trim(); m->d_centres.trim(); m->d_lat.trim(); m->d_cossin.trim(); m->d_coarse.trim(); m->d_resp.trim();
   m->d_tbl.trim(); m->d_part.trim(); m->d_big.trim(); m->d_results.trim(); m->d_dbg.trim(); m->d_query.trim(); m->d_qpose.trim();
+  for (auto& w : m->pipe_work) {
+    w.d_local.trim(); w.d_cossin.trim(); w.d_lat.trim(); w.d_coarse.trim(); w.d_resp.trim(); w.d_tbl.trim(); w.d_part.trim(); w.d_big.trim();
+  }
+}
+
+// Order the context stream behind every pipelined step still in flight.  Cheap when there is none.  Called by whatever
+// is about to change the grid or a workspace, read a result on the context stream, or synchronise the context.
+int pipe_join(lslam_matcher* m) {
+  lslam_context* ctx = m->ctx;
+  for (int i = 0; i < lslam_matcher::kMaxPipe; i++)
+    if (m->pipe_pending[i]) {
+      LSLAM_HIP(ctx, hipStreamWaitEvent(ctx->stream, m->pipe_done[i], 0));
+      m->pipe_pending[i] = false;
+    }
+  m->view_owner = -1;  // the context stream is behind every refresh now, and every later step is behind it
+  return LSLAM_OK;
+}
+int pipe_join_cb(void* p) { return pipe_join((lslam_matcher*)p); }
+
+void swap_step_work(lslam_matcher* m, lslam_matcher::StepWork& w) {
+  std::swap(m->d_local, w.d_local); std::swap(m->d_cossin, w.d_cossin); std::swap(m->d_lat, w.d_lat);
+  std::swap(m->d_coarse, w.d_coarse); std::swap(m->d_resp, w.d_resp); std::swap(m->d_tbl, w.d_tbl);
+  std::swap(m->d_part, w.d_part); std::swap(m->d_big, w.d_big);
 }
 
 struct BusyGuard {
@@ -3018,15 +3070,7 @@ int wait_record(lslam_matcher* m) {
   lslam_context* ctx = m->ctx;
   if (m->done_armed) {
     m->done_armed = false;
-    const int want = m->done_ticket;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spins = 0;; spins++) {
-      if (__atomic_load_n(m->h_done, __ATOMIC_ACQUIRE) == want) return LSLAM_OK;
-      __builtin_ia32_pause();
-      if ((spins & 1023u) == 1023u &&
-          std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= 20)
-        break;
-    }
+    if (spin_for_ticket(m->h_done, m->done_ticket)) return LSLAM_OK;
   }
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return LSLAM_OK;
@@ -3054,6 +3098,10 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
                      int do_penalize, int do_refine, lslam_match_result* d_out,
                      int32_t* dbg_coarse_sums /*device, optional*/, int force_generic) {
   lslam_context* ctx = m->ctx;
+  if (!m->pipe_in_step) {  // a plain match shares the workspaces of slot 0 and the context stream with nobody
+    int jrc = pipe_join(m);
+    if (jrc) return jrc;
+  }
   Geom g = m->g;
   // what the last grid rebuild prepared for THIS match (streaming front-end); consumed here whatever path the match
   // takes, error returns included, so that no later match can find stale flags
@@ -3074,6 +3122,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   if (S <= 0) return LSLAM_OK;
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
   if (g.n_beams == 0) {
+    m->done_armed = false;  // k_result_no_readings posts no ticket: wait_record goes to the stream at once
     launch(ctx, "result_no_readings", k_result_no_readings, dim3((S + 255) / 256), dim3(256), 0, S,
            d_poses, m->cfg.coarse_angle_resolution, d_out);
     return LSLAM_OK;
@@ -3415,12 +3464,86 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   return LSLAM_OK;
 }
 
+// Streams and events of the pipelined steps, created on first use.
+int pipe_init(lslam_matcher* m) {
+  lslam_context* ctx = m->ctx;
+  if (!m->pipe_in) LSLAM_HIP(ctx, hipEventCreateWithFlags(&m->pipe_in, hipEventDisableTiming));
+  if (!m->view_ready) LSLAM_HIP(ctx, hipEventCreateWithFlags(&m->view_ready, hipEventDisableTiming));
+  for (int i = 0; i < m->pipe_depth; i++) {
+    if (!m->pipe_stream[i]) LSLAM_HIP(ctx, hipStreamCreateWithFlags(&m->pipe_stream[i], hipStreamNonBlocking));
+    if (!m->pipe_done[i]) LSLAM_HIP(ctx, hipEventCreateWithFlags(&m->pipe_done[i], hipEventDisableTiming));
+  }
+  if (!m->pipe_registered) {  // lslam_synchronize(ctx) means "every step is done" too
+    ctx->pre_sync.emplace_back((void*)m, &pipe_join_cb);
+    m->pipe_registered = true;
+  }
+  return LSLAM_OK;
+}
+
+// One batched match as a pipelined step: the same kernels with the same arguments as match_batch_impl on the context
+// stream -- only on the next internal stream, in that slot's own workspaces.  Ordering: behind everything the context
+// stream held when the call was made (inputs, grid changes) and behind the last refresh of a grid view by another
+// slot; NOT behind the previous steps -- that is the point.  The context stream itself falls in behind the steps at
+// the next pipe_join (lslam_synchronize, any entry point that touches the grid or reads through the context stream).
+template <typename RT>
+int pipe_step(lslam_matcher* m, int S, const RT* d_ranges, int stride, const double* d_poses, int do_penalize,
+              int do_refine, lslam_match_result* d_out) {
+  lslam_context* ctx = m->ctx;
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = pipe_init(m);
+  if (rc) return rc;
+  const int slot = m->pipe_next % m->pipe_depth;
+  m->pipe_next = (slot + 1) % m->pipe_depth;
+  hipStream_t s = m->pipe_stream[slot];
+  LSLAM_HIP(ctx, hipEventRecord(m->pipe_in, ctx->stream));
+  LSLAM_HIP(ctx, hipStreamWaitEvent(s, m->pipe_in, 0));
+  if (m->view_owner >= 0 && m->view_owner != slot) LSLAM_HIP(ctx, hipStreamWaitEvent(s, m->view_ready, 0));
+  const bool v0[4] = {m->sub_dirty, m->occ_dirty, m->tile_dirty, m->ptile_dirty};
+  const void* const a0[2] = {m->d_tiles, m->d_ptiles};
+  if (slot) swap_step_work(m, m->pipe_work[slot]);
+  hipStream_t saved = ctx->stream;
+  ctx->stream = s;  // launch(), the memsets and the timer events of match_batch_impl all go through ctx->stream
+  m->pipe_in_step = true;
+  rc = match_batch_impl<RT>(m, S, d_ranges, stride, d_poses, do_penalize, do_refine, d_out, nullptr, 0);
+  m->pipe_in_step = false;
+  ctx->stream = saved;
+  if (slot) swap_step_work(m, m->pipe_work[slot]);
+  // whatever was enqueued, failed call or not, is fenced by this slot's event
+  const bool refreshed = v0[0] != m->sub_dirty || v0[1] != m->occ_dirty || v0[2] != m->tile_dirty ||
+                         v0[3] != m->ptile_dirty || a0[0] != m->d_tiles || a0[1] != m->d_ptiles;
+  if (refreshed) {
+    LSLAM_HIP(ctx, hipEventRecord(m->view_ready, s));
+    m->view_owner = slot;
+  }
+  LSLAM_HIP(ctx, hipEventRecord(m->pipe_done[slot], s));
+  m->pipe_pending[slot] = true;
+  m->pipe_steps++;
+  return rc;
+}
+
+// The batched device entry points: a pipelined step when the option asks for it and nothing stands in the way (the
+// instrumented / experimental kernels keep counters in shared buffers; flags a grid rebuild left for the next plain
+// match belong to slot 0's buffers on the context stream).
+template <typename RT>
+int match_batch_dev_entry(lslam_matcher* m, int S, const RT* d_ranges, int stride, const double* d_poses, int do_penalize,
+                          int do_refine, lslam_match_result* d_out) {
+  if (S <= 0) return LSLAM_OK;
+  const bool piped = m->pipe_depth > 1 && !m->collect_stats && !m->lds_staged && !m->prep_done && !m->resp_prezeroed &&
+                     !m->arm_next && m->g.n_beams > 0;
+  if (piped) return pipe_step<RT>(m, S, d_ranges, stride, d_poses, do_penalize, do_refine, d_out);
+  return match_batch_impl<RT>(m, S, d_ranges, stride, d_poses, do_penalize, do_refine, d_out, nullptr, 0);
+}
+
 constexpr int kRebuildNeedsContiguous = 1;  // internal return code of rebuild_grid_dev (never crosses the ABI)
 // AddScans on the device (Mapper.cpp:699-748) from world points already resident in HBM:
 // recentre, clear, FindValidPoints, mark + smear.  `world` is a ring of `cap` scans of n points.
 int rebuild_grid_dev(lslam_matcher* m, const double2* d_world, int ring_start, int B, int cap, const double center[3],
                      const RebuildExtras* extras = nullptr) {
   lslam_context* ctx = m->ctx;
+  {  // pipelined steps still in flight read the grid this is about to rewrite
+    int jrc = pipe_join(m);
+    if (jrc) return jrc;
+  }
   Geom& g = m->g;
   // Mapper.cpp:212-220: offset = scanPose - 0.5*(roi-1)*resolution
   g.off_x = center[0] - (0.5 * (g.roi_w - 1) * (1.0 / g.scale));
@@ -3697,7 +3820,29 @@ int lslam_matcher_create(lslam_context* ctx, const lslam_matcher_config* cfg, co
 void lslam_matcher_destroy(lslam_matcher* m) {
   if (!m) return;
   (void)hipSetDevice(m->ctx->device);
+  (void)pipe_join(m);
   (void)hipStreamSynchronize(m->ctx->stream);
+  if (m->pipe_registered) {
+    auto& ps = m->ctx->pre_sync;
+    for (size_t i = 0; i < ps.size(); i++)
+      if (ps[i].first == (void*)m) {
+        ps.erase(ps.begin() + i);
+        break;
+      }
+  }
+  for (int i = 0; i < lslam_matcher::kMaxPipe; i++) {
+    if (m->pipe_stream[i]) {
+      (void)hipStreamSynchronize(m->pipe_stream[i]);
+      (void)hipStreamDestroy(m->pipe_stream[i]);
+    }
+    if (m->pipe_done[i]) (void)hipEventDestroy(m->pipe_done[i]);
+  }
+  if (m->pipe_in) (void)hipEventDestroy(m->pipe_in);
+  if (m->view_ready) (void)hipEventDestroy(m->view_ready);
+  for (auto& w : m->pipe_work) {
+    w.d_local.release(); w.d_cossin.release(); w.d_lat.release(); w.d_coarse.release(); w.d_resp.release();
+    w.d_tbl.release(); w.d_part.release(); w.d_big.release();
+  }
   (void)hipFree(m->d_grid_alloc);
   if (m->d_marks_alloc) (void)hipFree(m->d_marks_alloc);
   (void)hipFree(m->d_kernel);
@@ -3731,6 +3876,10 @@ int lslam_matcher_grid_info(const lslam_matcher* m, int32_t out[8], double offse
 int lslam_matcher_get_grid_u8(lslam_matcher* m, uint8_t* out) {
   if (!m || !out) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_context* ctx = m->ctx;
+  {
+    int jrc = pipe_join(m);
+    if (jrc) return jrc;
+  }
   LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_grid, (size_t)m->g.data_size, hipMemcpyDeviceToHost, ctx->stream));
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return LSLAM_OK;
@@ -3747,6 +3896,10 @@ int lslam_matcher_get_kernel_u8(lslam_matcher* m, uint8_t* out) {
 int lslam_matcher_set_grid_u8(lslam_matcher* m, const uint8_t* grid, const double offset_xy[2]) {
   if (!m || !grid || !offset_xy) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_context* ctx = m->ctx;
+  {
+    int jrc = pipe_join(m);  // steps in flight read the grid
+    if (jrc) return jrc;
+  }
   LSLAM_HIP(ctx, hipMemcpyAsync(m->d_grid, grid, (size_t)m->g.data_size, hipMemcpyHostToDevice, ctx->stream));
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
   m->g.off_x = offset_xy[0];
@@ -3758,6 +3911,10 @@ int lslam_matcher_set_grid_u8(lslam_matcher* m, const uint8_t* grid, const doubl
 int lslam_matcher_set_grid_u8_dev(lslam_matcher* m, const uint8_t* grid_dev, const double offset_xy[2]) {
   if (!m || !grid_dev || !offset_xy) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_context* ctx = m->ctx;
+  {
+    int jrc = pipe_join(m);  // steps in flight read the grid and its views
+    if (jrc) return jrc;
+  }
   if (grid_dev != m->d_grid)
     LSLAM_HIP(ctx, hipMemcpyAsync(m->d_grid, grid_dev, (size_t)m->g.data_size, hipMemcpyDeviceToDevice, ctx->stream));
   m->g.off_x = offset_xy[0];
@@ -3778,6 +3935,16 @@ int lslam_matcher_set_option(lslam_matcher* m, int option, int value) {
     case LSLAM_OPT_LDS_STAGED:
       m->lds_staged = value != 0;
       return LSLAM_OK;
+    case LSLAM_OPT_PIPELINE_DEPTH: {
+      if (value < 1 || value > lslam_matcher::kMaxPipe)
+        return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "pipeline depth %d outside [1, %d]", value, lslam_matcher::kMaxPipe);
+      LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+      int rc = pipe_join(m);  // steps in flight keep their slots; the next step starts a fresh rotation
+      if (rc) return rc;
+      m->pipe_depth = value;
+      m->pipe_next = 0;
+      return LSLAM_OK;
+    }
     case LSLAM_OPT_COLLECT_STATS:
       if (value) {
         LSLAM_HIP(ctx, hipSetDevice(ctx->device));
@@ -3791,6 +3958,14 @@ int lslam_matcher_set_option(lslam_matcher* m, int option, int value) {
       return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "unknown matcher option %d", option);
   }
 }
+
+int lslam_matcher_flush(lslam_matcher* m) {
+  if (!m) return LSLAM_ERR_INVALID_ARGUMENT;
+  LSLAM_HIP(m->ctx, hipSetDevice(m->ctx->device));
+  return pipe_join(m);
+}
+
+int64_t lslam_matcher_pipelined_steps(const lslam_matcher* m) { return m ? (int64_t)m->pipe_steps : 0; }
 
 int lslam_matcher_read_stats(lslam_matcher* m, uint64_t out[4]) {
   if (!m || !out) return LSLAM_ERR_INVALID_ARGUMENT;
@@ -3808,7 +3983,7 @@ int lslam_matcher_read_beam_stats(lslam_matcher* m, uint64_t out[4]) {
   if (!m || !out) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_context* ctx = m->ctx;
   out[0] = out[1] = out[2] = out[3] = 0;
-  if (!m->d_stats.p || m->stats_scans <= 0) return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "no instrumented coarse pass has run");
+  if (!m->d_stats.p || m->stats_scans <= 0) return LSLAM_OK;  // no instrumented coarse pass has run: nothing counted
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
   std::vector<uint32_t> flags((size_t)m->stats_scans * m->g.n_beams);
   LSLAM_HIP(ctx, hipMemcpyAsync(flags.data(), (const uint32_t*)(m->d_stats.p + 8), flags.size() * sizeof(uint32_t), hipMemcpyDeviceToHost,
@@ -3855,12 +4030,40 @@ int lslam_matcher_match_batch(lslam_matcher* m, int S, const double* ranges, int
   LSLAM_NOT_REENTRANT(m);
   lslam_context* ctx = m->ctx;
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
-  int rc = upload_scans(m, S, ranges, stride, poses);
+  int rc = pipe_join(m);
   if (rc) return rc;
+  const int n = m->g.n_beams, row = std::max(n, 1);
+  // pipelined: the batch goes through as `pipe_depth` sub-batches taking turns on the internal streams -- the upload of
+  // one runs under the kernels of the one before, and so do its latency-bound reduce kernels.  Same records: every
+  // scan is matched on its own against the same grid, whatever sub-batch it travels in.
+  int chunks = 1;
+  if (m->pipe_depth > 1 && !m->collect_stats && !m->lds_staged && n > 0)
+    chunks = std::max(1, std::min(m->pipe_depth, S / kPipeMinChunk));
   LSLAM_HIP(ctx, m->d_results.reserve(S));
-  rc = match_batch_impl<double>(m, S, m->d_ranges64.p, std::max(m->g.n_beams, 1), m->d_poses.p, do_penalize,
-                                do_refine, m->d_results.p, nullptr, 0);
-  if (rc) return rc;
+  if (chunks == 1) {
+    rc = upload_scans(m, S, ranges, stride, poses);
+    if (rc) return rc;
+    rc = match_batch_impl<double>(m, S, m->d_ranges64.p, row, m->d_poses.p, do_penalize, do_refine, m->d_results.p, nullptr, 0);
+    if (rc) return rc;
+  } else {
+    if (stride < n) return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "ranges_stride %d < num_beams %d", stride, n);
+    LSLAM_HIP(ctx, m->d_ranges64.reserve((size_t)S * row));
+    LSLAM_HIP(ctx, m->d_poses.reserve((size_t)S * 3));
+    for (int c = 0; c < chunks; c++) {
+      const int lo = (int)((long long)c * S / chunks), hi = (int)((long long)(c + 1) * S / chunks);
+      LSLAM_HIP(ctx, hipMemcpy2DAsync(m->d_ranges64.p + (size_t)lo * row, (size_t)n * sizeof(double), ranges + (size_t)lo * stride,
+                                      (size_t)stride * sizeof(double), (size_t)n * sizeof(double), hi - lo, hipMemcpyHostToDevice,
+                                      ctx->stream));
+      LSLAM_HIP(ctx, hipMemcpyAsync(m->d_poses.p + (size_t)lo * 3, poses + (size_t)lo * 3, (size_t)(hi - lo) * 3 * sizeof(double),
+                                    hipMemcpyHostToDevice, ctx->stream));
+      rc = pipe_step<double>(m, hi - lo, m->d_ranges64.p + (size_t)lo * row, row, m->d_poses.p + (size_t)lo * 3, do_penalize,
+                             do_refine, m->d_results.p + lo);
+      if (rc) break;
+    }
+    const int jrc = pipe_join(m);  // also after a failed sub-batch: nothing may stay in flight behind the caller's back
+    if (rc) return rc;
+    if (jrc) return jrc;
+  }
   LSLAM_HIP(ctx, hipMemcpyAsync(out, m->d_results.p, (size_t)S * sizeof(lslam_match_result), hipMemcpyDeviceToHost,
                                 ctx->stream));
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -3874,7 +4077,7 @@ int lslam_matcher_match_batch_dev_f32(lslam_matcher* m, int S, const float* rang
   if (!m || S < 0 || (S > 0 && (!ranges_dev || !poses_dev || !out_dev))) return LSLAM_ERR_INVALID_ARGUMENT;
   if (stride < m->g.n_beams) return m->ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "ranges_stride < num_beams");
   LSLAM_NOT_REENTRANT(m);
-  return match_batch_impl<float>(m, S, ranges_dev, stride, poses_dev, do_penalize, do_refine, out_dev, nullptr, 0);
+  return match_batch_dev_entry<float>(m, S, ranges_dev, stride, poses_dev, do_penalize, do_refine, out_dev);
 }
 
 int lslam_matcher_match_batch_dev_f64(lslam_matcher* m, int S, const double* ranges_dev, int stride,
@@ -3883,7 +4086,7 @@ int lslam_matcher_match_batch_dev_f64(lslam_matcher* m, int S, const double* ran
   if (!m || S < 0 || (S > 0 && (!ranges_dev || !poses_dev || !out_dev))) return LSLAM_ERR_INVALID_ARGUMENT;
   if (stride < m->g.n_beams) return m->ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "ranges_stride < num_beams");
   LSLAM_NOT_REENTRANT(m);
-  return match_batch_impl<double>(m, S, ranges_dev, stride, poses_dev, do_penalize, do_refine, out_dev, nullptr, 0);
+  return match_batch_dev_entry<double>(m, S, ranges_dev, stride, poses_dev, do_penalize, do_refine, out_dev);
 }
 
 int lslam_matcher_match_scan(lslam_matcher* m, int n_base, const double* base_ranges, int stride,
@@ -3948,7 +4151,9 @@ int lslam_matcher_debug_lookup_table(lslam_matcher* m, const double* ranges, con
   int na = n_angles_of(angle_offset, angle_res);
   *n_angles_out = na;
   if (!out || g.n_beams == 0) return LSLAM_OK;
-  int rc = upload_scans(m, 1, ranges, g.n_beams, pose);
+  int rc = pipe_join(m);  // slot 0's d_local is a step workspace
+  if (rc) return rc;
+  rc = upload_scans(m, 1, ranges, g.n_beams, pose);
   if (rc) return rc;
   LSLAM_HIP(ctx, m->d_local.reserve((size_t)g.n_beams));
   LSLAM_HIP(ctx, m->d_dbg.reserve((size_t)na * g.n_beams));

@@ -26,8 +26,8 @@ def all_gather_results(results, world: int):
     import torch
     import torch.distributed as dist
 
-    if world == 1:
-        return results
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return results  # (a process group of ONE still runs the collectives: how the 1-GPU box exercises the RCCL path)
     n_local = torch.tensor([results.shape[0]], dtype=torch.int64, device=results.device)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local)

@@ -359,12 +359,13 @@ def hector_points(ranges_f32: np.ndarray, laser: Laser, scale_to_map: float, min
     """
     r = np.asarray(ranges_f32, dtype=np.float32)
     a = (laser.angle_min + np.arange(len(r)) * laser.angle_increment).astype(np.float32)
-    x = (r * np.cos(a).astype(np.float32)).astype(np.float32)
-    y = (r * np.sin(a).astype(np.float32)).astype(np.float32)
-    d2 = x * x + y * y
-    ok = np.isfinite(r) & (d2 > np.float32(min_dist * min_dist)) & (d2 < np.float32(max_dist * max_dist))
-    ok &= ~((x < 0) & (d2 < np.float32(0.5)))
-    ok &= ~(d2 > np.float32(use_max * use_max))
+    with np.errstate(invalid="ignore"):  # a dropout is inf: inf * cos(pi/2) = nan, filtered like the node filters it
+        x = (r * np.cos(a).astype(np.float32)).astype(np.float32)
+        y = (r * np.sin(a).astype(np.float32)).astype(np.float32)
+        d2 = x * x + y * y
+        ok = np.isfinite(r) & (d2 > np.float32(min_dist * min_dist)) & (d2 < np.float32(max_dist * max_dist))
+        ok &= ~((x < 0) & (d2 < np.float32(0.5)))
+        ok &= ~(d2 > np.float32(use_max * use_max))
     pts = np.stack([x[ok], y[ok]], axis=1) * np.float32(scale_to_map)
     return np.ascontiguousarray(pts, dtype=np.float32)
 
@@ -390,8 +391,9 @@ def hector_project(ranges_f32: np.ndarray, laser: Laser, scale_to_map: float, mi
         ok &= ~(d2.astype(np.float64) > np.float64(f32(use_max)) ** 2)
     lx, ly, lz, yaw = (np.float64(f32(v)) for v in laser_pose)
     cy, sy = math.cos(yaw), math.sin(yaw)
-    bx = (cy * x.astype(np.float64) + (-sy) * y.astype(np.float64) + 0.0) + lx
-    by = (sy * x.astype(np.float64) + cy * y.astype(np.float64) + 0.0) + ly
+    with np.errstate(invalid="ignore"):  # rows the filters above dropped may hold inf / nan (0 * inf)
+        bx = (cy * x.astype(np.float64) + (-sy) * y.astype(np.float64) + 0.0) + lx
+        by = (sy * x.astype(np.float64) + cy * y.astype(np.float64) + 0.0) + ly
     zl = f32((0.0 + lz) - lz)
     ok &= bool(zl > f32(z_min) and zl < f32(z_max))
     s = f32(scale_to_map)

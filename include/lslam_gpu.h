@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LSLAM_ABI_VERSION 4
+#define LSLAM_ABI_VERSION 5
 
 typedef enum lslam_status {
   LSLAM_OK = 0,
@@ -155,7 +155,23 @@ void* lslam_matcher_grid_dev_ptr(lslam_matcher* m);
 /*  LSLAM_OPT_LDS_STAGED (default 0): 1 routes the coarse pass of chip-filling batches through the LDS-staged variant of
  *    the hot kernel (phase B reads its rows from per-drain patches of the parity planes staged in LDS): an experiment that
  *    was measured and dropped, kept selectable so the measurement can be repeated. */
-enum { LSLAM_OPT_ROW_OCCUPANCY = 1, LSLAM_OPT_COLLECT_STATS = 2, LSLAM_OPT_LDS_STAGED = 3 };
+/*  LSLAM_OPT_PIPELINE_DEPTH (default 1; 1..4): with depth D > 1 consecutive lslam_matcher_match_batch_dev_* calls become
+ *    PIPELINED STEPS: they take turns on D internal HIP streams, each with its own set of per-step workspaces, so the
+ *    latency-bound reduce kernels of one step run under the response kernels of the next (what small per-GPU batches
+ *    of a sharded run need: 512 scans/step 0.118 -> 0.086 ms on one MI355X).  Same kernels, same arguments, byte-identical
+ *    records.  A step is ordered behind everything the CONTEXT stream held when the call was made (inputs, grid
+ *    changes) but not behind the steps before it; the context stream falls in behind all steps at the next
+ *    lslam_synchronize / lslam_matcher_flush or any matcher entry point that touches the grid.  The caller's side of
+ *    the contract: up to D steps are in flight at once, so D consecutive calls must not share an output buffer whose
+ *    earlier contents are still wanted, and results are read after lslam_synchronize (or lslam_matcher_flush + work on
+ *    the context stream).  lslam_matcher_match_batch (host arrays) splits its batch into up to D sub-batches of >= 256
+ *    scans and pipelines those, uploads included; it returns with everything done, as before.  The reference has no
+ *    counterpart: karto::ScanMatcher is one grid, one lookup table, one caller (Mapper.h:1273-1278). */
+enum { LSLAM_OPT_ROW_OCCUPANCY = 1, LSLAM_OPT_COLLECT_STATS = 2, LSLAM_OPT_LDS_STAGED = 3, LSLAM_OPT_PIPELINE_DEPTH = 4 };
+/* Order the context stream behind every pipelined step in flight (no host wait).  No-op at depth 1. */
+int lslam_matcher_flush(lslam_matcher* m);
+/* diagnostics: pipelined steps enqueued so far (0 while LSLAM_OPT_PIPELINE_DEPTH is 1) */
+int64_t lslam_matcher_pipelined_steps(const lslam_matcher* m);
 int lslam_matcher_set_option(lslam_matcher* m, int option, int value);
 int lslam_matcher_read_stats(lslam_matcher* m, uint64_t out[4]);
 /* after an instrumented pass: out[0] = readable (scan, beam) pairs of that batch, out[1] = those with a live lattice row in

@@ -105,13 +105,27 @@ struct ResidentScan {
   kt_int32s unique_id;        // -1: provisional (cached as the query of Mapper::Process before AddScan numbered it)
   const kt_double* readings;  // LocalizedRangeScan::GetRangeReadings() at upload time
   uint64_t checksum;          // of the uploaded readings; re-checked once, when a provisional entry is adopted
+  uint64_t fingerprint;       // of kFingerprintSamples readings spread over the scan; re-checked on EVERY hit
+  uint64_t last_use;          // Residents::clock at the last hit (capacity bound: least recently used goes first)
 };
 struct Residents {
   lslam_laser laser;
   lslam_scan_cache* cache = nullptr;
   std::unordered_map<const karto::LocalizedRangeScan*, ResidentScan> scans;
   int64_t next_id = 0;
+  uint64_t clock = 0;
 };
+// HBM held per resident scan: readings + world points + anchors = 28 B per beam (30.3 KB at 1081 beams).  Without a bound
+// the cache grows with the Mapper's Dataset -- the same lifetime the reference gives its scans on the host.
+// $LSLAM_KARTO_CACHE_MAX_SCANS (default 0 = unbounded) evicts the least recently used entries beyond it; an evicted
+// scan is simply uploaded again when a later MatchScan names it.
+static size_t cache_capacity() {
+  static const size_t cap = [] {
+    const char* e = std::getenv("LSLAM_KARTO_CACHE_MAX_SCANS");
+    return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)0;
+  }();
+  return cap;
+}
 static std::vector<Residents>& residents() {
   static std::vector<Residents> r;
   return r;
@@ -127,6 +141,21 @@ static uint64_t checksum(const kt_double* r, int n) {
   for (int i = 0; i < n; i++) {
     uint64_t b;
     std::memcpy(&b, r + i, 8);
+    h = (h ^ b) * 1099511628211ull;
+  }
+  return h;
+}
+
+// An address, an id and a readings pointer can all come back after a Dataset freed its scans and allocated new ones
+// (ADVICE r04): a hit is therefore also held against a fingerprint of the CONTENTS -- 16 readings spread over the scan,
+// a few loads per base scan per call where the full checksum would cost more than the device call it guards.
+constexpr int kFingerprintSamples = 16;
+static uint64_t fingerprint(const kt_double* r, int n) {
+  uint64_t h = 1469598103934665603ull ^ (uint64_t)n;
+  if (n <= 0) return h;
+  for (int k = 0; k < kFingerprintSamples; k++) {
+    uint64_t b;
+    std::memcpy(&b, r + (size_t)((long long)k * (n - 1) / (kFingerprintSamples - 1)), 8);
     h = (h ^ b) * 1099511628211ull;
   }
   return h;
@@ -153,12 +182,30 @@ static ResidentScan* find_resident(Residents& R, karto::LocalizedRangeScan* s, i
   const kt_int32s uid = s->GetUniqueId();
   auto it = R.scans.find(s);
   if (uid < 0 || it == R.scans.end() || it->second.readings != rd) return nullptr;
-  if (it->second.unique_id == uid) return &it->second;
+  if (it->second.fingerprint != fingerprint(rd, nb)) return nullptr;  // same address, other contents: a recycled scan
+  if (it->second.unique_id == uid) {
+    it->second.last_use = ++R.clock;
+    return &it->second;
+  }
   if (it->second.unique_id < 0 && it->second.checksum == checksum(rd, nb) && lslam_scan_cache_contains(R.cache, it->second.id)) {
     it->second.unique_id = uid;  // (contains: a match that threw may have left the provisional entry without its readings)
+    it->second.last_use = ++R.clock;
     return &it->second;
   }
   return nullptr;
+}
+
+// capacity bound: drop the least recently used entries (never one touched at or after `keep_from`, i.e. by this call)
+static void evict_beyond_capacity(Residents& R, uint64_t keep_from) {
+  const size_t cap = cache_capacity();
+  while (cap && R.scans.size() > cap) {
+    auto victim = R.scans.end();
+    for (auto it = R.scans.begin(); it != R.scans.end(); ++it)
+      if (it->second.last_use < keep_from && (victim == R.scans.end() || it->second.last_use < victim->second.last_use)) victim = it;
+    if (victim == R.scans.end()) return;  // everything resident is in use by this call
+    lslam_scan_cache_forget(R.cache, victim->second.id);
+    R.scans.erase(victim);
+  }
 }
 
 // id of a MANAGED scan in the cache, uploading its readings on a miss
@@ -171,6 +218,8 @@ static int64_t resident_id(Residents& R, karto::LocalizedRangeScan* s, int nb) {
   e.unique_id = s->GetUniqueId();
   e.readings = rd;
   e.checksum = checksum(rd, nb);
+  e.fingerprint = fingerprint(rd, nb);
+  e.last_use = ++R.clock;
   int rc = lslam_scan_cache_put(R.cache, e.id, rd);
   if (rc != LSLAM_OK) throw std::runtime_error(std::string("lslam_scan_cache_put: ") + lslam_last_error(context()));
   R.scans[s] = e;
@@ -246,6 +295,18 @@ bool SyncCorrelationGrid(karto::ScanMatcher* pMatcher) {
 
 extern "C" long long lslam_karto_gpu_match_calls(void) { return lslam_karto::gpu_match_calls(); }
 extern "C" void lslam_karto_gpu_release(void) { lslam_karto::release_all(); }
+// The hook a caller that removes scans from its Dataset while the Mapper lives calls per scan (before freeing it): the
+// resident copy (28 B per beam of HBM) is dropped and the address may be reused at once.  Unknown scans are ignored.
+extern "C" void lslam_karto_gpu_forget_scan(const karto::LocalizedRangeScan* scan) {
+  using namespace lslam_karto;
+  std::lock_guard<std::mutex> lock(mutex());
+  for (Residents& R : residents()) {
+    auto it = R.scans.find(scan);
+    if (it == R.scans.end()) continue;
+    if (R.cache) lslam_scan_cache_forget(R.cache, it->second.id);
+    R.scans.erase(it);
+  }
+}
 // out[8] = device MatchScan calls, of which through the scan cache, matcher instances alive, resident scans,
 //          scans uploaded, (scan, pose) refreshes in front of a match, ns spent inside MatchScan, ns of those inside the
 //          lslam_matcher_match_scan[_cached] call (upload + kernels + wait).  Counters of matchers already destroyed are
@@ -409,6 +470,7 @@ kt_double ScanMatcher::MatchScan(LocalizedRangeScan* pScan, const LocalizedRange
   if (managed) {
     // ---- base scans by id; the query's readings go up once (or not at all) ----------------------------------------
     Residents& R = residents_for(laser);
+    const uint64_t call_clock = R.clock + 1;  // entries touched from here on are this call's: never evicted by it
     g.ids.resize(n_base);
     for (size_t i = 0; i < n_base; i++) g.ids[i] = resident_id(R, rBaseScans[i], nb);
     int flags = (doPenalize ? LSLAM_MATCH_PENALIZE : 0) | (doRefineMatch ? LSLAM_MATCH_REFINE : 0);
@@ -427,6 +489,8 @@ kt_double ScanMatcher::MatchScan(LocalizedRangeScan* pScan, const LocalizedRange
       e.unique_id = -1;
       e.readings = qr;
       e.checksum = checksum(qr, nb);
+      e.fingerprint = fingerprint(qr, nb);
+      e.last_use = ++R.clock;
       R.scans[pScan] = e;
       qid = e.id;
       if (lslam_scan_cache_contains(R.cache, qid)) lslam_scan_cache_forget(R.cache, qid);  // stale provisional entry
@@ -437,6 +501,7 @@ kt_double ScanMatcher::MatchScan(LocalizedRangeScan* pScan, const LocalizedRange
                                          flags, &r);
     if (rc != LSLAM_OK) throw std::runtime_error(std::string("lslam_matcher_match_scan_cached: ") + lslam_last_error(context()));
     g.cached_calls++;
+    evict_beyond_capacity(R, call_clock);
     if (process_call && r.status == LSLAM_OK) {
       // prepare the scan (world points + FindValidPoints anchors) at the pose AddEdges is about to give it, behind this
       // call: the kernel runs while the reference's host code (AddScan, AddEdges, the graph search) does

@@ -14,16 +14,25 @@ pytestmark = pytest.mark.gpu
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 
 
-def run_bench(tmp_path, gpus, extra=(), backend=None):
+def run_bench(tmp_path, gpus, extra=(), backend=None, env_extra=None, may_fail=False, timeout=600):
     out = tmp_path / f"res_{gpus}.npy"
     env = dict(os.environ)
-    env.pop("WORLD_SIZE", None)
-    env.pop("RANK", None)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LSLAM_BENCH_BACKEND", "LSLAM_BENCH_FORCE_DIST",
+              "LSLAM_BENCH_SHARE_GPU"):
+        env.pop(k, None)
     if backend:
         env["LSLAM_BENCH_BACKEND"] = backend
+    env.update(env_extra or {})
     cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "1", "--no-cpu",
            "--no-diagnostics", "--batch", "1024", "--dump-results", str(out), *extra]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired as e:
+        if may_fail:
+            return None, "timeout: " + str(e)[:200]
+        raise
+    if may_fail and p.returncode != 0:
+        return None, p.stderr
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout  # ONE JSON line, from rank 0 only
@@ -73,3 +82,42 @@ def test_weak_scaling_mode_and_gpu_count_check(tmp_path):
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n + 1), "--steps", "1"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "visible" in (p.stderr + p.stdout)
+
+
+def test_rccl_backend_on_the_one_gpu_box(tmp_path):
+    """The torch `nccl` (= RCCL) branch of bench.py, executed here before an 8-GPU node executes it: a process group of ONE
+    rank (LSLAM_BENCH_FORCE_DIST=1) runs init_process_group(backend="nccl", device_id=...), the barrier, the max-over-ranks
+    all_reduce, the device-tensor all_gather of the records and the --broadcast-grid broadcast + set_grid_dev install on
+    real RCCL.  Records byte-equal to the plain single-process run."""
+    one, r1 = run_bench(tmp_path, 1)
+    assert one["backend"] is None and one["rccl_ranks"] is None and len(one["devices"]) == 1
+    nc, rn = run_bench(tmp_path, 1, extra=("--broadcast-grid",), backend="nccl", env_extra={"LSLAM_BENCH_FORCE_DIST": "1"})
+    assert nc["backend"] == "nccl" and nc["rccl_ranks"] == 1 and nc["n_gpus"] == 1
+    assert nc["gather_ms"] is not None and len(nc["per_rank_ms_per_step"]) == 1
+    assert len(nc["devices"]) == 1 and "cuda:0" in nc["devices"][0]
+    assert nc["pipelined_records_identical"] is True and nc["pipeline_depth"] == 2
+    assert r1.tobytes() == rn.tobytes()
+
+
+def test_rccl_two_ranks_sharing_the_gpu(tmp_path):
+    """Two RCCL ranks on device 0 (LSLAM_BENCH_SHARE_GPU=1).  RCCL is entitled to refuse a communicator with a duplicate
+    GPU; when it does the test is skipped with its message, when it does not the sharded records must equal the
+    single-rank ones."""
+    two, r2 = run_bench(tmp_path, 2, backend="nccl", env_extra={"LSLAM_BENCH_SHARE_GPU": "1"}, may_fail=True, timeout=180)
+    if two is None:
+        tail = (r2 or "")[-1500:]
+        assert any(w in tail for w in ("Duplicate GPU", "duplicate", "invalid usage", "ncclInvalidUsage", "NCCL", "RCCL", "timeout")), tail
+        pytest.skip("RCCL refuses two ranks on one device: " + (tail.strip().splitlines() or ["?"])[-1][:200])
+    one, r1 = run_bench(tmp_path, 1)
+    assert two["backend"] == "nccl" and two["rccl_ranks"] == 2 and two["results_ok"] == 1024
+    assert r1.tobytes() == r2.tobytes()
+
+
+def test_pipelined_timed_region_equals_plain(tmp_path):
+    """--pipeline-depth 1 / 2 / 4: the timed region's records are the same bytes."""
+    base, r1 = run_bench(tmp_path, 1, extra=("--pipeline-depth", "1"))
+    for d in (2, 4):
+        j, r = run_bench(tmp_path, 1, extra=("--pipeline-depth", str(d), "--steps", "9"))
+        assert j["pipeline_depth"] == d and j["pipelined_records_identical"] is True
+        assert j["plain"]["ms_per_step"] > 0 and j["roofline"]["leg"].startswith("plain steps")
+        assert r.tobytes() == r1.tobytes()

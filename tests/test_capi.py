@@ -27,7 +27,7 @@ def test_header_symbols_are_exported():
 
 def test_abi_version_and_struct_sizes():
     L = api.lib()
-    assert L.lslam_abi_version() == 4
+    assert L.lslam_abi_version() == 5
     assert ctypes.sizeof(api.MatchResult) == 112  # 104 B padded to 112
     assert ctypes.sizeof(api.MatcherConfig) == 96
     assert ctypes.sizeof(api.LaserParams) == 72

@@ -1,0 +1,135 @@
+"""Pipelined steps (LSLAM_OPT_PIPELINE_DEPTH): consecutive batched matches on the matcher's internal streams, each with
+its own per-step workspaces, must produce the records of the plain, one-step-at-a-time matcher byte for byte -- whatever
+the depth, the batch size (the batch size selects different kernels), and whatever happens to the grid between steps.
+The reference has one matcher, one grid, one caller (Mapper.h:1273-1278); its answer for every scan is the plain one."""
+import numpy as np
+import pytest
+import torch
+
+from lslam_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _workload(n_query, seed=31):
+    return synth.make_match_workload(n_base=20, n_query=n_query, seed=seed, query_spread=2.0)
+
+
+def _dev(wl, n):
+    dev = torch.device("cuda", 0)
+    r = torch.from_numpy(np.ascontiguousarray(wl.query_ranges[:n].astype(np.float32))).to(dev)
+    p = torch.from_numpy(np.ascontiguousarray(wl.query_poses[:n])).to(dev)
+    return r, p
+
+
+def _plain(ctx, gm, r, p, n):
+    out = torch.zeros((n, 112), dtype=torch.uint8, device=r.device)
+    gm.set_option("pipeline_depth", 1)
+    gm.match_batch_dev(n, r.data_ptr(), r.shape[1], p.data_ptr(), out.data_ptr(), dtype="f32")
+    ctx.synchronize()
+    return out.cpu().numpy().copy()
+
+
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_pipelined_steps_equal_plain_steps(ctx, depth):
+    """Steps of different sizes in flight together: 40 scans (beam-sliced small-batch kernels), 300 (linear planes,
+    256-thread reduces), 2100 (tiled planes, narrow reduces, three fine angles per wave)."""
+    wl = _workload(2100)
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(wl.laser))
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    r, p = _dev(wl, 2100)
+    sizes = [2100, 40, 300, 2100, 300, 40, 40, 2100]
+    want = {n: _plain(ctx, gm, r, p, n) for n in sorted(set(sizes))}
+    assert (want[2100].view(api.RESULT_DTYPE)["status"] == 0).all()
+    gm.set_option("pipeline_depth", depth)
+    before = gm.pipelined_steps
+    outs = [torch.zeros((n, 112), dtype=torch.uint8, device=r.device) for n in sizes]
+    for n, o in zip(sizes, outs):
+        gm.match_batch_dev(n, r.data_ptr(), r.shape[1], p.data_ptr(), o.data_ptr(), dtype="f32")
+    ctx.synchronize()  # joins the internal streams, then waits
+    assert gm.pipelined_steps - before == len(sizes)
+    for n, o in zip(sizes, outs):
+        assert o.cpu().numpy().tobytes() == want[n].tobytes(), n
+    gm.close()
+
+
+def test_grid_change_between_pipelined_steps(ctx):
+    """A grid rebuild (AddScans) and a grid install (set_grid_dev) while steps are in flight: the steps before see the
+    old grid, the steps after the new one -- each equal to the plain matcher on that grid."""
+    wl = _workload(700, seed=32)
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(wl.laser))
+    r, p = _dev(wl, 700)
+    gm.AddScans(wl.base_ranges[:8], wl.base_poses[:8], wl.center_pose)
+    want_a = _plain(ctx, gm, r, p, 700)
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    want_b = _plain(ctx, gm, r, p, 700)
+    grid_b = torch.from_numpy(gm.GetCorrelationGrid().copy()).to(r.device)
+    off_b = gm.grid_info()["offset"]
+    assert want_a.tobytes() != want_b.tobytes()
+    gm.AddScans(wl.base_ranges[:8], wl.base_poses[:8], wl.center_pose)
+    gm.set_option("pipeline_depth", 2)
+    outs = [torch.zeros((700, 112), dtype=torch.uint8, device=r.device) for _ in range(6)]
+
+    def step(o):
+        gm.match_batch_dev(700, r.data_ptr(), r.shape[1], p.data_ptr(), o.data_ptr(), dtype="f32")
+
+    step(outs[0]); step(outs[1])
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)  # joins, rebuilds on the context stream
+    step(outs[2]); step(outs[3])
+    gm.AddScans(wl.base_ranges[:8], wl.base_poses[:8], wl.center_pose)
+    step(outs[4])
+    gm.set_grid_dev(grid_b.data_ptr(), off_b)  # joins; the views are refreshed by the next step, for both streams
+    step(outs[5])
+    ctx.synchronize()
+    got = [o.cpu().numpy().tobytes() for o in outs]
+    assert got[0] == got[1] == got[4] == want_a.tobytes()
+    assert got[2] == got[3] == got[5] == want_b.tobytes()
+    gm.close()
+
+
+def test_host_batch_is_split_into_pipelined_sub_batches(ctx, oracle_lib):
+    """lslam_matcher_match_batch at depth 2: 700 scans travel as two sub-batches; same records as depth 1, and both equal
+    to the oracle's for a sample of the scans."""
+    wl = _workload(700, seed=33)
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(wl.laser))
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    plain = gm.match_batch(wl.query_ranges, wl.query_poses)
+    gm.set_option("pipeline_depth", 2)
+    before = gm.pipelined_steps
+    piped = gm.match_batch(wl.query_ranges, wl.query_poses)
+    assert gm.pipelined_steps - before == 2
+    assert piped.tobytes() == plain.tobytes()
+    small = gm.match_batch(wl.query_ranges[:100], wl.query_poses[:100])  # below 2 x 256 scans: one plain step
+    assert small.tobytes() == plain[:100].tobytes()
+    port = oracle_lib.PortKarto(oracle_lib.default_cfg(), oracle_lib.laser_struct(wl.laser))
+    port.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    for q in (0, 349, 350, 699):
+        mean, cov, resp = port.match(wl.query_ranges[q], wl.query_poses[q])
+        assert np.abs(piped["pose"][q] - mean).max() <= 1e-9 and abs(piped["response"][q] - resp) <= 1e-12
+    gm.close()
+
+
+def test_other_entry_points_join_the_pipeline(ctx):
+    """A plain single-scan MatchScan, a grid download and an option change right behind pipelined steps: each is ordered
+    behind them (shared grid, slot 0's workspaces) and none disturbs their records."""
+    wl = _workload(600, seed=34)
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(wl.laser))
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    r, p = _dev(wl, 600)
+    want = _plain(ctx, gm, r, p, 600)
+    grid = gm.GetCorrelationGrid().copy()
+    gm.set_option("pipeline_depth", 2)
+    outs = [torch.zeros((600, 112), dtype=torch.uint8, device=r.device) for _ in range(3)]
+    for o in outs[:2]:
+        gm.match_batch_dev(600, r.data_ptr(), r.shape[1], p.data_ptr(), o.data_ptr(), dtype="f32")
+    assert np.array_equal(gm.GetCorrelationGrid(), grid)
+    gm.match_batch_dev(600, r.data_ptr(), r.shape[1], p.data_ptr(), outs[2].data_ptr(), dtype="f32")
+    gm.set_option("pipeline_depth", 1)  # joins
+    one = gm.match_batch(wl.query_ranges[:1], wl.query_poses[:1])
+    ctx.synchronize()
+    for o in outs:
+        assert o.cpu().numpy().tobytes() == want.tobytes()
+    assert one.tobytes() == want[:1].tobytes()
+    with pytest.raises(api.LslamError):
+        gm.set_option("pipeline_depth", 5)
+    gm.close()

@@ -44,7 +44,7 @@ def run(steps):
                             "--cpu-sample", "100"], env=env, capture_output=True, text=True)
         try:
             d = json.loads(r.stdout.strip().splitlines()[-1])
-            k = d["kernel_ms_per_step"]
+            k = d["kernel_ms_one_instrumented_plain_step"]
             print(f"{so.stem:24s} {d['value']:12.0f}/s  step {d['ms_per_step']:.4f} ms  coarse {k.get('resp_rows_coarse', 0):.4f}"
                   f"  fine {k.get('resp_tile_fine', k.get('resp_rows_fine', 0)):.4f}  err {d['cpu_baseline']['max_pose_err_vs_gpu']:.2e}")
         except Exception as e:  # noqa: BLE001
