@@ -493,11 +493,22 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
   const int occ_wph = occ_wpc >> 1;  // words per (column, row parity)
 
   for (int j0 = 0; j0 < pc.ny; j0 += NYC) {
+    // PEEL (the chip-filling variants): the accumulators are NOT zeroed -- phase A runs in two stages: until the first 64
+    // beams are queued nothing is drained (the accumulators are not even live), the FIRST drain then WRITES them
+    // (drain_as<true>: perm results stored, not added) and the second stage adds as before.  66 v_mov and 66 v_add fewer
+    // per wave than "zero, then always add" (profiles/r05/inst_budget_resp_rows.md).
+#if defined(LSLAM_EXP_NO_PEEL)  // A/B switch (tools/ab_variants.py): round 4's form
+    constexpr bool PEEL = false;
+#else
+    constexpr bool PEEL = EST;
+#endif
     uint32_t acc[NYC][NXD][2];
+    if constexpr (!PEEL) {
 #pragma unroll
-    for (int j = 0; j < NYC; j++)
+      for (int j = 0; j < NYC; j++)
 #pragma unroll
-      for (int k = 0; k < NXD; k++) acc[j][k][0] = acc[j][k][1] = 0u;
+        for (int k = 0; k < NXD; k++) acc[j][k][0] = acc[j][k][1] = 0u;
+    }
     // The lane index as this iteration sees it, opaque to the optimiser: everything derived from it (offsets of the first
     // point loads, LDS addresses of the epilogue) is then computed where it is used instead of being hoisted out of this
     // loop into registers that the kernel -- 66 accumulators in a 128-VGPR budget -- would have to spill to scratch.
@@ -508,7 +519,8 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(all_lanes, __builtin_amdgcn_mbcnt_lo(all_lanes, 0u));
 
     // Phase B: one queued beam per lane -- load the rows its mask names, accumulate 4 candidates per dword
-    auto drain = [&](int head, int cnt) {
+    auto drain_as = [&](auto first_drain, int head, int cnt) {
+      constexpr bool FIRST = decltype(first_drain)::value;
       const int2 e = lane < cnt ? queue[(head + lane) & (kQueue - 1)] : make_int2(0, 0);
       // dword-ALIGNED loads of NXD+1 words covering the row, realigned in registers: the planes and
       // widthStep are multiples of 4, so every row of a beam has the same byte phase
@@ -598,10 +610,18 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       for (int j = 0; j < NYC; j++)
 #pragma unroll
         for (int k = 0; k < NXD; k++) {
-          acc[j][k][0] += __builtin_amdgcn_perm(wv[j][k + 1], wv[j][k], sel_e);  // candidates 4k, 4k+2
-          acc[j][k][1] += __builtin_amdgcn_perm(wv[j][k + 1], wv[j][k], sel_o);  // candidates 4k+1, 4k+3
+          const uint32_t pe = __builtin_amdgcn_perm(wv[j][k + 1], wv[j][k], sel_e);  // candidates 4k, 4k+2
+          const uint32_t po = __builtin_amdgcn_perm(wv[j][k + 1], wv[j][k], sel_o);  // candidates 4k+1, 4k+3
+          if constexpr (FIRST) {
+            acc[j][k][0] = pe;
+            acc[j][k][1] = po;
+          } else {
+            acc[j][k][0] += pe;
+            acc[j][k][1] += po;
+          }
         }
     };
+    auto drain = [&](int head, int cnt) { drain_as(std::false_type{}, head, cnt); };
 
     // Phase A: every beam -- table entry, row mask (bounds + exact row occupancy); survivors are queued.
     // The lattice lies inside the grid (k_pass_setup) and the grid has <= 2^30 cells, so for a beam whose
@@ -685,8 +705,8 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       }
       return c;
     };
-    auto emit = [&](auto two_blocks, int bA, bool validA, bool smallA, int gxA, int gyA, int bB, bool validB, bool smallB,
-                    int gxB, int gyB) {
+    auto enqueue = [&](auto two_blocks, int bA, bool validA, bool smallA, int gxA, int gyA, int bB, bool validB, bool smallB,
+                       int gxB, int gyB) {
       constexpr bool TWO = decltype(two_blocks)::value;  // false: block B does not exist (single-block callers)
       Cell cA = cell_of(validA, smallA, gxA, gyA), cB{0u, 0u, 0u, 0u, 0, false};
       if constexpr (TWO) cB = cell_of(validB, smallB, gxB, gyB);
@@ -731,6 +751,9 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
         qcount += __popcll(votesB);
       }
       __syncthreads();
+    };
+    auto drain_ready = [&](auto two_blocks) {
+      constexpr bool TWO = decltype(two_blocks)::value;
       if (qcount >= 64) {
         drain(qhead, 64);
         qhead = (qhead + 64) & (kQueue - 1);
@@ -743,6 +766,11 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
           qcount -= 64;
         }
       }
+    };
+    auto emit = [&](auto two_blocks, int bA, bool validA, bool smallA, int gxA, int gyA, int bB, bool validB, bool smallB,
+                    int gxB, int gyB) {
+      enqueue(two_blocks, bA, validA, smallA, gxA, gyA, bB, validB, smallB, gxB, gyB);
+      drain_ready(two_blocks);
     };
     // one block of beams on the estimate: cell, and whether the estimate decides it -- otherwise the beam is parked
     int acount = 0;
@@ -792,7 +820,9 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
     };
     if constexpr (EST) {
       float2 pA_next = point_f(64 * slice + lane), pB_next = point_f(64 * slice + bstride + lane);
-      for (int b0 = 64 * slice, it = 0; b0 < g.n_beams; b0 += 2 * bstride, it += 2) {
+      int b0 = 64 * slice, it = 0;
+      // one iteration of phase A up to the queue push (two blocks of 64 beams)
+      auto two_blocks_in = [&]() {
         const int bA = b0 + lane, bB = bA + bstride;
         const float2 pA = pA_next, pB = pB_next;  // fetched an iteration ahead: the latency hides behind this one's arithmetic
         pA_next = point_f(bA + 2 * bstride);
@@ -801,7 +831,35 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
         int gxA, gyA, gxB, gyB;
         estimate(it, pA, bA < g.n_beams, validA, gxA, gyA);
         estimate(it + 1, pB, bB < g.n_beams, validB, gxB, gyB);
-        emit(std::true_type{}, bA, validA, true, gxA, gyA, bB, validB, true, gxB, gyB);
+        enqueue(std::true_type{}, bA, validA, true, gxA, gyA, bB, validB, true, gxB, gyB);
+        b0 += 2 * bstride;
+        it += 2;
+      };
+      // stage 1: nothing to drain yet -- the accumulators do not exist
+      if constexpr (PEEL) {
+        while (b0 < g.n_beams && qcount < 64) two_blocks_in();
+        // the first drain writes them (a partial one when the scan ran out first; zeros when nothing is queued)
+        const int c = min(qcount, 64);
+        if (c > 0) {
+          drain_as(std::true_type{}, qhead, c);
+          qhead = (qhead + c) & (kQueue - 1);
+          qcount -= c;
+        } else {
+#pragma unroll
+          for (int j = 0; j < NYC; j++)
+#pragma unroll
+            for (int k = 0; k < NXD; k++) acc[j][k][0] = acc[j][k][1] = 0u;
+        }
+        if (qcount >= 64) {  // the iteration that crossed 64 may have brought in up to 128
+          drain(qhead, 64);
+          qhead = (qhead + 64) & (kQueue - 1);
+          qcount -= 64;
+        }
+      }
+      // stage 2: as before
+      while (b0 < g.n_beams) {
+        two_blocks_in();
+        drain_ready(std::true_type{});
       }
       for (int a0 = 0; a0 < acount; a0 += 64) {
         const bool valid = a0 + lane < acount;
@@ -856,7 +914,13 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
           uint32_t v = acc[j][k][q];
           v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
           v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-          v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+          // row_half_mirror; written as the fused DPP add the compiler emits for the two steps above but not for this one
+          // (it used v_mov_b32_dpp + v_add_u32: one VALU instruction more per accumulator, 66 per wave)
+#if defined(LSLAM_EXP_NO_FUSED_DPP)  // A/B switch: round 4's form
+          v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);
+#else
+          asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v));
+#endif
           if ((lane & 7) == 0) red[(j * NXD + k) * 2 + q][lane >> 3] = v;
         }
     __syncthreads();
@@ -926,7 +990,10 @@ k_tile4(const uint8_t* __restrict__ grid, int stride, int data_size, uint4* __re
 // gather unit 85 % busy; the coalesced 16-byte-per-lane point load is charged about as much as the block gather): the
 // angles share the point load, and their block gathers are independent loads in flight together.  Measured per 4096-scan launch: 1 angle per wave
 // 119 us, 2: 96, 3: 92, 4: 95; below ~1000 scans one angle per wave (more waves) is the faster form (256 scans: 14 vs 22 us).
-constexpr int kTile3ManyAngles = 3, kTile3ManyMinScans = 1536;
+#if !defined(LSLAM_TUNE_TILE3_MIN)
+#define LSLAM_TUNE_TILE3_MIN 1536
+#endif
+constexpr int kTile3ManyAngles = 3, kTile3ManyMinScans = LSLAM_TUNE_TILE3_MIN;
 template <int kTile3Angles>
 __global__ void __launch_bounds__(64)
 k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc, const Lattice* __restrict__ lat,
@@ -1053,7 +1120,10 @@ k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc,
 // Mapper.cpp:841-845.
 // ------------------------------------------------------------------------------------------
 constexpr int kPosChunk = 16;
-constexpr int kReduceNarrowMinScans = 2048;  // batches from here on run k_reduce_coarse_lds with 128-thread blocks
+#if !defined(LSLAM_TUNE_REDUCE_NARROW_MIN)
+#define LSLAM_TUNE_REDUCE_NARROW_MIN 2048
+#endif
+constexpr int kReduceNarrowMinScans = LSLAM_TUNE_REDUCE_NARROW_MIN;  // batches from here on run k_reduce_coarse_lds with 128-thread blocks
 // one work item = (angle a, chunk c of 16 lattice positions) of one scan, done by one wave
 __device__ __forceinline__ void generic_item(const uint8_t* __restrict__ grid, const Geom& g, const PassCfg& pc,
                                              const Lattice& L, const double2* __restrict__ lp, int32_t* r, int a,

@@ -40,15 +40,26 @@ def build(specs):
 def run(steps):
     for so in sorted(VDIR.glob("*.so")):
         env = dict(os.environ, LSLAM_GPU_LIB=str(so))
-        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", str(steps), "--warmup", "2",
-                            "--cpu-sample", "100"], env=env, capture_output=True, text=True)
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", str(steps), "--warmup", "5", "--cpu-sample", "256",
+                            "--no-secondary", "--no-diagnostics", "--sustained-s", "0", "--plain-steps", str(steps)],
+                           env=env, capture_output=True, text=True)
         try:
             d = json.loads(r.stdout.strip().splitlines()[-1])
             k = d["kernel_ms_one_instrumented_plain_step"]
-            print(f"{so.stem:24s} {d['value']:12.0f}/s  step {d['ms_per_step']:.4f} ms  coarse {k.get('resp_rows_coarse', 0):.4f}"
+            print(f"{so.stem:24s} {d['value']:12.0f}/s  step {d['ms_per_step']:.4f} ms  plain {d['plain']['ms_per_step']:.4f} ms  "
+                  f"coarse(events, plain leg) {d['roofline']['avg_launch_ms']:.4f}  coarse(1 step) {k.get('resp_rows_coarse', 0):.4f}"
                   f"  fine {k.get('resp_tile_fine', k.get('resp_rows_fine', 0)):.4f}  err {d['cpu_baseline']['max_pose_err_vs_gpu']:.2e}")
         except Exception as e:  # noqa: BLE001
             print(so.stem, "FAILED", e, r.stderr[-400:])
+        # the small per-GPU batch of an 8-GPU strong-scaling run, pipelined (depth 2) and plain
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "400", "--warmup", "20", "--batch", "512", "--no-cpu",
+                            "--no-secondary", "--no-diagnostics", "--sustained-s", "0", "--plain-steps", "400"],
+                           env=env, capture_output=True, text=True)
+        try:
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            print(f"{'':24s} batch 512: pipelined {d['ms_per_step']:.4f} ms  plain {d['plain']['ms_per_step']:.4f} ms  ok {d['results_ok']}")
+        except Exception as e:  # noqa: BLE001
+            print(so.stem, "batch 512 FAILED", e, r.stderr[-400:])
 
 
 if __name__ == "__main__":
