@@ -314,6 +314,8 @@ def gpu_cfg2(ctx, api, d):
     ctx.upload(d_all, allpts)
     bmap = api.OccGridMap(ctx, n, n, cell, off)
     bmap.setUpdateOccupiedFactor(0.9)
+    # points resident in HBM: the host never sees them, so it is told what the node knows -- no point beyond use_max = 20 m
+    bmap.set_option("batch_radius_cells", int(np.ceil(20.0 / cell)) + 1)
     bmap.updateByScans_dev(d_all, counts[:64], (0.0, 0.0), d["poses"][:64])  # allocates the byte planes
     bmap.reset()
     ctx.synchronize()
@@ -328,10 +330,11 @@ def gpu_cfg2(ctx, api, d):
     ctx.synchronize()
     ctx.profile(False)
     batch_prof = ctx.profile_read()
+    batch_stats = bmap.batch_stats()
     ctx.free(d_all)
     bmap.close()
     return {"single_s": single_s, "single_sha": single_sha, "single_prof": single_prof, "batch_s": batch_s,
-            "batch_sha": batch_sha, "batch_prof": batch_prof, "points": int(counts.sum())}
+            "batch_sha": batch_sha, "batch_prof": batch_prof, "points": int(counts.sum()), "batch_stats": batch_stats}
 
 
 def gpu_cfg3(ctx, api, d):
@@ -657,6 +660,11 @@ def build_secondary(gpu, cpu, job, args):
                 "kernel_algorithmic_GBs": round(alg / k_batch / 1e9, 2) if k_batch else None,
                 "measured_hbm_bytes_per_64_scan_call": tr.get("hbm_bytes_per_launch"),
                 "measured_hbm_source": tr.get("source"),
+                # the call's scratch: per-scan windows of 8x8-cell tiles in a slot pool (+ 64 flag bytes per tile), not 64
+                # byte planes of the whole map; `rounds` = passes the last 64-scan group needed under the budget
+                "scratch_bytes": g.get("batch_stats", {}).get("scratch_bytes"),
+                "scratch_rounds": g.get("batch_stats", {}).get("rounds"),
+                "window_misses": g.get("batch_stats", {}).get("window_misses"),
                 "bit_exact_vs_cpu": g["batch_sha"] == c["map_sha"]},
             "cpu": {"scans_per_s": round(c["scans_per_s"], 1), "kind": c["kind"], "cores": 1,
                     "restated_oracle_scans_per_s": round(c["port_scans_per_s"], 1), "reference_equals_restatement": c.get("ref_equals_port")},
@@ -665,6 +673,7 @@ def build_secondary(gpu, cpu, job, args):
         roof["cfg2_single_scans_per_s"] = out["cfg2"]["single_scan_per_call"]["scans_per_s"]
         roof["cfg2_batched_frac_of_hbm"] = out["cfg2"]["batched_64_per_call"]["frac_of_hbm_peak"]
         roof["cfg2_batched_scans_per_s"] = out["cfg2"]["batched_64_per_call"]["scans_per_s"]
+        roof["cfg2_batched_scratch_bytes"] = out["cfg2"]["batched_64_per_call"]["scratch_bytes"]
         roof["cfg2_bit_exact"] = bool(g["single_sha"] == c["map_sha"] and g["batch_sha"] == c["map_sha"])
         cpus["cfg2_scans_per_s"] = round(c["scans_per_s"], 1)
         cpus["cfg2_kind"] = c["kind"]

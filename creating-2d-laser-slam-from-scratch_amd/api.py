@@ -296,6 +296,7 @@ def lib() -> C.CDLL:
     L.lslam_map_match_data.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     L.lslam_map_cached_points.argtypes = [vp]
     L.lslam_map_set_option.argtypes = [vp, i32, i32]
+    L.lslam_map_batch_stats.argtypes = [vp, vp]
     L.lslam_map_read_logodds.argtypes = [vp, i32, vp]
     L.lslam_map_read_occupancy_i8.argtypes = [vp, i32, vp]
     L.lslam_map_flush.argtypes = [vp]
@@ -1034,7 +1035,14 @@ class OccGridMap:
 
     def set_option(self, name: str, value: int):
         """'ordered_sums': matchData adds its sums in point order (bit-equal to the CPU restatement) instead of in parallel."""
-        self.ctx.check(self.L.lslam_map_set_option(self.h, {"ordered_sums": 1}[name], int(value)))
+        self.ctx.check(self.L.lslam_map_set_option(self.h, {"ordered_sums": 1, "batch_scratch_mb": 2, "batch_radius_cells": 3}[name],
+                                                   int(value)))
+
+    def batch_stats(self) -> dict:
+        """Scratch of the batched update: bytes held, rounds of the last batch, cells outside their window (must be 0), budget."""
+        out = (C.c_int64 * 4)()
+        self.ctx.check(self.L.lslam_map_batch_stats(self.h, out))
+        return {"scratch_bytes": int(out[0]), "rounds": int(out[1]), "window_misses": int(out[2]), "budget_bytes": int(out[3])}
 
     def cached_points(self) -> int:
         return self.L.lslam_map_cached_points(self.h)

@@ -308,18 +308,30 @@ k_logodds_pipe_ml(PipeJobs J) {
 //                      walks ONLY the planes that touched the tile, in scan order, and applies
 //                      +free / [(v+free)-free] +occ-if-<50, the float sequence of the sequential reference
 //                      (H/map/OccGridMapBase.h:302-330).
-// Layout: planes and flags are TILED -- cell (x, y) of plane s is byte s*plane_bytes + tile*64 + (y&7)*8 + (x&7)
-// with tile = (y>>3)*tiles_x + (x>>3): 64 consecutive cells of a ray lie in ~8 tiles (eight 64-byte lines)
-// whichever way the ray runs, instead of 1 line for an x-major and 64 for a y-major ray in a row-major plane; and
-// flags[tile][s] (64 bytes per tile) is what lets the apply pass skip the ~90 % of (tile, scan) pairs no ray went
-// through.  Plane and flag bytes carry a 6-bit batch epoch, so they are cleared once per 63 batches, not per batch.
-// HBM-bound byte work; no atomics on the traversal path.
+// Layout: the byte planes are TILED and WINDOWED.  A tile is 8x8 cells = one 64-byte line, so 64 consecutive cells of a
+// ray lie in ~8 lines whichever way the ray runs (instead of 1 line for an x-major and 64 for a y-major ray in a
+// row-major plane).  Scan s does not own a plane of the whole map but a WINDOW of tiles -- the square of tiles its rays
+// can reach from its begin cell (host: begin cell +- the scan's longest point, ScanHdr::tx0 / ty0 / tw / th) -- stored
+// densely in a slot pool: cell (x, y) of scan s is byte
+//     pool[(base_s + (y>>3 - ty0_s) * tw_s + (x>>3 - tx0_s)) * 64 + (y&7)*8 + (x&7)].
+// A 1081-beam scan with 20 m of range on a 0.025 m map owns 202 x 202 tiles = 2.6 MB whatever the size of the map (a
+// plane of a 4000 x 4000 map is 16 MB, of an 8000 x 8000 map 64 MB); a window clipped by a small map IS the plane.
+// The scans of a call are cut into ROUNDS whose windows fit the scratch budget (LSLAM_MAP_OPT_BATCH_SCRATCH_MB,
+// default 192 MB): normally one.  flags[tile][s] (64 bytes per tile) is what lets the apply pass skip the ~90 % of
+// (tile, scan) pairs no ray went through.  Pool and flag bytes carry a 6-bit round epoch, so they are cleared once per
+// 63 rounds, not per batch.  HBM-bound byte work; no atomics on the traversal path.
 // ------------------------------------------------------------------------------------------
 struct ScanHdr {     // one scan of a batch on one pyramid level (host-computed like LevelGeom)
   float c, s, tx, ty;
   int bx, by;        // begin cell
   int n, pts_off;    // points of this scan: pts[2*(pts_off + i)]
+  // the scan's window of tiles (clipped to the map; tw = 0: nothing of it is inside) and its first tile slot in the pool:
+  // one aligned 16-byte record at offset 32, which k_lo_batch_apply reads with one vector load (lane = scan)
+  int tx0, ty0, tw;
+  uint32_t base;     // < 2^26: byte offsets into the pool stay below 2^32
+  int th, pad[3];
 };
+static_assert(sizeof(ScanHdr) == 64, "ScanHdr: 64 bytes, window record at offset 32");
 struct BatchGeom {
   int sx, sy, K;
   int tiles_x, n_tiles;
@@ -340,10 +352,18 @@ __device__ __forceinline__ Line batch_line(const BatchGeom& g, const ScanHdr& h,
 __device__ __forceinline__ uint32_t hash_slot0(uint32_t cell, uint32_t mask) { return (cell * 2654435761u) >> 7 & mask; }
 __device__ __forceinline__ uint32_t tile_of(const BatchGeom& g, int x, int y) { return (uint32_t)((y >> 3) * g.tiles_x + (x >> 3)); }
 __device__ __forceinline__ uint32_t in_tile(int x, int y) { return (uint32_t)(((y & 7) << 3) | (x & 7)); }
+// byte offset of cell (x, y) in the window of scan h; false when the cell lies outside it (a point farther from the
+// begin cell than the radius the host was given: counted in `misses`, never written -- nothing outside a window exists)
+__device__ __forceinline__ bool window_off(const ScanHdr& h, int x, int y, uint32_t& off) {
+  const unsigned wx = (unsigned)((x >> 3) - h.tx0), wy = (unsigned)((y >> 3) - h.ty0);
+  off = ((h.base + wy * (unsigned)h.tw + wx) << 6) + in_tile(x, y);  // 32-bit: the host keeps a round below 2^26 slots
+  return wx < (unsigned)h.tw && wy < (unsigned)h.th;
+}
 
 __global__ void __launch_bounds__(256)
-k_lo_batch_hits(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __restrict__ pts, uint8_t* __restrict__ planes,
-                uint8_t* __restrict__ flags, uint32_t* __restrict__ hkey, uint32_t* __restrict__ hhit) {
+k_lo_batch_hits(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __restrict__ pts, uint8_t* __restrict__ pool,
+                uint8_t* __restrict__ flags, uint32_t* __restrict__ hkey, uint32_t* __restrict__ hhit,
+                unsigned long long* __restrict__ misses) {
   const int sidx = blockIdx.y;
   const ScanHdr h = hdr[sidx];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -352,7 +372,12 @@ k_lo_batch_hits(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __res
   if (!l.valid) return;
   const uint32_t cell = (uint32_t)(l.y1 * g.sx + l.x1);
   const uint32_t t = tile_of(g, l.x1, l.y1);
-  planes[((size_t)sidx * g.n_tiles + t) * 64 + in_tile(l.x1, l.y1)] = (uint8_t)(g.tag | kCodeHit);
+  uint32_t off;
+  if (!window_off(h, l.x1, l.y1, off)) {
+    atomicAdd(misses, 1ull);
+    return;
+  }
+  pool[off] = (uint8_t)(g.tag | kCodeHit);
   flags[(size_t)t * kBatchSlots + sidx] = (uint8_t)(g.tag | 1u);
   const size_t hb = (size_t)sidx * (g.hash_mask + 1);
   uint32_t slot = hash_slot0(cell, g.hash_mask);
@@ -368,8 +393,9 @@ k_lo_batch_hits(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __res
 // returns a value, and a returning device-scope atomic is executed at the memory side -- a microsecond-class round trip
 // per probe; in LDS it is a few dozen cycles.  The finished table is written out with plain stores for k_lo_batch_rays.
 __global__ void __launch_bounds__(1024)
-k_lo_batch_hits_lds(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __restrict__ pts, uint8_t* __restrict__ planes,
-                    uint8_t* __restrict__ flags, uint32_t* __restrict__ hkey, uint32_t* __restrict__ hhit) {
+k_lo_batch_hits_lds(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __restrict__ pts, uint8_t* __restrict__ pool,
+                    uint8_t* __restrict__ flags, uint32_t* __restrict__ hkey, uint32_t* __restrict__ hhit,
+                    unsigned long long* __restrict__ misses) {
   extern __shared__ uint32_t sh_hash[];
   const uint32_t slots = g.hash_mask + 1;
   uint32_t* key = sh_hash;
@@ -383,7 +409,12 @@ k_lo_batch_hits_lds(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* _
     if (!l.valid) continue;
     const uint32_t cell = (uint32_t)(l.y1 * g.sx + l.x1);
     const uint32_t t = tile_of(g, l.x1, l.y1);
-    planes[((size_t)sidx * g.n_tiles + t) * 64 + in_tile(l.x1, l.y1)] = (uint8_t)(g.tag | kCodeHit);
+    uint32_t off;
+    if (!window_off(h, l.x1, l.y1, off)) {
+      atomicAdd(misses, 1ull);
+      continue;
+    }
+    pool[off] = (uint8_t)(g.tag | kCodeHit);
     flags[(size_t)t * kBatchSlots + sidx] = (uint8_t)(g.tag | 1u);
     uint32_t slot = hash_slot0(cell, g.hash_mask);
     for (;;) {
@@ -403,14 +434,13 @@ k_lo_batch_hits_lds(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* _
 
 constexpr int kRayBeamsPerWave = 4;  // consecutive beams one wave walks: fewer, longer waves (dispatch-rate bound otherwise)
 __global__ void __launch_bounds__(256)
-k_lo_batch_rays(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __restrict__ pts, uint8_t* __restrict__ planes,
+k_lo_batch_rays(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __restrict__ pts, uint8_t* __restrict__ pool,
                 uint8_t* __restrict__ flags, const uint32_t* __restrict__ hkey, uint32_t* __restrict__ hcross, int groups_per_scan) {
   const int lane = threadIdx.x & 63;
   const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave index = scan * groups_per_scan + beam group
   const int sidx = w / groups_per_scan, grp = w - sidx * groups_per_scan;
   if (sidx >= g.K) return;
   const ScanHdr h = hdr[sidx];
-  uint8_t* plane = planes + (size_t)sidx * g.n_tiles * 64;
   const uint32_t crossed = g.tag | kCodeCrossed, hit = g.tag | kCodeHit;
   const size_t hb = (size_t)sidx * (g.hash_mask + 1);
   for (int i = grp * kRayBeamsPerWave; i < min(h.n, (grp + 1) * kRayBeamsPerWave); i++) {
@@ -437,7 +467,11 @@ k_lo_batch_rays(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __res
       const int x = l.x0 + (xmajor ? (int)c * sgx : (int)q * sgx);
       const int y = l.y0 + (xmajor ? (int)q * sgy : (int)c * sgy);
       const uint32_t t = tile_of(g, x, y);
-      const size_t off = (size_t)t * 64 + in_tile(x, y);
+      uint32_t off;
+      if (!window_off(h, x, y, off)) {  // (the end cell of this beam is outside too: k_lo_batch_hits counted it)
+        continue;
+      }
+      uint8_t* plane = pool;  // (the window's bytes: `off` is an offset into the pool)
       const uint32_t b = plane[off];
       if (b == hit) {  // some beam of this scan ends here: remember the first beam that crosses it
         const uint32_t cell = (uint32_t)(y * g.sx + x);
@@ -456,8 +490,8 @@ k_lo_batch_rays(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __res
 // pass needs nothing but the plane bytes (per-cell hash look-ups there were serialised dependent loads on the
 // wall cells: 160 us per batch)
 __global__ void __launch_bounds__(256)
-k_lo_batch_resolve(BatchGeom g, const uint32_t* __restrict__ hkey, const uint32_t* __restrict__ hhit,
-                   const uint32_t* __restrict__ hcross, uint8_t* __restrict__ planes) {
+k_lo_batch_resolve(BatchGeom g, const ScanHdr* __restrict__ hdr, const uint32_t* __restrict__ hkey,
+                   const uint32_t* __restrict__ hhit, const uint32_t* __restrict__ hcross, uint8_t* __restrict__ pool) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t slots = (size_t)g.hash_mask + 1;
   if (idx >= slots * g.K) return;
@@ -465,14 +499,15 @@ k_lo_batch_resolve(BatchGeom g, const uint32_t* __restrict__ hkey, const uint32_
   if (cell == kHashEmpty) return;
   if (hcross[idx] < hhit[idx]) {
     const int x = (int)(cell % (uint32_t)g.sx), y = (int)(cell / (uint32_t)g.sx);
-    planes[((idx / slots) * (size_t)g.n_tiles + tile_of(g, x, y)) * 64 + in_tile(x, y)] = (uint8_t)(g.tag | kCodeHitUndo);
+    uint32_t off;
+    if (window_off(hdr[idx / slots], x, y, off)) pool[off] = (uint8_t)(g.tag | kCodeHitUndo);  // (entered only from inside)
   }
 }
 
 // one wave per tile: lane = plane slot when reading the flags, lane = cell of the tile when applying
 __global__ void __launch_bounds__(256)
-k_lo_batch_apply(BatchGeom g, const uint8_t* __restrict__ planes, const uint8_t* __restrict__ flags,
-                 float* __restrict__ logodds) {
+k_lo_batch_apply(BatchGeom g, const ScanHdr* __restrict__ hdr, const uint8_t* __restrict__ pool,
+                 const uint8_t* __restrict__ flags, float* __restrict__ logodds) {
   const int lane = threadIdx.x & 63;
   const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (t >= (uint32_t)g.n_tiles) return;
@@ -483,8 +518,14 @@ k_lo_batch_apply(BatchGeom g, const uint8_t* __restrict__ planes, const uint8_t*
   const bool in_map = x < g.sx && y < g.sy;
   float v = in_map ? logodds[(size_t)y * g.sx + x] : 0.f;
   bool dirty = false;
-  const uint8_t* pt = planes + (size_t)t * 64 + lane;
-  const size_t plane_bytes = (size_t)g.n_tiles * 64;
+  // lane s: where THIS tile sits in the window of scan s (one 16-byte load per lane; read back per touched scan by
+  // v_readlane with a uniform index)
+  const int ttx = (int)(t % (uint32_t)g.tiles_x), tty = (int)(t / (uint32_t)g.tiles_x);
+  uint32_t my_off = 0u;
+  if (lane < g.K) {
+    const int4 w = *(const int4*)((const char*)(hdr + lane) + 32);  // tx0, ty0, tw, base
+    my_off = (((uint32_t)w.w + (uint32_t)(tty - w.y) * (uint32_t)w.z + (uint32_t)(ttx - w.x)) << 6);
+  }
   while (touched) {  // ascending slot = scan order; eight planes' bytes in flight at a time (the mask is wave-uniform)
     int sl[8];
 #pragma unroll
@@ -494,7 +535,13 @@ k_lo_batch_apply(BatchGeom g, const uint8_t* __restrict__ planes, const uint8_t*
     }
     uint32_t bv[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) bv[u] = sl[u] >= 0 ? (uint32_t)pt[(size_t)sl[u] * plane_bytes] : 0u;
+    for (int u = 0; u < 8; u++) {
+      bv[u] = 0u;
+      if (sl[u] >= 0) {  // wave-uniform; a flagged tile lies inside the window of the scan that flagged it
+        const uint32_t tile_off = (uint32_t)__builtin_amdgcn_readlane((int)my_off, sl[u]);
+        bv[u] = (uint32_t)pool[tile_off + (uint32_t)lane];
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const uint32_t b = bv[u];
@@ -1073,12 +1120,13 @@ struct Level {
   bool pending = false;  // marks of scan `pend_g.epoch` are in plane set (epoch & 1); its apply has not been launched
   LevelGeom pend_g;
   int pend_n = 0;
-  // batched update (k_lo_batch_*): one byte plane per scan slot, allocated on first use
-  uint8_t* d_planes = nullptr;  // [plane_slots][n_tiles][64] tiled byte planes
-  uint8_t* d_flags = nullptr;   // [n_tiles][64]: tile touched by the scan in slot s
-  int plane_slots = 0;
+  // batched update (k_lo_batch_*): a pool of 64-byte tile slots holding one window of tiles per scan of a round,
+  // allocated on first use and grown on demand (never beyond the scratch budget unless ONE scan's window needs more)
+  DevBuf<uint8_t> d_pool;       // [pool_slots][64]
+  size_t pool_slots = 0;        // tile slots the epoch bookkeeping below covers (= d_pool.cap / 64 at the last clear)
+  uint8_t* d_flags = nullptr;   // [n_tiles][64]: tile touched by the scan in slot s of the round
   int tiles_x = 0, n_tiles = 0;
-  uint32_t batch_epoch = 0;
+  uint32_t batch_epoch = 0;     // 6-bit round epoch in the pool / flag bytes
 };
 
 }  // namespace
@@ -1097,6 +1145,12 @@ struct lslam_map {
   DevBuf<float> d_gn_out;
   // matchData, parallel-sum kernel (the default): the container goes up through pinned memory and is read -- and cached in
   // d_cached -- by the kernel itself; its 12 result floats land in pinned memory.  ordered_sums: k_gn_match instead.
+  // batched update: scratch budget of the tile-slot pools of ONE level (bytes), rounds used by the last call, cells
+  // found outside their scan's window (device counter; must stay 0: see lslam_map_batch_stats)
+  size_t batch_budget = (size_t)192 << 20;
+  int batch_radius_hint = 0;   // LSLAM_MAP_OPT_BATCH_RADIUS_CELLS: bound for callers whose points the host never sees
+  int batch_last_rounds = 0;
+  unsigned long long* d_batch_misses = nullptr;
   bool ordered_sums = false;  // lslam_map_set_option(LSLAM_MAP_OPT_ORDERED_SUMS) / LSLAM_GN_ORDERED=1
   int gn_threads = 512;       // LSLAM_GN_THREADS = 256 | 512 | 1024
   float* h_gn_pts = nullptr;
@@ -1384,9 +1438,10 @@ void lslam_map_destroy(lslam_map* map) {
     if (L.d_occ2) (void)hipFree(L.d_occ2);
     L.pipe_pts[0].release();
     L.pipe_pts[1].release();
-    if (L.d_planes) (void)hipFree(L.d_planes);
+    L.d_pool.release();
     if (L.d_flags) (void)hipFree(L.d_flags);
   }
+  if (map->d_batch_misses) (void)hipFree(map->d_batch_misses);
   map->d_pts.release();
   map->d_cached.release();
   map->d_gn_out.release();
@@ -1495,9 +1550,10 @@ namespace {
 constexpr int kBatchMaxScans = kBatchSlots;
 
 // K successive MapRepMultiMap::updateByScan calls (every level fed the same scan, i.e. each scan matched first) in
-// four launches per level.  d_pts: the K containers back to back; counts / origos / poses are host arrays.
+// four launches per level and round.  d_pts: the K containers back to back; counts / origos / poses are host arrays;
+// radius (host, may be null): per scan, the distance of its farthest point from its origo in level-0 cells.
 int update_batch_impl(lslam_map* map, int K, const float* d_pts, const int32_t* counts, const float* origos,
-                      const float* poses) {
+                      const float* poses, const float* radius) {
   lslam_context* ctx = map->ctx;
   {
     int rc = flush_pending(map);  // a single-scan update may still owe its apply
@@ -1517,11 +1573,19 @@ int update_batch_impl(lslam_map* map, int K, const float* d_pts, const int32_t* 
   while (slots < 2u * (uint32_t)n_max) slots *= 2;
   LSLAM_HIP(ctx, map->d_hash.reserve((size_t)3 * K * slots));
   LSLAM_HIP(ctx, map->d_hdr.reserve((size_t)K * map->levels.size()));
+  if (!map->d_batch_misses) {
+    LSLAM_HIP(ctx, hipMalloc((void**)&map->d_batch_misses, sizeof(unsigned long long)));
+    LSLAM_HIP(ctx, hipMemsetAsync(map->d_batch_misses, 0, sizeof(unsigned long long), ctx->stream));
+  }
   std::vector<ScanHdr> hdr((size_t)K * map->levels.size());
   std::vector<int> off(K + 1, 0);
   for (int k = 0; k < K; k++) off[k + 1] = off[k] + counts[k];
+  struct Round { int k0, k1; size_t slots; };
+  std::vector<std::vector<Round>> rounds(map->levels.size());
   for (size_t li = 0; li < map->levels.size(); li++) {
-    const Level& L = map->levels[li];
+    Level& L = map->levels[li];
+    L.tiles_x = (L.sx + 7) / 8;
+    L.n_tiles = L.tiles_x * ((L.sy + 7) / 8);
     const float factor = li == 0 ? 1.0f : (float)(1.0 / pow(2.0, (double)li));
     for (int k = 0; k < K; k++) {
       ScanHdr& h = hdr[li * K + k];
@@ -1540,77 +1604,132 @@ int update_batch_impl(lslam_map* map, int K, const float* d_pts, const int32_t* 
       h.by = (int)(byf + 0.5f);
       h.n = counts[k];
       h.pts_off = off[k];
+      // The window: every cell of a ray lies between the begin cell and the end cell, and the end cell is within
+      // |p - origo| * factor of the begin cell (a rotation), + 1 for the two roundings, + 1 for float32 slack.
+      double reach = -1.0;  // unknown: the whole map
+      if (radius) reach = (double)radius[k];
+      else if (map->batch_radius_hint > 0) reach = (double)map->batch_radius_hint;
+      long long x0 = 0, y0 = 0, x1 = L.sx - 1, y1 = L.sy - 1;
+      if (reach >= 0.0 && reach < 1e9) {
+        const long long R = (long long)ceil(reach * (double)factor) + 2;
+        x0 = std::max<long long>(x0, (long long)h.bx - R); x1 = std::min<long long>(x1, (long long)h.bx + R);
+        y0 = std::max<long long>(y0, (long long)h.by - R); y1 = std::min<long long>(y1, (long long)h.by + R);
+      }
+      if (h.n == 0 || x1 < x0 || y1 < y0 || h.bx < 0 || h.by < 0 || h.bx >= L.sx || h.by >= L.sy) {
+        h.tx0 = h.ty0 = h.tw = h.th = 0;  // nothing of this scan reaches the map (a begin cell outside drops every beam)
+      } else {
+        h.tx0 = (int)(x0 >> 3); h.ty0 = (int)(y0 >> 3);
+        h.tw = (int)(x1 >> 3) - h.tx0 + 1; h.th = (int)(y1 >> 3) - h.ty0 + 1;
+      }
+      h.base = 0; h.pad[0] = h.pad[1] = h.pad[2] = 0;
+    }
+    // rounds: consecutive scans whose windows fit the budget together (a scan alone may exceed it: it gets a round of its own)
+    const size_t budget_slots = std::max<size_t>(1, map->batch_budget / 64);
+    for (int k0 = 0; k0 < K;) {
+      size_t sum = 0;
+      int k1 = k0;
+      while (k1 < K) {
+        const size_t need = (size_t)hdr[li * K + k1].tw * (size_t)hdr[li * K + k1].th;
+        if (k1 > k0 && sum + need > budget_slots) break;
+        if (sum + need >= ((size_t)1 << 26)) break;  // byte offsets into the pool are 32-bit (window_off)
+        hdr[li * K + k1].base = (uint32_t)sum;
+        sum += need;
+        k1++;
+      }
+      if (k1 == k0) return ctx->fail(LSLAM_ERR_UNSUPPORTED, "batched update: a scan window of 2^26 tiles or more");
+      rounds[li].push_back(Round{k0, k1, sum});
+      k0 = k1;
     }
   }
+  map->batch_last_rounds = (int)rounds[0].size();
   LSLAM_HIP(ctx, hipMemcpyAsync(map->d_hdr.p, hdr.data(), hdr.size() * sizeof(ScanHdr), hipMemcpyHostToDevice, ctx->stream));
   for (size_t li = 0; li < map->levels.size(); li++) {
     Level& L = map->levels[li];
-    if (!L.d_planes) {
-      L.tiles_x = (L.sx + 7) / 8;
-      L.n_tiles = L.tiles_x * ((L.sy + 7) / 8);
-      const size_t plane_bytes = (size_t)L.n_tiles * 64;
-      if (hipMalloc((void**)&L.d_planes, plane_bytes * kBatchSlots) != hipSuccess ||
-          hipMalloc((void**)&L.d_flags, (size_t)L.n_tiles * kBatchSlots) != hipSuccess) {
+    if (!L.d_flags) {
+      if (hipMalloc((void**)&L.d_flags, (size_t)L.n_tiles * kBatchSlots) != hipSuccess) {
         (void)hipGetLastError();
-        if (L.d_planes) (void)hipFree(L.d_planes);
-        L.d_planes = nullptr;
-        return ctx->fail(LSLAM_ERR_HIP, "cannot allocate %d batch planes of %zu bytes", kBatchSlots, plane_bytes);
+        L.d_flags = nullptr;
+        return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the tile flags of the batched update (%zu bytes)", (size_t)L.n_tiles * kBatchSlots);
       }
-      L.plane_slots = kBatchSlots;
       L.batch_epoch = 0;
     }
-    if (L.batch_epoch == 0 || L.batch_epoch >= 63) {  // 6-bit epoch in the plane / flag bytes
-      LSLAM_HIP(ctx, hipMemsetAsync(L.d_planes, 0, (size_t)L.n_tiles * 64 * L.plane_slots, ctx->stream));
-      LSLAM_HIP(ctx, hipMemsetAsync(L.d_flags, 0, (size_t)L.n_tiles * kBatchSlots, ctx->stream));
-      L.batch_epoch = 0;
+    size_t need_slots = 1;
+    for (const Round& r : rounds[li]) need_slots = std::max(need_slots, r.slots);
+    if (need_slots * 64 > L.d_pool.cap) {
+      // grow to what this call needs, rounded up to 1 MB (rare: the windows of a trajectory have a steady size).  The
+      // old pool goes first -- nothing may still read it, so the stream is drained once -- instead of living on beside the new one
+      LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      L.d_pool.release();
+      const size_t bytes = ((need_slots * 64 + ((size_t)1 << 20) - 1) >> 20) << 20;
+      uint8_t* fresh = nullptr;
+      if (hipMalloc((void**)&fresh, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return ctx->fail(LSLAM_ERR_HIP, "cannot allocate %zu bytes of tile slots for the batched update", bytes);
+      }
+      L.d_pool.p = fresh;
+      L.d_pool.cap = bytes;
+      L.batch_epoch = 0;  // fresh memory: cleared below
     }
-    L.batch_epoch++;
-    const bool lds_hash = (size_t)slots * 8 <= 64 * 1024;  // k_lo_batch_hits_lds writes the key and first-hit tables whole
-    if (lds_hash)
-      LSLAM_HIP(ctx, hipMemsetAsync(map->d_hash.p + (size_t)2 * K * slots, 0xFF, (size_t)K * slots * sizeof(uint32_t), ctx->stream));
-    else
-      LSLAM_HIP(ctx, hipMemsetAsync(map->d_hash.p, 0xFF, (size_t)3 * K * slots * sizeof(uint32_t), ctx->stream));
-    BatchGeom g;
-    g.sx = L.sx; g.sy = L.sy; g.K = K;
-    g.tiles_x = L.tiles_x; g.n_tiles = L.n_tiles;
-    g.factor = li == 0 ? 1.0f : (float)(1.0 / pow(2.0, (double)li));
-    g.lo_free = map->lo_free; g.lo_occ = map->lo_occ;
-    g.tag = L.batch_epoch << 2;
-    g.hash_mask = slots - 1;
-    uint32_t* hkey = map->d_hash.p;
-    uint32_t* hhit = hkey + (size_t)K * slots;
-    uint32_t* hcross = hhit + (size_t)K * slots;
-    const ScanHdr* d_h = map->d_hdr.p + li * K;
-    if (lds_hash)
-      launch(ctx, "lo_batch_hits", k_lo_batch_hits_lds, dim3(K), dim3(1024), (size_t)slots * 8, g, d_h, d_pts, L.d_planes,
-             L.d_flags, hkey, hhit);
-    else
-      launch(ctx, "lo_batch_hits", k_lo_batch_hits, dim3((n_max + 255) / 256, K), dim3(256), 0, g, d_h, d_pts, L.d_planes,
-             L.d_flags, hkey, hhit);
-    const int groups = (n_max + kRayBeamsPerWave - 1) / kRayBeamsPerWave;
-    const long long waves = (long long)K * groups;
-    launch(ctx, "lo_batch_rays", k_lo_batch_rays, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, g, d_h, d_pts, L.d_planes,
-           L.d_flags, (const uint32_t*)hkey, hcross, groups);
-    launch(ctx, "lo_batch_resolve", k_lo_batch_resolve, dim3((unsigned)(((size_t)K * slots + 255) / 256)), dim3(256), 0, g,
-           (const uint32_t*)hkey, (const uint32_t*)hhit, (const uint32_t*)hcross, L.d_planes);
-    launch(ctx, "lo_batch_apply", k_lo_batch_apply, dim3((unsigned)((L.n_tiles + 3) / 4)), dim3(256), 0, g,
-           (const uint8_t*)L.d_planes, (const uint8_t*)L.d_flags, L.d_logodds);
+    for (const Round& r : rounds[li]) {
+      const int Kr = r.k1 - r.k0;
+      if (L.batch_epoch == 0 || L.batch_epoch >= 63) {  // 6-bit epoch in the pool / flag bytes
+        LSLAM_HIP(ctx, hipMemsetAsync(L.d_pool.p, 0, L.d_pool.cap, ctx->stream));
+        LSLAM_HIP(ctx, hipMemsetAsync(L.d_flags, 0, (size_t)L.n_tiles * kBatchSlots, ctx->stream));
+        L.batch_epoch = 0;
+      }
+      L.batch_epoch++;
+      L.pool_slots = L.d_pool.cap / 64;
+      const bool lds_hash = (size_t)slots * 8 <= 64 * 1024;  // k_lo_batch_hits_lds writes the key and first-hit tables whole
+      if (lds_hash)
+        LSLAM_HIP(ctx, hipMemsetAsync(map->d_hash.p + (size_t)2 * Kr * slots, 0xFF, (size_t)Kr * slots * sizeof(uint32_t), ctx->stream));
+      else
+        LSLAM_HIP(ctx, hipMemsetAsync(map->d_hash.p, 0xFF, (size_t)3 * Kr * slots * sizeof(uint32_t), ctx->stream));
+      BatchGeom g;
+      g.sx = L.sx; g.sy = L.sy; g.K = Kr;
+      g.tiles_x = L.tiles_x; g.n_tiles = L.n_tiles;
+      g.factor = li == 0 ? 1.0f : (float)(1.0 / pow(2.0, (double)li));
+      g.lo_free = map->lo_free; g.lo_occ = map->lo_occ;
+      g.tag = L.batch_epoch << 2;
+      g.hash_mask = slots - 1;
+      uint32_t* hkey = map->d_hash.p;
+      uint32_t* hhit = hkey + (size_t)Kr * slots;
+      uint32_t* hcross = hhit + (size_t)Kr * slots;
+      const ScanHdr* d_h = map->d_hdr.p + li * K + r.k0;
+      int nr_max = 0;
+      for (int k = r.k0; k < r.k1; k++) nr_max = std::max(nr_max, counts[k]);
+      if (nr_max == 0) continue;
+      if (lds_hash)
+        launch(ctx, "lo_batch_hits", k_lo_batch_hits_lds, dim3(Kr), dim3(1024), (size_t)slots * 8, g, d_h, d_pts, L.d_pool.p,
+               L.d_flags, hkey, hhit, map->d_batch_misses);
+      else
+        launch(ctx, "lo_batch_hits", k_lo_batch_hits, dim3((nr_max + 255) / 256, Kr), dim3(256), 0, g, d_h, d_pts, L.d_pool.p,
+               L.d_flags, hkey, hhit, map->d_batch_misses);
+      const int groups = (nr_max + kRayBeamsPerWave - 1) / kRayBeamsPerWave;
+      const long long waves = (long long)Kr * groups;
+      launch(ctx, "lo_batch_rays", k_lo_batch_rays, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, g, d_h, d_pts, L.d_pool.p,
+             L.d_flags, (const uint32_t*)hkey, hcross, groups);
+      launch(ctx, "lo_batch_resolve", k_lo_batch_resolve, dim3((unsigned)(((size_t)Kr * slots + 255) / 256)), dim3(256), 0, g,
+             d_h, (const uint32_t*)hkey, (const uint32_t*)hhit, (const uint32_t*)hcross, L.d_pool.p);
+      launch(ctx, "lo_batch_apply", k_lo_batch_apply, dim3((unsigned)((L.n_tiles + 3) / 4)), dim3(256), 0, g, d_h,
+             (const uint8_t*)L.d_pool.p, (const uint8_t*)L.d_flags, L.d_logodds);
+    }
   }
   LSLAM_HIP(ctx, hipGetLastError());
   return LSLAM_OK;
 }
 }  // namespace
 
+namespace {
 // n_scans containers back to back in points_xy; batches larger than 64 scans are cut into groups of 64
-int lslam_map_update_batch_dev(lslam_map* map, int n_scans, const float* points_xy_dev, const int32_t* n_points,
-                               const float* origos_xy, const float* poses_world) {
-  if (!map || n_scans < 0 || !n_points || !origos_xy || !poses_world) return LSLAM_ERR_INVALID_ARGUMENT;
+int update_batch_dev_impl(lslam_map* map, int n_scans, const float* points_xy_dev, const int32_t* n_points,
+                          const float* origos_xy, const float* poses_world, const float* radius) {
   lslam_context* ctx = map->ctx;
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
   size_t done_pts = 0;
   for (int k0 = 0; k0 < n_scans; k0 += kBatchMaxScans) {
     const int K = std::min(kBatchMaxScans, n_scans - k0);
-    int rc = update_batch_impl(map, K, points_xy_dev + 2 * done_pts, n_points + k0, origos_xy + 2 * k0, poses_world + 3 * k0);
+    int rc = update_batch_impl(map, K, points_xy_dev + 2 * done_pts, n_points + k0, origos_xy + 2 * k0, poses_world + 3 * k0,
+                               radius ? radius + k0 : nullptr);
     if (rc) return rc;
     for (int k = 0; k < K; k++) done_pts += (size_t)n_points[k0 + k];
   }
@@ -1628,6 +1747,14 @@ int lslam_map_update_batch_dev(lslam_map* map, int n_scans, const float* points_
   }
   return LSLAM_OK;
 }
+}  // namespace
+
+int lslam_map_update_batch_dev(lslam_map* map, int n_scans, const float* points_xy_dev, const int32_t* n_points,
+                               const float* origos_xy, const float* poses_world) {
+  if (!map || n_scans < 0 || !n_points || !origos_xy || !poses_world) return LSLAM_ERR_INVALID_ARGUMENT;
+  // the host never sees these points: the windows come from LSLAM_MAP_OPT_BATCH_RADIUS_CELLS, or cover the whole map
+  return update_batch_dev_impl(map, n_scans, points_xy_dev, n_points, origos_xy, poses_world, nullptr);
+}
 
 int lslam_map_update_batch(lslam_map* map, int n_scans, const float* points_xy, const int32_t* n_points,
                            const float* origos_xy, const float* poses_world) {
@@ -1641,9 +1768,55 @@ int lslam_map_update_batch(lslam_map* map, int n_scans, const float* points_xy, 
   }
   if (total > 0 && !points_xy) return LSLAM_ERR_INVALID_ARGUMENT;
   if (total > (size_t)INT32_MAX / 2) return ctx->fail(LSLAM_ERR_UNSUPPORTED, "batch too large");
+  // The scans' reach, where it decides anything: on a map whose whole planes fit the budget every window is the map
+  // anyway.  One pass over the points the host is about to copy: max |p - origo| per scan, in level-0 cells.
+  std::vector<float> radius;
+  if (!map->levels.empty()) {
+    const Level& L0 = map->levels[0];
+    const size_t plane = (size_t)((L0.sx + 7) / 8) * (size_t)((L0.sy + 7) / 8) * 64;
+    if (plane * (size_t)std::min(n_scans, kBatchMaxScans) > map->batch_budget) {
+      radius.resize((size_t)n_scans);
+      size_t at = 0;
+      for (int k = 0; k < n_scans; k++) {
+        const float ox = origos_xy[2 * k], oy = origos_xy[2 * k + 1];
+        float m2 = 0.f;
+        bool finite = true;
+        for (int i = 0; i < n_points[k]; i++) {
+          const float dx = points_xy[2 * (at + i)] - ox, dy = points_xy[2 * (at + i) + 1] - oy;
+          const float d2 = dx * dx + dy * dy;
+          finite = finite && (d2 == d2) && d2 < 1e18f;
+          m2 = d2 > m2 ? d2 : m2;
+        }
+        at += (size_t)n_points[k];
+        radius[k] = finite ? sqrtf(m2) * 1.0001f + 1.0f : 2e9f;  // a non-finite point: no bound (such a beam is dropped anyway)
+      }
+    }
+  }
   int rc = stage_points(map, points_xy, (int)total);
   if (rc) return rc;
-  return lslam_map_update_batch_dev(map, n_scans, map->d_pts.p, n_points, origos_xy, poses_world);
+  return update_batch_dev_impl(map, n_scans, map->d_pts.p, n_points, origos_xy, poses_world, radius.empty() ? nullptr : radius.data());
+}
+
+// out[0] = bytes of scratch the batched update holds right now over all levels (tile-slot pools + tile flags),
+// out[1] = rounds level 0 of the last batch needed, out[2] = cells found outside their scan's window since the map was
+// created (0 unless LSLAM_MAP_OPT_BATCH_RADIUS_CELLS understated a scan's reach; synchronises), out[3] = the budget
+int lslam_map_batch_stats(lslam_map* map, int64_t out[4]) {
+  if (!map || !out) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = map->ctx;
+  size_t bytes = 0;
+  for (const Level& L : map->levels) bytes += L.d_pool.cap + (L.d_flags ? (size_t)L.n_tiles * kBatchSlots : 0);
+  out[0] = (int64_t)bytes;
+  out[1] = map->batch_last_rounds;
+  out[2] = 0;
+  out[3] = (int64_t)map->batch_budget;
+  if (map->d_batch_misses) {
+    unsigned long long m = 0;
+    LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+    LSLAM_HIP(ctx, hipMemcpyAsync(&m, map->d_batch_misses, sizeof m, hipMemcpyDeviceToHost, ctx->stream));
+    LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out[2] = (int64_t)m;
+  }
+  return LSLAM_OK;
 }
 
 int lslam_map_set_scan(lslam_map* map, const float* ranges, int n, const lslam_hector_scan* sp, int* n_points) {
@@ -1840,6 +2013,16 @@ int lslam_map_set_option(lslam_map* map, int option, int value) {
   if (!map) return LSLAM_ERR_INVALID_ARGUMENT;
   if (option == LSLAM_MAP_OPT_ORDERED_SUMS) {
     map->ordered_sums = value != 0;
+    return LSLAM_OK;
+  }
+  if (option == LSLAM_MAP_OPT_BATCH_SCRATCH_MB) {
+    if (value < 1) return map->ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "batch scratch budget must be >= 1 MB");
+    map->batch_budget = (size_t)value << 20;
+    return LSLAM_OK;
+  }
+  if (option == LSLAM_MAP_OPT_BATCH_RADIUS_CELLS) {
+    if (value < 0) return map->ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "batch radius hint must be >= 0 (0 = none)");
+    map->batch_radius_hint = value;
     return LSLAM_OK;
   }
   return map->ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "unknown map option %d", option);

@@ -488,8 +488,21 @@ int lslam_map_match_data(lslam_map* map, const float* points_xy, int n, const fl
  * within 1e-5 of the reference's poses on the test sequences, tolerance 1e-4 m / 1e-4 rad.  LSLAM_MAP_OPT_ORDERED_SUMS = 1
  * selects the kernel that adds them in point order like the reference's sequential loop (H/matcher/ScanMatcher.h:94-126)
  * and evaluates the libm calls in double like its host code: bit-equal to the CPU restatement, ~4x slower. */
-enum { LSLAM_MAP_OPT_ORDERED_SUMS = 1 };
+/* The batched update's scratch (lslam_map_update_batch*): every scan of a batch owns a WINDOW of 8x8-cell tiles -- the
+ * square its rays can reach from its begin cell -- in a pool of 64-byte tile slots, not a byte plane of the whole map
+ * (a 1081-beam scan with 20 m of range on a 0.025 m map: 2.6 MB, whatever the map's size).
+ *  LSLAM_MAP_OPT_BATCH_SCRATCH_MB (default 192): budget of one pyramid level's pool; the scans of a call are applied in
+ *    rounds whose windows fit it (one round normally; a single scan whose window is larger gets a round -- and the
+ *    memory -- of its own).  Results do not depend on it.
+ *  LSLAM_MAP_OPT_BATCH_RADIUS_CELLS (default 0 = none): for lslam_map_update_batch_dev, whose points the host never
+ *    sees: an upper bound, in level-0 cells, on |point - origo| of every scan handed in.  Without it such scans get
+ *    windows the size of the map (the rounds still keep the scratch inside the budget, there are just more of them).
+ *    A bound that is too small loses cells: lslam_map_batch_stats counts them, and must read 0. */
+enum { LSLAM_MAP_OPT_ORDERED_SUMS = 1, LSLAM_MAP_OPT_BATCH_SCRATCH_MB = 2, LSLAM_MAP_OPT_BATCH_RADIUS_CELLS = 3 };
 int lslam_map_set_option(lslam_map* map, int option, int value);
+/* out[0] = bytes of batched-update scratch held over all levels (tile-slot pools + tile flags), out[1] = rounds level 0
+ * of the last batch took, out[2] = cells found outside their scan's window so far (synchronises), out[3] = budget, bytes */
+int lslam_map_batch_stats(lslam_map* map, int64_t out[4]);
 /* LaserScan -> DataContainer ON THE DEVICE: HectorMappingRos::scanCallback's pre-processing (hector_slam.cc:186-205):
  * laser_geometry's projectLaser(scan, cloud, 30.0) and rosPointCloudToDataContainer (hector_slam.cc:320-362).  The
  * container stays resident in HBM; lslam_map_match_container / lslam_map_update_by_container are matchData /
