@@ -407,6 +407,27 @@ def test_loop_closure_size_lattice(ctx, oracle_lib, search_size, nx):
     for q in range(len(res)):
         mean, cov, resp = port.match(wl.query_ranges[q], wl.query_poses[q], False, False)
         _assert_result(res[q], mean, cov, resp)
+    # the dense kernel's zero-window pruning (8x8-block occupancy -> one live mask per beam and row tile) is exact: with
+    # it switched off every numerator and every record is the same; and a search centre near the grid's edge -- windows
+    # that hang over the first row / wrap past widthStep stay live -- still equals the oracle
+    gm.set_option("row_occupancy", 0)
+    assert np.array_equal(gm.coarse_sums(wl.query_ranges[0], p0), sums)
+    res_off = gm.match_batch(wl.query_ranges, wl.query_poses, doPenalize=False, doRefineMatch=False)
+    gm.set_option("row_occupancy", 1)
+    assert res_off.tobytes() == res.tobytes()
+    gi = gm.grid_info()
+    edge = np.array([gi["offset"][0] + 0.5 * search_size + 0.3, gi["offset"][1] + 0.5 * search_size + 0.2, p0[2]])
+    _, _, _, st_e, sums_e = port.correlate_scan(wl.query_ranges[0], edge, edge, off, 0.1, 0.349, 0.0349, False, False,
+                                                want_sums=True)
+    if st_e == 0:
+        assert np.array_equal(gm.coarse_sums(wl.query_ranges[0], edge), sums_e)
+    # a batch large enough for the 4-row-slot form of the kernel (other tile geometry, same masks' meaning)
+    many_r = np.repeat(wl.query_ranges, 24, axis=0)
+    many_p = np.repeat(wl.query_poses, 24, axis=0) + np.linspace(0, 0.4, 72)[:, None] * np.array([1.0, -0.5, 0.02])
+    res_m = gm.match_batch(many_r, many_p, doPenalize=False, doRefineMatch=False)
+    for q in (0, 17, 40, 71):
+        mean, cov, resp = port.match(many_r[q], many_p[q], False, False)
+        _assert_result(res_m[q], mean, cov, resp)
     # with refinement too (TryCloseLoop's second, fine MatchScan uses the sequential matcher; this only checks
     # that a fine pass behind a big coarse lattice works)
     res = gm.match_batch(wl.query_ranges[:1], wl.query_poses[:1], doPenalize=False, doRefineMatch=True)
