@@ -13,6 +13,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 (timeout 300 python bench.py > $O/bench.json 2> $O/bench.err); echo "bench rc=$?"
+(timeout 200 python bench.py --steps 20 --warmup 5 > $O/bench_driver_protocol.json 2> $O/bench_driver_protocol.err); echo "bench (driver protocol) rc=$?"
 (timeout 300 bash tools/prof_stats.sh > $O/prof_stats.log 2>&1); cp gpurun_out/prof_stats/kernel_stats.csv $O/kernel_stats_bench_default.csv
 (PMC_OUT=pmc_$TAG timeout 600 bash tools/pmc_passes.sh > $O/pmc_passes.log 2>&1)
 python tools/pmc_summary.py gpurun_out/pmc_$TAG > $O/pmc_per_launch.json
@@ -27,7 +28,7 @@ python tools/make_traffic.py $O/pmc_per_launch.json 4096 $O/pmc_cfg2_per_launch.
 (timeout 300 python tools/dropin_bench.py 2>/dev/null | grep "^{" > $O/dropin.jsonl)
 (timeout 200 python tools/batch_sweep.py > $O/batch_sweep.txt 2>&1)
 (timeout 120 python tools/chain_profile.py --scans 600 2>/dev/null | grep "^{" > $O/chain_profile.json)
-mkdir -p gpurun_out/prof512 && (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof512 -o s -- python $R/bench.py --batch 512 --no-cpu --sustained-s 0 > $O/bench_batch512.json 2> $O/bench_batch512.err)
+mkdir -p gpurun_out/prof512 && (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof512 -o s -- python $R/bench.py --batch 512 --no-cpu --no-secondary --sustained-s 0 > $O/bench_batch512.json 2> $O/bench_batch512.err)
 find gpurun_out/prof512 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_bench_batch512.csv
 rm -rf gpurun_out/prof512
 ls -la $O
