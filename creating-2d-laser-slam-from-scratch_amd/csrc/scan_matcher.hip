@@ -436,7 +436,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // LDSB = true is the MEASURED-AND-DROPPED variant the north star's wording asks about ("grid pyramid staged in LDS
 // tiles"): phase B stages, per drain of 64 queued beams, the bounding patch of their rows from the
 // linear parity planes in LDS (one patch per parity) and reads the row words with ds_read instead of global gathers;
-// drains whose patch does not fit 6 KB per parity take the global path.  Same bytes, same sums.  DESIGN 5.0 has the numbers.
+// drains whose patch does not fit 6 KB per parity take the global path.  Same bytes, same sums.  DESIGN_HISTORY.md (B, "LDS-staged experiment") has the numbers.
 constexpr int kPatchDw = 1536;  // dwords per parity patch
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   v = min(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true));
@@ -3380,7 +3380,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
         LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         m->stats_scans = S;
       }
-      if (m->lds_staged && variant == 2 && step == 2) {  // experiment: phase B through LDS patches
+      if (m->lds_staged && variant == 2 && step == 2) {  // experiment (DESIGN_HISTORY.md B): phase B through LDS patches
         if (m->collect_stats)
           launch(ctx, name, k_resp_rows<3, 11, false, true, true>, LSLAM_ROWS_ARGS(s0, s1));
         else

@@ -154,7 +154,7 @@ void* lslam_matcher_grid_dev_ptr(lslam_matcher* m);
  *    after pruning, [2] readable beam x angle pairs, [3] those with at least one live row. */
 /*  LSLAM_OPT_LDS_STAGED (default 0): 1 routes the coarse pass of chip-filling batches through the LDS-staged variant of
  *    the hot kernel (phase B reads its rows from per-drain patches of the parity planes staged in LDS): an experiment that
- *    was measured and dropped, kept selectable so the measurement can be repeated. */
+ *    was measured and dropped (DESIGN_HISTORY.md B, "LDS-staged experiment"), kept selectable so the measurement can be repeated. */
 /*  LSLAM_OPT_PIPELINE_DEPTH (default 1; 1..4): with depth D > 1 consecutive lslam_matcher_match_batch_dev_* calls become
  *    PIPELINED STEPS: they take turns on D internal HIP streams, each with its own set of per-step workspaces, so the
  *    latency-bound reduce kernels of one step run under the response kernels of the next (what small per-GPU batches
