@@ -1549,6 +1549,51 @@ int lslam_map_update_by_scan(lslam_map* map, const float* pts, int n, const floa
 namespace {
 constexpr int kBatchMaxScans = kBatchSlots;
 
+// The window of tiles of one scan on one level: every cell of a ray lies between the begin cell and the end cell, and the
+// end cell is within |p - origo| * factor of the begin cell (a rotation), + 1 for the two roundings, + 1 for float32
+// slack.  reach < 0 (or absurdly large) = unknown: the whole map.  out = tx0, ty0, tw, th (tw = 0: nothing reaches the map).
+void plan_window(int sx, int sy, int bx, int by, int n, double reach, double factor, int out[4]) {
+  long long x0 = 0, y0 = 0, x1 = sx - 1, y1 = sy - 1;
+  if (reach >= 0.0 && reach < 1e9) {
+    const long long R = (long long)ceil(reach * factor) + 2;
+    x0 = std::max<long long>(x0, (long long)bx - R); x1 = std::min<long long>(x1, (long long)bx + R);
+    y0 = std::max<long long>(y0, (long long)by - R); y1 = std::min<long long>(y1, (long long)by + R);
+  }
+  if (n == 0 || x1 < x0 || y1 < y0 || bx < 0 || by < 0 || bx >= sx || by >= sy) {
+    out[0] = out[1] = out[2] = out[3] = 0;  // (a begin cell outside the map drops every beam, H/map/OccGridMapBase.h:226-238)
+  } else {
+    out[0] = (int)(x0 >> 3); out[1] = (int)(y0 >> 3);
+    out[2] = (int)(x1 >> 3) - out[0] + 1; out[3] = (int)(y1 >> 3) - out[1] + 1;
+  }
+}
+// Rounds: consecutive scans whose windows fit the budget together; a scan whose window alone exceeds it gets a round
+// -- and the memory -- of its own.  base[k] = first tile slot of scan k inside its round; round_of[k] (may be null).
+// Returns the number of rounds, or -1 when one window has 2^26 tiles or more (byte offsets into the pool are 32-bit).
+int plan_rounds(const int* tw, const int* th, int K, size_t budget_bytes, uint32_t* base, int* round_of, size_t* max_slots) {
+  const size_t budget_slots = std::max<size_t>(1, budget_bytes / 64);
+  int n_rounds = 0;
+  size_t most = 0;
+  for (int k0 = 0; k0 < K;) {
+    size_t sum = 0;
+    int k1 = k0;
+    while (k1 < K) {
+      const size_t need = (size_t)tw[k1] * (size_t)th[k1];
+      if (k1 > k0 && sum + need > budget_slots) break;
+      if (sum + need >= ((size_t)1 << 26)) break;
+      base[k1] = (uint32_t)sum;
+      if (round_of) round_of[k1] = n_rounds;
+      sum += need;
+      k1++;
+    }
+    if (k1 == k0) return -1;
+    most = std::max(most, sum);
+    n_rounds++;
+    k0 = k1;
+  }
+  if (max_slots) *max_slots = most;
+  return n_rounds;
+}
+
 // K successive MapRepMultiMap::updateByScan calls (every level fed the same scan, i.e. each scan matched first) in
 // four launches per level and round.  d_pts: the K containers back to back; counts / origos / poses are host arrays;
 // radius (host, may be null): per scan, the distance of its farthest point from its origo in level-0 cells.
@@ -1604,41 +1649,27 @@ int update_batch_impl(lslam_map* map, int K, const float* d_pts, const int32_t* 
       h.by = (int)(byf + 0.5f);
       h.n = counts[k];
       h.pts_off = off[k];
-      // The window: every cell of a ray lies between the begin cell and the end cell, and the end cell is within
-      // |p - origo| * factor of the begin cell (a rotation), + 1 for the two roundings, + 1 for float32 slack.
       double reach = -1.0;  // unknown: the whole map
       if (radius) reach = (double)radius[k];
       else if (map->batch_radius_hint > 0) reach = (double)map->batch_radius_hint;
-      long long x0 = 0, y0 = 0, x1 = L.sx - 1, y1 = L.sy - 1;
-      if (reach >= 0.0 && reach < 1e9) {
-        const long long R = (long long)ceil(reach * (double)factor) + 2;
-        x0 = std::max<long long>(x0, (long long)h.bx - R); x1 = std::min<long long>(x1, (long long)h.bx + R);
-        y0 = std::max<long long>(y0, (long long)h.by - R); y1 = std::min<long long>(y1, (long long)h.by + R);
-      }
-      if (h.n == 0 || x1 < x0 || y1 < y0 || h.bx < 0 || h.by < 0 || h.bx >= L.sx || h.by >= L.sy) {
-        h.tx0 = h.ty0 = h.tw = h.th = 0;  // nothing of this scan reaches the map (a begin cell outside drops every beam)
-      } else {
-        h.tx0 = (int)(x0 >> 3); h.ty0 = (int)(y0 >> 3);
-        h.tw = (int)(x1 >> 3) - h.tx0 + 1; h.th = (int)(y1 >> 3) - h.ty0 + 1;
-      }
+      int w[4];
+      plan_window(L.sx, L.sy, h.bx, h.by, h.n, reach, (double)factor, w);
+      h.tx0 = w[0]; h.ty0 = w[1]; h.tw = w[2]; h.th = w[3];
       h.base = 0; h.pad[0] = h.pad[1] = h.pad[2] = 0;
     }
-    // rounds: consecutive scans whose windows fit the budget together (a scan alone may exceed it: it gets a round of its own)
-    const size_t budget_slots = std::max<size_t>(1, map->batch_budget / 64);
-    for (int k0 = 0; k0 < K;) {
-      size_t sum = 0;
-      int k1 = k0;
-      while (k1 < K) {
-        const size_t need = (size_t)hdr[li * K + k1].tw * (size_t)hdr[li * K + k1].th;
-        if (k1 > k0 && sum + need > budget_slots) break;
-        if (sum + need >= ((size_t)1 << 26)) break;  // byte offsets into the pool are 32-bit (window_off)
-        hdr[li * K + k1].base = (uint32_t)sum;
-        sum += need;
-        k1++;
+    {
+      std::vector<int> tw(K), th(K), round_of(K);
+      std::vector<uint32_t> base(K);
+      for (int k = 0; k < K; k++) { tw[k] = hdr[li * K + k].tw; th[k] = hdr[li * K + k].th; }
+      const int nr = plan_rounds(tw.data(), th.data(), K, map->batch_budget, base.data(), round_of.data(), nullptr);
+      if (nr < 0) return ctx->fail(LSLAM_ERR_UNSUPPORTED, "batched update: a scan window of 2^26 tiles or more");
+      for (int k = 0; k < K; k++) {
+        hdr[li * K + k].base = base[k];
+        if (k == 0 || round_of[k] != round_of[k - 1]) rounds[li].push_back(Round{k, k, 0});
+        Round& r = rounds[li].back();
+        r.k1 = k + 1;
+        r.slots = std::max(r.slots, (size_t)base[k] + (size_t)tw[k] * (size_t)th[k]);
       }
-      if (k1 == k0) return ctx->fail(LSLAM_ERR_UNSUPPORTED, "batched update: a scan window of 2^26 tiles or more");
-      rounds[li].push_back(Round{k0, k1, sum});
-      k0 = k1;
     }
   }
   map->batch_last_rounds = (int)rounds[0].size();
@@ -1795,6 +1826,28 @@ int lslam_map_update_batch(lslam_map* map, int n_scans, const float* points_xy, 
   int rc = stage_points(map, points_xy, (int)total);
   if (rc) return rc;
   return update_batch_dev_impl(map, n_scans, map->d_pts.p, n_points, origos_xy, poses_world, radius.empty() ? nullptr : radius.data());
+}
+
+// Host-only: what a batched update of these scans would allocate on a level of sx x sy cells -- the planner
+// update_batch_impl itself uses.  No context, no GPU.
+int lslam_map_plan_batch_windows(int sx, int sy, int n_scans, const int32_t* begin_cells_xy, const int32_t* n_points,
+                                 const double* reach_cells, double level_factor, int64_t budget_bytes, int32_t* windows_out,
+                                 uint32_t* base_out, int32_t* round_out, int64_t* pool_bytes_out) {
+  if (sx <= 0 || sy <= 0 || n_scans < 0 || budget_bytes < 64 || (n_scans > 0 && (!begin_cells_xy || !n_points || !windows_out || !base_out)))
+    return LSLAM_ERR_INVALID_ARGUMENT;
+  std::vector<int> tw((size_t)n_scans), th((size_t)n_scans);
+  for (int k = 0; k < n_scans; k++) {
+    int w[4];
+    plan_window(sx, sy, begin_cells_xy[2 * k], begin_cells_xy[2 * k + 1], n_points[k], reach_cells ? reach_cells[k] : -1.0,
+                level_factor, w);
+    for (int i = 0; i < 4; i++) windows_out[4 * k + i] = w[i];
+    tw[k] = w[2]; th[k] = w[3];
+  }
+  size_t most = 0;
+  const int nr = plan_rounds(tw.data(), th.data(), n_scans, (size_t)budget_bytes, base_out, round_out, &most);
+  if (nr < 0) return LSLAM_ERR_UNSUPPORTED;
+  if (pool_bytes_out) *pool_bytes_out = (int64_t)(most * 64);
+  return nr;
 }
 
 // out[0] = bytes of scratch the batched update holds right now over all levels (tile-slot pools + tile flags),

@@ -3067,7 +3067,7 @@ struct lslam_matcher {
   hipStream_t pipe_stream[kMaxPipe] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t pipe_done[kMaxPipe] = {nullptr, nullptr, nullptr, nullptr};
   bool pipe_pending[kMaxPipe] = {false, false, false, false};
-  hipEvent_t pipe_in = nullptr;      // the context stream at the moment a step was enqueued (inputs, grid changes)
+  hipEvent_t pipe_in[kMaxPipe] = {nullptr, nullptr, nullptr, nullptr};  // the context stream when slot i's step was enqueued
   hipEvent_t view_ready = nullptr;   // behind the last refresh of a grid view (parity planes, bitmap, tiles) by a step
   int view_owner = -1;               // slot whose stream recorded view_ready (-1: none since the last join)
   StepWork pipe_work[kMaxPipe];      // slot 0 is unused: it works in the members above
@@ -3537,11 +3537,11 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
 // Streams and events of the pipelined steps, created on first use.
 int pipe_init(lslam_matcher* m) {
   lslam_context* ctx = m->ctx;
-  if (!m->pipe_in) LSLAM_HIP(ctx, hipEventCreateWithFlags(&m->pipe_in, hipEventDisableTiming));
   if (!m->view_ready) LSLAM_HIP(ctx, hipEventCreateWithFlags(&m->view_ready, hipEventDisableTiming));
   for (int i = 0; i < m->pipe_depth; i++) {
     if (!m->pipe_stream[i]) LSLAM_HIP(ctx, hipStreamCreateWithFlags(&m->pipe_stream[i], hipStreamNonBlocking));
     if (!m->pipe_done[i]) LSLAM_HIP(ctx, hipEventCreateWithFlags(&m->pipe_done[i], hipEventDisableTiming));
+    if (!m->pipe_in[i]) LSLAM_HIP(ctx, hipEventCreateWithFlags(&m->pipe_in[i], hipEventDisableTiming));
   }
   if (!m->pipe_registered) {  // lslam_synchronize(ctx) means "every step is done" too
     ctx->pre_sync.emplace_back((void*)m, &pipe_join_cb);
@@ -3565,8 +3565,8 @@ int pipe_step(lslam_matcher* m, int S, const RT* d_ranges, int stride, const dou
   const int slot = m->pipe_next % m->pipe_depth;
   m->pipe_next = (slot + 1) % m->pipe_depth;
   hipStream_t s = m->pipe_stream[slot];
-  LSLAM_HIP(ctx, hipEventRecord(m->pipe_in, ctx->stream));
-  LSLAM_HIP(ctx, hipStreamWaitEvent(s, m->pipe_in, 0));
+  LSLAM_HIP(ctx, hipEventRecord(m->pipe_in[slot], ctx->stream));  // (one event per slot: never re-recorded under a pending wait of another stream)
+  LSLAM_HIP(ctx, hipStreamWaitEvent(s, m->pipe_in[slot], 0));
   if (m->view_owner >= 0 && m->view_owner != slot) LSLAM_HIP(ctx, hipStreamWaitEvent(s, m->view_ready, 0));
   const bool v0[4] = {m->sub_dirty, m->occ_dirty, m->tile_dirty, m->ptile_dirty};
   const void* const a0[2] = {m->d_tiles, m->d_ptiles};
@@ -3906,8 +3906,8 @@ void lslam_matcher_destroy(lslam_matcher* m) {
       (void)hipStreamDestroy(m->pipe_stream[i]);
     }
     if (m->pipe_done[i]) (void)hipEventDestroy(m->pipe_done[i]);
+    if (m->pipe_in[i]) (void)hipEventDestroy(m->pipe_in[i]);
   }
-  if (m->pipe_in) (void)hipEventDestroy(m->pipe_in);
   if (m->view_ready) (void)hipEventDestroy(m->view_ready);
   for (auto& w : m->pipe_work) {
     w.d_local.release(); w.d_cossin.release(); w.d_lat.release(); w.d_coarse.release(); w.d_resp.release();

@@ -503,6 +503,15 @@ int lslam_map_set_option(lslam_map* map, int option, int value);
 /* out[0] = bytes of batched-update scratch held over all levels (tile-slot pools + tile flags), out[1] = rounds level 0
  * of the last batch took, out[2] = cells found outside their scan's window so far (synchronises), out[3] = budget, bytes */
 int lslam_map_batch_stats(lslam_map* map, int64_t out[4]);
+/* Host-only planner (no context, no GPU): the windows and rounds a batched update of n_scans scans would use on a level of
+ * sx x sy cells.  begin_cells_xy: the scans' begin cells on that level; reach_cells: per scan the distance of its farthest
+ * point from its origo in LEVEL-0 cells (NULL or < 0: unknown = the whole map); level_factor: 1, 0.5, 0.25 ... for levels
+ * 0, 1, 2.  windows_out[4k..] = first tile x, first tile y, tiles wide, tiles high (8x8-cell tiles; 0 wide = nothing
+ * of the scan reaches the map); base_out[k] = first tile slot inside its round; round_out[k] (may be NULL);
+ * *pool_bytes_out = bytes the largest round needs.  Returns the number of rounds (>= 0) or a negative lslam_status. */
+int lslam_map_plan_batch_windows(int sx, int sy, int n_scans, const int32_t* begin_cells_xy, const int32_t* n_points,
+                                 const double* reach_cells, double level_factor, int64_t budget_bytes,
+                                 int32_t* windows_out, uint32_t* base_out, int32_t* round_out, int64_t* pool_bytes_out);
 /* LaserScan -> DataContainer ON THE DEVICE: HectorMappingRos::scanCallback's pre-processing (hector_slam.cc:186-205):
  * laser_geometry's projectLaser(scan, cloud, 30.0) and rosPointCloudToDataContainer (hector_slam.cc:320-362).  The
  * container stays resident in HBM; lslam_map_match_container / lslam_map_update_by_container are matchData /

@@ -133,3 +133,50 @@ def test_other_entry_points_join_the_pipeline(ctx):
     with pytest.raises(api.LslamError):
         gm.set_option("pipeline_depth", 5)
     gm.close()
+
+
+def test_random_sequences_of_steps_and_grid_changes(ctx):
+    """A seeded random walk over everything that can meet in flight: step sizes from 1 to 2300 scans, depths changed on the
+    way, grid rebuilds and installs, plain host batches in between.  Every record of every step equals the plain matcher's
+    answer for the grid that step was enqueued against."""
+    rng = np.random.default_rng(99)
+    wl = _workload(2300, seed=35)
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(wl.laser))
+    ref = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(wl.laser))  # never pipelined
+    r, p = _dev(wl, 2300)
+    windows = [(0, 6), (0, 20), (8, 20)]
+
+    def install(k):
+        a, b = windows[k]
+        for g in (gm, ref):
+            g.AddScans(wl.base_ranges[a:b], wl.base_poses[a:b], wl.center_pose)
+
+    install(0)
+    pending = []  # (n, out tensor, expected bytes)
+    depth = 2
+    gm.set_option("pipeline_depth", depth)
+    for it in range(60):
+        what = rng.integers(0, 10)
+        if what == 0:
+            install(int(rng.integers(0, 3)))
+        elif what == 1:
+            depth = int(rng.integers(1, 5))
+            gm.set_option("pipeline_depth", depth)
+        elif what == 2:
+            n = int(rng.integers(1, 40))
+            got = gm.match_batch(wl.query_ranges[:n], wl.query_poses[:n])
+            assert got.tobytes() == ref.match_batch(wl.query_ranges[:n], wl.query_poses[:n]).tobytes()
+        else:
+            n = int(rng.choice([1, 7, 64, 97, 98, 300, 1024, 1536, 2047, 2048, 2300]))
+            out = torch.zeros((n, 112), dtype=torch.uint8, device=r.device)
+            gm.match_batch_dev(n, r.data_ptr(), r.shape[1], p.data_ptr(), out.data_ptr(), dtype="f32")
+            want = torch.zeros((n, 112), dtype=torch.uint8, device=r.device)
+            ref.match_batch_dev(n, r.data_ptr(), r.shape[1], p.data_ptr(), want.data_ptr(), dtype="f32")
+            pending.append((n, out, want))
+        if len(pending) >= 6 or it == 59:
+            ctx.synchronize()
+            for n, out, want in pending:
+                assert torch.equal(out, want), n
+            pending = []
+    gm.close()
+    ref.close()
