@@ -180,3 +180,22 @@ def test_random_sequences_of_steps_and_grid_changes(ctx):
             pending = []
     gm.close()
     ref.close()
+
+
+def test_pool_shares_travel_as_pipelined_sub_batches(ctx):
+    """lslam_pool_*: every device's share of a batch goes through lslam_matcher_match_batch at depth 2 (two sub-batches of
+    >= 256 scans, uploads included).  A pool naming GPU 0 twice -- how the 1-GPU box shards -- returns the records of one
+    plain matcher, in scan order."""
+    wl = _workload(1300, seed=36)
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(wl.laser))
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    want = gm.match_batch(wl.query_ranges, wl.query_poses)
+    pool = api.MatcherPool(api.baseline_config(), api.laser_params(wl.laser), devices=[0, 0])
+    assert pool.devices == 2
+    pool.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    got = pool.match_batch(wl.query_ranges, wl.query_poses)
+    assert got.tobytes() == want.tobytes()
+    small = pool.match_batch(wl.query_ranges[:9], wl.query_poses[:9])  # shares below the sub-batch minimum: plain steps
+    assert small.tobytes() == want[:9].tobytes()
+    pool.close()
+    gm.close()
