@@ -1598,7 +1598,7 @@ int plan_rounds(const int* tw, const int* th, int K, size_t budget_bytes, uint32
 // four launches per level and round.  d_pts: the K containers back to back; counts / origos / poses are host arrays;
 // radius (host, may be null): per scan, the distance of its farthest point from its origo in level-0 cells.
 int update_batch_impl(lslam_map* map, int K, const float* d_pts, const int32_t* counts, const float* origos,
-                      const float* poses, const float* radius) {
+                      const float* poses, const float* radius, bool use_hint) {
   lslam_context* ctx = map->ctx;
   {
     int rc = flush_pending(map);  // a single-scan update may still owe its apply
@@ -1651,7 +1651,7 @@ int update_batch_impl(lslam_map* map, int K, const float* d_pts, const int32_t* 
       h.pts_off = off[k];
       double reach = -1.0;  // unknown: the whole map
       if (radius) reach = (double)radius[k];
-      else if (map->batch_radius_hint > 0) reach = (double)map->batch_radius_hint;
+      else if (use_hint && map->batch_radius_hint > 0) reach = (double)map->batch_radius_hint;  // device-resident points only
       int w[4];
       plan_window(L.sx, L.sy, h.bx, h.by, h.n, reach, (double)factor, w);
       h.tx0 = w[0]; h.ty0 = w[1]; h.tw = w[2]; h.th = w[3];
@@ -1753,14 +1753,14 @@ int update_batch_impl(lslam_map* map, int K, const float* d_pts, const int32_t* 
 namespace {
 // n_scans containers back to back in points_xy; batches larger than 64 scans are cut into groups of 64
 int update_batch_dev_impl(lslam_map* map, int n_scans, const float* points_xy_dev, const int32_t* n_points,
-                          const float* origos_xy, const float* poses_world, const float* radius) {
+                          const float* origos_xy, const float* poses_world, const float* radius, bool use_hint) {
   lslam_context* ctx = map->ctx;
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
   size_t done_pts = 0;
   for (int k0 = 0; k0 < n_scans; k0 += kBatchMaxScans) {
     const int K = std::min(kBatchMaxScans, n_scans - k0);
     int rc = update_batch_impl(map, K, points_xy_dev + 2 * done_pts, n_points + k0, origos_xy + 2 * k0, poses_world + 3 * k0,
-                               radius ? radius + k0 : nullptr);
+                               radius ? radius + k0 : nullptr, use_hint);
     if (rc) return rc;
     for (int k = 0; k < K; k++) done_pts += (size_t)n_points[k0 + k];
   }
@@ -1784,7 +1784,7 @@ int lslam_map_update_batch_dev(lslam_map* map, int n_scans, const float* points_
                                const float* origos_xy, const float* poses_world) {
   if (!map || n_scans < 0 || !n_points || !origos_xy || !poses_world) return LSLAM_ERR_INVALID_ARGUMENT;
   // the host never sees these points: the windows come from LSLAM_MAP_OPT_BATCH_RADIUS_CELLS, or cover the whole map
-  return update_batch_dev_impl(map, n_scans, points_xy_dev, n_points, origos_xy, poses_world, nullptr);
+  return update_batch_dev_impl(map, n_scans, points_xy_dev, n_points, origos_xy, poses_world, nullptr, true);
 }
 
 int lslam_map_update_batch(lslam_map* map, int n_scans, const float* points_xy, const int32_t* n_points,
@@ -1825,7 +1825,9 @@ int lslam_map_update_batch(lslam_map* map, int n_scans, const float* points_xy, 
   }
   int rc = stage_points(map, points_xy, (int)total);
   if (rc) return rc;
-  return update_batch_dev_impl(map, n_scans, map->d_pts.p, n_points, origos_xy, poses_world, radius.empty() ? nullptr : radius.data());
+  // (the hint is for points the host cannot see; these it has just measured, or their windows are the map anyway)
+  return update_batch_dev_impl(map, n_scans, map->d_pts.p, n_points, origos_xy, poses_world, radius.empty() ? nullptr : radius.data(),
+                               false);
 }
 
 // Host-only: what a batched update of these scans would allocate on a level of sx x sy cells -- the planner
