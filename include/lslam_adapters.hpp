@@ -110,6 +110,10 @@ class GpuScanMatcher {
     return out;
   }
 
+  // MatchBatch as `depth` pipelined sub-batches (LSLAM_OPT_PIPELINE_DEPTH, 1..4; lslam_gpu.h): uploads and the latency-bound
+  // reduce kernels of one sub-batch run under the response kernels of the other.  Same records.  No reference counterpart.
+  void SetPipelineDepth(int depth) { check(lslam_matcher_set_option(h_, LSLAM_OPT_PIPELINE_DEPTH, depth)); }
+
   // LocalizedRangeScan::GetSensorAt / SetSensorPose (Karto.h:5280-5313)
   Pose2 SensorPoseFromRobot(const Pose2& robot) const {
     const double r[3] = {robot.x, robot.y, robot.heading};

@@ -57,6 +57,21 @@ int main(int argc, char**) {
     std::vector<lslam_match_result> one(S);
     if (lslam_matcher_set_base_scans(m->handle(), 1, a.data(), 360, zero, zero) != LSLAM_OK) return 5;
     if (lslam_matcher_match_batch(m->handle(), S, rr.data(), 360, pp.data(), 1, 1, one.data()) != LSLAM_OK) return 5;
+    {  // the same batch, 16 times over, as two pipelined sub-batches of 296 scans (SetPipelineDepth): same records
+      const int R = 16;
+      std::vector<double> r2((size_t)S * R * 360), p2((size_t)S * R * 3);
+      for (int q = 0; q < R; q++) {
+        std::memcpy(&r2[(size_t)q * S * 360], rr.data(), sizeof(double) * (size_t)S * 360);
+        std::memcpy(&p2[(size_t)q * S * 3], pp.data(), sizeof(double) * (size_t)S * 3);
+      }
+      std::vector<lslam_match_result> big((size_t)S * R);
+      m->SetPipelineDepth(2);
+      if (lslam_matcher_match_batch(m->handle(), S * R, r2.data(), 360, p2.data(), 1, 1, big.data()) != LSLAM_OK) return 7;
+      m->SetPipelineDepth(1);
+      for (int i = 0; i < S * R; i++)
+        if (std::memcmp(&big[i], &one[i % S], sizeof(lslam_match_result)) != 0) { std::printf("pipelined mismatch at %d\n", i); return 7; }
+      std::printf("pipelined ok\n");
+    }
     lslam::GpuMatcherPool all(0, cfg, laser);
     lslam::GpuMatcherPool two(std::vector<int>{0, 0}, cfg, laser);
     std::printf("pool devices %d / %d\n", all.devices(), two.devices());
@@ -101,4 +116,4 @@ def test_adapters_run_on_gpu(tmp_path):
     exe = _build(tmp_path)
     r = subprocess.run([str(exe), "need-gpu"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "response" in r.stdout and "nonzero cells 71" in r.stdout and "pool ok" in r.stdout
+    assert "response" in r.stdout and "nonzero cells 71" in r.stdout and "pool ok" in r.stdout and "pipelined ok" in r.stdout
