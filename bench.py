@@ -1164,6 +1164,7 @@ def main():
                          "timed_region_depth": depth}
             sizes = sorted({max(64, n_mine // 8), max(64, n_mine // 4), max(64, n_mine // 2), n_mine})
             ring4 = [torch.zeros((n_mine, 112), dtype=torch.uint8, device=dev) for _ in range(4)]
+            torch.cuda.synchronize()  # torch's fill kernels run on torch's stream: done before the library's streams write
             table, same_all = {}, True
             for nb in sizes:
                 row = {}
