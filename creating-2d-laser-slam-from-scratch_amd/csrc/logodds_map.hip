@@ -1691,7 +1691,10 @@ int update_batch_impl(lslam_map* map, int K, const float* d_pts, const int32_t* 
       // old pool goes first -- nothing may still read it, so the stream is drained once -- instead of living on beside the new one
       LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
       L.d_pool.release();
-      const size_t bytes = ((need_slots * 64 + ((size_t)1 << 20) - 1) >> 20) << 20;
+      // a sixteenth of headroom: the windows of the next 64 scans are clipped a little differently by the map's edges, and
+      // growing again means draining the stream again
+      const size_t want = need_slots * 64 + need_slots * 4;
+      const size_t bytes = ((want + ((size_t)1 << 20) - 1) >> 20) << 20;
       uint8_t* fresh = nullptr;
       if (hipMalloc((void**)&fresh, bytes) != hipSuccess) {
         (void)hipGetLastError();
