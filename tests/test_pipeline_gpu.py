@@ -204,3 +204,52 @@ def test_pool_shares_travel_as_pipelined_sub_batches(ctx):
     assert small.tobytes() == want[:9].tobytes()
     pool.close()
     gm.close()
+
+
+@pytest.mark.parametrize("kind", ["loop_lattice", "response_expansion"])
+def test_pipelined_steps_on_the_other_kernel_families(ctx, kind):
+    """The per-step workspaces also carry the big-lattice scratch (materialised tables, beam-slice partial sums, reduce
+    scratch: the loop-closure matcher's 81 x 81 x 21 search) and the expansion passes' state: pipelined steps of those
+    configurations equal the plain ones too."""
+    import math
+
+    if kind == "loop_lattice":
+        laser = synth.Laser(range_max=30.0)
+        cfg = api.baseline_config(range_threshold=12.0, search_size=8.0, resolution=0.05, smear_deviation=0.03)
+        world = synth.arena(size=40.0, n_axis=12, n_rot=4, seed=14)
+        wl = synth.make_match_workload(n_base=16, n_query=40, seed=14, laser=laser, world=world, err_xy=2.0,
+                                       err_th=math.radians(12.0), query_spread=1.0)
+        gm = api.ScanMatcher(ctx, cfg, api.laser_params(laser, 12.0))
+        kw = dict(doPenalize=False, doRefineMatch=False)
+        sizes = [1, 40, 3, 40, 17, 1]
+    else:
+        wl = _workload(300, seed=37)
+        gm = api.ScanMatcher(ctx, api.baseline_config(use_response_expansion=1), api.laser_params(wl.laser))
+        kw = dict(doPenalize=True, doRefineMatch=True)
+        sizes = [300, 5, 120, 300, 5]
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    n_all = max(sizes)
+    r, p = _dev(wl, n_all)
+    if kind == "response_expansion":  # scans without a reading: the response stays 0 and the search expands three times
+        blind = wl.query_ranges[:n_all].astype(np.float32).copy()
+        blind[::7] = np.nan
+        r = torch.from_numpy(np.ascontiguousarray(blind)).to(r.device)
+    torch.cuda.synchronize()
+
+    def run(depth):
+        gm.set_option("pipeline_depth", depth)
+        outs = [torch.empty((n, 112), dtype=torch.uint8, device=r.device) for n in sizes]
+        torch.cuda.synchronize()
+        for n, o in zip(sizes, outs):
+            gm.match_batch_dev(n, r.data_ptr(), r.shape[1], p.data_ptr(), o.data_ptr(), dtype="f32", **kw)
+        ctx.synchronize()
+        return [o.cpu().numpy().tobytes() for o in outs]
+
+    plain = run(1)
+    rec = np.frombuffer(plain[sizes.index(n_all)], dtype=api.RESULT_DTYPE)
+    assert (rec["response"] > 0).any()
+    if kind == "response_expansion":
+        assert (rec["flags"][::7] & 1).all()  # the expansion passes really ran for the blind scans
+    for depth in (2, 3):
+        assert run(depth) == plain
+    gm.close()
