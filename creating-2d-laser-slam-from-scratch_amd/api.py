@@ -265,6 +265,8 @@ def lib() -> C.CDLL:
     L.lslam_frontend_num_scans.argtypes = [vp]
     L.lslam_frontend_scan_pose.argtypes = [vp, i32, vp]
     L.lslam_frontend_stats.argtypes = [vp, vp]
+    L.lslam_frontend_process_many.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.lslam_frontend_lookahead_stats.argtypes = [vp, vp]
     L.lslam_occgrid_create_from_scans.argtypes = [vp, C.POINTER(LaserParams), i32, vp, i32, vp, dbl, C.POINTER(vp)]
     L.lslam_occgrid_destroy.argtypes = [vp]
     L.lslam_occgrid_destroy.restype = None
@@ -778,6 +780,28 @@ class FrontEnd:
         self.ctx.check(self.L.lslam_frontend_process_stamped(self.h, r.ctypes.data, r.shape[0], o.ctypes.data, time_s,
                                                              C.byref(ok), pose.ctypes.data, cov.ctypes.data, C.byref(resp)))
         return bool(ok.value), pose, cov.reshape(3, 3), resp.value
+
+    def ProcessMany(self, ranges, odom_poses, times_s=None):
+        """Mapper::Process over scans already at hand, with one scan of look-ahead (the loop search of scan t and the
+        running-window match of scan t + 1 share the device).  -> (processed [n] bool, corrected robot poses [n, 3],
+        covariances [n, 3, 3], responses [n]); identical to n Process calls."""
+        r = _f64(ranges)
+        r = r.reshape(-1, r.shape[-1])
+        o = _f64(odom_poses).reshape(-1, 3)
+        n = r.shape[0]
+        assert o.shape[0] == n
+        t = None if times_s is None else _f64(times_s)
+        ok = np.zeros(n, dtype=np.int32)
+        pose, cov, resp = np.zeros((n, 3)), np.zeros((n, 9)), np.zeros(n)
+        self.ctx.check(self.L.lslam_frontend_process_many(self.h, n, r.ctypes.data, r.shape[1], o.ctypes.data,
+                                                          None if t is None else t.ctypes.data, ok.ctypes.data, pose.ctypes.data,
+                                                          cov.ctypes.data, resp.ctypes.data))
+        return ok.astype(bool), pose, cov.reshape(n, 3, 3), resp
+
+    def lookahead_stats(self) -> dict:
+        out = np.zeros(3, dtype=np.int64)
+        self.ctx.check(self.L.lslam_frontend_lookahead_stats(self.h, out.ctypes.data))
+        return {"started": int(out[0]), "accepted": int(out[1]), "discarded": int(out[2])}
 
     def num_scans(self) -> int:
         return self.L.lslam_frontend_num_scans(self.h)

@@ -68,6 +68,31 @@ struct lslam_frontend {
   std::vector<double> cos_a, sin_a;        // cos / sin of minimum_angle + i * angular_resolution
   bool have_last = false;
   int64_t n_chain_matches = 0, n_loop_coarse = 0, n_loop_fine = 0, n_loops_closed = 0, n_edges = 0;
+  // ---- look-ahead (lslam_frontend_process_many) ---------------------------------------------------------------------
+  // The loop search of scan t is a chain of lone, latency-bound matches on the loop matchers, and 98 % of them close
+  // nothing.  When the caller has handed over scan t + 1 already, its running-window match -- which reads the poses as
+  // they stand, exactly what the sequential walk reads unless a loop closes -- is enqueued on the main matcher WHILE the
+  // loop candidates of scan t are in flight.  Process(t + 1) then finds its match done.  A loop that does close re-poses
+  // scan t: the speculative match is discarded and redone (every accepted result is the sequential walk's).
+  struct LookAhead {
+    const double* ranges;
+    const double* odom;
+    double time;
+  };
+  const LookAhead* la = nullptr;  // the scan after the one being processed (process_many only)
+  struct Spec {
+    bool started = false, finished = false, invalid = false;
+    const double* ranges = nullptr;
+    double odom[3] = {0, 0, 0}, time = 0;
+    int id = -1;
+    double sp[3] = {0, 0, 0};          // the sensor pose the match was started from
+    double last_robot[3] = {0, 0, 0};  // the previous scan's robot pose it was derived from
+    lslam_match_result r;
+    int rc = 0;
+  } spec;
+  lslam_match_result* h_res_spec = nullptr;  // pinned: the speculative match's record
+  DevBuf<double> d_q_spec;
+  int64_t n_spec_started = 0, n_spec_used = 0, n_spec_discarded = 0;
 };
 
 namespace {
@@ -319,6 +344,66 @@ std::pair<int, int> fe_possible_loop_closure(const lslam_frontend* f, int id, co
   return {first, count};  // the reference returns whatever is left when the scans run out
 }
 
+// Mapper::Process up to the match (Mapper.cpp:2021-2031, 2087-2120): the odometry-corrected robot pose of a new scan and
+// HasMovedEnough, from the last processed scan as it stands
+void fe_prologue(const lslam_frontend* f, const double odom_pose[3], double time_s, double corrected[3], bool* moved) {
+  const lslam_laser* laser = &f->m->laser;
+  const lslam_frontend_scan& last = f->scans.back();
+  PoseXform t = pose_xform(last.odom, last.robot);  // :2021-2025
+  pose_xform_apply(t, odom_pose, corrected);
+  // HasMovedEnough (:2087-2120): time first, then the ODOMETRIC sensor poses
+  bool mv = (time_s - last.time) >= f->cfg.minimum_time_interval;
+  if (!mv) {
+    double lsp[3], csp[3];
+    lslam_sensor_pose_from_robot(laser, last.odom, lsp);
+    lslam_sensor_pose_from_robot(laser, odom_pose, csp);
+    const double dh = normalize_angle(csp[2] - lsp[2]);
+    mv = fabs(dh) >= f->cfg.minimum_travel_heading;
+    if (!mv) mv = sq_dist2(lsp, csp) >= ksq(f->cfg.minimum_travel_distance) - kTol;
+  }
+  *moved = mv;
+}
+
+// wait for the speculative match (if one is in flight) and keep its record
+void fe_spec_finish(lslam_frontend* f) {
+  if (!f->spec.started || f->spec.finished) return;
+  f->spec.rc = fe_match_finish(f->m, f->h_res_spec, &f->spec.r);
+  f->spec.finished = true;
+}
+
+// Enqueue the running-window match of the NEXT scan (f->la) on the main matcher, now -- called by the loop search once
+// its first candidates are in flight.  Nothing of the graph or the scan list is touched: Process(t + 1) repeats the
+// (cheap) prologue and accepts the record only if it started from the very same poses.
+void fe_spec_try_start(lslam_frontend* f) {
+  if (!f->la || f->spec.started || !f->have_last || !f->h_res_spec) return;
+  lslam_matcher* m = f->m;
+  const int n = m->g.n_beams;
+  const int id = (int)f->scans.size();
+  if (n <= 0 || id + 1 > f->cap) return;  // (growing the resident arrays frees the old ones: not under matches in flight)
+  double corrected[3];
+  bool moved = false;
+  fe_prologue(f, f->la->odom, f->la->time, corrected, &moved);
+  if (!moved) return;  // Process(t + 1) will reject the scan: nothing to match
+  lslam_frontend::Spec& sp = f->spec;
+  sp = lslam_frontend::Spec{};
+  sp.ranges = f->la->ranges;
+  for (int i = 0; i < 3; i++) sp.odom[i] = f->la->odom[i];
+  sp.time = f->la->time;
+  sp.id = id;
+  for (int i = 0; i < 3; i++) sp.last_robot[i] = f->scans.back().robot[i];
+  lslam_sensor_pose_from_robot(&m->laser, corrected, sp.sp);
+  memcpy(f->h_ranges, f->la->ranges, (size_t)n * sizeof(double));  // staged: the match's first kernel moves them into HBM
+  f->pending_ranges = f->h_ranges;
+  const int rc = fe_match_enqueue(f, m, f->d_q_spec.p, f->h_res_spec, id, sp.sp, f->run_start, f->run_count, 1, 1);
+  f->pending_ranges = nullptr;
+  if (rc) {  // could not even be enqueued: Process(t + 1) does it the plain way (and reports whatever is wrong)
+    (void)hipStreamSynchronize(m->ctx->stream);
+    return;
+  }
+  sp.started = true;
+  f->n_spec_started++;
+}
+
 // TryCloseLoop (Mapper.cpp:976-1051), one sensor.
 //
 // The reference matches the candidate chains strictly one after another; 98.7 % of those coarse matches close nothing
@@ -335,6 +420,7 @@ int fe_close_after_coarse(lslam_frontend* f, int id, const std::pair<int, int>& 
       coarse.covariance[0] < f->cfg.loop_match_maximum_variance_coarse &&
       coarse.covariance[4] < f->cfg.loop_match_maximum_variance_coarse) {
     lslam_match_result fine;  // tmpScan.SetSensorPose(bestPose); MatchScan(&tmpScan, chain, ..., false)
+    fe_spec_finish(f);  // the fine match runs on the sequential matcher: a look-ahead match in flight there completes first
     int rc = fe_match(f, f->m, id, coarse.pose, chain.first, chain.second, 0, 1, &fine);
     if (rc) return rc;
     f->n_loop_fine++;
@@ -345,6 +431,7 @@ int fe_close_after_coarse(lslam_frontend* f, int id, const std::pair<int, int>& 
       fe_link_chain_to_scan(f, chain.first, chain.second, id);
       f->n_loops_closed++;  // CorrectPoses(): no ScanSolver attached
       *closed = true;
+      if (f->spec.started) f->spec.invalid = true;  // the look-ahead match read this scan at its old pose
     }
   }
   return LSLAM_OK;
@@ -370,7 +457,21 @@ int fe_try_close_loop(lslam_frontend* f, int id) {
     }
     if (chains.empty()) return LSLAM_OK;
     bool closed = false;
-    if (chains.size() == 1) {
+    // which matcher takes candidate k of a round.  With a look-ahead scan waiting (process_many) the pool's matchers --
+    // own streams -- go first and the loop matcher proper, which shares the main stream with the sequential matcher, last:
+    // the look-ahead match is enqueued on that stream and must not queue up behind a candidate.
+    const bool ahead = f->la != nullptr && !f->loop_pool.empty() && !ctx->timer.enabled;
+    struct Slot { lslam_matcher* m; double* d_q; lslam_match_result* h_res; bool pooled; };
+    auto slot_of = [&](size_t k) -> Slot {
+      const size_t P = f->loop_pool.size();
+      if (ahead) {
+        if (k < P) return Slot{f->loop_pool[k].m, f->loop_pool[k].d_q.p, f->loop_pool[k].h_res, true};
+        return Slot{f->loop_m, f->d_q.p, f->h_res, false};
+      }
+      if (k == 0) return Slot{f->loop_m, f->d_q.p, f->h_res, false};
+      return Slot{f->loop_pool[k - 1].m, f->loop_pool[k - 1].d_q.p, f->loop_pool[k - 1].h_res, true};
+    };
+    if (chains.size() == 1 && !ahead) {
       lslam_match_result coarse;
       int rc = fe_match(f, f->loop_m, id, f->scans[id].sensor, chains[0].first, chains[0].second, 0, 0, &coarse);
       if (rc) return rc;
@@ -380,26 +481,26 @@ int fe_try_close_loop(lslam_frontend* f, int id) {
       start_num = resume[0];
       continue;  // closed or not: the next round re-reads the graph, like the reference's next FindPossibleLoopClosure
     }
-    // ---- several chains: all coarse matches in flight at once ----
+    // ---- several chains (or one, with a look-ahead scan waiting): all coarse matches in flight at once ----
     LSLAM_HIP(ctx, hipEventRecord(f->ev_ready, ctx->stream));  // the scan's world points etc. are ordered before this
     for (size_t k = 0; k < chains.size(); k++) {
-      lslam_matcher* lm = k == 0 ? f->loop_m : f->loop_pool[k - 1].m;
-      if (k > 0) LSLAM_HIP(ctx, hipStreamWaitEvent(lm->ctx->stream, f->ev_ready, 0));
-      int rc = fe_match_enqueue(f, lm, k == 0 ? f->d_q.p : f->loop_pool[k - 1].d_q.p, k == 0 ? f->h_res : f->loop_pool[k - 1].h_res,
-                                id, f->scans[id].sensor, chains[k].first, chains[k].second, 0, 0);
+      const Slot sl = slot_of(k);
+      if (sl.pooled) LSLAM_HIP(ctx, hipStreamWaitEvent(sl.m->ctx->stream, f->ev_ready, 0));
+      int rc = fe_match_enqueue(f, sl.m, sl.d_q, sl.h_res, id, f->scans[id].sensor, chains[k].first, chains[k].second, 0, 0);
       if (rc) {
-        if (k > 0) ctx->last_error = lm->ctx->last_error;
-        for (size_t j = 0; j < k; j++) (void)hipStreamSynchronize((j == 0 ? f->loop_m : f->loop_pool[j - 1].m)->ctx->stream);
+        if (sl.pooled) ctx->last_error = sl.m->ctx->last_error;
+        for (size_t j = 0; j < k; j++) (void)hipStreamSynchronize(slot_of(j).m->ctx->stream);
         return rc;
       }
     }
+    fe_spec_try_start(f);  // the next scan's running-window match goes out now, under the candidates (no-op without look-ahead)
     // wait for all of them (the slowest sets the pace either way), then consume in the reference's order
     std::vector<lslam_match_result> res(chains.size());
     std::vector<int> rcs(chains.size(), LSLAM_OK);
     for (size_t k = 0; k < chains.size(); k++) {
-      lslam_matcher* lm = k == 0 ? f->loop_m : f->loop_pool[k - 1].m;
-      rcs[k] = fe_match_finish(lm, k == 0 ? f->h_res : f->loop_pool[k - 1].h_res, &res[k]);
-      if (rcs[k] && k > 0) ctx->last_error = lm->ctx->last_error;
+      const Slot sl = slot_of(k);
+      rcs[k] = fe_match_finish(sl.m, sl.h_res, &res[k]);
+      if (rcs[k] && sl.pooled) ctx->last_error = sl.m->ctx->last_error;
     }
     size_t used = 0;
     for (size_t k = 0; k < chains.size(); k++) {
@@ -486,8 +587,9 @@ int lslam_frontend_create_ex(lslam_matcher* m, const lslam_frontend_config* cfg,
       return ctx->fail(LSLAM_ERR_HIP, "hipEventCreate failed");
     }
   }
-  if (f->d_q.reserve(4 + 4 * 8) != hipSuccess || f->d_res.reserve(1) != hipSuccess ||
+  if (f->d_q.reserve(4 + 4 * 8) != hipSuccess || f->d_res.reserve(1) != hipSuccess || f->d_q_spec.reserve(4 + 4 * 8) != hipSuccess ||
       hipHostMalloc((void**)&f->h_res, sizeof(lslam_match_result), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&f->h_res_spec, sizeof(lslam_match_result), hipHostMallocDefault) != hipSuccess ||
       hipHostMalloc((void**)&f->h_ranges, sizeof(double) * (size_t)std::max(m->g.n_beams, 1), hipHostMallocDefault) != hipSuccess) {
     (void)hipGetLastError();
     lslam_frontend_destroy(f);
@@ -541,7 +643,9 @@ void lslam_frontend_destroy(lslam_frontend* f) {
   if (f->d_next) (void)hipFree(f->d_next);
   f->d_q.release();
   f->d_res.release();
+  f->d_q_spec.release();
   if (f->h_res) (void)hipHostFree(f->h_res);
+  if (f->h_res_spec) (void)hipHostFree(f->h_res_spec);
   if (f->h_ranges) (void)hipHostFree(f->h_ranges);
   delete f;
 }
@@ -552,6 +656,9 @@ int lslam_frontend_reset(lslam_frontend* f) {
   f->run_start = f->run_count = 0;
   f->have_last = false;
   f->n_chain_matches = f->n_loop_coarse = f->n_loop_fine = f->n_loops_closed = f->n_edges = f->n_loop_discarded = 0;
+  if (f->spec.started) fe_spec_finish(f);
+  f->spec = lslam_frontend::Spec{};
+  f->n_spec_started = f->n_spec_used = f->n_spec_discarded = 0;
   return LSLAM_OK;
 }
 
@@ -593,28 +700,38 @@ int lslam_frontend_process_stamped(lslam_frontend* f, const double* ranges, int 
   if (covariance) memcpy(covariance, cov, sizeof cov);  // also what a rejected scan reports
   if (response) *response = 0.0;
   if (f->have_last) {
-    const lslam_frontend_scan& last = f->scans.back();
-    PoseXform t = pose_xform(last.odom, last.robot);  // :2021-2025
-    pose_xform_apply(t, odom_pose, corrected);
-    // HasMovedEnough (:2087-2120): time first, then the ODOMETRIC sensor poses
-    bool moved = (time_s - last.time) >= f->cfg.minimum_time_interval;
-    if (!moved) {
-      double lsp[3], csp[3];
-      lslam_sensor_pose_from_robot(laser, last.odom, lsp);
-      lslam_sensor_pose_from_robot(laser, odom_pose, csp);
-      const double dh = normalize_angle(csp[2] - lsp[2]);
-      moved = fabs(dh) >= f->cfg.minimum_travel_heading;
-      if (!moved) moved = sq_dist2(lsp, csp) >= ksq(f->cfg.minimum_travel_distance) - kTol;
-    }
+    bool moved = false;
+    fe_prologue(f, odom_pose, time_s, corrected, &moved);  // :2021-2031, HasMovedEnough :2087-2120
     if (!moved) {
       for (int i = 0; i < 3; i++) corrected_pose[i] = corrected[i];
       return LSLAM_OK;
     }
   }
   const int id = (int)f->scans.size();
+  double sp[3];
+  lslam_sensor_pose_from_robot(laser, corrected, sp);
+  // A look-ahead match of THIS scan may be in flight (process_many: enqueued under the previous scan's loop search).  It
+  // counts only if it is this scan's, started from the very poses the plain walk has now; anything else is waited for
+  // and dropped.
+  bool have_spec = false;
+  lslam_match_result spec_r;
+  if (f->spec.started) {
+    fe_spec_finish(f);
+    const lslam_frontend::Spec& q = f->spec;
+    have_spec = f->have_last && !q.invalid && q.rc == LSLAM_OK && q.id == id && q.ranges == ranges && q.time == time_s &&
+                memcmp(q.odom, odom_pose, sizeof q.odom) == 0 && memcmp(q.sp, sp, sizeof sp) == 0 &&
+                memcmp(q.last_robot, f->scans.back().robot, sizeof q.last_robot) == 0;
+    if (have_spec) {
+      spec_r = q.r;
+      f->n_spec_used++;
+    } else {
+      f->n_spec_discarded++;
+    }
+    f->spec.started = false;
+  }
   int rc = fe_grow(f, id + 1);
   if (rc) return rc;
-  if (n > 0) {
+  if (n > 0 && !have_spec) {  // (an accepted look-ahead match has already moved the readings into their resident row)
     if (f->have_last) {  // a match follows at once: stage the readings, its first kernel moves them (one operation fewer)
       memcpy(f->h_ranges, ranges, (size_t)n * sizeof(double));
       f->pending_ranges = f->h_ranges;
@@ -633,12 +750,14 @@ int lslam_frontend_process_stamped(lslam_frontend* f, const double* ranges, int 
       s.nfilt++;
     }
   }
-  double sp[3];
-  lslam_sensor_pose_from_robot(laser, corrected, sp);
   if (f->have_last) {  // MatchScan(pScan, runningScans) + SetSensorPose(bestPose) (:2037-2045)
     lslam_match_result r;
-    rc = fe_match(f, m, id, sp, f->run_start, f->run_count, 1, 1, &r);
-    if (rc) return rc;
+    if (have_spec) {
+      r = spec_r;
+    } else {
+      rc = fe_match(f, m, id, sp, f->run_start, f->run_count, 1, 1, &r);
+      if (rc) return rc;
+    }
     resp = r.response;
     for (int i = 0; i < 9; i++) cov[i] = r.covariance[i];
     for (int i = 0; i < 3; i++) sp[i] = r.pose[i];
@@ -697,6 +816,50 @@ int lslam_frontend_process_stamped(lslam_frontend* f, const double* ranges, int 
 int lslam_frontend_process(lslam_frontend* f, const double* ranges, int n_ranges, const double odom_pose[3],
                            int* processed, double corrected_pose[3], double covariance[9], double* response) {
   return lslam_frontend_process_stamped(f, ranges, n_ranges, odom_pose, 0.0, processed, corrected_pose, covariance, response);
+}
+
+// Mapper::Process for n scans the caller already holds (offline / batch use), one after the other, with ONE scan of
+// look-ahead: see lslam_frontend::la.  Scan for scan the same poses, edges and graph as n calls of
+// lslam_frontend_process_stamped -- the loop search of scan t and the running-window match of scan t + 1 merely share
+// the device.  Stops at the first error.
+int lslam_frontend_process_many(lslam_frontend* f, int n_scans, const double* ranges, int ranges_stride, const double* odom_poses,
+                                const double* times_s, int32_t* processed, double* corrected_poses, double* covariances,
+                                double* responses) {
+  if (!f || n_scans < 0 || (n_scans > 0 && (!ranges || !odom_poses || !processed || !corrected_poses)))
+    return LSLAM_ERR_INVALID_ARGUMENT;
+  if (ranges_stride < f->m->g.n_beams) return f->m->ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "ranges_stride < num_beams");
+  int rc = LSLAM_OK;
+  for (int t = 0; t < n_scans && rc == LSLAM_OK; t++) {
+    lslam_frontend::LookAhead next;
+    if (t + 1 < n_scans) {
+      next.ranges = ranges + (size_t)(t + 1) * ranges_stride;
+      next.odom = odom_poses + 3 * (size_t)(t + 1);
+      next.time = times_s ? times_s[t + 1] : 0.0;
+      f->la = &next;
+    }
+    int done = 0;
+    rc = lslam_frontend_process_stamped(f, ranges + (size_t)t * ranges_stride, ranges_stride, odom_poses + 3 * (size_t)t,
+                                        times_s ? times_s[t] : 0.0, &done, corrected_poses + 3 * (size_t)t,
+                                        covariances ? covariances + 9 * (size_t)t : nullptr, responses ? responses + t : nullptr);
+    processed[t] = done;
+    f->la = nullptr;
+  }
+  if (f->spec.started) {  // an error left a look-ahead match behind: nothing of it is used
+    fe_spec_finish(f);
+    f->spec.started = false;
+    f->n_spec_discarded++;
+  }
+  return rc;
+}
+
+// out[0] = look-ahead matches started, [1] = accepted, [2] = discarded (a loop closed in between, or the scan was not the one
+// announced)
+int lslam_frontend_lookahead_stats(const lslam_frontend* f, int64_t out[3]) {
+  if (!f || !out) return LSLAM_ERR_INVALID_ARGUMENT;
+  out[0] = f->n_spec_started;
+  out[1] = f->n_spec_used;
+  out[2] = f->n_spec_discarded;
+  return LSLAM_OK;
 }
 
 }  // extern "C"

@@ -354,6 +354,19 @@ int lslam_frontend_process(lslam_frontend* f, const double* ranges, int n_ranges
 int lslam_frontend_process_stamped(lslam_frontend* f, const double* ranges, int n_ranges, const double odom_pose[3],
                                    double time_s, int* processed, double corrected_pose[3], double covariance[9],
                                    double* response);
+/* Mapper::Process for n_scans scans the caller ALREADY HOLDS (offline / batch use: a recorded trajectory), one after the
+ * other, with one scan of look-ahead: while the loop search of scan t -- a chain of lone, latency-bound matches on the
+ * loop matchers, 98 % of which close nothing -- is in flight, the running-window match of scan t + 1 is enqueued on the
+ * sequential matcher; Process(t + 1) finds it done.  A loop that does close re-poses scan t: the look-ahead match is
+ * dropped and redone, so scan for scan the poses, the edges and the graph are those of n_scans calls of
+ * lslam_frontend_process_stamped.  ranges: n_scans rows of ranges_stride doubles; odom_poses n_scans*3; times_s n_scans or
+ * NULL (= 0); processed n_scans; corrected_poses n_scans*3; covariances n_scans*9 or NULL; responses n_scans or NULL.
+ * The reference has no counterpart (Mapper::Process takes one scan: Mapper.cpp:1999-2079). */
+int lslam_frontend_process_many(lslam_frontend* f, int n_scans, const double* ranges, int ranges_stride,
+                                const double* odom_poses, const double* times_s, int32_t* processed,
+                                double* corrected_poses, double* covariances, double* responses);
+/* out[3] = look-ahead matches started, accepted, discarded */
+int lslam_frontend_lookahead_stats(const lslam_frontend* f, int64_t out[3]);
 /* GetAllProcessedScans().size(); corrected ROBOT pose of processed scan `scan_id` as it stands now (a closed loop
  * re-poses the closing scan); out[6] = scans, graph edges, near-chain matches, loop coarse matches, loop fine
  * matches, loops closed */

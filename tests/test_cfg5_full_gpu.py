@@ -97,3 +97,32 @@ def test_cfg5_sequential_loop_search_gives_the_same_record(ctx, cfg5, monkeypatc
     assert np.abs(poses - d["corrected"][:n]).max() <= 1e-9
     assert np.array_equal(edges, d["edges"][:n].astype(np.int64))
     assert fe.stats()["loop_coarse_matches"] > 100
+
+
+def test_cfg5_with_one_scan_of_look_ahead_gives_the_same_record(ctx, cfg5):
+    """lslam_frontend_process_many: the running-window match of scan t + 1 enqueued under the loop search of scan t, all
+    10 000 scans in calls of 64.  Every pose at the time it was processed, every processed flag, the edge count at the end
+    of every call, the final poses and the graph statistics equal the reference's record; look-ahead matches that a closed
+    loop overtook are dropped and redone (the counters say how many)."""
+    d, laser, path, odom, scans32 = cfg5
+    n = int(d["n"])
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
+    fe = api.FrontEnd(gm, config=api.frontend_config(**GRAPH))
+    r64 = np.stack([synth.ranges_to_f64(s) for s in scans32])
+    poses, ok_all = np.zeros((n, 3)), np.zeros(n, bool)
+    for i0 in range(0, n, 64):
+        i1 = min(n, i0 + 64)
+        ok_all[i0:i1], poses[i0:i1], _, _ = fe.ProcessMany(r64[i0:i1], odom[i0:i1])
+        assert fe.stats()["edges"] == int(d["edges"][i1 - 1]), i1
+    assert np.array_equal(ok_all, d["processed"].astype(bool))
+    err = np.abs(poses - d["corrected"]).max(axis=1)
+    assert err.max() <= 1e-9, (int(err.argmax()), err.max())
+    final = np.stack([fe.scan_pose(i) for i in range(fe.num_scans())])
+    assert np.abs(final - d["final_poses"]).max() <= 1e-9
+    st, la = fe.stats(), fe.lookahead_stats()
+    if n == 10000:
+        assert (st["edges"], st["chain_matches"], st["loop_coarse_matches"], st["loop_fine_matches"], st["loops_closed"]) == \
+               (10531, 947, 13324, 300, 170), st
+    assert la["started"] > n // 4 and la["accepted"] + la["discarded"] == la["started"], la
+    assert la["discarded"] <= st["loops_closed"] + 5, (la, st)  # only a closed loop (or a call boundary) costs a look-ahead match
+    print("cfg 5 with look-ahead: max pose difference %.3g, look-ahead %s" % (err.max(), la))
