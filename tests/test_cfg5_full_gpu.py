@@ -97,6 +97,14 @@ def test_cfg5_sequential_loop_search_gives_the_same_record(ctx, cfg5, monkeypatc
     assert np.abs(poses - d["corrected"][:n]).max() <= 1e-9
     assert np.array_equal(edges, d["edges"][:n].astype(np.int64))
     assert fe.stats()["loop_coarse_matches"] > 100
+    # process_many on the one-matcher configuration: nothing to overlap with (the loop matcher shares the main stream), so no
+    # look-ahead match is ever started -- and the record is the same
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
+    fe2 = api.FrontEnd(gm, config=api.frontend_config(**GRAPH))
+    r64 = np.stack([synth.ranges_to_f64(s) for s in scans32[:n]])
+    _, poses2, _, _ = fe2.ProcessMany(r64, odom[:n])
+    assert np.array_equal(poses2, poses) and fe2.lookahead_stats()["started"] == 0
+    assert fe2.stats() == fe.stats()
 
 
 def test_cfg5_with_one_scan_of_look_ahead_gives_the_same_record(ctx, cfg5):
