@@ -180,6 +180,16 @@ class GpuFrontEnd {
         for (int j = 0; j < 3; j++) covariance->m[i][j] = cov[3 * i + j];
     return processed != 0;
   }
+  // Process for a recorded trajectory (nScans scans already at hand, rows of rangesStride doubles, poses as x, y, heading
+  // triples): one scan of look-ahead, same results (lslam_frontend_process_many).  processed[i] / corrected[3 i ..] as Process.
+  void ProcessMany(const double* ranges, int rangesStride, const double* odometricPoses, int nScans, std::vector<int32_t>& processed,
+                   std::vector<double>& corrected) {
+    processed.assign((size_t)nScans, 0);
+    corrected.assign((size_t)nScans * 3, 0.0);
+    int rc = lslam_frontend_process_many(h_, nScans, ranges, rangesStride, odometricPoses, nullptr, processed.data(), corrected.data(),
+                                         nullptr, nullptr);
+    if (rc != LSLAM_OK) throw MatcherError(rc, lslam_last_error(ctx_));
+  }
   int RunningScans() const { return lslam_frontend_running_scans(h_); }
 
  private:
