@@ -1205,8 +1205,10 @@ def main():
                     t0 = time.perf_counter()
                     for k in range(n_st):
                         gm.match_batch_dev(nb, ranges32.data_ptr(), N_BEAMS, poses.data_ptr(), ring4[k % d].data_ptr(), dtype="f32")
+                    t_enq = time.perf_counter() - t0  # the host's share: every call has returned, nothing awaited yet
                     ctx.synchronize()
                     row["depth_%d_ms" % d] = round(1e3 * (time.perf_counter() - t0) / n_st, 4)
+                    row["depth_%d_host_enqueue_ms" % d] = round(1e3 * t_enq / n_st, 4)
                     same_all = same_all and all(bool(torch.equal(ring4[k][:nb], results[:nb])) for k in range(d))
                 row["steps"] = n_st
                 table["batch_%d" % nb] = row

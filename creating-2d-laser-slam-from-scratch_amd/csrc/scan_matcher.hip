@@ -3093,6 +3093,9 @@ int pipe_join(lslam_matcher* m) {
   lslam_context* ctx = m->ctx;
   for (int i = 0; i < lslam_matcher::kMaxPipe; i++)
     if (m->pipe_pending[i]) {
+      // recorded HERE, once per join, not once per step: an event record is a marker packet in front of the slot's next
+      // kernel (~5 us of the GPU's time each, rocprofv3 timeline in profiles/r05/experiments/pipe_lockstep)
+      LSLAM_HIP(ctx, hipEventRecord(m->pipe_done[i], m->pipe_stream[i]));
       LSLAM_HIP(ctx, hipStreamWaitEvent(ctx->stream, m->pipe_done[i], 0));
       m->pipe_pending[i] = false;
     }
@@ -3565,28 +3568,35 @@ int pipe_step(lslam_matcher* m, int S, const RT* d_ranges, int stride, const dou
   const int slot = m->pipe_next % m->pipe_depth;
   m->pipe_next = (slot + 1) % m->pipe_depth;
   hipStream_t s = m->pipe_stream[slot];
-  LSLAM_HIP(ctx, hipEventRecord(m->pipe_in[slot], ctx->stream));  // (one event per slot: never re-recorded under a pending wait of another stream)
-  LSLAM_HIP(ctx, hipStreamWaitEvent(s, m->pipe_in[slot], 0));
+  // "behind everything the context stream held": nothing to wait for when that stream has drained (the steady state of
+  // back-to-back steps -- the query costs the host a microsecond, the record + wait pair cost the GPU ~10 us per step)
+  const hipError_t idle = hipStreamQuery(ctx->stream);
+  if (idle != hipSuccess) {
+    (void)hipGetLastError();
+    if (idle != hipErrorNotReady) LSLAM_HIP(ctx, idle);
+    LSLAM_HIP(ctx, hipEventRecord(m->pipe_in[slot], ctx->stream));  // (one event per slot: never re-recorded under a pending wait of another stream)
+    LSLAM_HIP(ctx, hipStreamWaitEvent(s, m->pipe_in[slot], 0));
+  }
   if (m->view_owner >= 0 && m->view_owner != slot) LSLAM_HIP(ctx, hipStreamWaitEvent(s, m->view_ready, 0));
   const bool v0[4] = {m->sub_dirty, m->occ_dirty, m->tile_dirty, m->ptile_dirty};
   const void* const a0[2] = {m->d_tiles, m->d_ptiles};
   if (slot) swap_step_work(m, m->pipe_work[slot]);
   hipStream_t saved = ctx->stream;
   ctx->stream = s;  // launch(), the memsets and the timer events of match_batch_impl all go through ctx->stream
+  // whatever gets enqueued, failed call or not, is fenced by this slot's event: pipe_join records it, once, and it covers
+  // everything the stream holds by then
+  m->pipe_pending[slot] = true;
   m->pipe_in_step = true;
   rc = match_batch_impl<RT>(m, S, d_ranges, stride, d_poses, do_penalize, do_refine, d_out, nullptr, 0);
   m->pipe_in_step = false;
   ctx->stream = saved;
   if (slot) swap_step_work(m, m->pipe_work[slot]);
-  // whatever was enqueued, failed call or not, is fenced by this slot's event
   const bool refreshed = v0[0] != m->sub_dirty || v0[1] != m->occ_dirty || v0[2] != m->tile_dirty ||
                          v0[3] != m->ptile_dirty || a0[0] != m->d_tiles || a0[1] != m->d_ptiles;
   if (refreshed) {
     LSLAM_HIP(ctx, hipEventRecord(m->view_ready, s));
     m->view_owner = slot;
   }
-  LSLAM_HIP(ctx, hipEventRecord(m->pipe_done[slot], s));
-  m->pipe_pending[slot] = true;
   m->pipe_steps++;
   return rc;
 }
