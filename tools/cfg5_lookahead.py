@@ -10,6 +10,7 @@ import bench
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+with_map = len(sys.argv) > 3 and sys.argv[3] == "map"  # + the 4000 x 4000 log-odds map updated after every call (own context)
 laser = synth.Laser()
 path = synth.rings_trajectory(n)
 world = synth.arena_around_path(path, size=100.0, n_axis=30, n_rot=10, seed=6)
@@ -20,6 +21,12 @@ ctx = api.Context(0)
 cfg = api.frontend_config(scan_buffer_size=70, scan_buffer_maximum_scan_distance=20.0, do_loop_closing=1,
                           link_scan_maximum_distance=1.5, loop_search_maximum_distance=3.0, loop_match_minimum_chain_size=10)
 res = {}
+gmap = pts_all = None
+if with_map:
+    ctx_map = api.Context(0)
+    gmap = api.OccGridMap(ctx_map, 4000, 4000, 0.025, (50.0, 50.0))
+    gmap.setUpdateOccupiedFactor(0.9)
+    pts_all = [synth.hector_points(r, laser, 40.0, use_max=20.0) for r in scans32]
 for mode in ("process", "process_many", "process", "process_many"):
     gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
     fe = api.FrontEnd(gm, config=cfg)
@@ -33,8 +40,14 @@ for mode in ("process", "process_many", "process", "process_many"):
     else:
         for i0 in range(0, n, chunk):
             i1 = min(n, i0 + chunk)
-            _, poses[i0:i1], _, _ = fe.ProcessMany(r64[i0:i1], odom[i0:i1])
+            ok, poses[i0:i1], _, _ = fe.ProcessMany(r64[i0:i1], odom[i0:i1])
+            if gmap is not None:
+                idx = [i for i in range(i0, i1) if ok[i - i0]]
+                if idx:
+                    gmap.updateByScans([pts_all[i] for i in idx], (0.0, 0.0), poses[idx].astype(np.float32))
     ctx.synchronize()
+    if gmap is not None:
+        ctx_map.synchronize(); gmap.reset()
     dt = time.perf_counter() - t0
     st = fe.stats()
     print("%-13s %8.1f scans/s  %6.1f us/scan  edges %d loops %d  look-ahead %s" % (mode, n / dt, 1e6 * dt / n, st["edges"], st["loops_closed"],
