@@ -3049,8 +3049,9 @@ struct lslam_matcher {
   DevBuf<double> d_query, d_qpose;
   // ---- pipelined steps (LSLAM_OPT_PIPELINE_DEPTH > 1) ----------------------------------------------------------------
   // Consecutive batched matches take turns on `pipe_depth` internal streams, each with its OWN set of the workspaces a
-  // step writes between its first and its last kernel (StepWork), so that one step's latency-bound reduce kernels run
-  // under the next step's response kernels.  The grid and everything derived from it are shared and read-only while
+  // step writes between its first and its last kernel (StepWork), so that the steps in flight share the chip (in practice
+  // they run the same phase side by side: the response kernels fill each other's tails, the latency-bound prep / reduce
+  // kernels are paid once per `pipe_depth` steps -- DESIGN.md 6).  The grid and everything derived from it are shared and read-only while
   // steps are in flight: whoever changes them joins the internal streams into the context stream first (pipe_join).
   struct StepWork {
     DevBuf<double2> d_local, d_cossin;
@@ -4114,7 +4115,7 @@ int lslam_matcher_match_batch(lslam_matcher* m, int S, const double* ranges, int
   if (rc) return rc;
   const int n = m->g.n_beams, row = std::max(n, 1);
   // pipelined: the batch goes through as `pipe_depth` sub-batches taking turns on the internal streams -- the upload of
-  // one runs under the kernels of the one before, and so do its latency-bound reduce kernels.  Same records: every
+  // one runs under the kernels of the one before, and the sub-batches' kernels share the chip.  Same records: every
   // scan is matched on its own against the same grid, whatever sub-batch it travels in.
   int chunks = 1;
   if (m->pipe_depth > 1 && !m->collect_stats && !m->lds_staged && n > 0)

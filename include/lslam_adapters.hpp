@@ -110,8 +110,8 @@ class GpuScanMatcher {
     return out;
   }
 
-  // MatchBatch as `depth` pipelined sub-batches (LSLAM_OPT_PIPELINE_DEPTH, 1..4; lslam_gpu.h): uploads and the latency-bound
-  // reduce kernels of one sub-batch run under the response kernels of the other.  Same records.  No reference counterpart.
+  // MatchBatch as `depth` pipelined sub-batches (LSLAM_OPT_PIPELINE_DEPTH, 1..4; lslam_gpu.h): the upload of one
+  // runs under the kernels of the other, their response kernels fill each other's tails.  Same records.  No reference counterpart.
   void SetPipelineDepth(int depth) { check(lslam_matcher_set_option(h_, LSLAM_OPT_PIPELINE_DEPTH, depth)); }
 
   // LocalizedRangeScan::GetSensorAt / SetSensorPose (Karto.h:5280-5313)

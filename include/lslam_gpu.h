@@ -156,9 +156,10 @@ void* lslam_matcher_grid_dev_ptr(lslam_matcher* m);
  *    the hot kernel (phase B reads its rows from per-drain patches of the parity planes staged in LDS): an experiment that
  *    was measured and dropped (DESIGN_HISTORY.md B, "LDS-staged experiment"), kept selectable so the measurement can be repeated. */
 /*  LSLAM_OPT_PIPELINE_DEPTH (default 1; 1..4): with depth D > 1 consecutive lslam_matcher_match_batch_dev_* calls become
- *    PIPELINED STEPS: they take turns on D internal HIP streams, each with its own set of per-step workspaces, so the
- *    latency-bound reduce kernels of one step run under the response kernels of the next (what small per-GPU batches
- *    of a sharded run need: 512 scans/step 0.118 -> 0.086 ms on one MI355X).  Same kernels, same arguments, byte-identical
+ *    PIPELINED STEPS: they take turns on D internal HIP streams, each with its own set of per-step workspaces, so that
+ *    D steps share the chip: their response kernels fill each other's tails and their latency-bound prep / reduce
+ *    kernels run side by side instead of one step after the other (what small per-GPU batches of a sharded run need:
+ *    512 scans/step 0.118 -> 0.086 ms on one MI355X; DESIGN.md 6 has the timeline).  Same kernels, same arguments, byte-identical
  *    records.  A step is ordered behind everything the CONTEXT stream held when the call was made (inputs, grid
  *    changes) but not behind the steps before it; the context stream falls in behind all steps at the next
  *    lslam_synchronize / lslam_matcher_flush or any matcher entry point that touches the grid.  The caller's side of
