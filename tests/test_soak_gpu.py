@@ -16,6 +16,7 @@ import os
 
 # (seed, batch): 256 = the wide-block reduce kernels, 2304 = the chip-filling variants (128 / 64-thread reduce blocks,
 # one scan_prep block per scan).  LSLAM_SOAK_SEEDS="10,11,12" adds 2304-scan batches for those seeds (ad-hoc soak).
+# LSLAM_SOAK_DEPTH=2..4 runs them as PIPELINED sub-batches (LSLAM_OPT_PIPELINE_DEPTH; lslam_matcher_match_batch splits the batch).
 _CASES = [(0, 256), (1, 256), (2, 256), (3, 2304)] + [(int(x), 2304) for x in os.environ.get("LSLAM_SOAK_SEEDS", "").split(",") if x]
 
 
@@ -30,6 +31,8 @@ def test_random_world_batches_vs_reference(ctx, oracle_lib, seed, B):
                                    world=world, query_spread=rng.uniform(0.5, 4.0))
     gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
     gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    if os.environ.get("LSLAM_SOAK_DEPTH"):
+        gm.set_option("pipeline_depth", int(os.environ["LSLAM_SOAK_DEPTH"]))
     idx = np.arange(B) % 32
     poses = synth.perturb(wl.truth_poses[idx], rng.uniform(0.05, 0.45), math.radians(rng.uniform(2, 18)), 400 + seed)
     ranges = wl.query_ranges[idx].copy()
@@ -51,6 +54,16 @@ def test_random_world_batches_vs_reference(ctx, oracle_lib, seed, B):
     d = res["pose"] - c_poses
     d[:, 2] = np.arctan2(np.sin(d[:, 2]), np.cos(d[:, 2]))
     assert np.abs(d).max() <= 1e-12
-    assert np.abs(res["response"] - c_resp).max() == 0.0
+    # The response numerators are integers and equal bit for bit (the un-penalised check below).  The PENALISED response of a
+    # refined match can differ in its last bit: the fine pass is centred on the coarse mean, whose heading goes through
+    # atan2 / sin / cos -- the device libm's differ from glibc's in the last bit for ~1.5 % of the headings (4.4e-16 rad), and
+    # once in a few thousand matches the angle penalty (Mapper.cpp:408-411) of the best fine candidate then rounds the other
+    # way (tools/soak_probe.py 45: 1 of 2304).  One ulp of a value in (0.5, 1] is 1.1e-16.
+    dr = np.abs(res["response"] - c_resp)
+    assert dr.max() <= 2.3e-16 and np.count_nonzero(dr) <= max(1, B // 500), (dr.max(), np.count_nonzero(dr))
+    if po.have_ref():  # without the odometry penalty the response IS the integer ratio: exact, refined or not
+        res0 = gm.match_batch(ranges, poses, doPenalize=False)
+        _, _, _, c_resp0 = ref.match_fixed_grid(ranges, poses, do_penalize=False)
+        assert np.abs(res0["response"] - c_resp0).max() == 0.0
     assert np.abs(res["covariance"].reshape(B, 9) - c_covs).max() <= 1e-12
     assert res["response"].mean() > 0.3  # the matches are real ones
