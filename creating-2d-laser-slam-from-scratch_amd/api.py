@@ -251,6 +251,7 @@ def lib() -> C.CDLL:
     L.lslam_matcher_debug_lookup_table.argtypes = [vp, vp, vp, dbl, dbl, dbl, vp, C.POINTER(i32)]
     L.lslam_matcher_debug_coarse_sums.argtypes = [vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32),
                                                   C.POINTER(i32), i32]
+    L.lslam_matcher_debug_coarse_sums_batch.argtypes = [vp, i32, vp, i32, vp, vp]
     L.lslam_matcher_debug_valid_mask.argtypes = [vp, vp, vp, vp, vp]
     L.lslam_frontend_create.argtypes = [vp, i32, dbl, dbl, dbl, C.POINTER(vp)]
     L.lslam_frontend_destroy.argtypes = [vp]
@@ -594,6 +595,19 @@ class ScanMatcher:
         self.ctx.check(self.L.lslam_matcher_debug_coarse_sums(self.h, r.ctypes.data, p.ctypes.data, out.ctypes.data,
                                                               C.byref(nx), C.byref(ny), C.byref(na),
                                                               int(force_generic)))
+        return out
+
+    def coarse_sums_batch(self, ranges, sensor_poses) -> np.ndarray:
+        """Coarse-pass response numerators of EVERY scan of a batch, [n_scans, ny, nx, na] int32, through the launches a
+        coarse-only match of that batch takes (lslam_matcher_debug_coarse_sums_batch)."""
+        r, p = _f64(ranges), _f64(sensor_poses)
+        n = r.shape[0]
+        nx, ny, na = C.c_int(), C.c_int(), C.c_int()
+        self.ctx.check(self.L.lslam_matcher_debug_coarse_sums(self.h, r.ctypes.data, p.ctypes.data, None,
+                                                              C.byref(nx), C.byref(ny), C.byref(na), 0))
+        out = np.zeros((n, ny.value, nx.value, na.value), dtype=np.int32)
+        self.ctx.check(self.L.lslam_matcher_debug_coarse_sums_batch(self.h, n, r.ctypes.data, r.shape[1], p.ctypes.data,
+                                                                    out.ctypes.data))
         return out
 
     def valid_mask(self, ranges, sensor_pose, viewpoint) -> np.ndarray:

@@ -463,7 +463,7 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
   __shared__ int2 queue[kQueue];  // circular; .x = first row index m0, .y = row mask | parity << 31
   __shared__ uint16_t ambq[TILED ? 64 * kMaxBeamsPerLane : 1];  // beams whose fp32 estimate could not decide the rounding (phase A)
   __shared__ uint32_t patch[LDSB ? 2 : 1][LDSB ? kPatchDw : 1];  // LDSB: the drain's bounding patch of each parity plane
-  const int lane = threadIdx.x;
+  [[maybe_unused]] const int lane = threadIdx.x;
   int w = blockIdx.x;
   const int slice = w % beam_slices;
   w /= beam_slices;
@@ -490,7 +490,7 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
   const uint8_t* zbase = TILED ? src0 : src0 - kRowZero;
   const uint32_t plane_delta = TILED ? 0u : (uint32_t)(src1 - src0);
   const uint32_t strip_bytes = (uint32_t)tile_rows * 32u;  // one 32-byte-wide strip, all class rows
-  const int occ_wph = occ_wpc >> 1;  // words per (column, row parity)
+  [[maybe_unused]] const int occ_wph = occ_wpc >> 1;  // words per (column, row parity)
 
   for (int j0 = 0; j0 < pc.ny; j0 += NYC) {
     // PEEL (the chip-filling variants): the accumulators are NOT zeroed -- phase A runs in two stages: until the first 64
@@ -3038,6 +3038,8 @@ struct lslam_matcher {
   DevBuf<double> d_big;      // large lattices: reduce scratch
   DevBuf<lslam_match_result> d_results;
   DevBuf<int32_t> d_dbg;
+  bool dbg_all = false;        // debug_coarse_sums_batch: copy the coarse numerators of EVERY scan of the batch, not the first's
+  size_t dbg_resp_stride = 0;  // ints per scan in that copy
   // single-scan matches: the last kernel posts a ticket in pinned memory behind its record and the host spins on it
   int* h_done = nullptr;   // pinned
   int done_ticket = 0;
@@ -3231,6 +3233,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     return ctx->fail(LSLAM_ERR_UNSUPPORTED, "search lattice %dx%dx%d exceeds the built limits (%d,%d,%d)",
                      pc.nx, pc.ny, na_max, kMaxLattice, kMaxLattice, kMaxAngles);
   const size_t resp_stride = (size_t)std::max(pc.nx * pc.ny, pf.nx * pf.ny) * na_max;
+  m->dbg_resp_stride = resp_stride;
 
   LSLAM_HIP(ctx, m->d_local.reserve((size_t)S * g.n_beams));
   LSLAM_HIP(ctx, m->d_lat.reserve(S));
@@ -3468,7 +3471,8 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
              (const unsigned long long*)best_bits, big_final_out, big_final_out ? done_flag : (int*)nullptr, done_ticket);
     if (big_final_out) record_written = true;
     if (dbg_coarse_sums && pass_index == 0)  // after the reduce: it fills in scans the packed kernel skipped
-      LSLAM_HIP(ctx, hipMemcpyAsync(dbg_coarse_sums, m->d_resp.p, (size_t)p.nx * p.ny * p.na * sizeof(int32_t),
+      LSLAM_HIP(ctx, hipMemcpyAsync(dbg_coarse_sums, m->d_resp.p,
+                                    (m->dbg_all ? (size_t)S * resp_stride : (size_t)p.nx * p.ny * p.na) * sizeof(int32_t),
                                     hipMemcpyDeviceToDevice, ctx->stream));
     return LSLAM_OK;
   };
@@ -3505,7 +3509,8 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       launch(ctx, "reduce_coarse", k_reduce_coarse<false>, dim3(S), dim3(256), reduce_lds(p, false), LSLAM_REDUCE_ARGS);
 #undef LSLAM_REDUCE_ARGS
     if (dbg_coarse_sums && pass_index == 0)  // after the reduce: it fills in scans the packed kernel skipped
-      LSLAM_HIP(ctx, hipMemcpyAsync(dbg_coarse_sums, m->d_resp.p, (size_t)p.nx * p.ny * p.na * sizeof(int32_t),
+      LSLAM_HIP(ctx, hipMemcpyAsync(dbg_coarse_sums, m->d_resp.p,
+                                    (m->dbg_all ? (size_t)S * resp_stride : (size_t)p.nx * p.ny * p.na) * sizeof(int32_t),
                                     hipMemcpyDeviceToDevice, ctx->stream));
     return LSLAM_OK;
   };
@@ -4275,6 +4280,40 @@ int lslam_matcher_debug_coarse_sums(lslam_matcher* m, const double* ranges, cons
   const int ncand = lx * lx;  // device layout is angle-major; the reference order is y, x, angle
   for (int a = 0; a < la; a++)
     for (int c = 0; c < ncand; c++) out[(size_t)c * la + a] = tmp[(size_t)a * ncand + c];
+  return LSLAM_OK;
+}
+
+int lslam_matcher_debug_coarse_sums_batch(lslam_matcher* m, int n_scans, const double* ranges, int ranges_stride,
+                                          const double* poses, int32_t* out) {
+  if (!m || !ranges || !poses || !out || n_scans <= 0) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = m->ctx;
+  LSLAM_NOT_REENTRANT(m);
+  const Geom g = m->g;
+  if (g.n_beams == 0) return LSLAM_OK;
+  const double res = 1.0 / g.scale;
+  const double off = 0.5 * ((double)g.probs_side - 1) * res;
+  const int lx = lattice_count(off, 2 * res);
+  const int la = n_angles_of(m->cfg.coarse_search_angle_offset, m->cfg.coarse_angle_resolution);
+  int rc = upload_scans(m, n_scans, ranges, ranges_stride, poses);
+  if (rc) return rc;
+  LSLAM_HIP(ctx, m->d_results.reserve(n_scans));
+  // the batch goes through the same launches a match of n_scans scans takes (coarse pass only): whichever variant of the
+  // response kernel that batch size selects is the one whose numerators come back
+  const size_t cap = (size_t)n_scans * (size_t)std::max(lx * lx, 16) * (size_t)kMaxAngles;  // >= n_scans * resp_stride
+  LSLAM_HIP(ctx, m->d_dbg.reserve(cap));
+  m->dbg_all = true;
+  rc = match_batch_impl<double>(m, n_scans, m->d_ranges64.p, g.n_beams, m->d_poses.p, 1, 0, m->d_results.p, m->d_dbg.p, 0);
+  m->dbg_all = false;
+  if (rc) return rc;
+  const size_t stride = m->dbg_resp_stride;
+  std::vector<int32_t> tmp((size_t)n_scans * stride);
+  LSLAM_HIP(ctx, hipMemcpyAsync(tmp.data(), m->d_dbg.p, tmp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int ncand = lx * lx;  // device layout is angle-major per scan; the reference order is y, x, angle
+  for (int s = 0; s < n_scans; s++)
+    for (int a = 0; a < la; a++)
+      for (int c = 0; c < ncand; c++)
+        out[((size_t)s * ncand + c) * la + a] = tmp[(size_t)s * stride + (size_t)a * ncand + c];
   return LSLAM_OK;
 }
 

@@ -275,6 +275,11 @@ int lslam_matcher_debug_lookup_table(lslam_matcher* m, const double* ranges,
 int lslam_matcher_debug_coarse_sums(lslam_matcher* m, const double* ranges,
                                     const double sensor_pose[3], int32_t* out_host, int* nx,
                                     int* ny, int* na, int force_generic_kernel);
+/* the same for a BATCH: the n_scans scans go through exactly the launches a coarse-only match of that batch takes (so the
+ * variant of the response kernel the batch size selects -- beam slices, linear or tiled planes, fp64 or estimate-first table
+ * cells -- is the one whose numerators come back); out: n_scans * ny * nx * na int32, each scan in the order y, x, angle */
+int lslam_matcher_debug_coarse_sums_batch(lslam_matcher* m, int n_scans, const double* ranges, int ranges_stride,
+                                          const double* sensor_poses, int32_t* out);
 /* FindValidPoints mask (Mapper.cpp:756-811) of one scan: out[num_beams] bytes, 1 = kept */
 int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges,
                                    const double sensor_pose[3], const double viewpoint[2],

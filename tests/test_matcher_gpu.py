@@ -118,6 +118,36 @@ def test_coarse_response_sums_bit_exact(ctx, oracle_lib, workload):
         assert np.array_equal(slow, sums_cpu)  # generic per-candidate kernel
 
 
+@pytest.mark.parametrize("S", [40, 160, 2304])
+def test_coarse_sums_of_whole_batches_bit_exact(ctx, oracle_lib, workload_spread, S):
+    """The coarse numerators of EVERY scan and EVERY candidate of a batch (GetResponse, Mapper.cpp:819-856; 11 x 11 x 21 per
+    scan), through the launches a match of that batch size takes: 40 scans = beam slices on the linear parity planes, table
+    cells on the reference's fp64 tree; 160 = the tiled planes, cells decided on the fp32 estimate (the hot kernel of the
+    bench); 2304 = the same behind one prep block per scan.  A match result only shows the best candidate's sum; here a
+    wrong sum anywhere on a lattice would show."""
+    wl = workload_spread
+    port, gm = make_pair(ctx, oracle_lib)
+    port.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    nq = len(wl.query_ranges)
+    idx = np.arange(S) % nq
+    poses = wl.query_poses[idx].copy()
+    rng = np.random.default_rng(S)
+    far = np.arange(S) >= nq  # the repeats get poses of their own: different lattices, different table cells
+    poses[far, :2] += rng.uniform(-0.4, 0.4, size=(int(far.sum()), 2))
+    poses[far, 2] += rng.uniform(-0.3, 0.3, size=int(far.sum()))
+    ranges = wl.query_ranges[idx].copy()
+    ranges[rng.random(ranges.shape) < 0.01] = np.nan
+    got = gm.coarse_sums_batch(ranges, poses)
+    assert got.shape[0] == S and got.any()
+    check = np.unique(np.concatenate([np.arange(min(S, nq)), rng.integers(0, S, size=40)]))
+    for q in check:
+        _, _, _, st, sums_cpu = port.correlate_scan(ranges[q], poses[q], poses[q], 0.5, 0.1, 0.349, 0.0349, True, False,
+                                                    want_sums=True)
+        assert st == 0
+        assert np.array_equal(got[q], sums_cpu), q
+
+
 @pytest.mark.parametrize("heading", [0.0, math.pi / 2])
 def test_beams_on_half_cell_boundaries(ctx, oracle_lib, heading):
     """Phase A of k_resp_rows decides a beam's table cell on an fp32 estimate and parks the beams whose coordinate lies

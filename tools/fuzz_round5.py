@@ -9,7 +9,12 @@
             every pose bit for bit, same graph.  Random closed-loop trajectories (rings of random size and count -> different
             loop structure), random chunk sizes 1..300, random loop-search parameters, pools of 1 / 2 / 4 loop matchers.
 
-usage: fuzz_round5.py [windows|lookahead|all] [N_CASES] [FIRST_SEED]      (prints one line per case, exit code 1 on a mismatch)
+  sums      lslam_matcher_debug_coarse_sums_batch -- the coarse numerators of every candidate of every scan of a batch through
+            the launches a match of that size takes (beam slices + fp64 table cells / tiled planes + fp32-estimate cells) --
+            against the restatement's GetResponse sums (Mapper.cpp:819-856): integers, bit for bit.  Random worlds, windows,
+            batch sizes 8..600, pose errors up to the search window and beyond, 1 % unreadable beams.
+
+usage: fuzz_round5.py [windows|lookahead|sums|all] [N_CASES] [FIRST_SEED]   (prints one line per case, exit code 1 on a mismatch)
 """
 import os
 import sys
@@ -140,6 +145,40 @@ def fuzz_lookahead(ctx, seed):
     return same
 
 
+def fuzz_sums(ctx, seed):
+    import math
+
+    rng = np.random.default_rng(seed)
+    laser = synth.Laser()
+    world = synth.arena(size=rng.uniform(25, 90), n_axis=int(rng.integers(6, 30)), n_rot=int(rng.integers(2, 10)), seed=seed)
+    wl = synth.make_match_workload(n_base=int(rng.integers(5, 70)), n_query=32, seed=seed + 1, laser=laser, world=world,
+                                   query_spread=rng.uniform(0.3, 4.0))
+    S = int(rng.choice([8, 40, 100, 128, 256, 600]))
+    idx = np.arange(S) % 32
+    poses = synth.perturb(wl.truth_poses[idx], rng.uniform(0.02, 0.8), math.radians(rng.uniform(1, 30)), seed + 2)
+    ranges = wl.query_ranges[idx].copy()
+    ranges[rng.random(ranges.shape) < 0.01] = np.inf
+    ranges[rng.random(ranges.shape) < 0.003] = np.nan
+    port = po.PortKarto(po.default_cfg(), po.laser_struct(laser))
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
+    port.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    got = gm.coarse_sums_batch(ranges, poses)
+    check = np.unique(rng.integers(0, S, size=min(S, 48)))
+    n_bad, total = 0, 0
+    for q in check:
+        _, _, _, st, sums_cpu = port.correlate_scan(ranges[q], poses[q], poses[q], 0.5, 0.1, 0.349, 0.0349, True, False, want_sums=True)
+        if st != 0:
+            continue
+        total += int(sums_cpu.sum() > 0)
+        n_bad += not np.array_equal(got[q], sums_cpu)
+    ok = n_bad == 0
+    print("sums      seed %d: batch %3d, %d scans checked (%d with non-zero lattices) x 2541 candidates -> %s" %
+          (seed, S, len(check), total, "equal" if ok else "MISMATCH in %d scans" % n_bad), flush=True)
+    gm.close()
+    return ok
+
+
 import torch  # (initialised before the library's own HIP context, like bench.py and the tests do)
 
 torch.cuda.init()
@@ -150,5 +189,7 @@ for k in range(n_cases):
         bad += not fuzz_windows(ctx, seed0 + k)
     if what in ("lookahead", "all"):
         bad += not fuzz_lookahead(ctx, seed0 + k)
+    if what in ("sums", "all"):
+        bad += not fuzz_sums(ctx, seed0 + k)
 print("%d case(s) differ; %.0f s" % (bad, time.time() - t0))
 sys.exit(1 if bad else 0)
