@@ -252,6 +252,7 @@ def lib() -> C.CDLL:
     L.lslam_matcher_debug_coarse_sums.argtypes = [vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32),
                                                   C.POINTER(i32), i32]
     L.lslam_matcher_debug_coarse_sums_batch.argtypes = [vp, i32, vp, i32, vp, vp]
+    L.lslam_matcher_debug_fine_sums_batch.argtypes = [vp, i32, vp, i32, vp, vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.lslam_matcher_debug_valid_mask.argtypes = [vp, vp, vp, vp, vp]
     L.lslam_frontend_create.argtypes = [vp, i32, dbl, dbl, dbl, C.POINTER(vp)]
     L.lslam_frontend_destroy.argtypes = [vp]
@@ -609,6 +610,21 @@ class ScanMatcher:
         self.ctx.check(self.L.lslam_matcher_debug_coarse_sums_batch(self.h, n, r.ctypes.data, r.shape[1], p.ctypes.data,
                                                                     out.ctypes.data))
         return out
+
+    def fine_sums_batch(self, ranges, sensor_poses):
+        """Fine-pass numerators of every scan of a batch and the centre each fine pass was searched around:
+        ([n_scans, ny, nx, na] int32, [n_scans, 3]) (lslam_matcher_debug_fine_sums_batch)."""
+        r, p = _f64(ranges), _f64(sensor_poses)
+        n = r.shape[0]
+        nx, ny, na = C.c_int(), C.c_int(), C.c_int()
+        self.ctx.check(self.L.lslam_matcher_debug_fine_sums_batch(self.h, n, r.ctypes.data, r.shape[1], p.ctypes.data, None, None,
+                                                                  C.byref(nx), C.byref(ny), C.byref(na)))
+        out = np.zeros((n, ny.value, nx.value, na.value), dtype=np.int32)
+        centers = np.zeros((n, 3))
+        self.ctx.check(self.L.lslam_matcher_debug_fine_sums_batch(self.h, n, r.ctypes.data, r.shape[1], p.ctypes.data,
+                                                                  centers.ctypes.data, out.ctypes.data, C.byref(nx), C.byref(ny),
+                                                                  C.byref(na)))
+        return out, centers
 
     def valid_mask(self, ranges, sensor_pose, viewpoint) -> np.ndarray:
         r, p, v = _f64(ranges), _f64(sensor_pose), _f64(viewpoint)

@@ -3040,6 +3040,7 @@ struct lslam_matcher {
   DevBuf<int32_t> d_dbg;
   bool dbg_all = false;        // debug_coarse_sums_batch: copy the coarse numerators of EVERY scan of the batch, not the first's
   size_t dbg_resp_stride = 0;  // ints per scan in that copy
+  int32_t* dbg_fine = nullptr;  // debug_fine_sums_batch: device buffer the fine numerators of every scan are copied to
   // single-scan matches: the last kernel posts a ticket in pinned memory behind its record and the host spins on it
   int* h_done = nullptr;   // pinned
   int done_ticket = 0;
@@ -3539,6 +3540,9 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
            (const uint8_t*)m->d_grid, g, pf, sc, (const Lattice*)m->d_lat.p, m->d_resp.p, resp_stride,
            (const double2*)m->d_local.p, (const CoarseOut*)m->d_coarse.p, d_out, do_refine, do_refine ? fb_step : 0,
            done_flag, done_ticket);
+  if (m->dbg_fine)  // behind the reduce: its blocks fill in the scans the packed kernel skipped
+    LSLAM_HIP(ctx, hipMemcpyAsync(m->dbg_fine, m->d_resp.p, (size_t)S * resp_stride * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                                  ctx->stream));
   LSLAM_HIP(ctx, hipGetLastError());
   return LSLAM_OK;
 }
@@ -4314,6 +4318,46 @@ int lslam_matcher_debug_coarse_sums_batch(lslam_matcher* m, int n_scans, const d
     for (int a = 0; a < la; a++)
       for (int c = 0; c < ncand; c++)
         out[((size_t)s * ncand + c) * la + a] = tmp[(size_t)s * stride + (size_t)a * ncand + c];
+  return LSLAM_OK;
+}
+
+int lslam_matcher_debug_fine_sums_batch(lslam_matcher* m, int n_scans, const double* ranges, int ranges_stride,
+                                        const double* poses, double* centers_out, int32_t* out, int* nx, int* ny, int* na) {
+  if (!m || !ranges || !poses || n_scans <= 0) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = m->ctx;
+  LSLAM_NOT_REENTRANT(m);
+  const Geom g = m->g;
+  const double res = 1.0 / g.scale;
+  const double coarse_res = 2 * res;
+  const int fx = lattice_count(coarse_res * 0.5, res);  // Mapper.cpp:276-281
+  const int fa = n_angles_of(0.5 * m->cfg.coarse_angle_resolution, m->cfg.fine_search_angle_offset);
+  if (nx) *nx = fx;
+  if (ny) *ny = fx;
+  if (na) *na = fa;
+  if (!out || !centers_out || g.n_beams == 0) return LSLAM_OK;
+  int rc = upload_scans(m, n_scans, ranges, ranges_stride, poses);
+  if (rc) return rc;
+  LSLAM_HIP(ctx, m->d_results.reserve(n_scans));
+  const double off = 0.5 * ((double)g.probs_side - 1) * res;
+  const int lx = lattice_count(off, coarse_res);
+  LSLAM_HIP(ctx, m->d_dbg.reserve((size_t)n_scans * (size_t)std::max(lx * lx, 16) * (size_t)kMaxAngles));  // >= n * resp_stride
+  m->dbg_fine = m->d_dbg.p;
+  rc = match_batch_impl<double>(m, n_scans, m->d_ranges64.p, g.n_beams, m->d_poses.p, 1, 1, m->d_results.p, nullptr, 0);
+  m->dbg_fine = nullptr;
+  if (rc) return rc;
+  const size_t stride = m->dbg_resp_stride;
+  std::vector<int32_t> tmp((size_t)n_scans * stride);
+  std::vector<CoarseOut> co((size_t)n_scans);
+  LSLAM_HIP(ctx, hipMemcpyAsync(tmp.data(), m->d_dbg.p, tmp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  LSLAM_HIP(ctx, hipMemcpyAsync(co.data(), m->d_coarse.p, co.size() * sizeof(CoarseOut), hipMemcpyDeviceToHost, ctx->stream));
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int ncand = fx * fx;  // device layout is angle-major per scan; the reference order is y, x, angle
+  for (int s = 0; s < n_scans; s++) {
+    for (int i = 0; i < 3; i++) centers_out[3 * (size_t)s + i] = co[s].status == 0 ? co[s].mean[i] : __builtin_nan("");
+    for (int a = 0; a < fa; a++)
+      for (int c = 0; c < ncand; c++)
+        out[((size_t)s * ncand + c) * fa + a] = tmp[(size_t)s * stride + (size_t)a * ncand + c];
+  }
   return LSLAM_OK;
 }
 

@@ -280,6 +280,13 @@ int lslam_matcher_debug_coarse_sums(lslam_matcher* m, const double* ranges,
  * cells -- is the one whose numerators come back); out: n_scans * ny * nx * na int32, each scan in the order y, x, angle */
 int lslam_matcher_debug_coarse_sums_batch(lslam_matcher* m, int n_scans, const double* ranges, int ranges_stride,
                                           const double* sensor_poses, int32_t* out);
+/* ... and of the FINE pass (Mapper.cpp:276-281: 3 x 3 positions x 11 angles around the coarse pass's mean) of every scan of a
+ * batch, through the launches a complete match of that batch takes; centers_out: n_scans * 3, the mean each fine pass was
+ * centred on (NaN where the coarse pass failed); out: n_scans * ny * nx * na int32, order y, x, angle.  With out == NULL
+ * only the counts are returned. */
+int lslam_matcher_debug_fine_sums_batch(lslam_matcher* m, int n_scans, const double* ranges, int ranges_stride,
+                                        const double* sensor_poses, double* centers_out, int32_t* out, int* nx, int* ny,
+                                        int* na);
 /* FindValidPoints mask (Mapper.cpp:756-811) of one scan: out[num_beams] bytes, 1 = kept */
 int lslam_matcher_debug_valid_mask(lslam_matcher* m, const double* ranges,
                                    const double sensor_pose[3], const double viewpoint[2],

@@ -146,6 +146,19 @@ def test_coarse_sums_of_whole_batches_bit_exact(ctx, oracle_lib, workload_spread
                                                     want_sums=True)
         assert st == 0
         assert np.array_equal(got[q], sums_cpu), q
+    # the fine pass of the same batches (3 x 3 x 11 around the device's own coarse mean, Mapper.cpp:276-281): k_resp_rows<1,4>
+    # with beam slices at 40 scans, the 4x4-block kernel k_resp_tile3 (one / three angles per wave) at 160 / 2304
+    fine, centers = gm.fine_sums_batch(ranges, poses)
+    n_fine = 0
+    for q in check:
+        if np.isnan(centers[q]).any():
+            continue
+        _, _, _, st, fine_cpu = port.correlate_scan(ranges[q], poses[q], centers[q], 0.05, 0.05, 0.5 * 0.0349, 0.00349, True, True,
+                                                    want_sums=True)
+        if st == 0:
+            assert np.array_equal(fine[q], fine_cpu), q
+            n_fine += int(fine_cpu.any())
+    assert n_fine >= len(check) // 2
 
 
 @pytest.mark.parametrize("heading", [0.0, math.pi / 2])

@@ -12,7 +12,7 @@
   sums      lslam_matcher_debug_coarse_sums_batch -- the coarse numerators of every candidate of every scan of a batch through
             the launches a match of that size takes (beam slices + fp64 table cells / tiled planes + fp32-estimate cells) --
             against the restatement's GetResponse sums (Mapper.cpp:819-856): integers, bit for bit.  Random worlds, windows,
-            batch sizes 8..600, pose errors up to the search window and beyond, 1 % unreadable beams.
+            batch sizes 8..1600, pose errors up to the search window and beyond, 1 % unreadable beams.
 
 usage: fuzz_round5.py [windows|lookahead|sums|all] [N_CASES] [FIRST_SEED]   (prints one line per case, exit code 1 on a mismatch)
 """
@@ -153,7 +153,7 @@ def fuzz_sums(ctx, seed):
     world = synth.arena(size=rng.uniform(25, 90), n_axis=int(rng.integers(6, 30)), n_rot=int(rng.integers(2, 10)), seed=seed)
     wl = synth.make_match_workload(n_base=int(rng.integers(5, 70)), n_query=32, seed=seed + 1, laser=laser, world=world,
                                    query_spread=rng.uniform(0.3, 4.0))
-    S = int(rng.choice([8, 40, 100, 128, 256, 600]))
+    S = int(rng.choice([8, 40, 100, 128, 256, 600, 1600]))
     idx = np.arange(S) % 32
     poses = synth.perturb(wl.truth_poses[idx], rng.uniform(0.02, 0.8), math.radians(rng.uniform(1, 30)), seed + 2)
     ranges = wl.query_ranges[idx].copy()
@@ -164,17 +164,26 @@ def fuzz_sums(ctx, seed):
     port.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
     gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
     got = gm.coarse_sums_batch(ranges, poses)
+    got_f, centers = gm.fine_sums_batch(ranges, poses)  # fine pass (Mapper.cpp:276-281) around the device's own coarse mean
     check = np.unique(rng.integers(0, S, size=min(S, 48)))
-    n_bad, total = 0, 0
+    n_bad, n_bad_f, total, total_f = 0, 0, 0, 0
     for q in check:
         _, _, _, st, sums_cpu = port.correlate_scan(ranges[q], poses[q], poses[q], 0.5, 0.1, 0.349, 0.0349, True, False, want_sums=True)
         if st != 0:
             continue
         total += int(sums_cpu.sum() > 0)
         n_bad += not np.array_equal(got[q], sums_cpu)
-    ok = n_bad == 0
-    print("sums      seed %d: batch %3d, %d scans checked (%d with non-zero lattices) x 2541 candidates -> %s" %
-          (seed, S, len(check), total, "equal" if ok else "MISMATCH in %d scans" % n_bad), flush=True)
+        if np.isnan(centers[q]).any():
+            continue
+        _, _, _, st, fine_cpu = port.correlate_scan(ranges[q], poses[q], centers[q], 0.05, 0.05, 0.5 * 0.0349, 0.00349, True, True,
+                                                    want_sums=True)
+        if st != 0:
+            continue
+        total_f += int(fine_cpu.sum() > 0)
+        n_bad_f += not np.array_equal(got_f[q], fine_cpu)
+    ok = n_bad == 0 and n_bad_f == 0
+    print("sums      seed %d: batch %3d, %d scans checked: coarse %d non-zero lattices x 2541 candidates, fine %d x 99 -> %s" %
+          (seed, S, len(check), total, total_f, "equal" if ok else "MISMATCH in %d coarse / %d fine lattices" % (n_bad, n_bad_f)), flush=True)
     gm.close()
     return ok
 
