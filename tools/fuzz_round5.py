@@ -14,7 +14,10 @@
             against the restatement's GetResponse sums (Mapper.cpp:819-856): integers, bit for bit.  Random worlds, windows,
             batch sizes 8..1600, pose errors up to the search window and beyond, 1 % unreadable beams.
 
-usage: fuzz_round5.py [windows|lookahead|sums|all] [N_CASES] [FIRST_SEED]   (prints one line per case, exit code 1 on a mismatch)
+  dense     the same for the loop-closure matcher's lattices (Mapper.cpp:862-871, 976-1051: search space 4-10 m -> 41^2..101^2
+            positions x 21 angles, k_resp_dense in its lone and batched forms), 2 scans per case against the restatement.
+
+usage: fuzz_round5.py [windows|lookahead|sums|dense|all] [N_CASES] [FIRST_SEED]   (prints one line per case, exit code 1 on a mismatch)
 """
 import os
 import sys
@@ -188,6 +191,41 @@ def fuzz_sums(ctx, seed):
     return ok
 
 
+def fuzz_dense(ctx, seed):
+    import math
+
+    rng = np.random.default_rng(seed)
+    laser = synth.Laser(range_max=30.0)
+    search = float(rng.choice([4.0, 6.0, 8.0, 10.0]))
+    kw = dict(search_size=search, resolution=0.05, smear_deviation=0.03)
+    port = po.PortKarto(po.default_cfg(**kw), po.laser_struct(laser, 12.0, (0, 0, 0)))
+    gm = api.ScanMatcher(ctx, api.baseline_config(range_threshold=12.0, **kw), api.laser_params(laser, 12.0, (0, 0, 0)))
+    world = synth.arena(size=rng.uniform(30, 60), n_axis=int(rng.integers(6, 20)), n_rot=int(rng.integers(2, 8)), seed=seed)
+    wl = synth.make_match_workload(n_base=int(rng.integers(8, 40)), n_query=8, seed=seed + 1, laser=laser, world=world,
+                                   err_xy=rng.uniform(0.2, 0.45 * search), err_th=math.radians(rng.uniform(2, 18)), query_spread=1.0)
+    port.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    S = int(rng.choice([1, 3, 8, 24, 72]))
+    idx = np.arange(S) % 8
+    poses = wl.query_poses[idx] + rng.uniform(-0.2, 0.2, size=(S, 3)) * np.array([1.0, 1.0, 0.1])
+    ranges = wl.query_ranges[idx].copy()
+    ranges[rng.random(ranges.shape) < 0.01] = np.nan
+    got = gm.coarse_sums_batch(ranges, poses) if S > 1 else gm.coarse_sums(ranges[0], poses[0])[None]
+    off = 0.5 * (round(search / 0.05)) * 0.05
+    n_bad, n_chk = 0, 0
+    for q in np.unique(rng.integers(0, S, size=2)):
+        _, _, _, st, sums = port.correlate_scan(ranges[q], poses[q], poses[q], off, 0.1, 0.349, 0.0349, False, False, want_sums=True)
+        if st != 0:
+            continue
+        n_chk += 1
+        n_bad += not np.array_equal(got[q], sums)
+    ok = n_bad == 0
+    print("dense     seed %d: search %4.1f m (%d^2 x 21), batch %2d, %d scans checked -> %s" %
+          (seed, search, got.shape[1], S, n_chk, "equal" if ok else "MISMATCH in %d" % n_bad), flush=True)
+    gm.close()
+    return ok
+
+
 import torch  # (initialised before the library's own HIP context, like bench.py and the tests do)
 
 torch.cuda.init()
@@ -200,5 +238,7 @@ for k in range(n_cases):
         bad += not fuzz_lookahead(ctx, seed0 + k)
     if what in ("sums", "all"):
         bad += not fuzz_sums(ctx, seed0 + k)
+    if what in ("dense", "all"):
+        bad += not fuzz_dense(ctx, seed0 + k)
 print("%d case(s) differ; %.0f s" % (bad, time.time() - t0))
 sys.exit(1 if bad else 0)
