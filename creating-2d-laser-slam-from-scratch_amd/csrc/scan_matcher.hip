@@ -448,29 +448,50 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }
 
-template <int NXD, int NYC, bool TILED, bool STATS = false, bool LDSB = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))  // <= 128 VGPRs
-k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int step, int limit, Geom g,
-            PassCfg pc, const Lattice* __restrict__ lat, const double2* __restrict__ cossin,
-            const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int beam_slices,
-            int S, const uint2* __restrict__ occ_t, int occ_wpc, int tile_rows, uint32_t tile_class_bytes,
-            unsigned long long* __restrict__ stats) {
+constexpr int kRowsQueue = 256;  // >= 63 waiting + two blocks of 64 coming in
+// LDS of ONE wave of the row kernel.  SOLO (k_resp_rows, a block = a wave): four arrays of their own.  In the scan-resident
+// step kernel (k_match_step: several waves per block, each on its own angle) a wave's area is 2.4 KB: `red` (epilogue) and
+// `queue` (phases A / B) are never live together and share their bytes, and the beams the fp32 estimate cannot decide are
+// remembered as one 64-bit lane mask per block of beams (`ambm`) instead of a list.
+struct RowsLds {
+  uint32_t (*red)[8];            // [packed word][group of 8 lanes]
+  int2* queue;                   // circular; .x = first row index m0, .y = row mask | parity << 31
+  uint16_t* ambq;                // SOLO: beams whose fp32 estimate could not decide the rounding (phase A)
+  uint32_t (*patch)[kPatchDw];   // LDSB: the drain's bounding patch of each parity plane
+  unsigned long long* ambm;      // !SOLO: [kMaxBeamsPerLane] lane masks of the undecided beams
+};
+// barrier between a wave's own LDS writes and reads: the whole block when the block IS the wave, else the wave alone
+// (LDS operations of one wave are performed in order; the fence keeps the compiler from reordering them)
+template <bool SOLO>
+__device__ __forceinline__ void wsync() {
+  if constexpr (SOLO) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// One wave64: all nX*nY numerators of (scan s, angle a[, beam slice]).  SOLO: written to resp (global, angle-major; beam
+// slices accumulate with atomics); !SOLO: stored to lds_out[a * ncand + ...] (the block's numerators live in LDS).
+template <int NXD, int NYC, bool TILED, bool STATS, bool LDSB, bool SOLO, bool OUT_LDS = !SOLO>
+__device__ __forceinline__ void resp_rows_wave(
+    const int s, const int a, const int slice, const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int step,
+    int limit, const Geom& g, const PassCfg& pc, const Lattice* __restrict__ lat, const double2* __restrict__ cossin,
+    const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int beam_slices,
+    const uint2* __restrict__ occ_t, int occ_wpc, int tile_rows, uint32_t tile_class_bytes,
+    unsigned long long* __restrict__ stats, const RowsLds lds, int32_t* lds_out) {
   constexpr int NW = NXD * NYC * 2;
   constexpr bool EST = TILED;  // phase A on the fp32 estimate, two blocks in flight: the chip-filling batches (see phase A)
-  constexpr int kQueue = 256;  // >= 63 waiting + two blocks of 64 coming in
+  constexpr int kQueue = kRowsQueue;
   static_assert(NYC <= 16 && 2 * (NYC - 1) < 32, "row mask / occupancy window width");
-  __shared__ __align__(16) uint32_t red[NW][8];  // [packed word][group of 8 lanes]
-  __shared__ int2 queue[kQueue];  // circular; .x = first row index m0, .y = row mask | parity << 31
-  __shared__ uint16_t ambq[TILED ? 64 * kMaxBeamsPerLane : 1];  // beams whose fp32 estimate could not decide the rounding (phase A)
-  __shared__ uint32_t patch[LDSB ? 2 : 1][LDSB ? kPatchDw : 1];  // LDSB: the drain's bounding patch of each parity plane
-  [[maybe_unused]] const int lane = threadIdx.x;
-  int w = blockIdx.x;
-  const int slice = w % beam_slices;
-  w /= beam_slices;
-  const int xcd = w & 7, r = w >> 3;
-  const int s = (r / pc.na) * 8 + xcd;
-  const int a = r % pc.na;
-  if (s >= S) return;
+  static_assert(SOLO || (TILED && !STATS && !LDSB), "multi-wave blocks run the tiled production variant only");
+  static_assert(!(SOLO && OUT_LDS), "a lone wave writes its numerators to global memory");
+  uint32_t (*const red)[8] = lds.red;
+  int2* const queue = lds.queue;
+  [[maybe_unused]] uint16_t* const ambq = lds.ambq;
+  [[maybe_unused]] uint32_t (*const patch)[kPatchDw] = lds.patch;
+  [[maybe_unused]] unsigned long long* const ambm = lds.ambm;
   const Lattice& L = lat[s];
   if (!L.active || L.status != 0 || L.step_x != step || L.step_y != step) return;
 
@@ -583,7 +604,7 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
                 patch[q][idx] = v;
               }
             }
-            __syncthreads();
+            wsync<SOLO>();
             const int q = p1 ? 1 : 0;
             const uint32_t base = on ? (ry - rmin[q]) * W[q] + ((cx - cmin[q]) >> 2) : 0u;
 #pragma unroll
@@ -592,7 +613,7 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
 #pragma unroll
               for (int k = 0; k <= NXD; k++) wv[j][k] = live ? patch[q][base + (uint32_t)j * W[q] + (uint32_t)k] : 0u;
             }
-            __syncthreads();  // the next drain restages the patches
+            wsync<SOLO>();  // the next drain restages the patches
           }
         }
         if (!staged) {
@@ -750,7 +771,7 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
         }
         qcount += __popcll(votesB);
       }
-      __syncthreads();
+      wsync<SOLO>();
     };
     auto drain_ready = [&](auto two_blocks) {
       constexpr bool TWO = decltype(two_blocks)::value;
@@ -774,6 +795,7 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
     };
     // one block of beams on the estimate: cell, and whether the estimate decides it -- otherwise the beam is parked
     int acount = 0;
+    [[maybe_unused]] uint32_t amb_its = 0u;  // !SOLO: blocks of 64 beams that parked at least one (bit = block index `it`)
     auto estimate = [&](int it, float2 p, bool in_scan, bool& valid, int& gx, int& gy) {
       float t1, t2, fx, fy;
       asm("v_mul_f32 %0, %1, %2" : "=v"(t1) : "s"(sin_sc), "v"(p.y));
@@ -791,11 +813,16 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
         const bool park = !valid && in_scan && reach == reach;  // a beam the estimate does not decide
         if constexpr (STATS) st_beams += (valid || park) ? 1u : 0u;
         const unsigned long long parked = __ballot(park);
-        if (park) {
-          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(parked >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)parked, 0u));
-          ambq[acount + rank] = (uint16_t)(it * 64 + lane);  // (block of the slice, lane): < 64 kMaxBeamsPerLane
+        if constexpr (SOLO) {
+          if (park) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(parked >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)parked, 0u));
+            ambq[acount + rank] = (uint16_t)(it * 64 + lane);  // (block of the slice, lane): < 64 kMaxBeamsPerLane
+          }
+          acount += __popcll(parked);
+        } else if (parked) {  // the block's lane mask; `amb_its` (uniform) remembers which blocks have one
+          if (lane == 0) ambm[it] = parked;
+          amb_its |= 1u << it;
         }
-        acount += __popcll(parked);
       } else {
         if constexpr (STATS) st_beams += 1u;
       }
@@ -861,14 +888,28 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
         two_blocks_in();
         drain_ready(std::true_type{});
       }
-      for (int a0 = 0; a0 < acount; a0 += 64) {
-        const bool valid = a0 + lane < acount;
-        const int parked_at = valid ? (int)ambq[a0 + lane] : 0;
-        const int b = 64 * slice + (parked_at >> 6) * bstride + (parked_at & 63);
-        int gx = 0, gy = 0;
-        bool small = true;
-        if (valid) exact_cell(*(const double2*)((const char*)lp + ((uint32_t)b << 4)), gx, gy, small);
-        emit(std::false_type{}, b, valid, small, gx, gy, 0, false, true, 0, 0);
+      if constexpr (SOLO) {
+        for (int a0 = 0; a0 < acount; a0 += 64) {
+          const bool valid = a0 + lane < acount;
+          const int parked_at = valid ? (int)ambq[a0 + lane] : 0;
+          const int b = 64 * slice + (parked_at >> 6) * bstride + (parked_at & 63);
+          int gx = 0, gy = 0;
+          bool small = true;
+          if (valid) exact_cell(*(const double2*)((const char*)lp + ((uint32_t)b << 4)), gx, gy, small);
+          emit(std::false_type{}, b, valid, small, gx, gy, 0, false, true, 0, 0);
+        }
+      } else {
+        wsync<SOLO>();  // lane 0's mask words
+        while (amb_its) {  // one pass per block of beams that parked any (a few beams in 10^4 park at all)
+          const int pit = __builtin_ctz(amb_its);
+          amb_its &= amb_its - 1u;
+          const bool valid = (ambm[pit] >> lane) & 1ull;
+          const int b = 64 * slice + pit * bstride + lane;
+          int gx = 0, gy = 0;
+          bool small = true;
+          if (valid) exact_cell(*(const double2*)((const char*)lp + ((uint32_t)b << 4)), gx, gy, small);
+          emit(std::false_type{}, b, valid, small, gx, gy, 0, false, true, 0, 0);
+        }
       }
     } else {
       // Launches that do not fill the chip (a lone MatchScan is 21 x 8 waves) end when their SLOWEST wave does: a parked
@@ -890,7 +931,7 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       }
     }
     if (qcount > 0) drain(qhead, qcount);
-    __syncthreads();
+    wsync<SOLO>();
     if constexpr (STATS) {
       const uint32_t t0 = wave_sum(st_rows), t1 = wave_sum(st_live), t2 = wave_sum(st_beams), t3 = wave_sum(st_queued);
       if (lane == 0 && stats) {
@@ -923,7 +964,7 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
 #endif
           if ((lane & 7) == 0) red[(j * NXD + k) * 2 + q][lane >> 3] = v;
         }
-    __syncthreads();
+    wsync<SOLO>();
     for (int idx = lane; idx < NW; idx += 64) {
       uint32_t lo = 0, hi = 0;
 #pragma unroll
@@ -935,18 +976,84 @@ k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, 
       const int par2 = idx & 1, jk = idx >> 1;
       const int j = j0 + jk / NXD, i = 4 * (jk % NXD) + par2;
       if (j < pc.ny) {
-        int32_t* o = resp + (size_t)s * resp_stride + (size_t)a * ncand + (size_t)j * pc.nx + i;
-        if (beam_slices == 1) {
+        if constexpr (OUT_LDS) {
+          int32_t* o = lds_out + a * ncand + j * pc.nx + i;
           if (i < pc.nx) o[0] = (int32_t)lo;
           if (i + 2 < pc.nx) o[2] = (int32_t)hi;
         } else {
-          if (i < pc.nx) atomicAdd(o, (int32_t)lo);
-          if (i + 2 < pc.nx) atomicAdd(o + 2, (int32_t)hi);
+          int32_t* o = resp + (size_t)s * resp_stride + (size_t)a * ncand + (size_t)j * pc.nx + i;
+          if (beam_slices == 1) {
+            if (i < pc.nx) o[0] = (int32_t)lo;
+            if (i + 2 < pc.nx) o[2] = (int32_t)hi;
+          } else {
+            if (i < pc.nx) atomicAdd(o, (int32_t)lo);
+            if (i + 2 < pc.nx) atomicAdd(o + 2, (int32_t)hi);
+          }
         }
       }
     }
-    __syncthreads();
+    wsync<SOLO>();
   }
+}
+
+// The row kernel proper: one wave64 per block.
+template <int NXD, int NYC, bool TILED, bool STATS = false, bool LDSB = false>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))  // <= 128 VGPRs
+k_resp_rows(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int step, int limit, Geom g,
+            PassCfg pc, const Lattice* __restrict__ lat, const double2* __restrict__ cossin,
+            const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int beam_slices,
+            int S, const uint2* __restrict__ occ_t, int occ_wpc, int tile_rows, uint32_t tile_class_bytes,
+            unsigned long long* __restrict__ stats) {
+  constexpr int NW = NXD * NYC * 2;
+  __shared__ __align__(16) uint32_t red[NW][8];
+  __shared__ int2 queue[kRowsQueue];
+  __shared__ uint16_t ambq[TILED ? 64 * kMaxBeamsPerLane : 1];
+  __shared__ uint32_t patch[LDSB ? 2 : 1][LDSB ? kPatchDw : 1];
+  int w = blockIdx.x;
+  const int slice = w % beam_slices;
+  w /= beam_slices;
+  const int xcd = w & 7, r = w >> 3;
+  const int s = (r / pc.na) * 8 + xcd;
+  const int a = r % pc.na;
+  if (s >= S) return;
+  resp_rows_wave<NXD, NYC, TILED, STATS, LDSB, true>(s, a, slice, src0, src1, step, limit, g, pc, lat, cossin, local, resp,
+                                                     resp_stride, beam_slices, occ_t, occ_wpc, tile_rows, tile_class_bytes,
+                                                     stats, RowsLds{red, queue, ambq, (uint32_t (*)[kPatchDw])patch, nullptr},
+                                                     nullptr);
+}
+
+// The same waves in blocks of WAVES: the waves of a block take WAVES consecutive angles of ONE scan, so they run on ONE CU
+// and share its L1 -- the angles of a scan read the same 17 KB of points, neighbouring occupancy words and largely the
+// same lines of the tiled planes (a 2-degree step moves a beam's end point by 7 cells at 10 m; a line is a 64 x 8 cell
+// patch).  k_resp_rows' one-wave blocks of a scan are dealt round robin over the CUs of the scan's XCD and share only
+// the L2: 17 % of its L1 lookups miss, and a miss costs the CU's gather pipe 2.3 clocks against 0.5 for a hit
+// (profiles/r06/micro_ta_rate.txt).  No barrier anywhere: every wave has its own LDS area and its own angle.
+template <int NXD>
+constexpr int rows_wave_area() {  // bytes of LDS per wave: max(red, queue) + the undecided-beam masks
+  return (NXD == 3 ? 3 * 11 * 2 * 8 * 4 : 4 * 8 * 2 * 8 * 4) > kRowsQueue * 8
+             ? (NXD == 3 ? 3 * 11 * 2 * 8 * 4 : 4 * 8 * 2 * 8 * 4) + kMaxBeamsPerLane * 8
+             : kRowsQueue * 8 + kMaxBeamsPerLane * 8;
+}
+template <int NXD, int NYC, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8)))
+k_resp_rows_mw(const uint8_t* __restrict__ ptiles, int limit, Geom g, PassCfg pc, const Lattice* __restrict__ lat,
+               const double2* __restrict__ cossin, const double2* __restrict__ local, int32_t* __restrict__ resp,
+               size_t resp_stride, int S, const uint2* __restrict__ occ_t, int occ_wpc, int tile_rows,
+               uint32_t tile_class_bytes) {
+  constexpr int kArea = rows_wave_area<NXD>();
+  __shared__ __align__(16) unsigned char areas[WAVES * kArea];
+  const int wave = (int)threadIdx.x >> 6;
+  const int groups = (pc.na + WAVES - 1) / WAVES;
+  const int w = blockIdx.x;
+  const int xcd = w & 7, r = w >> 3;
+  const int s = (r / groups) * 8 + xcd;  // all blocks of a scan on one XCD
+  const int a = (r % groups) * WAVES + wave;
+  if (s >= S || a >= pc.na) return;
+  unsigned char* wa = areas + wave * kArea;
+  const RowsLds lds{(uint32_t (*)[8])wa, (int2*)wa, nullptr, nullptr, (unsigned long long*)(wa + (kArea - kMaxBeamsPerLane * 8))};
+  resp_rows_wave<NXD, NYC, true, false, false, false, false>(s, a, 0, ptiles, ptiles, 2, limit, g, pc, lat, cossin, local, resp,
+                                                             resp_stride, 1, occ_t, occ_wpc, tile_rows, tile_class_bytes,
+                                                             (unsigned long long*)nullptr, lds, (int32_t*)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -994,17 +1101,13 @@ k_tile4(const uint8_t* __restrict__ grid, int stride, int data_size, uint4* __re
 #define LSLAM_TUNE_TILE3_MIN 1536
 #endif
 constexpr int kTile3ManyAngles = 3, kTile3ManyMinScans = LSLAM_TUNE_TILE3_MIN;
+// One wave64: the 9 numerators of each of the angles a0 .. a0 + kTile3Angles - 1 of scan s, written to r_scan[a * 9 + c]
+// (r_scan = the scan's numerators: resp + s * resp_stride in k_resp_tile3, the block's LDS copy in k_match_step).
 template <int kTile3Angles>
-__global__ void __launch_bounds__(64)
-k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc, const Lattice* __restrict__ lat,
-             const double2* __restrict__ cossin, const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int S) {
-  const int lane = threadIdx.x;
-  const int w = blockIdx.x;
-  const int xcd = w & 7, r = w >> 3;
-  const int pairs = (pc.na + kTile3Angles - 1) / kTile3Angles;
-  const int s = (r / pairs) * 8 + xcd;  // all angles of a scan on one XCD, like k_resp_rows
-  const int a0 = (r % pairs) * kTile3Angles;
-  if (s >= S) return;
+__device__ __forceinline__ void resp_tile3_wave(const int s, const int a0, const int lane, const uint4* __restrict__ tiles,
+                                                int tile_cols, const Geom& g, const PassCfg& pc,
+                                                const Lattice* __restrict__ lat, const double2* __restrict__ cossin,
+                                                const double2* __restrict__ local, int32_t* r_scan) {
   const Lattice& L = lat[s];
   if (!L.active || L.status != 0 || L.step_x != 1 || L.step_y != 1) return;
 
@@ -1109,8 +1212,21 @@ k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc,
 #pragma unroll
     for (int c = 0; c < 9; c++)
       if (lane == c) mine = tot[c];
-    if (lane < 9 && angle_on[q]) resp[(size_t)s * resp_stride + (size_t)(a0 + q) * 9 + lane] = (int32_t)mine;
+    if (lane < 9 && angle_on[q]) r_scan[(a0 + q) * 9 + lane] = (int32_t)mine;
   }
+}
+
+template <int kTile3Angles>
+__global__ void __launch_bounds__(64)
+k_resp_tile3(const uint4* __restrict__ tiles, int tile_cols, Geom g, PassCfg pc, const Lattice* __restrict__ lat,
+             const double2* __restrict__ cossin, const double2* __restrict__ local, int32_t* __restrict__ resp, size_t resp_stride, int S) {
+  const int w = blockIdx.x;
+  const int xcd = w & 7, r = w >> 3;
+  const int pairs = (pc.na + kTile3Angles - 1) / kTile3Angles;
+  const int s = (r / pairs) * 8 + xcd;  // all angles of a scan on one XCD, like k_resp_rows
+  const int a0 = (r % pairs) * kTile3Angles;
+  if (s >= S) return;
+  resp_tile3_wave<kTile3Angles>(s, a0, (int)threadIdx.x, tiles, tile_cols, g, pc, lat, cossin, local, resp + (size_t)s * resp_stride);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1429,27 +1545,26 @@ k_reduce_coarse(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict__ la
 // ------------------------------------------------------------------------------------------
 // NT threads per block: 128 when the batch fills the chip (a block is mostly single-thread ordered sums, so residency --
 // 32 waves per CU = 16 such blocks -- buys more than lanes), 256 for small batches (latency of the one block that runs).
+// The block's work as a function of (scan s, thread tid of NT): `r` = the scan's numerators (angle-major: global in
+// k_reduce_coarse_lds, the block's LDS copy in k_match_step), `smem` = reduce_lds_nocache() bytes of LDS scratch.
 template <int NT>
-__global__ void __launch_bounds__(NT)
-k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
-                    int32_t* resp, size_t resp_stride, CoarseOut* __restrict__ out,
-                    int use_expansion, int pass_index, const uint8_t* __restrict__ grid,
-                const double2* __restrict__ local, int fb_step, PassCfg fine_pc,
-                    double2* fine_cossin, int fine_step, int zero_fine_words, int parts) {
-  extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void reduce_coarse_lds_block(
+    const int s, const int tid, const Geom& g, const PassCfg& pc, const SearchCfg& sc, Lattice* lat, int32_t* r,
+    CoarseOut* __restrict__ out, int use_expansion, int pass_index, const uint8_t* __restrict__ grid,
+    const double2* __restrict__ local, int fb_step, const PassCfg& fine_pc, double2* fine_cossin, int fine_step,
+    int zero_fine_words, int parts, unsigned char* smem) {
   __shared__ double sh[NT];
   __shared__ double s_ap[kMaxAngles];
   __shared__ unsigned long long s_nz[4];
   __shared__ double s_avg[3];
-  __shared__ int s_status, s_bad, s_ntie, s_wcnt[NT / 64];
-  const int s = blockIdx.x, tid = threadIdx.x;
+  __shared__ int s_status, s_bad, s_ntie, s_wcnt[(NT + 63) / 64];
   const Lattice& L = lat[s];
   if (!L.active) return;
   if (L.status != 0) {
     if (tid == 0) { out[s].status = L.status; out[s].expand = 0; out[s].best = 0.0; }
     return;
   }
-  block_generic_fallback(grid, g, pc, L, local + (size_t)s * g.n_beams, resp + (size_t)s * resp_stride, fb_step, tid, NT);
+  block_generic_fallback(grid, g, pc, L, local + (size_t)s * g.n_beams, r, fb_step, tid, NT);
   const int ncand = pc.nx * pc.ny;
   const int total = ncand * pc.na;
   const int words = (total + 31) / 32;  // <= 256 (host)
@@ -1464,7 +1579,6 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
   int* cell = (int*)(mask + words);
   int* tie = cell + ncand;  // lattice cells that may hold a tie with the best response
   double* dpen = terms;  // distance penalty per lattice cell; dead before `terms` is written
-  const int32_t* r = resp + (size_t)s * resp_stride;
   const double center[3] = {L.center[0], L.center[1], L.center[2]};
 
   // per-cell and per-angle penalty factors (Mapper.cpp:399-414) + search-space cell of every lattice
@@ -1616,7 +1730,7 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
     __syncthreads();
     int off = n_pass;
     for (int w = 0; w < (tid >> 6); w++) off += s_wcnt[w];
-    for (int w = 0; w < NT / 64; w++) n_pass += s_wcnt[w];
+    for (int w = 0; w < (NT + 63) / 64; w++) n_pass += s_wcnt[w];
     if (pass) {
       const int k = off + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
       terms[4 * k + 0] = rr; terms[4 * k + 1] = t1; terms[4 * k + 2] = t2; terms[4 * k + 3] = t3;
@@ -1667,7 +1781,20 @@ k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
   }
   // The fine pass follows at once and its beam-sliced form accumulates with atomics: clear its numerators here (every read
   // of this scan's coarse numerators is behind the barriers above) instead of a fill operation on the stream.
-  for (int i = tid; i < zero_fine_words; i += NT) resp[(size_t)s * resp_stride + i] = 0;
+  for (int i = tid; i < zero_fine_words; i += NT) r[i] = 0;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT)
+k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
+                    int32_t* resp, size_t resp_stride, CoarseOut* __restrict__ out,
+                    int use_expansion, int pass_index, const uint8_t* __restrict__ grid,
+                const double2* __restrict__ local, int fb_step, PassCfg fine_pc,
+                    double2* fine_cossin, int fine_step, int zero_fine_words, int parts) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  reduce_coarse_lds_block<NT>((int)blockIdx.x, (int)threadIdx.x, g, pc, sc, lat, resp + (size_t)blockIdx.x * resp_stride, out,
+                              use_expansion, pass_index, grid, local, fb_step, fine_pc, fine_cossin, fine_step, zero_fine_words,
+                              parts, smem);
 }
 
 
@@ -2298,13 +2425,13 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
 // ComputeAngularCovariance (Mapper.cpp:641-692): nA more response sums at the best cell,
 // gathered by the whole block; final result record.  Dynamic LDS: mask words.
 // ------------------------------------------------------------------------------------------
-template <int NT>  // threads per block: 128 for chip-filling batches (residency), 256 otherwise; see k_reduce_coarse_lds
-__global__ void __launch_bounds__(NT)
-k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc,
-              const Lattice* __restrict__ lat, int32_t* resp, size_t resp_stride,
-              const double2* __restrict__ local, const CoarseOut* __restrict__ coarse,
-              lslam_match_result* __restrict__ out, int do_refine, int fb_step, int* done_flag, int done_ticket) {
-  extern __shared__ __align__(16) unsigned char smem[];
+// The block's work as a function of (scan s, thread tid of NT): `r` = the scan's fine numerators (global in k_reduce_fine,
+// the block's LDS copy in k_match_step), `smem` = the mask words.
+template <int NT>
+__device__ __forceinline__ void reduce_fine_block(
+    const int s, const int tid, const uint8_t* __restrict__ grid, const Geom& g, const PassCfg& pc, const SearchCfg& sc,
+    const Lattice* __restrict__ lat, int32_t* r, const double2* __restrict__ local, const CoarseOut* __restrict__ coarse,
+    lslam_match_result* __restrict__ out, int do_refine, int fb_step, int* done_flag, int done_ticket, unsigned char* smem) {
   __shared__ double sh[NT];
   __shared__ int32_t asum[kMaxAngles];
   // done_flag (single-scan matches whose record goes to pinned host memory): after the record, a system-scope fence and the
@@ -2320,7 +2447,6 @@ k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc
   __shared__ double s_best;
   __shared__ int s_status, s_pos;
   uint32_t* mask = (uint32_t*)smem;
-  const int s = blockIdx.x, tid = threadIdx.x;
   const CoarseOut& co = coarse[s];
   if (!do_refine || co.status != 0) {
     if (tid == 0) {
@@ -2347,10 +2473,9 @@ k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc
     }
     return;
   }
-  block_generic_fallback(grid, g, pc, L, local + (size_t)s * g.n_beams, resp + (size_t)s * resp_stride, fb_step, tid, NT);
+  block_generic_fallback(grid, g, pc, L, local + (size_t)s * g.n_beams, r, fb_step, tid, NT);
   const int ncand = pc.nx * pc.ny;
   const int total = ncand * pc.na;
-  const int32_t* r = resp + (size_t)s * resp_stride;
   const double center[3] = {L.center[0], L.center[1], L.center[2]};
   // every thread keeps its candidates' penalised responses (the usual fine lattice has 99 of them:
   // one per thread) instead of evaluating the division and the penalty twice
@@ -2461,6 +2586,92 @@ k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc
   }
   out[s] = res;
   signal_done();
+}
+
+template <int NT>  // threads per block: 128 for chip-filling batches (residency), 256 otherwise; see k_reduce_coarse_lds
+__global__ void __launch_bounds__(NT)
+k_reduce_fine(const uint8_t* __restrict__ grid, Geom g, PassCfg pc, SearchCfg sc,
+              const Lattice* __restrict__ lat, int32_t* resp, size_t resp_stride,
+              const double2* __restrict__ local, const CoarseOut* __restrict__ coarse,
+              lslam_match_result* __restrict__ out, int do_refine, int fb_step, int* done_flag, int done_ticket) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  reduce_fine_block<NT>((int)blockIdx.x, (int)threadIdx.x, grid, g, pc, sc, lat, resp + (size_t)blockIdx.x * resp_stride, local,
+                        coarse, out, do_refine, fb_step, done_flag, done_ticket, smem);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_match_step -- ONE LAUNCH PER STEP: a scan-resident workgroup (round 6).
+// The five kernels of a batched match are a dependent chain per SCAN only -- scans never exchange anything -- so a
+// workgroup of WAVES waves takes ONE scan through all of it with __syncthreads() between the phases:
+//   0  scan_prep_block        ranges -> scan-frame points (+ coarse lattice, cos/sin of the angles)      [all threads]
+//   1  resp_rows_wave         the nA coarse angles, one angle per wave at a time, numerators -> LDS      [wave = angle]
+//   2  reduce_coarse_lds_block penalties, max, tie average, covariance, fine lattice                     [all threads]
+//   3  resp_tile3_wave        the fine angles, kStepFineAngles per wave, numerators -> LDS                [wave = angles]
+//   4  reduce_fine_block      max, tie average, angular covariance, the 112-byte record                  [all threads]
+// Same device functions, same arguments, same order of every rounding as the five-kernel path: records are byte-identical.
+// What changes is where things live and what overlaps: the int32 numerators (10 KB per scan) never leave LDS (the
+// five-kernel step writes and re-reads 41.6 MB of them per 4096 scans), four launches and their drain / fill gaps are gone,
+// and the latency-bound phases of one scan run under the gathers of the other scans resident on the same SIMDs -- each
+// block is in its own phase -- which stream pipelining could not arrange (profiles/r05/experiments/pipe_lockstep).
+// LDS per block: numerators + max(WAVES x 2.4 KB of wave areas, the reduce scratch) ~ 21-24 KB; 128 VGPRs -> the waves of
+// 16 / WAVES blocks per CU.  The reference has no counterpart (one ScanMatcher, one scan at a time: Mapper.cpp:184-291).
+// ------------------------------------------------------------------------------------------
+constexpr int kStepFineAngles = 4;  // fine angles per wave in phase 3 (11 fine angles = 4 + 4 + 3: three balanced items)
+template <int NXD>
+constexpr int step_wave_area() { return rows_wave_area<NXD>(); }  // bytes of LDS one wave of phase 1 owns
+struct StepGrid {  // the read-only views of the correlation grid the phases gather from
+  const uint8_t* ptiles;     // tiled parity planes (k_tile_planes)
+  const uint2* occ;          // row-occupancy word pairs (k_occ_pairs); nullptr = no pruning
+  const uint4* tiles4;       // overlapping 4x4 blocks (k_tile4)
+  const uint8_t* grid;       // the grid itself (fallback paths of the reduce blocks)
+  int limit, occ_wpc, ptile_rows, tile4_cols;
+  uint32_t ptile_class_bytes;
+};
+template <int NXD, int NYC, int WAVES, typename RT>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 8)))
+k_match_step(const RT* __restrict__ ranges, int stride, const double* __restrict__ poses, Geom g, PassCfg pc, PassCfg pf,
+             SearchCfg sc, StepGrid v, Lattice* lat, double2* cossin, double2* local, CoarseOut* coarse,
+             lslam_match_result* __restrict__ out, int parts, uint32_t phase_off, int32_t* dbg_coarse, int32_t* dbg_fine,
+             size_t dbg_stride) {
+  constexpr int NT = 64 * WAVES;
+  constexpr int kArea = step_wave_area<NXD>();
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int s = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int32_t* const num = (int32_t*)smem;        // the scan's numerators, angle-major: coarse pass, then fine pass
+  unsigned char* const phase = smem + phase_off;  // wave areas (phase 1) / reduce scratch (phases 2, 4)
+
+  // 0: LocalizedRangeScan::Update + InverseTransformPose (Karto.h:5384-5388, 6423-6434), coarse lattice (Mapper.cpp:339-393)
+  scan_prep_block(ranges, stride, poses[3 * s], poses[3 * s + 1], poses[3 * s + 2], g, local, (double2*)nullptr, pc, lat, cossin, 2,
+                  0, 1, s);
+  __syncthreads();
+  // 1: coarse response numerators (Mapper.cpp:373-424, 819-856)
+  {
+    unsigned char* wa = phase + wave * kArea;
+    const RowsLds lds{(uint32_t (*)[8])wa, (int2*)wa, nullptr, nullptr,
+                      (unsigned long long*)(wa + (kArea - kMaxBeamsPerLane * 8))};
+    for (int a = wave; a < pc.na; a += WAVES)
+      resp_rows_wave<NXD, NYC, true, false, false, false>(s, a, 0, v.ptiles, v.ptiles, 2, v.limit, g, pc, lat, cossin, local,
+                                                          (int32_t*)nullptr, 0, 1, v.occ, v.occ_wpc, v.ptile_rows,
+                                                          v.ptile_class_bytes, (unsigned long long*)nullptr, lds, num);
+  }
+  __syncthreads();
+  // 2: Mapper.cpp:431-501, 535-630 (+ the fine lattice around the mean: :276-281)
+  reduce_coarse_lds_block<NT>(s, tid, g, pc, sc, lat, num, coarse, 0, 0, v.grid, local, 2, pf, cossin, 1, 0, parts, phase);
+  __syncthreads();
+  if (dbg_coarse) {  // diagnostics (lslam_matcher_debug_coarse_sums_batch): the numerators as the reduce saw them
+    for (int i = tid, n = pc.nx * pc.ny * pc.na; i < n; i += NT) dbg_coarse[(size_t)s * dbg_stride + i] = num[i];
+    __syncthreads();
+  }
+  // 3: fine response numerators, 3 x 3 x nA (same function, one-cell steps)
+  for (int a0 = wave * kStepFineAngles; a0 < pf.na; a0 += WAVES * kStepFineAngles)
+    resp_tile3_wave<kStepFineAngles>(s, a0, lane, v.tiles4, v.tile4_cols, g, pf, lat, cossin, local, num);
+  __syncthreads();
+  // 4: Mapper.cpp:431-506, 641-692, the record
+  reduce_fine_block<NT>(s, tid, v.grid, g, pf, sc, lat, num, local, coarse, out, 1, 1, (int*)nullptr, 0, phase);
+  if (dbg_fine) {
+    __syncthreads();
+    for (int i = tid, n = pf.nx * pf.ny * pf.na; i < n; i += NT) dbg_fine[(size_t)s * dbg_stride + i] = num[i];
+  }
 }
 
 // result for a laser with zero beams (Mapper.cpp:199-209)
@@ -3004,6 +3215,10 @@ struct lslam_matcher {
   bool use_row_occupancy = true;    // lslam_matcher_set_option(LSLAM_OPT_ROW_OCCUPANCY)
   bool collect_stats = false;       // lslam_matcher_set_option(LSLAM_OPT_COLLECT_STATS): instrumented coarse kernel
   bool lds_staged = false;          // lslam_matcher_set_option(LSLAM_OPT_LDS_STAGED): the measured-and-dropped LDS-staged phase B
+  int rows_waves = 1;               // lslam_matcher_set_option(LSLAM_OPT_ROWS_WAVES): waves per block of the tiled coarse kernel (1 = k_resp_rows, 2 / 4 / 8 = k_resp_rows_mw)
+  int step_waves = 0;               // lslam_matcher_set_option(LSLAM_OPT_STEP_KERNEL): 0 = five launches per step, 3 / 4 = k_match_step with that many waves per scan
+  int step_min_scans = 64;          // batches below this keep the five-kernel path (its beam-sliced kernels fill the chip)
+  uint64_t step_launches = 0;       // k_match_step launches so far (diagnostics / tests)
   int stats_scans = 0;              // scans the per-(scan, beam) flag words behind the counters are sized for
   DevBuf<unsigned long long> d_stats;
   uint32_t* d_occ_t = nullptr;      // transposed row-occupancy bitmap (k_row_occupancy)
@@ -3249,11 +3464,8 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   SearchCfg sc{m->cfg.distance_variance_penalty, m->cfg.angle_variance_penalty,
                m->cfg.minimum_distance_penalty, m->cfg.minimum_angle_penalty, do_penalize, m->fast_div, m->inv_denom};
 
-  // scan_prep also lays out the coarse lattice of pass 0 (mode 0 needs only the pose): one launch fewer
-  if (prep_was_done && S == 1) {  // k_rebuild_begin's extra blocks did it (streaming front-end)
-  } else
-    launch(ctx, "scan_prep", k_scan_prep<RT>, dim3(S >= kReduceNarrowMinScans ? 1 : (g.n_beams + 255) / 256, S), dim3(256), 0, d_ranges,
-           stride, d_poses, g, m->d_local.p, (double2*)nullptr, pc, m->d_lat.p, m->d_cossin.p, 2, PoseArg{});
+  // scan_prep also lays out the coarse lattice of pass 0 (mode 0 needs only the pose): one launch fewer.  It is
+  // launched further down, once it is clear that the step does not go out as ONE kernel (k_match_step preps its own scan).
   bool setup_done = true;  // consumed by the first pass
 
 
@@ -3275,6 +3487,54 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
            (const uint32_t*)m->d_occ_t, g.stride, m->occ_wpc / 2, m->d_occ_x);
     m->occ_dirty = false;
   }
+  // the 2-D tiled parity planes (coarse pass of chip-filling batches) and the overlapping 4x4 blocks (their fine pass):
+  // allocated on first use, refreshed when the grid changed; false = not available (allocation failed / too big)
+  auto ensure_ptiles = [&]() -> bool {
+    if (m->ptile_failed) return false;
+    if (!m->d_ptiles) {
+      m->ptile_tx = (g.stride / 2 + 15) / 16;
+      m->ptile_rows = (((g.height - 1 + kTileYOff) / 2 + 1) + 3) & ~3;  // class rows, whole 4-row lines
+      const size_t bytes = (size_t)kTilePad + 4 * (size_t)m->ptile_rows * m->ptile_tx * 32;
+      if (bytes >= (1ull << 32) || hipMalloc((void**)&m->d_ptiles, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        m->d_ptiles = nullptr;
+        m->ptile_failed = true;  // keep to the linear planes
+        return false;
+      }
+      if (hipMemsetAsync(m->d_ptiles, 0, kTilePad, ctx->stream) != hipSuccess) return false;
+    }
+    if (m->ptile_dirty) {
+      const size_t dwords = (size_t)m->ptile_rows * m->ptile_tx * 32;  // 4 classes x class_bytes / 4
+      launch(ctx, "tile_planes", k_tile_planes, dim3((unsigned)((dwords + 255) / 256)), dim3(256), 0,
+             (const uint8_t*)m->d_grid, g.stride, g.data_size, (uint32_t*)m->d_ptiles, m->ptile_tx, m->ptile_rows);
+      m->ptile_dirty = false;
+    }
+    return true;
+  };
+  auto tiles4_possible = [&]() -> bool {
+    return g.n_beams <= 16384 && !m->tile_failed &&
+           (unsigned long long)g.data_size * 4ull + (1ull << 24) < (1ull << 32);  // k_resp_tile3 uses 32-bit offsets
+  };
+  auto ensure_tiles4 = [&]() -> bool {
+    if (!tiles4_possible()) return false;
+    if (!m->d_tiles) {
+      m->tile_cols = g.stride / 2;
+      m->tile_rows = (g.height + 1) / 2 + kTileYPad / 2 + 1;
+      m->tile_rows += m->tile_rows & 1;  // lines hold block rows in pairs
+      if (hipMalloc((void**)&m->d_tiles, (size_t)((m->tile_cols + 3) / 4) * 4 * m->tile_rows * sizeof(uint4)) != hipSuccess) {
+        (void)hipGetLastError();
+        m->d_tiles = nullptr;
+        m->tile_failed = true;  // not enough HBM for the 4x copy: keep to the row kernel
+        return false;
+      }
+    }
+    if (m->tile_dirty) {
+      launch(ctx, "tile4", k_tile4, dim3((m->tile_cols + 255) / 256, m->tile_rows), dim3(256), 0,
+             (const uint8_t*)m->d_grid, g.stride, g.data_size, m->d_tiles, m->tile_cols, m->tile_rows);
+      m->tile_dirty = false;
+    }
+    return true;
+  };
   auto reduce_lds = [&](const PassCfg& p, bool cache) -> size_t {
     size_t total = (size_t)p.nx * p.ny * p.na;
     return (cache ? total * 8 : 0) + (size_t)p.nx * p.ny * (8 + 32 + 4) + (size_t)g.probs_side * g.probs_side * 8 +
@@ -3301,26 +3561,9 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     setup_done = false;
     const long long waves = (long long)((S + 7) / 8) * 8 * p.na;
     // fine pass of a batch big enough to fill the chip: one 16-byte load per beam from the 4x4 blocks
-    bool tiled = variant == 1 && step == 1 && p.nx == 3 && p.ny == 3 && waves >= kTileMinWaves &&
-                 g.n_beams <= 16384 && !m->tile_failed &&
-                 (unsigned long long)g.data_size * 4ull + (1ull << 24) < (1ull << 32);  // k_resp_tile3 uses 32-bit offsets
-    if (tiled && !m->d_tiles) {
-      m->tile_cols = g.stride / 2;
-      m->tile_rows = (g.height + 1) / 2 + kTileYPad / 2 + 1;
-      m->tile_rows += m->tile_rows & 1;  // lines hold block rows in pairs
-      if (hipMalloc((void**)&m->d_tiles, (size_t)((m->tile_cols + 3) / 4) * 4 * m->tile_rows * sizeof(uint4)) != hipSuccess) {
-        (void)hipGetLastError();
-        m->d_tiles = nullptr;
-        m->tile_failed = true;  // not enough HBM for the 4x copy: keep to the row kernel
-        tiled = false;
-      }
-    }
+    bool tiled = variant == 1 && step == 1 && p.nx == 3 && p.ny == 3 && waves >= kTileMinWaves && tiles4_possible();
+    if (tiled) tiled = ensure_tiles4();
     if (tiled) {
-      if (m->tile_dirty) {
-        launch(ctx, "tile4", k_tile4, dim3((m->tile_cols + 255) / 256, m->tile_rows), dim3(256), 0,
-               (const uint8_t*)m->d_grid, g.stride, g.data_size, m->d_tiles, m->tile_cols, m->tile_rows);
-        m->tile_dirty = false;
-      }
 #define LSLAM_TILE3_ARGS                                                                                                \
   (const uint4*)m->d_tiles, m->tile_cols, g, p, (const Lattice*)m->d_lat.p, (const double2*)m->d_cossin.p,              \
       (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S
@@ -3350,26 +3593,8 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       // coarse pass of a batch that fills the chip on its own: gather from the TILED parity planes
       bool ptiled = step == 2 && slices == 1 && waves >= kTileMinWaves && !m->ptile_failed &&
                     !(m->lds_staged && variant == 2);  // the LDS-staged experiment reads the LINEAR planes
-      if (ptiled && !m->d_ptiles) {
-        m->ptile_tx = (g.stride / 2 + 15) / 16;
-        m->ptile_rows = (((g.height - 1 + kTileYOff) / 2 + 1) + 3) & ~3;  // class rows, whole 4-row lines
-        const size_t bytes = (size_t)kTilePad + 4 * (size_t)m->ptile_rows * m->ptile_tx * 32;
-        if (bytes >= (1ull << 32) || hipMalloc((void**)&m->d_ptiles, bytes) != hipSuccess) {
-          (void)hipGetLastError();
-          m->d_ptiles = nullptr;
-          m->ptile_failed = true;  // keep to the linear planes
-          ptiled = false;
-        } else {
-          LSLAM_HIP(ctx, hipMemsetAsync(m->d_ptiles, 0, kTilePad, ctx->stream));
-        }
-      }
+      if (ptiled) ptiled = ensure_ptiles();
       const uint32_t class_bytes = (uint32_t)((size_t)m->ptile_rows * m->ptile_tx * 32);
-      if (ptiled && m->ptile_dirty) {
-        const size_t dwords = (size_t)class_bytes;  // 4 classes x class_bytes / 4
-        launch(ctx, "tile_planes", k_tile_planes, dim3((unsigned)((dwords + 255) / 256)), dim3(256), 0,
-               (const uint8_t*)m->d_grid, g.stride, g.data_size, (uint32_t*)m->d_ptiles, m->ptile_tx, m->ptile_rows);
-        m->ptile_dirty = false;
-      }
 #define LSLAM_ROWS_ARGS(SRC0, SRC1)                                                                              \
   grid, dim3(64), 0, SRC0, SRC1, step, limit, g, p, (const Lattice*)m->d_lat.p, (const double2*)m->d_cossin.p, \
       (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc, m->ptile_rows, class_bytes, \
@@ -3400,7 +3625,21 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
           launch(ctx, name, k_resp_rows<3, 11, false, true>, LSLAM_ROWS_ARGS(s0, s1));
       } else if (variant == 1)
         launch(ctx, name, k_resp_rows<1, 4, false>, LSLAM_ROWS_ARGS(s0, s1));
-      else if (variant == 2 && ptiled)
+      else if ((variant == 2 || variant == 3) && ptiled && m->rows_waves > 1 && g.n_beams <= 64 * kMaxBeamsPerLane) {
+        const int W = m->rows_waves, groups = (p.na + W - 1) / W;
+        const dim3 mw_grid((unsigned)((long long)((S + 7) / 8) * 8 * groups));
+#define LSLAM_MW(NXD_, NYC_, W_)                                                                                         \
+  launch(ctx, name, k_resp_rows_mw<NXD_, NYC_, W_>, mw_grid, dim3(64 * W_), 0, pt, limit, g, p, (const Lattice*)m->d_lat.p, \
+         (const double2*)m->d_cossin.p, (const double2*)m->d_local.p, m->d_resp.p, resp_stride, S, occ, m->occ_wpc,      \
+         m->ptile_rows, class_bytes)
+        if (variant == 2 && W == 2) LSLAM_MW(3, 11, 2);
+        else if (variant == 2 && W == 4) LSLAM_MW(3, 11, 4);
+        else if (variant == 2 && W == 8) LSLAM_MW(3, 11, 8);
+        else if (variant == 3 && W == 2) LSLAM_MW(4, 8, 2);
+        else if (variant == 3 && W == 4) LSLAM_MW(4, 8, 4);
+        else LSLAM_MW(4, 8, 8);
+#undef LSLAM_MW
+      } else if (variant == 2 && ptiled)
         launch(ctx, name, k_resp_rows<3, 11, true>, LSLAM_ROWS_ARGS(pt, pt));
       else if (variant == 2)
         launch(ctx, name, k_resp_rows<3, 11, false>, LSLAM_ROWS_ARGS(s0, s1));
@@ -3515,6 +3754,56 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
                                     hipMemcpyDeviceToDevice, ctx->stream));
     return LSLAM_OK;
   };
+
+  // ONE launch for the whole step (k_match_step) when the batch takes the tiled production kernels anyway and nothing
+  // needs the numerators or the intermediate records in HBM: no expansion passes, refinement on, the <3,11> / <4,8>
+  // coarse and the 3x3 fine instantiations, the LDS form of the coarse reduce.  Everything else -- and every batch below
+  // step_min_scans -- keeps the five-kernel path below, which stays the reference point (LSLAM_OPT_STEP_KERNEL 0).
+  if (m->step_waves > 0 && S >= m->step_min_scans) {
+    const int cvar = (pc.nx <= 4 && pc.ny <= 4) ? 1 : (pc.nx <= 12) ? 2 : (pc.nx <= 16) ? 3 : 0;
+    const size_t ctotal = (size_t)pc.nx * pc.ny * pc.na, ftotal = (size_t)pf.nx * pf.ny * pf.na;
+    bool ok = !force_generic && n_exp == 0 && do_refine && !m->collect_stats && !m->lds_staged && !done_flag &&
+              (cvar == 2 || cvar == 3) && pc.ny <= 32 && pf.nx == 3 && pf.ny == 3 && g.probs_side <= 63 &&
+              g.n_beams <= 64 * kMaxBeamsPerLane && (ctotal + 31) / 32 <= 256 &&
+              (ftotal + 31) / 32 <= 256 && !(prep_was_done && S == 1);
+    if (ok) ok = ensure_ptiles();
+    if (ok) ok = ensure_tiles4();
+    if (ok) {
+      const int W = m->step_waves, NT = 64 * W;
+      const int parts = reduce_parts(pc, NT);
+      const int area = cvar == 2 ? step_wave_area<3>() : step_wave_area<4>();
+      const size_t num_bytes = ((std::max(ctotal, ftotal) * 4 + 15) / 16) * 16;
+      const size_t phase_bytes = std::max<size_t>({(size_t)W * area, reduce_lds_nocache(pc, parts), ((ftotal + 31) / 32) * 4 + 16});
+      const size_t lds = num_bytes + ((phase_bytes + 15) / 16) * 16;
+      // the bitmap covers row spans of occ_win grid bytes: 2 (nX - 1) + 1 must fit
+      const uint2* occ = (want_occ && 2 * (pc.nx - 1) + 1 <= m->occ_win) ? m->d_occ_x : (const uint2*)nullptr;
+      StepGrid v{m->d_ptiles, occ, m->d_tiles, m->d_grid, g.data_size / 2, m->occ_wpc, m->ptile_rows, m->tile_cols,
+                 (uint32_t)((size_t)m->ptile_rows * m->ptile_tx * 32)};
+      int32_t* dbg_c = dbg_coarse_sums && m->dbg_all ? dbg_coarse_sums : (int32_t*)nullptr;
+      if (dbg_coarse_sums && !m->dbg_all) ok = false;  // the single-scan debug entry reads d_resp's layout
+      if (ok && lds <= 64 * 1024) {
+#define LSLAM_STEP(NXD_, NYC_, W_)                                                                                       \
+  launch(ctx, "match_step", k_match_step<NXD_, NYC_, W_, RT>, dim3(S), dim3(64 * W_), lds, d_ranges, stride, d_poses, g, pc, \
+         pf, sc, v, m->d_lat.p, m->d_cossin.p, m->d_local.p, m->d_coarse.p, d_out, parts, (uint32_t)num_bytes, dbg_c,   \
+         m->dbg_fine, resp_stride)
+        if (cvar == 2 && W == 3) LSLAM_STEP(3, 11, 3);
+        else if (cvar == 2 && W == 4) LSLAM_STEP(3, 11, 4);
+        else if (cvar == 3 && W == 3) LSLAM_STEP(4, 8, 3);
+        else if (cvar == 3 && W == 4) LSLAM_STEP(4, 8, 4);
+        else ok = false;
+#undef LSLAM_STEP
+        if (ok) {
+          m->step_launches++;
+          LSLAM_HIP(ctx, hipGetLastError());
+          return LSLAM_OK;
+        }
+      }
+    }
+  }
+  // the five-kernel path starts with the prep (unless the rebuild's extra blocks ran it)
+  if (!(prep_was_done && S == 1))
+    launch(ctx, "scan_prep", k_scan_prep<RT>, dim3(S >= kReduceNarrowMinScans ? 1 : (g.n_beams + 255) / 256, S), dim3(256), 0, d_ranges,
+           stride, d_poses, g, m->d_local.p, (double2*)nullptr, pc, m->d_lat.p, m->d_cossin.p, 2, PoseArg{});
 
   int rc = run_coarse(pc, 0);
   if (rc) return rc;
@@ -4035,6 +4324,29 @@ int lslam_matcher_set_option(lslam_matcher* m, int option, int value) {
       m->pipe_next = 0;
       return LSLAM_OK;
     }
+    case LSLAM_OPT_STEP_KERNEL: {
+      if (value != 0 && value != 3 && value != 4)
+        return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "step kernel: 0 (five launches per step), 3 or 4 (waves per scan), not %d", value);
+      LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+      int rc = pipe_join(m);
+      if (rc) return rc;
+      m->step_waves = value;
+      return LSLAM_OK;
+    }
+    case LSLAM_OPT_ROWS_WAVES: {
+      if (value != 1 && value != 2 && value != 4 && value != 8)
+        return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "coarse kernel: 1, 2, 4 or 8 waves per block, not %d", value);
+      LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+      int rc = pipe_join(m);
+      if (rc) return rc;
+      m->rows_waves = value;
+      return LSLAM_OK;
+    }
+    case LSLAM_OPT_STEP_MIN_SCANS: {
+      if (value < 1) return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "step kernel: minimum batch %d < 1", value);
+      m->step_min_scans = value;
+      return LSLAM_OK;
+    }
     case LSLAM_OPT_COLLECT_STATS:
       if (value) {
         LSLAM_HIP(ctx, hipSetDevice(ctx->device));
@@ -4056,6 +4368,7 @@ int lslam_matcher_flush(lslam_matcher* m) {
 }
 
 int64_t lslam_matcher_pipelined_steps(const lslam_matcher* m) { return m ? (int64_t)m->pipe_steps : 0; }
+int64_t lslam_matcher_step_kernel_launches(const lslam_matcher* m) { return m ? (int64_t)m->step_launches : 0; }
 
 int lslam_matcher_read_stats(lslam_matcher* m, uint64_t out[4]) {
   if (!m || !out) return LSLAM_ERR_INVALID_ARGUMENT;
@@ -4306,7 +4619,9 @@ int lslam_matcher_debug_coarse_sums_batch(lslam_matcher* m, int n_scans, const d
   const size_t cap = (size_t)n_scans * (size_t)std::max(lx * lx, 16) * (size_t)kMaxAngles;  // >= n_scans * resp_stride
   LSLAM_HIP(ctx, m->d_dbg.reserve(cap));
   m->dbg_all = true;
-  rc = match_batch_impl<double>(m, n_scans, m->d_ranges64.p, g.n_beams, m->d_poses.p, 1, 0, m->d_results.p, m->d_dbg.p, 0);
+  // (with the step kernel selected the batch goes through IT -- which always refines; the records are not looked at)
+  rc = match_batch_impl<double>(m, n_scans, m->d_ranges64.p, g.n_beams, m->d_poses.p, 1, m->step_waves > 0 ? 1 : 0, m->d_results.p,
+                                m->d_dbg.p, 0);
   m->dbg_all = false;
   if (rc) return rc;
   const size_t stride = m->dbg_resp_stride;

@@ -168,11 +168,26 @@ void* lslam_matcher_grid_dev_ptr(lslam_matcher* m);
  *    the context stream).  lslam_matcher_match_batch (host arrays) splits its batch into up to D sub-batches of >= 256
  *    scans and pipelines those, uploads included; it returns with everything done, as before.  The reference has no
  *    counterpart: karto::ScanMatcher is one grid, one lookup table, one caller (Mapper.h:1273-1278). */
-enum { LSLAM_OPT_ROW_OCCUPANCY = 1, LSLAM_OPT_COLLECT_STATS = 2, LSLAM_OPT_LDS_STAGED = 3, LSLAM_OPT_PIPELINE_DEPTH = 4 };
+/*  LSLAM_OPT_ROWS_WAVES (1, 2, 4 or 8; default 1): waves per block of the coarse response kernel of chip-filling batches.
+ *    With W > 1 the W waves of a block take W consecutive candidate angles of ONE scan (k_resp_rows_mw), so they run on one
+ *    CU and share its L1 (points, occupancy words, lines of the tiled planes); 1 = one wave per block (k_resp_rows).  Same
+ *    numerators either way. */
+/*  LSLAM_OPT_STEP_KERNEL (0, 3 or 4): ONE launch per batched match instead of five.  With 3 or 4 a workgroup of that
+ *    many wave64s takes one scan through scan_prep -> coarse responses -> coarse reduce -> fine responses -> fine reduce
+ *    (k_match_step: the same device functions in the same order, byte-identical records); the int32 response numerators
+ *    stay in LDS and the latency-bound phases of one scan run under the gathers of the scans resident beside it.  Applies
+ *    to batches of at least LSLAM_OPT_STEP_MIN_SCANS scans (default 64) whose configuration takes the tiled production
+ *    kernels: no response expansion, refinement on, coarse lattice rows of 5..16 positions, the 3 x 3 fine lattice;
+ *    everything else keeps the five-kernel path (value 0 = always).  lslam_matcher_step_kernel_launches counts the
+ *    launches that did go out as one kernel.  The reference has no counterpart (Mapper.cpp:184-291 is one scan at a time). */
+enum { LSLAM_OPT_ROW_OCCUPANCY = 1, LSLAM_OPT_COLLECT_STATS = 2, LSLAM_OPT_LDS_STAGED = 3, LSLAM_OPT_PIPELINE_DEPTH = 4,
+       LSLAM_OPT_STEP_KERNEL = 5, LSLAM_OPT_STEP_MIN_SCANS = 6, LSLAM_OPT_ROWS_WAVES = 7 };
 /* Order the context stream behind every pipelined step in flight (no host wait).  No-op at depth 1. */
 int lslam_matcher_flush(lslam_matcher* m);
 /* diagnostics: pipelined steps enqueued so far (0 while LSLAM_OPT_PIPELINE_DEPTH is 1) */
 int64_t lslam_matcher_pipelined_steps(const lslam_matcher* m);
+/* diagnostics: batched matches that went out as ONE launch (LSLAM_OPT_STEP_KERNEL) so far */
+int64_t lslam_matcher_step_kernel_launches(const lslam_matcher* m);
 int lslam_matcher_set_option(lslam_matcher* m, int option, int value);
 int lslam_matcher_read_stats(lslam_matcher* m, uint64_t out[4]);
 /* after an instrumented pass: out[0] = readable (scan, beam) pairs of that batch, out[1] = those with a live lattice row in
