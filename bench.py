@@ -277,6 +277,115 @@ def secondary_workloads(n_map_scans, n_single, n_stream, procs):
     return out
 
 
+# mapper_params.yaml as karto_slam.cc applies it (setParamDistanceVariancePenalty / ...AngleVariancePenalty square their
+# argument, Mapper.cpp:1919-1927; `use_scan_range` becomes the laser's range threshold, karto_slam.cc:98,395)
+INDOOR = {"search_size": 0.3, "resolution": 0.01, "smear_deviation": 0.03, "use_response_expansion": 1,
+          "distance_variance_penalty": 0.5 ** 2, "angle_variance_penalty": 0.1 ** 2, "range_threshold": 12.0}
+
+
+def batch_leg_workloads(n_scans, procs):
+    """Two more batched-match workloads, each `n_scans` DISTINCT scans against one shared grid:
+    `indoor`  the configuration the reference SHIPS (lesson6/config/mapper_params.yaml: 0.01 m cells, 0.3 m search space,
+              12 m range threshold, response expansion on -> 2445 x 2445 grid, 13 x 13 smear kernel, 16 x 16 x 21 coarse
+              lattice) in a cluttered 24 m world;
+    `dense`   the headline's configuration in a world of 140 obstacles per 60 m x 60 m (median range 3 m instead of 24 m):
+              what the exact zero-row pruning is worth when the grid is NOT mostly empty."""
+    import math
+
+    from lslam_amd import synth
+
+    out = {}
+    laser_in = synth.Laser(range_max=30.0)
+    world_in = synth.arena(size=24.0, n_axis=8, n_rot=3, seed=12)
+    wl = synth.make_match_workload(n_base=40, n_query=1, seed=12, laser=laser_in, world=world_in, err_xy=0.08,
+                                   err_th=math.radians(6.0), query_spread=0.5)
+    truth = query_poses(world_in, wl.center_pose, n_scans, 1.5, seed=121)
+    out["indoor"] = {"wl": wl, "q_r32": cast_scans(world_in, laser_in, truth, 0, 123, procs),
+                     "q_p": synth.perturb(truth, 0.08, math.radians(6.0), 122), "cfg": dict(INDOOR),
+                     "what": "lesson6/config/mapper_params.yaml: res 0.01, search 0.3, range 12, smear 0.03, response expansion on "
+                             "(2445x2445 grid, 13x13 smear, coarse 16x16x21 + fine 3x3x11), %d distinct scans in a cluttered 24 m "
+                             "world, 40-scan window" % n_scans}
+    world_d = synth.arena(size=60.0, n_axis=100, n_rot=40, seed=21)
+    wld = synth.make_match_workload(n_base=70, n_query=1, seed=21, query_spread=3.0, world=world_d)
+    truth = query_poses(world_d, wld.center_pose, n_scans, 3.0, seed=211)
+    out["dense"] = {"wl": wld, "q_r32": cast_scans(world_d, synth.Laser(), truth, 0, 213, procs),
+                    "q_p": synth.perturb(truth, 0.3, np.deg2rad(10.0), 212), "cfg": {},
+                    "what": "the headline's configuration (BASELINE configs[3]) in a DENSE world: 140 obstacles on 60 m x 60 m "
+                            "(median range ~3 m; the headline's arena: 32 on 80 m x 80 m, ~24 m), %d distinct scans, 70-scan window"
+                            % n_scans}
+    return out
+
+
+def _cpu_batch_share(job):
+    """One host core: the reference's CorrelateScan (+ MatchScan's response expansion) on every `cores`-th scan of a batch leg."""
+    GO_MULTI.wait()
+    from oracle import pyoracle as po
+
+    name, i, cores = job
+    d = _JOB[name]
+    wl, cfg = d["wl"], dict(d["cfg"])
+    thr = cfg.pop("range_threshold", 49.5)
+    from lslam_amd import synth
+
+    ref = po.RefKarto(po.default_cfg(**cfg), po.laser_struct(wl.laser, thr))
+    ref.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    idx = np.arange(i, len(d["q_p"]), cores)
+    sec, poses, _, resp = ref.match_fixed_grid(synth.ranges_to_f64(d["q_r32"][idx]), d["q_p"][idx])
+    return {"idx": idx, "busy_s": sec * len(idx), "poses": poses, "resp": resp}
+
+
+def gpu_batch_leg(ctx, api, d, steps=60):
+    """A batch leg on the GPU: plain steps of all the job's scans against its grid (float32 ranges, poses and records resident
+    in HBM), the exact pruning's statistics, the step with pruning off, the records of one step."""
+    import torch
+
+    wl, cfg = d["wl"], dict(d["cfg"])
+    thr = cfg.pop("range_threshold", 49.5)
+    gm = api.ScanMatcher(ctx, api.baseline_config(range_threshold=thr, **cfg), api.laser_params(wl.laser, thr))
+    gi = gm.grid_info()
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    dev = torch.device("cuda", ctx.device)
+    r = torch.from_numpy(np.ascontiguousarray(d["q_r32"])).to(dev)
+    p = torch.from_numpy(np.ascontiguousarray(d["q_p"])).to(dev)
+    n = r.shape[0]
+    out = torch.empty((n, 112), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        gm.match_batch_dev(n, r.data_ptr(), r.shape[1], p.data_ptr(), out.data_ptr(), dtype="f32")
+
+    def timed(k):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        ctx.synchronize()
+        return (time.perf_counter() - t0) / k
+
+    step(); step()
+    t = timed(steps)
+    rec = out.cpu().numpy().view(api.RESULT_DTYPE).reshape(-1).copy()
+    ctx.profile(True); ctx.profile_only(None); ctx.profile_reset()
+    step()
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    gm.set_option("collect_stats", 1)
+    step(); ctx.synchronize()
+    st = gm.read_stats()
+    gm.set_option("collect_stats", 0)
+    gm.set_option("row_occupancy", 0)
+    step()
+    t_off = timed(max(4, steps // 4))
+    rec_off = out.cpu().numpy().view(api.RESULT_DTYPE).reshape(-1).copy()
+    gm.set_option("row_occupancy", 1)
+    gm.close()
+    return {"n": n, "grid": [gi["width"], gi["height"]], "kernel_size": gi["kernel_size"], "s_per_step": t, "s_per_step_pruning_off": t_off,
+            "records": rec, "pruning_off_identical": bool(rec.tobytes() == rec_off.tobytes()),
+            "pruned_row_fraction": round(1.0 - st["rows_live"] / max(st["rows_in_range"], 1), 5),
+            "beam_angles_with_no_live_row": round(1.0 - st["beam_angles_queued"] / max(st["beam_angles"], 1), 5),
+            "kernel_ms": {k: round(v[1], 4) for k, v in sorted(prof.items())}}
+
+
 def gpu_cfg2(ctx, api, d):
     """config 2 on the GPU: one scan per call (points resident in HBM, asynchronous updates) and the batched entry."""
     n, cell, off = d["n"], d["cell"], d["off"]
@@ -827,6 +936,47 @@ def build_secondary(gpu, cpu, job, args):
                 roof["dropin_%s_scans_per_s" % key] = round(h["gpu_scans_per_s"], 1)
                 cpus["dropin_%s_reference_scans_per_s" % key] = round(h["cpu_reference_scans_per_s"], 1)
         out["dropin"] = o
+    # ---- the two extra batched-match legs: every record against the reference's CorrelateScan (all host cores) --------
+    for leg, key in (("indoor", "cfg_indoor_default"), ("dense", "headline_dense_world")):
+        g, c = gpu.get(leg), cpu.get(leg)
+        if g is None:
+            continue
+        if "error" in g or not isinstance(c, list):
+            out[key] = g if "error" in g else {"error": "no CPU leg", "gpu_scans_per_s": round(g["n"] / g["s_per_step"], 1)}
+            continue
+        n = g["n"]
+        rec = g["records"]
+        pose_err, resp_err, checked = 0.0, 0.0, 0
+        for part in c:
+            gi = rec[part["idx"]]
+            ok = gi["status"] == 0
+            d = np.abs(gi["pose"][ok] - part["poses"][ok])
+            d[:, 2] = np.abs(np.remainder(d[:, 2] + np.pi, 2 * np.pi) - np.pi)
+            pose_err = max(pose_err, float(d.max()) if d.size else 0.0)
+            resp_err = max(resp_err, float(np.abs(gi["response"][ok] - part["resp"][ok]).max()) if ok.any() else 0.0)
+            checked += int(ok.sum())
+        busy = [p["busy_s"] for p in c]
+        per_core = [len(p["idx"]) / p["busy_s"] for p in c if p["busy_s"] > 0]
+        out[key] = {
+            "config": job[leg]["what"], "scans_per_step": n, "grid": g["grid"], "smear_kernel": g["kernel_size"],
+            "ms_per_step": round(1e3 * g["s_per_step"], 4), "scans_per_s": round(n / g["s_per_step"], 1),
+            "ms_per_step_pruning_off": round(1e3 * g["s_per_step_pruning_off"], 4),
+            "scans_per_s_pruning_off": round(n / g["s_per_step_pruning_off"], 1),
+            "pruned_row_fraction": g["pruned_row_fraction"], "beam_angles_with_no_live_row": g["beam_angles_with_no_live_row"],
+            "results_identical_pruning_off": g["pruning_off_identical"], "kernel_ms_one_instrumented_step": g["kernel_ms"],
+            "records_ok": int((rec["status"] == 0).sum()), "zero_response_records": int((rec["response"] == 0.0).sum()),
+            "records_checked_vs_reference": checked, "max_pose_err_vs_reference": pose_err, "max_response_err_vs_reference": resp_err,
+            "cpu": {"kind": "reference", "scans_per_s_per_core": round(float(np.median(per_core)), 2), "cores": len(c),
+                    "scans_per_s_all_cores": round(n / max(busy), 1),
+                    "note": "oracle/_ref: the reference's CorrelateScan (coarse, MatchScan's response expansion, fine) vs the same "
+                            "grid, every %d-th scan per host process" % len(c)},
+        }
+        short = "indoor_default" if leg == "indoor" else "dense_world"
+        roof[short + "_scans_per_s"] = out[key]["scans_per_s"]
+        roof[short + "_pruned_row_fraction"] = out[key]["pruned_row_fraction"]
+        roof[short + "_scans_per_s_pruning_off"] = out[key]["scans_per_s_pruning_off"]
+        roof[short + "_max_pose_err"] = pose_err
+        cpus[short + "_reference_scans_per_s_per_core"] = out[key]["cpu"]["scans_per_s_per_core"]
     out["roofline_summary"], out["cpu_summary"] = roof, cpus
     return out
 
@@ -872,9 +1022,14 @@ def main():
     ap.add_argument("--no-full-cfg5", action="store_true", help="skip config 5 at its stated size (10 000 scans, ~2 s of GPU time)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in legs (reference orchestrators on the HIP path)")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8(f) rows")
-    ap.add_argument("--pipeline-depth", type=int, default=2,
-                    help="LSLAM_OPT_PIPELINE_DEPTH of the timed region (1 = plain steps, one after the other; 2..4 = that many "
-                         "steps in flight on the matcher's internal streams).  The roofline leg is always the plain step.")
+    ap.add_argument("--no-batch-legs", action="store_true",
+                    help="skip the two extra batched-match legs (the reference's shipped indoor configuration; the dense world)")
+    ap.add_argument("--pipeline-depth", type=int, default=1,
+                    help="LSLAM_OPT_PIPELINE_DEPTH of the contract's timed region (default 1: one step after the other, the "
+                         "library's default and what a caller that consumes each step's poses gets).")
+    ap.add_argument("--pipelined-leg-depth", type=int, default=2,
+                    help="depth of the separate, labelled `pipelined_leg` (independent steps overlapping on the matcher's internal "
+                         "streams: the product's option for callers whose steps do not depend on each other); 0 = skip")
     ap.add_argument("--plain-steps", type=int, default=0, help="steps of the plain (depth-1) roofline leg (0 = min(--steps, 300))")
     args = ap.parse_args()
     backend = os.environ.get("LSLAM_BENCH_BACKEND", "nccl")  # gloo: the N>1 control flow on a 1-GPU box (tests)
@@ -882,6 +1037,7 @@ def main():
     # too -- how the 1-GPU test box executes the RCCL branch before an 8-GPU node does
     force_dist = os.environ.get("LSLAM_BENCH_FORCE_DIST", "0") not in ("", "0")
     depth = max(1, min(4, args.pipeline_depth))
+    leg_depth = max(0, min(4, args.pipelined_leg_depth))
     # LSLAM_BENCH_SHARE_GPU=1 (tests only): ranks beyond the visible GPUs wrap around -- with nccl this asks RCCL for a
     # communicator with two ranks on one device, which it may refuse
     share_gpu = os.environ.get("LSLAM_BENCH_SHARE_GPU", "0") not in ("", "0")
@@ -939,8 +1095,8 @@ def main():
 
     # ---- CPU legs: fork the workers now (no HIP / CUDA state in this process yet); they start when GO is set ------
     global GO, GO_MULTI
-    do_cpu = (not args.no_cpu) and world_size == 1
-    do_secondary = do_cpu and not args.no_secondary
+    do_cpu = (not args.no_cpu) and rank == 0  # N > 1: rank 0 times the 1-core leg too (released after the timed region)
+    do_secondary = do_cpu and not args.no_secondary and world_size == 1
     pool, tasks = None, {}
     cores = args.cpu_cores or min(os.cpu_count() or 1, 64)
     if do_cpu:
@@ -948,15 +1104,18 @@ def main():
 
         from oracle import pyoracle as po
 
-        sample = max(8, min(args.cpu_sample, n_mine))
+        sample = max(8, min(args.cpu_sample if world_size == 1 else min(args.cpu_sample, 2048), n_mine))
         _JOB.update({"wl": wl, "q_r": synth.ranges_to_f64(my_ranges[:sample]), "q_p": my_odom[:sample]})
         if do_secondary:
             t_sec = time.perf_counter()
             _JOB.update(secondary_workloads(args.map_scans, args.single, args.stream_scans, procs))
+            if not args.no_batch_legs:
+                _JOB.update(batch_leg_workloads(min(args.batch, 4096), procs))
             t_gen_secondary = time.perf_counter() - t_sec
         fork = mp.get_context("fork")
         GO, GO_MULTI = fork.Event(), fork.Event()
-        n_workers = 1 + (cores if po.have_ref() else 0) + (3 if do_secondary else 0)
+        multi = po.have_ref() and world_size == 1  # the all-core leg would compete with the other ranks' host threads
+        n_workers = 1 + (cores if multi else 0) + (3 if do_secondary else 0)
         pool = fork.Pool(n_workers, initializer=_quiet_worker)
         if do_secondary:  # longest first
             tasks["cfg5"] = pool.apply_async(_cpu_cfg5, (0,))
@@ -964,8 +1123,11 @@ def main():
         if do_secondary:
             tasks["cfg3"] = pool.apply_async(_cpu_cfg3, (0,))
             tasks["cfg2"] = pool.apply_async(_cpu_cfg2, (0,))
-        if po.have_ref():
+        if multi:
             tasks["cfg4_multi"] = [pool.apply_async(_cpu_cfg4_share, (i,)) for i in range(cores)]
+            for leg in ("indoor", "dense"):  # behind the cfg-4 shares on the same worker processes
+                if leg in _JOB:
+                    tasks[leg] = [pool.apply_async(_cpu_batch_share, ((leg, i, cores),)) for i in range(cores)]
 
     import torch
 
@@ -1002,7 +1164,7 @@ def main():
     ranges32 = torch.from_numpy(np.ascontiguousarray(my_ranges)).to(dev)
     poses = torch.from_numpy(my_odom).to(dev)
     # one record buffer per step in flight: pipelined steps must not share an output buffer (lslam_gpu.h)
-    results_ring = [torch.zeros((max(n_mine, 1), 112), dtype=torch.uint8, device=dev) for _ in range(depth)]
+    results_ring = [torch.zeros((max(n_mine, 1), 112), dtype=torch.uint8, device=dev) for _ in range(max(depth, leg_depth, 1))]
     results = results_ring[0]
     torch.cuda.synchronize()
     step_no, cur_depth = [0], [1]
@@ -1062,10 +1224,25 @@ def main():
     ctx.profile(True)
     ctx.profile_only(dom_name)
     ctx.profile_reset()
+    clk0 = ctx.clock_sample()
     elapsed_plain = timed(n_plain)
+    clk1 = ctx.clock_sample()
+    clock_ghz = ctx.clock_ghz(clk0, clk1)  # the shader clock the leg ran at (s_memtime / s_memrealtime), not an assumed 2.4 GHz
     ctx.profile(False)
     prof = ctx.profile_read()  # the dominant kernel, timed live over the plain leg
     ctx.profile_only(None)
+    # ---- the pipelined leg (labelled, never `value` unless --pipeline-depth asks for it): the same step with
+    # `leg_depth` steps in flight on the matcher's internal streams
+    pipelined_leg = None
+    if leg_depth > 1 and n_mine:
+        set_depth(leg_depth)
+        for _ in range(max(args.warmup, leg_depth)):
+            step()
+        el_leg = timed(args.steps)
+        pipelined_leg = {"depth": leg_depth, "steps": args.steps, "ms_per_step": round(1e3 * el_leg / args.steps, 4),
+                         "value": round(n_total * args.steps / el_leg, 1), "unit": "scan-matches/s",
+                         "note": "INDEPENDENT steps overlapping (LSLAM_OPT_PIPELINE_DEPTH): every step matches the same inputs into "
+                                 "its own record buffer; a caller whose step t + 1 needs the poses of step t cannot use it"}
     set_depth(depth)
     per_rank_ms = None
     if distributed:  # every rank's own time per step: a measured scaling curve can be diagnosed (stragglers, small-batch floor)
@@ -1198,7 +1375,7 @@ def main():
         try:
             pipelined = {"note": "one ScanMatcher, LSLAM_OPT_PIPELINE_DEPTH = d: d steps in flight on the matcher's internal "
                                  "streams, own per-step workspaces, shared grid; ms = wall time / steps; depth 1 = plain",
-                         "timed_region_depth": depth}
+                         "timed_region_depth": depth, "predicted_efficiency_depth": (leg_depth if leg_depth > 1 else depth)}
             sizes = sorted({max(64, n_mine // 8), max(64, n_mine // 4), max(64, n_mine // 2), n_mine})
             ring4 = [torch.zeros((n_mine, 112), dtype=torch.uint8, device=dev) for _ in range(4)]
             torch.cuda.synchronize()  # torch's fill kernels run on torch's stream: done before the library's streams write
@@ -1223,7 +1400,7 @@ def main():
                 table["batch_%d" % nb] = row
             pipelined["ms_per_step"] = table
             pipelined["results_identical"] = same_all
-            key = "depth_%d_ms" % depth
+            key = "depth_%d_ms" % (leg_depth if leg_depth > 1 else depth)  # the pipelined prediction; `_plain` below is depth 1
             t_full = table["batch_%d" % n_mine][key]
             pipelined["predicted_strong_scaling_efficiency"] = {
                 str(n): round(t_full / (n * table["batch_%d" % max(64, n_mine // n)][key]), 4) for n in (2, 4, 8)
@@ -1255,6 +1432,12 @@ def main():
                 sec_gpu[name] = fn(ctx, api, _JOB[name])
             except Exception as e:  # a failed leg is reported, it does not take the headline down
                 sec_gpu[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        for leg in ("indoor", "dense"):
+            if leg in _JOB:
+                try:
+                    sec_gpu[leg] = gpu_batch_leg(ctx, api, _JOB[leg])
+                except Exception as e:
+                    sec_gpu[leg] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if not args.no_next_rows:
             sec_gpu["next_rows"] = gpu_next_rows(ctx, api)
         if not args.no_dropin:
@@ -1288,39 +1471,93 @@ def main():
         # PMC pass counts the wave64 VALU instructions of one launch; the chip issues at most SIMDs*clk/2 per second.
         insts = rec.get("valu_insts_per_launch")
         scans_ref = rec.get("scans_per_launch")
-        if insts and scans_ref:
-            insts_here = insts * n_mine / scans_ref  # same kernel, same per-scan work: scale to this launch's scans
+        scale = (n_mine / scans_ref) if scans_ref else None  # same kernel, same per-scan work: PMC figures scale with the scans
+        ceil, mix = {}, {}
+        try:
+            ceil = json.loads((ROOT / "profiles" / "ceilings.json").read_text())
+            mix = json.loads((ROOT / "profiles" / "valu_mix.json").read_text()).get(dom_name, {})
+        except Exception:
+            pass
+        # the launch in CLOCKS, live: its HIP-event time x the shader clock the plain leg ran at (lslam_clock_sample around
+        # the leg: s_memtime / s_memrealtime) -- no 2.4 GHz assumed anywhere below except in `peak` / `frac`, which keep the
+        # guide's convention (2 cycles per wave64 VALU instruction at the peak clock) so that rounds stay comparable
+        cycles_live = avg_ms * 1e-3 * clock_ghz * 1e9 if clock_ghz else None
+        hbm_frac = round(hbm_alg / HBM_PEAK_GBS, 5)
+        meas_hbm = (round(rec["hbm_bytes_per_launch"] * scale / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                    if rec.get("hbm_bytes_per_launch") and scale else None)
+        worst = round(n_total / (pruning["ms_per_step_pruning_off"] * 1e-3), 1) if pruning else None
+        if insts and scale:
+            insts_here = insts * scale
             achieved = insts_here / (avg_ms * 1e-3)
             waves_here = n_mine * na_c  # one wave64 per (scan, coarse angle) from 98 scans up (no beam slices)
+            valu_mix_frac = l1_rate = l1_frac = gather_model = None
+            if cycles_live and mix.get("floor_cycles_per_simd_w8") and mix.get("scans_per_launch"):
+                valu_mix_frac = round(mix["floor_cycles_per_simd_w8"] * n_mine / mix["scans_per_launch"] / cycles_live, 4)
+            if cycles_live and rec.get("l1_line_lookups_per_launch"):
+                look = rec["l1_line_lookups_per_launch"] * scale
+                l1_rate = look / N_CU / cycles_live
+                if ceil.get("l1_hit_lookups_per_cu_clk_max"):
+                    l1_frac = round(l1_rate / ceil["l1_hit_lookups_per_cu_clk_max"], 4)
+                if rec.get("l2_read_requests_per_launch") and ceil.get("l1_hit_lookups_per_cu_clk_max") and ceil.get("l1_miss_lines_per_cu_clk"):
+                    miss = rec["l2_read_requests_per_launch"] * scale
+                    gather_model = round(((look - miss) / ceil["l1_hit_lookups_per_cu_clk_max"] + miss / ceil["l1_miss_lines_per_cu_clk"])
+                                         / N_CU / cycles_live, 4)
+            # the contract's keys first, scalars before anything nested (the driver's record keeps the head of the object)
             roofline = {
-                "bound": "valu_issue", "kernel": dom_name, "achieved": round(achieved / 1e12, 4),
-                "peak": round(VALU_ISSUE_PEAK / 1e12, 4), "unit": "T wave64-VALU-instructions/s",
+                "bound": "valu_issue", "kernel": dom_name,
                 "frac": round(achieved / VALU_ISSUE_PEAK, 4),
-                "peak_definition": "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction",
-                "valu_insts_per_launch": int(insts_here),
+                "achieved": round(achieved / 1e12, 4), "peak": round(VALU_ISSUE_PEAK / 1e12, 4), "unit": "T wave64-VALU-instructions/s",
+                "traffic": rec.get("hbm_bytes_per_launch"),
+                "hbm_algorithmic_frac": hbm_frac, "measured_hbm_frac": meas_hbm,
+                "avg_launch_ms": round(avg_ms, 4),
                 "valu_insts_per_wave": round(insts_here / max(waves_here, 1), 1),
-                "valu_insts_source": rec.get("source", "profiles/traffic.json") + " (rocprofv3 --pmc SQ_INSTS_VALU pass of "
-                                     "this command; a static property of kernel + workload, not re-measured in this run)",
-                "valu_busy_pmc": rec.get("valu_busy"), "instruction_mix": rec.get("instruction_mix"),
-                # the other two units this kernel leans on (PMC, static like the instruction count): the texture-address
-                # (gather) unit, and the L1 -> L2 read requests priced against the L2's bandwidth
-                "gather_unit_busy": rec.get("gather_unit_busy"), "l2_hit": rec.get("l2_hit"),
-                "l2_read_frac": (round(rec["l2_read_requests_per_launch"] * 128.0 * n_mine / scans_ref / (avg_ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4)
+                "valu_mix_frac": valu_mix_frac,
+                "l1_lookup_frac": l1_frac,
+                "worst_case_value": worst,
+                "pmc_inputs_stale": None,  # filled in below
+                "gather_pipe_model_frac": gather_model,
+                "gather_unit_busy": rec.get("gather_unit_busy"),
+                "l1_lookups_per_cu_clk": round(l1_rate, 4) if l1_rate else None,
+                "l1_miss_ratio": rec.get("l1_miss_ratio"),
+                "shader_clock_ghz": round(clock_ghz, 4) if clock_ghz else None,
+                "launch_cycles": round(cycles_live, 0) if cycles_live else None,
+                "valu_mix_frac_w4": (round(mix["floor_cycles_per_simd_w4"] * n_mine / mix["scans_per_launch"] / cycles_live, 4)
+                                     if cycles_live and mix.get("floor_cycles_per_simd_w4") else None),
+                "avg_issue_cycles_per_valu_inst": mix.get("avg_cycles_per_valu_inst_w8"),
+                "l2_hit": rec.get("l2_hit"),
+                "l2_read_frac": (round(rec["l2_read_requests_per_launch"] * 128.0 * scale / (avg_ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4)
                                  if rec.get("l2_read_requests_per_launch") else None),
-                "l2_read_frac_definition": "TCP_TCC_READ_REQ x 128 B / launch time / 34.5 TB/s",
-                # the gather rate itself: L1 tag lookups (one per distinct 128-B line an instruction touches) against one
-                # lookup per CU per clock -- the unit `gather_unit_busy` says is the busiest besides the VALUs
-                "l1_lookup_frac": (round(rec["l1_line_lookups_per_launch"] * n_mine / scans_ref / (avg_ms * 1e-3) / (256 * 2.4e9), 4)
-                                   if rec.get("l1_line_lookups_per_launch") else None),
-                "l1_lookup_frac_definition": "TCP_TOTAL_CACHE_ACCESSES / launch time / (256 CUs x 2.4 GHz)",
                 "l1_line_lookups_per_vmem_read": rec.get("l1_line_lookups_per_vmem_read"),
-                # world sparsity: the exact zero-row pruning makes the headline depend on how empty the grid is; with pruning
-                # off every in-range row is gathered -- the worst case over worlds, measured in this run (`pruning`)
-                "worst_case_value": (round(n_total / (pruning["ms_per_step_pruning_off"] * 1e-3), 1) if pruning else None),
+                "valu_insts_per_launch": int(insts_here),
+                "definitions": {
+                    "frac": "wave64 VALU instructions per second of the launch (PMC SQ_INSTS_VALU / live HIP-event time) / (256 CUs x 4 "
+                            "SIMDs x 2.4 GHz / 2 cycles): the guide's convention, kept so that rounds compare; it UNDERSTATES how busy the "
+                            "issue ports are because only v_fma/mul/add_f32, v_add/sub_u32, v_and/or/xor, v_mov, v_lshrrev issue in ~2 cycles "
+                            "-- every VOP3-only opcode (v_perm_b32 ...), DPP / SDWA form, conversion, compare, and ANY instruction with an "
+                            "SGPR source takes 4.1 (tools/micro/valu_rate.hip, cycle counters: profiles/r06/micro_valu_rate.txt)",
+                    "valu_mix_frac": "the cycles the SIMDs' issue ports NEED for this kernel's instruction mix at their best measured "
+                                     "rates (8 waves per SIMD; _w4: at the kernel's own 4) / the launch's cycles (live time x live shader "
+                                     "clock) -- tools/valu_mix_floor.py, profiles/valu_mix.json; <= 1 by construction",
+                    "l1_lookup_frac": "TCP_TOTAL_CACHE_ACCESSES per CU per clock / the highest rate any tools/micro/ta_rate.hip pattern "
+                                      "reaches (profiles/ceilings.json: %s, L1 hits spread over the tag banks)" % ceil.get("l1_hit_lookups_per_cu_clk_max"),
+                    "gather_pipe_model_frac": "(L1 hits / %s per clock + L1 misses / %s per clock) / launch cycles per CU: what the CU's "
+                                              "address + L1 pipe needs for this kernel's lookups at the measured hit and miss rates; agrees with "
+                                              "gather_unit_busy (TA_TA_BUSY per CU per clock of the PMC pass; the saturating micro patterns read "
+                                              "%s)" % (ceil.get("l1_hit_lookups_per_cu_clk_max"), ceil.get("l1_miss_lines_per_cu_clk"), ceil.get("ta_busy_max")),
+                    "traffic": "HBM bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE of the PMC passes (gfx950 correction of the guide)",
+                    "hbm_algorithmic_frac": "SURVEY 8(d) algorithmic bytes / launch time / 8 TB/s: > 1, not a bound for a gather from an "
+                                            "L2-resident 4 MB grid with exact zero-row pruning",
+                    "worst_case_value": "scan-matches/s with the exact zero-row pruning switched off (every in-range row gathered): the "
+                                        "floor over world sparsity, measured in this run",
+                },
+                "valu_insts_source": rec.get("source", "profiles/traffic.json") + " (rocprofv3 --pmc passes of this command; static "
+                                     "properties of kernel + workload, scaled to this launch's scans, not re-measured in this run)",
+                "instruction_mix": rec.get("instruction_mix"),
             }
         else:
-            roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(hbm_alg, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(hbm_alg / HBM_PEAK_GBS, 5)}
+            roofline = {"bound": "hbm", "kernel": dom_name, "frac": hbm_frac, "achieved": round(hbm_alg, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "traffic": rec.get("hbm_bytes_per_launch"), "hbm_algorithmic_frac": hbm_frac,
+                        "measured_hbm_frac": meas_hbm, "avg_launch_ms": round(avg_ms, 4), "worst_case_value": worst}
         # the PMC inputs are static files: tools/make_traffic.py records the hash of the kernel source they were
         # collected from; a different source today means `frac` / `traffic` describe an older kernel
         meta = {}
@@ -1333,34 +1570,25 @@ def main():
         hashed = meta.get("source_sha256", {})
         need = ("scan_matcher.hip", "common.hpp", "karto_math.hpp", "scan_cache_impl.hpp", "frontend_impl.hpp")
         stale = [f for f in need if hashed.get(f) != _source_sha(csrc / f)]
+        roofline["pmc_inputs_stale"] = bool(stale)
         roofline.update({
-            "pmc_inputs_stale": bool(stale), "pmc_inputs_stale_files": stale,
+            "pmc_inputs_stale_files": stale,
             "pmc_inputs_source_sha256": {f: hashed.get(f) for f in need},
-            "avg_launch_ms": round(avg_ms, 4),
             "leg": "plain steps (LSLAM_OPT_PIPELINE_DEPTH 1: one kernel after the other on one stream), %d of them timed like the "
-                   "contract's region right after it, HIP events around this kernel only; `value` / `ms_per_step` at the top of the "
-                   "line are the pipelined steps (depth %d), in which kernels of neighbouring steps overlap and a per-kernel "
-                   "duration means nothing" % (n_plain, depth),
+                   "contract's region right after it, HIP events around this kernel only" % n_plain,
             "plain_ms_per_step": round(1e3 * elapsed_plain / n_plain, 4),
             "plain_value": round(n_total * n_plain / elapsed_plain, 1),
-            # SURVEY 8(d)'s two HBM figures as scalars (the driver's record keeps scalars only): algorithmic bytes / launch
-            # time / 8 TB/s (> 1: not a bound for an L2-resident gather), and the PMC-measured HBM traffic / launch time / 8 TB/s
-            "hbm_algorithmic_frac": round(hbm_alg / HBM_PEAK_GBS, 5),
-            "measured_hbm_frac": round(rec["hbm_bytes_per_launch"] * n_mine / rec["scans_per_launch"] / (avg_ms * 1e-3) / 1e9
-                                       / HBM_PEAK_GBS, 5) if rec.get("hbm_bytes_per_launch") and scans_ref else None,
-            "traffic": rec.get("hbm_bytes_per_launch"),
             "traffic_source": (rec.get("source", "profiles/traffic.json") + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                "this command (tools/pmc_passes.sh), per launch of %s scans; NOT measured in this run"
                                % rec.get("scans_per_launch")) if rec.get("hbm_bytes_per_launch") else None,
-            # SURVEY §8(d)'s convention, kept for the record: algorithmic bytes / time against the HBM peak.  It is
+            # SURVEY 8(d)'s convention, kept for the record: algorithmic bytes / time against the HBM peak.  It is
             # NOT a bound for this kernel (see above); the measured HBM traffic is ~1 % of the algorithmic bytes.
             "hbm_algorithmic": {
-                "achieved": round(hbm_alg, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_alg / HBM_PEAK_GBS, 5),
+                "achieved": round(hbm_alg, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
                 "algorithmic_bytes_per_launch": per_launch_bytes,
                 "whole_match_GBs": round(value / world_size * match_bytes / 1e9, 2),
                 "whole_match_frac": round(value / world_size * match_bytes / 1e9 / HBM_PEAK_GBS, 5),
-                "measured_hbm_frac": round(rec["hbm_bytes_per_launch"] * n_mine / rec["scans_per_launch"] / (avg_ms * 1e-3) / 1e9
-                                           / HBM_PEAK_GBS, 5) if rec.get("hbm_bytes_per_launch") and scans_ref else None,
+                "measured_hbm_frac": meas_hbm,
             },
         })
 
@@ -1391,7 +1619,14 @@ def main():
             except Exception as e:  # pragma: no cover
                 cpu_baseline["multicore"] = {"error": str(e)[:120]}
     if do_secondary:
-        secondary = build_secondary(sec_gpu, {k: tasks[k].get() for k in ("cfg2", "cfg3", "cfg5")}, _JOB, args)
+        cpu_legs = {k: tasks[k].get() for k in ("cfg2", "cfg3", "cfg5")}
+        for leg in ("indoor", "dense"):
+            if leg in tasks:
+                try:
+                    cpu_legs[leg] = [t.get() for t in tasks[leg]]
+                except Exception as e:  # pragma: no cover
+                    cpu_legs[leg] = {"error": str(e)[:200]}
+        secondary = build_secondary(sec_gpu, cpu_legs, _JOB, args)
         secondary["workload_gen_s"] = round(t_gen_secondary, 2)
         # compact copies where the driver's record keeps nested objects
         if roofline is not None:
@@ -1435,13 +1670,18 @@ def main():
         "pruning": pruning,
         "pipelined": pipelined,
         "lds_staged_experiment": lds_experiment,
-        "value_leg": "the %d timed steps of the contract (barrier + synchronize on both sides), pipelined steps of depth %d "
-                     "(lslam_matcher_set_option LSLAM_OPT_PIPELINE_DEPTH: the product's option, byte-identical records); `plain` "
-                     "is the same step at depth 1 (the roofline leg), `sustained` the pipelined step for >= 10 s" % (args.steps, depth),
+        "value_leg": ("the %d timed steps of the contract (barrier + synchronize on both sides) at LSLAM_OPT_PIPELINE_DEPTH %d%s; "
+                      "`pipelined_leg` is the same step with independent steps overlapping on the matcher's internal streams (a "
+                      "labelled option, not `value`), `sustained` the timed region's step for >= 10 s"
+                      % (args.steps, depth, " = the library's default: one step after the other" if depth == 1 else "")),
         "pipeline_depth": depth,
         "pipelined_records_identical": ring_identical,
+        "pipelined_leg": pipelined_leg,
+        "pipelined_value": pipelined_leg["value"] if pipelined_leg else None,
+        "pipelined_ms_per_step": pipelined_leg["ms_per_step"] if pipelined_leg else None,
         "plain": {"steps": n_plain, "ms_per_step": round(1e3 * elapsed_plain / n_plain, 4),
-                  "value": round(n_total * n_plain / elapsed_plain, 1), "unit": "scan-matches/s"},
+                  "value": round(n_total * n_plain / elapsed_plain, 1), "unit": "scan-matches/s",
+                  "note": "the roofline leg: plain steps again, HIP events around the dominant kernel only"},
         "backend": (backend if distributed else None),
         "rccl_ranks": rccl_ranks,
         "devices": device_names,

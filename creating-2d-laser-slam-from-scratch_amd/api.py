@@ -322,6 +322,8 @@ def lib() -> C.CDLL:
     L.lslam_pool_set_base_scans.argtypes = [vp, i32, vp, i32, vp, vp, i32]
     L.lslam_pool_match_batch.argtypes = [vp, i32, vp, i32, vp, i32, i32, vp]
     L.lslam_deskew_scan.argtypes = [vp, vp, i32, C.POINTER(DeskewParams), vp, vp, vp, vp, i32, vp, vp]
+    L.lslam_clock_sample.argtypes = [vp, vp]
+    L.lslam_matcher_get_option.argtypes = [vp, i32]
     L.lslam_matcher_set_option.argtypes = [vp, i32, i32]
     L.lslam_matcher_flush.argtypes = [vp]
     L.lslam_matcher_pipelined_steps.argtypes = [vp]
@@ -388,6 +390,25 @@ class Context:
 
     def synchronize(self):
         self.check(self.L.lslam_synchronize(self.h))
+
+    def clock_sample(self) -> np.ndarray:
+        """[256][3] uint64: {CU id + 1, shader-clock ticks, 100 MHz ticks} from 256 single-wave blocks (lslam_clock_sample)."""
+        out = np.zeros(768, dtype=np.uint64)
+        self.check(self.L.lslam_clock_sample(self.h, out.ctypes.data))
+        return out.reshape(256, 3)
+
+    @staticmethod
+    def clock_ghz(before: np.ndarray, after: np.ndarray):
+        """Average shader clock [GHz] between two clock_sample() results: per CU that reported in both, (t1 - t0) / ((r1 - r0) /
+        100 MHz); the median over those CUs (None when no CU is in both samples)."""
+        b = {int(k): (int(t), int(r)) for k, t, r in before if k}
+        ratios = []
+        for k, t, r in after:
+            if int(k) in b:
+                t0, r0 = b[int(k)]
+                if int(r) > r0 and int(t) > t0:
+                    ratios.append((int(t) - t0) / ((int(r) - r0) / 1e8))
+        return float(np.median(ratios)) / 1e9 if ratios else None
 
     @property
     def stream(self) -> int:
@@ -503,7 +524,7 @@ class ScanMatcher:
 
     def set_option(self, name: str, value: int):
         opt = {"row_occupancy": 1, "collect_stats": 2, "lds_staged": 3, "pipeline_depth": 4, "step_kernel": 5,
-               "step_min_scans": 6, "rows_waves": 7}[name]
+               "step_min_scans": 6, "rows_waves": 7, "check_output_reuse": 8}[name]
         self.ctx.check(self.L.lslam_matcher_set_option(self.h, opt, int(value)))
 
     @property

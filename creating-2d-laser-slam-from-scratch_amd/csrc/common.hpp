@@ -76,6 +76,9 @@ struct lslam_context {
   // work that objects of this context have deferred and that must be on the stream before a synchronise means
   // "everything is done" (the log-odds map's pipelined apply): (object, flush function)
   std::vector<std::pair<void*, int (*)(void*)>> pre_sync;
+  // checks that can only be made once the stream has drained (a counter kernels bump in pinned host memory): run by
+  // lslam_synchronize AFTER the wait; the first failure is the call's result
+  std::vector<std::pair<void*, int (*)(void*)>> post_sync;
 
   int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -182,6 +185,50 @@ inline bool spin_for_ticket(const int* word, int want, int budget_ms = 20) {
       return false;
   }
 }
+
+// ---- phase stamps (diagnostic builds only: -DLSLAM_PHASE_STAMPS, tools/phase_stamps.py) -------------------------------
+// Where INSIDE a kernel the time goes: a wave reads the shader-clock counter (s_memtime) at phase boundaries and adds the
+// deltas into a per-translation-unit table [kernel][phase] (cycles, visits).  The product build compiles all of it away.
+#if defined(LSLAM_PHASE_STAMPS)
+constexpr int kStampKernels = 8, kStampSlots = 16384;  // [kernel][wave slot][8 cycle sums | 8 visit counts]
+#define LSLAM_STAMP_TABLE(NAME) __device__ unsigned long long NAME##_slots[lslam::kStampKernels][lslam::kStampSlots][16];
+struct PhaseClock {  // deltas are summed in registers; ONE flush per wave at the end of the kernel writes them out
+  unsigned long long t;
+  unsigned long long acc[8];
+  unsigned int cnt[8];
+  __device__ __forceinline__ PhaseClock() {
+#pragma unroll
+    for (int i = 0; i < 8; i++) { acc[i] = 0ull; cnt[i] = 0u; }
+    t = __builtin_readcyclecounter();
+  }
+  __device__ __forceinline__ void mark(int i) {
+    const unsigned long long n = __builtin_readcyclecounter();
+    acc[i] += n - t;
+    cnt[i] += 1u;
+    t = n;
+  }
+  // `who`: the one lane that reports for its wave (or block); `slot`: any id that spreads the reporters (wave index) --
+  // every reporter adds into its own line of the table, so the flush itself does not queue up behind other waves' flushes
+  __device__ __forceinline__ void flush(unsigned long long (*tab)[kStampSlots][16], int k, unsigned slot, bool who) {
+    if (!who) return;
+    unsigned long long* row = tab[k][slot % (unsigned)kStampSlots];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      if (cnt[i]) {
+        atomicAdd(&row[i], acc[i]);
+        atomicAdd(&row[8 + i], (unsigned long long)cnt[i]);
+      }
+  }
+};
+#define LSLAM_PHASE_CLOCK(pc) lslam::PhaseClock pc
+#define LSLAM_PHASE_MARK(pc, i) pc.mark(i)
+#define LSLAM_PHASE_FLUSH(pc, NAME, k, slot, who) pc.flush(NAME##_slots, k, slot, who)
+#else
+#define LSLAM_STAMP_TABLE(NAME)
+#define LSLAM_PHASE_CLOCK(pc)
+#define LSLAM_PHASE_MARK(pc, i)
+#define LSLAM_PHASE_FLUSH(pc, NAME, k, slot, who)
+#endif
 
 // Launch with optional HIP-event timing on the context stream.
 template <typename K, typename... Args>

@@ -5,9 +5,44 @@ namespace lslam {
 thread_local std::string g_last_error;
 }
 
+namespace {
+// 256 single-wave blocks: each reports WHERE it ran (XCC_ID and HW_ID: shader engine, array, CU), the shader-clock counter
+// (s_memtime: one tick per shader cycle, MI355X_MICROARCH.md) and the constant 100 MHz counter (s_memrealtime).  Two samples
+// around a timed region give the clock the region actually ran at -- compared per CU, so that nothing depends on whether the
+// counters of different CUs / XCDs agree.  The bench line prices cycles with it instead of assuming the 2.4 GHz peak.
+constexpr int kClockBlocks = 256;
+__global__ void __launch_bounds__(64) k_clock_sample(unsigned long long* out) {
+  unsigned long long t, r;
+  uint32_t xcc, hw;
+  asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)\n s_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n s_getreg_b32 %3, hwreg(HW_REG_HW_ID)"
+               : "=s"(t), "=s"(r), "=s"(xcc), "=s"(hw));
+  if (threadIdx.x == 0) {
+    unsigned long long* o = out + 3 * (size_t)blockIdx.x;
+    o[0] = (((unsigned long long)(xcc & 0xFu)) << 16 | (hw & 0xFF00u)) + 1ull;  // se, sh, cu of this XCD (+1: 0 = no report)
+    o[1] = t;
+    o[2] = r;
+  }
+}
+}  // namespace
+
 extern "C" {
 
 int lslam_abi_version(void) { return LSLAM_ABI_VERSION; }
+
+int lslam_clock_sample(lslam_context* ctx, uint64_t out[768]) {
+  if (!ctx || !out) return LSLAM_ERR_INVALID_ARGUMENT;
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  unsigned long long* d = nullptr;
+  const size_t bytes = 3 * (size_t)kClockBlocks * sizeof(unsigned long long);
+  LSLAM_HIP(ctx, hipMalloc((void**)&d, bytes));
+  LSLAM_HIP(ctx, hipMemsetAsync(d, 0, bytes, ctx->stream));
+  hipLaunchKernelGGL(k_clock_sample, dim3(kClockBlocks), dim3(64), 0, ctx->stream, d);
+  hipError_t e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  LSLAM_HIP(ctx, e);
+  return LSLAM_OK;
+}
 
 int lslam_create(int device, lslam_context** out) {
   if (!out) return LSLAM_ERR_INVALID_ARGUMENT;
@@ -58,6 +93,10 @@ int lslam_synchronize(lslam_context* ctx) {
     if (rc) return rc;
   }
   LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& f : ctx->post_sync) {
+    int rc = f.second(f.first);
+    if (rc) return rc;
+  }
   return LSLAM_OK;
 }
 

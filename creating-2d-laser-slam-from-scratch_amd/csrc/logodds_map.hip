@@ -432,7 +432,11 @@ k_lo_batch_hits_lds(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* _
   }
 }
 
-constexpr int kRayBeamsPerWave = 4;  // consecutive beams one wave walks: fewer, longer waves (dispatch-rate bound otherwise)
+#if !defined(LSLAM_TUNE_RAY_BEAMS)
+#define LSLAM_TUNE_RAY_BEAMS 4
+#endif
+LSLAM_STAMP_TABLE(g_map_stamps)  // kernel 0 = k_lo_batch_rays: 0 header, 1 beam line, 2 cell addresses, 3 plane bytes back, 4 marks issued
+constexpr int kRayBeamsPerWave = LSLAM_TUNE_RAY_BEAMS;  // consecutive beams one wave walks: fewer, longer waves (dispatch-rate bound otherwise)
 __global__ void __launch_bounds__(256)
 k_lo_batch_rays(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __restrict__ pts, uint8_t* __restrict__ pool,
                 uint8_t* __restrict__ flags, const uint32_t* __restrict__ hkey, uint32_t* __restrict__ hcross, int groups_per_scan) {
@@ -440,11 +444,25 @@ k_lo_batch_rays(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __res
   const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave index = scan * groups_per_scan + beam group
   const int sidx = w / groups_per_scan, grp = w - sidx * groups_per_scan;
   if (sidx >= g.K) return;
+  LSLAM_PHASE_CLOCK(pck);
   const ScanHdr h = hdr[sidx];
   const uint32_t crossed = g.tag | kCodeCrossed, hit = g.tag | kCodeHit;
   const size_t hb = (size_t)sidx * (g.hash_mask + 1);
-  for (int i = grp * kRayBeamsPerWave; i < min(h.n, (grp + 1) * kRayBeamsPerWave); i++) {
-    const Line l = batch_line(g, h, pts, i);
+  LSLAM_PHASE_MARK(pck, 0);
+  // The wave's points in ONE load (lane j = beam j of the group), handed out by v_readlane: the per-beam point load was a
+  // round trip of its own in front of every beam's cells -- 1 850 of a beam's ~5 400 cycles (tools/phase_stamps.py rays,
+  // profiles/r06/phase_stamps_rays.json).  The line itself is evaluated per beam from the broadcast point, bit for bit as before.
+  const int i_first = grp * kRayBeamsPerWave, i_end = min(h.n, (grp + 1) * kRayBeamsPerWave);
+  float2 my_pt = make_float2(0.f, 0.f);
+  if (lane < kRayBeamsPerWave && i_first + lane < i_end) my_pt = ((const float2*)pts)[(size_t)h.pts_off + i_first + lane];
+  for (int i = i_first; i < i_end; i++) {
+    const float bpt[2] = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_pt.x), i - i_first)),
+                          __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_pt.y), i - i_first))};
+    LevelGeom lg;
+    lg.sx = g.sx; lg.sy = g.sy; lg.c = h.c; lg.s = h.s; lg.tx = h.tx; lg.ty = h.ty; lg.factor = g.factor;
+    lg.just_once = 0; lg.bx = h.bx; lg.by = h.by; lg.metres_per_cell = 0.0;
+    const Line l = beam_line(lg, bpt, 0);  // (batch_line with the point already in registers)
+    LSLAM_PHASE_MARK(pck, 1);
     if (!l.valid) continue;
     // the reference's traversal (H/map/OccGridMapBase.h:240-299) in closed form, here as (x, y): cell c of the ray is c
     // major steps and q(c) = floor((abs_da/2 + c*abs_db) / abs_da) minor steps from the begin cell (see ray_cell)
@@ -457,6 +475,7 @@ k_lo_batch_rays(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __res
     // within +-1 of it and two integer corrections make it exact (a 64-bit integer division per cell otherwise)
     const float rcp_da = 1.0f / (float)abs_da;
     for (unsigned c = lane; c < abs_da; c += 64) {
+      LSLAM_PHASE_MARK(pck, 2);
       const unsigned num = abs_da / 2 + c * abs_db;
       unsigned q = (unsigned)((float)num * rcp_da);
       int rem = (int)(num - q * abs_da);
@@ -473,6 +492,7 @@ k_lo_batch_rays(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __res
       }
       uint8_t* plane = pool;  // (the window's bytes: `off` is an offset into the pool)
       const uint32_t b = plane[off];
+      LSLAM_PHASE_MARK(pck, 3);
       if (b == hit) {  // some beam of this scan ends here: remember the first beam that crosses it
         const uint32_t cell = (uint32_t)(y * g.sx + x);
         uint32_t slot = hash_slot0(cell, g.hash_mask);
@@ -482,8 +502,10 @@ k_lo_batch_rays(BatchGeom g, const ScanHdr* __restrict__ hdr, const float* __res
         plane[off] = (uint8_t)crossed;
         flags[(size_t)t * kBatchSlots + sidx] = (uint8_t)(g.tag | 1u);
       }
+      LSLAM_PHASE_MARK(pck, 4);
     }
   }
+  LSLAM_PHASE_FLUSH(pck, g_map_stamps, 0, (unsigned)w, lane == 0);
 }
 
 // hash entry -> plane byte: a hit cell that an EARLIER beam of the same scan crossed becomes HIT_UNDO, so the apply
@@ -1150,7 +1172,9 @@ struct lslam_map {
   size_t batch_budget = (size_t)192 << 20;
   int batch_radius_hint = 0;   // LSLAM_MAP_OPT_BATCH_RADIUS_CELLS: bound for callers whose points the host never sees
   int batch_last_rounds = 0;
-  unsigned long long* d_batch_misses = nullptr;
+  unsigned long long* d_batch_misses = nullptr;  // PINNED HOST memory (device-visible): the kernels' atomicAdd lands where the
+                                                 // host can read it after any synchronise, without a copy on the stream
+  unsigned long long batch_misses_reported = 0;  // of those, how many a synchronise has already reported as an error
   bool ordered_sums = false;  // lslam_map_set_option(LSLAM_MAP_OPT_ORDERED_SUMS) / LSLAM_GN_ORDERED=1
   int gn_threads = 512;       // LSLAM_GN_THREADS = 256 | 512 | 1024
   float* h_gn_pts = nullptr;
@@ -1417,6 +1441,20 @@ int lslam_map_create(lslam_context* ctx, int size_x, int size_y, float cell_leng
   }
   (void)hipStreamSynchronize(ctx->stream);
   ctx->pre_sync.emplace_back((void*)map, [](void* m) { return lslam_map_flush((lslam_map*)m); });  // lslam_synchronize flushes
+  // ... and, once the stream has drained, makes a window miss LOUD: cells that LSLAM_MAP_OPT_BATCH_RADIUS_CELLS left outside
+  // their scan's window were dropped -- the map no longer equals the reference's -- so the synchronise that learns of it fails
+  ctx->post_sync.emplace_back((void*)map, [](void* mp) {
+    lslam_map* m = (lslam_map*)mp;
+    if (!m->d_batch_misses) return (int)LSLAM_OK;
+    const unsigned long long now = __atomic_load_n(m->d_batch_misses, __ATOMIC_ACQUIRE);
+    if (now == m->batch_misses_reported) return (int)LSLAM_OK;
+    const unsigned long long fresh = now - m->batch_misses_reported;
+    m->batch_misses_reported = now;
+    return m->ctx->fail(LSLAM_ERR_INVALID_ARGUMENT,
+                        "lslam_map_update_batch_dev: %llu hit / free cells lay outside their scan's window and were DROPPED "
+                        "(LSLAM_MAP_OPT_BATCH_RADIUS_CELLS understates a scan's reach): the map has diverged from "
+                        "updateByScan's (OccGridMapBase.h:118-168); raise the hint or set it to 0 (whole-map windows)", fresh);
+  });
   *out = map;
   return LSLAM_OK;
 }
@@ -1426,6 +1464,11 @@ void lslam_map_destroy(lslam_map* map) {
   for (size_t i = 0; i < map->ctx->pre_sync.size(); i++)
     if (map->ctx->pre_sync[i].first == (void*)map) {
       map->ctx->pre_sync.erase(map->ctx->pre_sync.begin() + (long)i);
+      break;
+    }
+  for (size_t i = 0; i < map->ctx->post_sync.size(); i++)
+    if (map->ctx->post_sync[i].first == (void*)map) {
+      map->ctx->post_sync.erase(map->ctx->post_sync.begin() + (long)i);
       break;
     }
   (void)hipSetDevice(map->ctx->device);
@@ -1441,7 +1484,7 @@ void lslam_map_destroy(lslam_map* map) {
     L.d_pool.release();
     if (L.d_flags) (void)hipFree(L.d_flags);
   }
-  if (map->d_batch_misses) (void)hipFree(map->d_batch_misses);
+  if (map->d_batch_misses) (void)hipHostFree(map->d_batch_misses);
   map->d_pts.release();
   map->d_cached.release();
   map->d_gn_out.release();
@@ -1619,8 +1662,8 @@ int update_batch_impl(lslam_map* map, int K, const float* d_pts, const int32_t* 
   LSLAM_HIP(ctx, map->d_hash.reserve((size_t)3 * K * slots));
   LSLAM_HIP(ctx, map->d_hdr.reserve((size_t)K * map->levels.size()));
   if (!map->d_batch_misses) {
-    LSLAM_HIP(ctx, hipMalloc((void**)&map->d_batch_misses, sizeof(unsigned long long)));
-    LSLAM_HIP(ctx, hipMemsetAsync(map->d_batch_misses, 0, sizeof(unsigned long long), ctx->stream));
+    LSLAM_HIP(ctx, hipHostMalloc((void**)&map->d_batch_misses, sizeof(unsigned long long), hipHostMallocDefault));
+    *map->d_batch_misses = 0ull;
   }
   std::vector<ScanHdr> hdr((size_t)K * map->levels.size());
   std::vector<int> off(K + 1, 0);
@@ -1868,11 +1911,10 @@ int lslam_map_batch_stats(lslam_map* map, int64_t out[4]) {
   out[2] = 0;
   out[3] = (int64_t)map->batch_budget;
   if (map->d_batch_misses) {
-    unsigned long long m = 0;
     LSLAM_HIP(ctx, hipSetDevice(ctx->device));
-    LSLAM_HIP(ctx, hipMemcpyAsync(&m, map->d_batch_misses, sizeof m, hipMemcpyDeviceToHost, ctx->stream));
     LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    out[2] = (int64_t)m;
+    out[2] = (int64_t)__atomic_load_n(map->d_batch_misses, __ATOMIC_ACQUIRE);
+    map->batch_misses_reported = (unsigned long long)out[2];  // the caller has seen the count: not an error a second time
   }
   return LSLAM_OK;
 }
@@ -2129,6 +2171,29 @@ void* lslam_map_cells_dev_ptr(lslam_map* map, int level) {
 // Enqueue whatever a single-scan update still owes the float planes (the deferred apply of the pipelined path).
 // lslam_map_read_*, lslam_map_match_*, the batched update and lslam_synchronize do this themselves; a caller that reads
 // the plane behind lslam_map_cells_dev_ptr from its OWN stream calls it before recording its event on lslam_stream().
+#if defined(LSLAM_PHASE_STAMPS)
+// diagnostic builds only: out[kernel][8 cycle sums | 8 visit counts] of this translation unit's stamp table (summed over the
+// wave slots); reset != 0 clears it
+int lslam_debug_map_stamps(lslam_context* ctx, unsigned long long* out, int reset) {
+  if (!ctx || !out) return LSLAM_ERR_INVALID_ARGUMENT;
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t n = (size_t)lslam::kStampKernels * lslam::kStampSlots * 16;
+  std::vector<unsigned long long> h(n);
+  LSLAM_HIP(ctx, hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_map_stamps_slots), n * sizeof(unsigned long long)));
+  for (int k = 0; k < lslam::kStampKernels; k++)
+    for (int i = 0; i < 16; i++) {
+      unsigned long long sum = 0;
+      for (int sl = 0; sl < lslam::kStampSlots; sl++) sum += h[((size_t)k * lslam::kStampSlots + sl) * 16 + i];
+      out[k * 16 + i] = sum;
+    }
+  if (reset) {
+    std::fill(h.begin(), h.end(), 0ull);
+    LSLAM_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_map_stamps_slots), h.data(), n * sizeof(unsigned long long)));
+  }
+  return LSLAM_OK;
+}
+#endif
+
 int lslam_map_flush(lslam_map* map) {
   if (!map) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_context* ctx = map->ctx;

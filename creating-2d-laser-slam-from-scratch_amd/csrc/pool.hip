@@ -43,9 +43,9 @@ int lslam_pool_create_on(const int* devices, int n_devices, const lslam_matcher_
       return rc;
     }
     p->m.push_back(mm);
-    // every device's share of a batch goes through as two pipelined sub-batches (upload of one under the kernels of the
-    // other, reduce chains overlapped): lslam_matcher_match_batch does the splitting
-    (void)lslam_matcher_set_option(mm, LSLAM_OPT_PIPELINE_DEPTH, 2);
+    // (the matchers stay at the default LSLAM_OPT_PIPELINE_DEPTH 1: lslam_pool_matcher hands them out BORROWED, and a
+    // borrower who orders its own work with an event on lslam_stream() relies on the plain contract -- lslam_pool_match_batch
+    // raises the depth around its own call only)
   }
   *out = p;
   return LSLAM_OK;
@@ -143,8 +143,20 @@ int lslam_pool_match_batch(lslam_pool* p, int n_scans, const double* ranges, int
     const long long lo = (long long)r * n_scans / W, hi = (long long)(r + 1) * n_scans / W;
     if (hi <= lo) continue;
     th.emplace_back([=, &rcs]() {
-      rcs[r] = lslam_matcher_match_batch(p->m[r], (int)(hi - lo), ranges + (size_t)lo * ranges_stride, ranges_stride,
-                                         sensor_poses + 3 * lo, do_penalize, do_refine, out + lo);
+      // every device's share goes through as two pipelined sub-batches (upload of one under the kernels of the other, reduce
+      // chains overlapped: lslam_matcher_match_batch does the splitting and joins before it returns); the depth the matcher
+      // had -- a borrower may have set its own -- is restored afterwards, and a refused option is an error, not ignored
+      lslam_matcher* mm = p->m[r];
+      const int depth_before = lslam_matcher_get_option(mm, LSLAM_OPT_PIPELINE_DEPTH);
+      int rc = depth_before < 2 ? lslam_matcher_set_option(mm, LSLAM_OPT_PIPELINE_DEPTH, 2) : LSLAM_OK;
+      if (rc == LSLAM_OK)
+        rc = lslam_matcher_match_batch(mm, (int)(hi - lo), ranges + (size_t)lo * ranges_stride, ranges_stride, sensor_poses + 3 * lo,
+                                       do_penalize, do_refine, out + lo);
+      if (depth_before >= 1 && depth_before < 2) {
+        const int rc2 = lslam_matcher_set_option(mm, LSLAM_OPT_PIPELINE_DEPTH, depth_before);
+        if (rc == LSLAM_OK) rc = rc2;
+      }
+      rcs[r] = rc;
     });
   }
   for (auto& t : th) t.join();

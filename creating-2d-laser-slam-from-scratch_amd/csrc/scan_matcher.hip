@@ -3291,6 +3291,11 @@ struct lslam_matcher {
   int view_owner = -1;               // slot whose stream recorded view_ready (-1: none since the last join)
   StepWork pipe_work[kMaxPipe];      // slot 0 is unused: it works in the members above
   uint64_t pipe_steps = 0;           // pipelined steps enqueued so far (diagnostics)
+  // LSLAM_OPT_CHECK_OUTPUT_REUSE (debug): the record buffer [begin, end) of the step each slot has in flight; a pipelined
+  // step whose records would land in a buffer an unfinished step is still writing is refused instead of corrupting it
+  bool check_out_reuse = false;
+  const char* pipe_out_lo[kMaxPipe] = {nullptr, nullptr, nullptr, nullptr};
+  const char* pipe_out_hi[kMaxPipe] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -3317,6 +3322,7 @@ int pipe_join(lslam_matcher* m) {
       LSLAM_HIP(ctx, hipEventRecord(m->pipe_done[i], m->pipe_stream[i]));
       LSLAM_HIP(ctx, hipStreamWaitEvent(ctx->stream, m->pipe_done[i], 0));
       m->pipe_pending[i] = false;
+      m->pipe_out_lo[i] = m->pipe_out_hi[i] = nullptr;
     }
   m->view_owner = -1;  // the context stream is behind every refresh now, and every later step is behind it
   return LSLAM_OK;
@@ -3600,7 +3606,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       (const double2*)m->d_local.p, m->d_resp.p, resp_stride, slices, S, occ, m->occ_wpc, m->ptile_rows, class_bytes, \
       (unsigned long long*)(m->collect_stats ? m->d_stats.p : nullptr)
       const uint8_t* pt = m->d_ptiles;
-      if (m->collect_stats && variant == 2 && step == 2 && m->stats_scans < S) {
+      if (m->collect_stats && (variant == 2 || variant == 3) && step == 2 && m->stats_scans < S) {
         // (re)size the per-(scan, beam) flag words behind the counters; the counters collected so far are carried over
         unsigned long long keep[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         LSLAM_HIP(ctx, hipMemcpyAsync(keep, m->d_stats.p, sizeof keep, hipMemcpyDeviceToHost, ctx->stream));
@@ -3623,6 +3629,11 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
           launch(ctx, name, k_resp_rows<3, 11, true, true>, LSLAM_ROWS_ARGS(pt, pt));
         else
           launch(ctx, name, k_resp_rows<3, 11, false, true>, LSLAM_ROWS_ARGS(s0, s1));
+      } else if (m->collect_stats && variant == 3 && step == 2) {  // the same for lattice rows of 13..16 positions
+        if (ptiled)
+          launch(ctx, name, k_resp_rows<4, 8, true, true>, LSLAM_ROWS_ARGS(pt, pt));
+        else
+          launch(ctx, name, k_resp_rows<4, 8, false, true>, LSLAM_ROWS_ARGS(s0, s1));
       } else if (variant == 1)
         launch(ctx, name, k_resp_rows<1, 4, false>, LSLAM_ROWS_ARGS(s0, s1));
       else if ((variant == 2 || variant == 3) && ptiled && m->rows_waves > 1 && g.n_beams <= 64 * kMaxBeamsPerLane) {
@@ -3727,13 +3738,18 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
   g, p, sc, (const Lattice*)m->d_lat.p, m->d_resp.p, resp_stride, m->d_coarse.p,                              \
       (int)m->cfg.use_response_expansion, pass_index, (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, \
       fb_step
-    if (cache && ((size_t)p.nx * p.ny * p.na + 31) / 32 <= 256) {
+    // the LDS form keeps no per-candidate cache, so it also covers lattices whose cached form would not fit (the reference's
+    // shipped 16 x 16 x 21: 62 KB cached, 21 KB here -- k_reduce_coarse<false> was 0.36 ms of that configuration's 1.98 ms step)
+    const int nt_sel = S >= kReduceNarrowMinScans ? 128 : (S <= 8 ? 1024 : 256);
+    if (((size_t)p.nx * p.ny * p.na + 31) / 32 <= 256 && reduce_lds_nocache(p, reduce_parts(p, nt_sel)) <= 60 * 1024) {
       const bool fuse_fine = n_exp == 0 && do_refine;  // nothing between this pass and the fine pass
+      // (the block also clears the fine numerators -- unless a debug caller is about to copy the COARSE ones out of the same words)
+      const bool fuse_zero = fuse_fine && !(dbg_coarse_sums && pass_index == 0);
 #define LSLAM_RC_LDS(NT)                                                                                                 \
   launch(ctx, "reduce_coarse", k_reduce_coarse_lds<NT>, dim3(S), dim3(NT), reduce_lds_nocache(p, reduce_parts(p, NT)), g, p,  \
          sc, m->d_lat.p, m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,            \
          (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step, pf,                                               \
-         fuse_fine ? m->d_cossin.p : (double2*)nullptr, 1, fuse_fine ? pf.nx * pf.ny * pf.na : 0, reduce_parts(p, NT))
+         fuse_fine ? m->d_cossin.p : (double2*)nullptr, 1, fuse_zero ? pf.nx * pf.ny * pf.na : 0, reduce_parts(p, NT))
       // 128 threads: residency for chip-filling batches; 1024: a lone block (streaming front-end, MatchScan) splits a cell's
       // angles over 8 threads -- its fill phase was 11 fp64 divisions in a row per thread
       if (S >= kReduceNarrowMinScans) LSLAM_RC_LDS(128);
@@ -3741,7 +3757,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       else LSLAM_RC_LDS(256);
 #undef LSLAM_RC_LDS
       setup_done = fuse_fine;
-      fine_prezeroed = fuse_fine;
+      fine_prezeroed = fuse_zero;
     }
     else if (cache)
       launch(ctx, "reduce_coarse", k_reduce_coarse<true>, dim3(S), dim3(256), reduce_lds(p, true), LSLAM_REDUCE_ARGS);
@@ -3865,6 +3881,20 @@ int pipe_step(lslam_matcher* m, int S, const RT* d_ranges, int stride, const dou
   int rc = pipe_init(m);
   if (rc) return rc;
   const int slot = m->pipe_next % m->pipe_depth;
+  if (m->check_out_reuse) {
+    // Up to pipe_depth steps are in flight: the step that ran on THIS slot before is finished by stream order (this step
+    // queues behind it), every other pending slot may still be writing its records.
+    const char* lo = (const char*)d_out;
+    const char* hi = lo + (size_t)S * sizeof(lslam_match_result);
+    for (int i = 0; i < m->pipe_depth; i++)
+      if (i != slot && m->pipe_pending[i] && m->pipe_out_lo[i] && lo < m->pipe_out_hi[i] && m->pipe_out_lo[i] < hi)
+        return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT,
+                         "pipelined step: its result buffer overlaps the one of a step still in flight (slot %d); with "
+                         "LSLAM_OPT_PIPELINE_DEPTH %d consecutive calls need %d distinct result buffers",
+                         i, m->pipe_depth, m->pipe_depth);
+    m->pipe_out_lo[slot] = lo;
+    m->pipe_out_hi[slot] = hi;
+  }
   m->pipe_next = (slot + 1) % m->pipe_depth;
   hipStream_t s = m->pipe_stream[slot];
   // "behind everything the context stream held": nothing to wait for when that stream has drained (the steady state of
@@ -4333,6 +4363,9 @@ int lslam_matcher_set_option(lslam_matcher* m, int option, int value) {
       m->step_waves = value;
       return LSLAM_OK;
     }
+    case LSLAM_OPT_CHECK_OUTPUT_REUSE:
+      m->check_out_reuse = value != 0;
+      return LSLAM_OK;
     case LSLAM_OPT_ROWS_WAVES: {
       if (value != 1 && value != 2 && value != 4 && value != 8)
         return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "coarse kernel: 1, 2, 4 or 8 waves per block, not %d", value);
@@ -4361,6 +4394,21 @@ int lslam_matcher_set_option(lslam_matcher* m, int option, int value) {
   }
 }
 
+int lslam_matcher_get_option(const lslam_matcher* m, int option) {
+  if (!m) return LSLAM_ERR_INVALID_ARGUMENT;
+  switch (option) {
+    case LSLAM_OPT_ROW_OCCUPANCY: return m->use_row_occupancy ? 1 : 0;
+    case LSLAM_OPT_COLLECT_STATS: return m->collect_stats ? 1 : 0;
+    case LSLAM_OPT_LDS_STAGED: return m->lds_staged ? 1 : 0;
+    case LSLAM_OPT_PIPELINE_DEPTH: return m->pipe_depth;
+    case LSLAM_OPT_STEP_KERNEL: return m->step_waves;
+    case LSLAM_OPT_STEP_MIN_SCANS: return m->step_min_scans;
+    case LSLAM_OPT_ROWS_WAVES: return m->rows_waves;
+    case LSLAM_OPT_CHECK_OUTPUT_REUSE: return m->check_out_reuse ? 1 : 0;
+    default: return LSLAM_ERR_INVALID_ARGUMENT;
+  }
+}
+
 int lslam_matcher_flush(lslam_matcher* m) {
   if (!m) return LSLAM_ERR_INVALID_ARGUMENT;
   LSLAM_HIP(m->ctx, hipSetDevice(m->ctx->device));
@@ -4386,7 +4434,8 @@ int lslam_matcher_read_beam_stats(lslam_matcher* m, uint64_t out[4]) {
   if (!m || !out) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_context* ctx = m->ctx;
   out[0] = out[1] = out[2] = out[3] = 0;
-  if (!m->d_stats.p || m->stats_scans <= 0) return LSLAM_OK;  // no instrumented coarse pass has run: nothing counted
+  if (!m->d_stats.p || m->stats_scans <= 0)  // zeros here would read like a measurement
+    return ctx->fail(LSLAM_ERR_NO_DATA, "no instrumented coarse pass has run (LSLAM_OPT_COLLECT_STATS + a batched match first)");
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
   std::vector<uint32_t> flags((size_t)m->stats_scans * m->g.n_beams);
   LSLAM_HIP(ctx, hipMemcpyAsync(flags.data(), (const uint32_t*)(m->d_stats.p + 8), flags.size() * sizeof(uint32_t), hipMemcpyDeviceToHost,
@@ -4440,8 +4489,11 @@ int lslam_matcher_match_batch(lslam_matcher* m, int S, const double* ranges, int
   // one runs under the kernels of the one before, and the sub-batches' kernels share the chip.  Same records: every
   // scan is matched on its own against the same grid, whatever sub-batch it travels in.
   int chunks = 1;
-  if (m->pipe_depth > 1 && !m->collect_stats && !m->lds_staged && n > 0)
+  // the same predicate as match_batch_dev_entry's: flags a grid rebuild left for the NEXT plain match (prep_done,
+  // resp_prezeroed) or an armed ticket describe slot 0's buffers on the context stream -- such a call goes out as one plain step
+  if (m->pipe_depth > 1 && !m->collect_stats && !m->lds_staged && !m->prep_done && !m->resp_prezeroed && !m->arm_next && n > 0)
     chunks = std::max(1, std::min(m->pipe_depth, S / kPipeMinChunk));
+  if (chunks > 1) m->pipe_next = 0;  // sub-batch c always travels on slot c
   LSLAM_HIP(ctx, m->d_results.reserve(S));
   if (chunks == 1) {
     rc = upload_scans(m, S, ranges, stride, poses);
@@ -4605,6 +4657,10 @@ int lslam_matcher_debug_coarse_sums_batch(lslam_matcher* m, int n_scans, const d
   if (!m || !ranges || !poses || !out || n_scans <= 0) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_context* ctx = m->ctx;
   LSLAM_NOT_REENTRANT(m);
+  {  // pipelined steps in flight read the upload buffers and slot 0's workspaces this call is about to reuse
+    const int jrc = pipe_join(m);
+    if (jrc) return jrc;
+  }
   const Geom g = m->g;
   if (g.n_beams == 0) return LSLAM_OK;
   const double res = 1.0 / g.scale;
@@ -4641,6 +4697,10 @@ int lslam_matcher_debug_fine_sums_batch(lslam_matcher* m, int n_scans, const dou
   if (!m || !ranges || !poses || n_scans <= 0) return LSLAM_ERR_INVALID_ARGUMENT;
   lslam_context* ctx = m->ctx;
   LSLAM_NOT_REENTRANT(m);
+  {  // pipelined steps in flight read the upload buffers and slot 0's workspaces this call is about to reuse
+    const int jrc = pipe_join(m);
+    if (jrc) return jrc;
+  }
   const Geom g = m->g;
   const double res = 1.0 / g.scale;
   const double coarse_res = 2 * res;

@@ -46,7 +46,8 @@ typedef enum lslam_status {
   LSLAM_ERR_NO_BEST_POSE = -5,        /* "Unable to find best position" (Mapper.cpp:484-487) */
   LSLAM_ERR_HIP = -6,
   LSLAM_ERR_SMEAR_DEVIATION = -7,     /* CalculateKernel range check (Mapper.h:1041-1053) */
-  LSLAM_ERR_UNSUPPORTED = -8
+  LSLAM_ERR_UNSUPPORTED = -8,
+  LSLAM_ERR_NO_DATA = -9              /* a diagnostic was read before anything had been collected for it */
 } lslam_status;
 
 typedef struct lslam_context lslam_context;
@@ -75,6 +76,11 @@ typedef struct lslam_kernel_time {
   int64_t launches;
   double total_ms;
 } lslam_kernel_time;
+/* Diagnostics: 256 samples {where + 1, shader-clock ticks (s_memtime), 100 MHz ticks (s_memrealtime)} from 256 single-wave
+ * blocks; `where` = XCD << 16 | shader engine / array / CU bits of HW_ID; 0 = that block did not report.  Two calls around a timed
+ * region give the clock it ran at -- (t1 - t0) / ((r1 - r0) / 1e8), taken per CU present in both samples, so that nothing depends
+ * on whether the counters of different CUs agree.  Synchronises the context stream.  (bench.py prices cycles with it.) */
+int lslam_clock_sample(lslam_context* ctx, uint64_t out[768]);
 int lslam_profile_enable(lslam_context* ctx, int on);
 /* restrict the timing to kernels launched under this name (NULL or "" = every kernel): two events per
  * launch cost ~3 us of stream time, which matters when a batch is five kernels */
@@ -168,6 +174,9 @@ void* lslam_matcher_grid_dev_ptr(lslam_matcher* m);
  *    the context stream).  lslam_matcher_match_batch (host arrays) splits its batch into up to D sub-batches of >= 256
  *    scans and pipelines those, uploads included; it returns with everything done, as before.  The reference has no
  *    counterpart: karto::ScanMatcher is one grid, one lookup table, one caller (Mapper.h:1273-1278). */
+/*  LSLAM_OPT_CHECK_OUTPUT_REUSE (default 0; debug): with 1 a pipelined step whose result buffer overlaps the buffer of a
+ *    step that may still be in flight returns LSLAM_ERR_INVALID_ARGUMENT instead of letting two steps write the same
+ *    records (the caller's side of the LSLAM_OPT_PIPELINE_DEPTH contract, checked on the host: no device cost). */
 /*  LSLAM_OPT_ROWS_WAVES (1, 2, 4 or 8; default 1): waves per block of the coarse response kernel of chip-filling batches.
  *    With W > 1 the W waves of a block take W consecutive candidate angles of ONE scan (k_resp_rows_mw), so they run on one
  *    CU and share its L1 (points, occupancy words, lines of the tiled planes); 1 = one wave per block (k_resp_rows).  Same
@@ -181,7 +190,9 @@ void* lslam_matcher_grid_dev_ptr(lslam_matcher* m);
  *    everything else keeps the five-kernel path (value 0 = always).  lslam_matcher_step_kernel_launches counts the
  *    launches that did go out as one kernel.  The reference has no counterpart (Mapper.cpp:184-291 is one scan at a time). */
 enum { LSLAM_OPT_ROW_OCCUPANCY = 1, LSLAM_OPT_COLLECT_STATS = 2, LSLAM_OPT_LDS_STAGED = 3, LSLAM_OPT_PIPELINE_DEPTH = 4,
-       LSLAM_OPT_STEP_KERNEL = 5, LSLAM_OPT_STEP_MIN_SCANS = 6, LSLAM_OPT_ROWS_WAVES = 7 };
+       LSLAM_OPT_STEP_KERNEL = 5, LSLAM_OPT_STEP_MIN_SCANS = 6, LSLAM_OPT_ROWS_WAVES = 7, LSLAM_OPT_CHECK_OUTPUT_REUSE = 8 };
+/* current value of an option (negative: error code) */
+int lslam_matcher_get_option(const lslam_matcher* m, int option);
 /* Order the context stream behind every pipelined step in flight (no host wait).  No-op at depth 1. */
 int lslam_matcher_flush(lslam_matcher* m);
 /* diagnostics: pipelined steps enqueued so far (0 while LSLAM_OPT_PIPELINE_DEPTH is 1) */

@@ -595,6 +595,16 @@ double kref_match_fixed_grid(void* h, int n_ranges, const double* q_ranges_all, 
       kt_double best = sm->CorrelateScan(pScan, scanPose, coarseSearchOffset, coarseSearchResolution,
                                          mp->m_pCoarseSearchAngleOffset->GetValue(),
                                          mp->m_pCoarseAngleResolution->GetValue(), do_penalize != 0, mean, cov, false);
+      // MatchScan's response expansion (Mapper.cpp:242-267), when the configuration has it on: a zero best response
+      // widens the angular window by 20 degrees, up to three times -- the reference's own CorrelateScan each time
+      if (mp->m_pUseResponseExpansion->GetValue() && math::DoubleEqual(best, 0.0)) {
+        kt_double wider = mp->m_pCoarseSearchAngleOffset->GetValue();
+        for (int e = 0; e < 3 && math::DoubleEqual(best, 0.0); e++) {
+          wider += math::DegreesToRadians(20);
+          best = sm->CorrelateScan(pScan, scanPose, coarseSearchOffset, coarseSearchResolution, wider,
+                                   mp->m_pCoarseAngleResolution->GetValue(), do_penalize != 0, mean, cov, false);
+        }
+      }
       if (do_refine) {
         Vector2<kt_double> fineSearchOffset(coarseSearchResolution * 0.5);
         Vector2<kt_double> fineSearchResolution(g->GetResolution(), g->GetResolution());

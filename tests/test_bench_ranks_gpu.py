@@ -95,7 +95,7 @@ def test_rccl_backend_on_the_one_gpu_box(tmp_path):
     assert nc["backend"] == "nccl" and nc["rccl_ranks"] == 1 and nc["n_gpus"] == 1
     assert nc["gather_ms"] is not None and len(nc["per_rank_ms_per_step"]) == 1
     assert len(nc["devices"]) == 1 and "cuda:0" in nc["devices"][0]
-    assert nc["pipelined_records_identical"] is True and nc["pipeline_depth"] == 2
+    assert nc["pipelined_records_identical"] is True and nc["pipeline_depth"] == 1 and nc["pipelined_leg"]["depth"] == 2
     assert r1.tobytes() == rn.tobytes()
 
 
@@ -120,3 +120,42 @@ def test_pipelined_timed_region_equals_plain(tmp_path):
         assert j["pipeline_depth"] == d and j["pipelined_records_identical"] is True
         assert j["plain"]["ms_per_step"] > 0 and j["roofline"]["leg"].startswith("plain steps")
         assert r.tobytes() == r1.tobytes()
+
+
+def test_n1_line_through_torchrun_equals_plain_invocation(tmp_path):
+    """The driver's SCALE protocol starts every N -- N = 1 included -- through `python -m torch.distributed.run`; its BENCH
+    protocol runs `python bench.py`.  The two N = 1 lines must describe the same measurement: same metric / config / leg,
+    same records, `value` within the run-to-run noise of a 40-step region, and roofline + cpu_baseline present in both."""
+    common = ("--steps", "40", "--warmup", "5", "--batch", "4096", "--no-secondary", "--no-diagnostics", "--sustained-s", "0",
+              "--cpu-sample", "64", "--cpu-cores", "1")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LSLAM_BENCH_BACKEND", "LSLAM_BENCH_FORCE_DIST",
+              "LSLAM_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+
+    def run(cmd, tag):
+        out = tmp_path / f"{tag}.npy"
+        p = subprocess.run([*cmd, str(ROOT / "bench.py"), "--gpus", "1", *common, "--dump-results", str(out)], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout
+        return json.loads(lines[0]), np.load(out)
+
+    plain, rp = run([sys.executable], "plain")
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    tr, rt = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                  "--master-port", str(port)], "torchrun")
+    assert rp.tobytes() == rt.tobytes()
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "scaling", "dtype", "pipeline_depth", "results_ok"):
+        assert plain[k] == tr[k], k
+    assert plain["config"] == tr["config"]
+    assert tr["backend"] is None and plain["backend"] is None  # WORLD_SIZE 1: no process group either way (same barriers, same clock)
+    for line in (plain, tr):
+        assert line["roofline"]["kernel"] == "resp_rows_coarse" and line["roofline"]["valu_mix_frac"] is not None
+        assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["max_pose_err_vs_gpu"] < 1e-9
+    assert abs(tr["value"] / plain["value"] - 1.0) < 0.08, (tr["value"], plain["value"])

@@ -119,3 +119,11 @@ def test_device_points_need_a_radius_hint_or_rounds(ctx, oracle_lib):
     wrong.set_option("batch_radius_cells", 100)  # 2.5 m: most walls are farther
     wrong.updateByScans_dev(d_pts.data_ptr(), counts, (0.0, 0.0), poses)
     assert wrong.batch_stats()["window_misses"] > 0
+    # ... and LOUD for a caller that never polls the counter: the synchronise that learns of dropped cells fails, once
+    _, wrong2 = pair(ctx, oracle_lib, n, cell)
+    wrong2.set_option("batch_radius_cells", 100)
+    wrong2.updateByScans_dev(d_pts.data_ptr(), counts, (0.0, 0.0), poses)
+    with pytest.raises(Exception, match="DROPPED"):
+        ctx.synchronize()
+    ctx.synchronize()  # reported once; the context stays usable
+    assert wrong2.batch_stats()["window_misses"] > 0

@@ -253,3 +253,40 @@ def test_pipelined_steps_on_the_other_kernel_families(ctx, kind):
     for depth in (2, 3):
         assert run(depth) == plain
     gm.close()
+
+
+def test_output_buffer_reuse_is_detected(ctx):
+    """LSLAM_OPT_CHECK_OUTPUT_REUSE: the caller's side of the pipelining contract (D consecutive calls need D result buffers),
+    checked on the host -- a step whose records would land in the buffer of a step still in flight is refused, not corrupted."""
+    wl = _workload(300, seed=35)
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(wl.laser))
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    r, p = _dev(wl, 300)
+    want = _plain(ctx, gm, r, p, 300)
+    a = torch.empty((300, 112), dtype=torch.uint8, device=r.device)
+    b = torch.empty((300, 112), dtype=torch.uint8, device=r.device)
+    torch.cuda.synchronize()
+    gm.set_option("pipeline_depth", 2)
+    gm.set_option("check_output_reuse", 1)
+
+    def step(o, n=300):
+        gm.match_batch_dev(n, r.data_ptr(), r.shape[1], p.data_ptr(), o.data_ptr(), dtype="f32")
+
+    step(a)
+    with pytest.raises(api.LslamError, match="result buffer"):
+        step(a)  # the first step may still be writing `a`
+    with pytest.raises(api.LslamError, match="result buffer"):
+        gm.match_batch_dev(100, r.data_ptr(), r.shape[1], p.data_ptr(), a.data_ptr() + 112 * 250, dtype="f32")  # partial overlap
+    step(b)      # the refused calls consumed no slot
+    step(a)      # slot 0 again: behind the first step by stream order
+    ctx.synchronize()
+    assert a.cpu().numpy().tobytes() == want.tobytes() and b.cpu().numpy().tobytes() == want.tobytes()
+    step(a)
+    ctx.synchronize()  # joined: nothing in flight
+    step(a)
+    ctx.synchronize()
+    gm.set_option("check_output_reuse", 0)
+    step(a); step(a)  # unchecked (the default): the documented contract is the caller's
+    ctx.synchronize()
+    gm.set_option("pipeline_depth", 1)
+    gm.close()

@@ -17,7 +17,11 @@ import os
 # (seed, batch): 256 = the wide-block reduce kernels, 2304 = the chip-filling variants (128 / 64-thread reduce blocks,
 # one scan_prep block per scan).  LSLAM_SOAK_SEEDS="10,11,12" adds 2304-scan batches for those seeds (ad-hoc soak).
 # LSLAM_SOAK_DEPTH=2..4 runs them as PIPELINED sub-batches (LSLAM_OPT_PIPELINE_DEPTH; lslam_matcher_match_batch splits the batch).
-_CASES = [(0, 256), (1, 256), (2, 256), (3, 2304)] + [(int(x), 2304) for x in os.environ.get("LSLAM_SOAK_SEEDS", "").split(",") if x]
+# Seeds 45 and 46 are the pinned regression of round 5's extended soak (34 x 2304 matches against the reference): the two
+# batches in which the PENALISED response of a refined match came out one ulp off (1 of 2304 each; tools/soak_probe.py) --
+# they keep the <= 2 ulp / <= 0.2 % clause below honest: without them no case of the suite exercises it.
+_CASES = ([(0, 256), (1, 256), (2, 256), (3, 2304), (45, 2304), (46, 2304)] +
+          [(int(x), 2304) for x in os.environ.get("LSLAM_SOAK_SEEDS", "").split(",") if x])
 
 
 @pytest.mark.parametrize("seed,B", _CASES)

@@ -166,6 +166,8 @@ def fuzz_sums(ctx, seed):
     gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
     port.set_base_scans(wl.base_ranges, wl.base_poses, wl.center_pose)
     gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    if os.environ.get("LSLAM_FUZZ_STEP_KERNEL"):  # the same batches through the scan-resident workgroup kernel (3 / 4 waves)
+        gm.set_option("step_kernel", int(os.environ["LSLAM_FUZZ_STEP_KERNEL"]))
     got = gm.coarse_sums_batch(ranges, poses)
     got_f, centers = gm.fine_sums_batch(ranges, poses)  # fine pass (Mapper.cpp:276-281) around the device's own coarse mean
     check = np.unique(rng.integers(0, S, size=min(S, 48)))

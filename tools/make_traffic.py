@@ -69,27 +69,31 @@ def main(path, scans, cfg2_path=None):
             rec["valu_insts_per_launch"] = int(c["SQ_INSTS_VALU"])
             if c.get("SQ_WAVES"):
                 rec["valu_insts_per_wave"] = round(c["SQ_INSTS_VALU"] / c["SQ_WAVES"], 1)
-        if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
-            # SQ_ACTIVE_INST_VALU ticks once per 4 busy SIMD-cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        if c.get("GRBM_GUI_ACTIVE"):
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs: the launch's duration in clocks.  (Round 5's `valu_busy` /
+            # `avg_busy_cycles_per_valu_inst` are gone: SQ_ACTIVE_INST_VALU ticks once per instruction whatever the
+            # instruction -- ratio 1.0000 for v_fma_f32 and v_perm_b32 alike, profiles/r06/micro_valu_rate_pmc.txt -- so it
+            # said nothing the instruction count did not.  The VALU side is priced by tools/valu_mix_floor.py instead.)
             cycles = c["GRBM_GUI_ACTIVE"] / 8.0
-            rec["valu_busy"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles), 3)
+            rec["cycles_per_launch"] = round(cycles, 1)
             if c.get("SQ_INSTS_VALU"):
                 rec["instruction_mix"] = {
-                    "avg_busy_cycles_per_valu_inst": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"], 2),
                     "salu_per_valu": round(c.get("SQ_INSTS_SALU", 0.0) / c["SQ_INSTS_VALU"], 3),
                     "vmem_rd_per_valu": round(c.get("SQ_INSTS_VMEM_RD", 0.0) / c["SQ_INSTS_VALU"], 4),
                     "lds_per_valu": round(c.get("SQ_INSTS_LDS", 0.0) / c["SQ_INSTS_VALU"], 4),
-                    "note": "tools/micro/valu_rate.hip: VOP2 integer ~3 cycles, VOP3 three-operand (v_perm_b32, v_bfi, "
-                            "v_mad_u32_u24) and fp64 add/mul ~4.7-5 cycles per wave64 instruction at 4 waves/SIMD",
                 }
         if c.get("TA_TA_BUSY_sum") and c.get("GRBM_GUI_ACTIVE"):
             rec["gather_unit_busy"] = round(c["TA_TA_BUSY_sum"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 256), 3)  # 256 TAs, cycles per XCD
         if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
-            # L1 (TCP) tag lookups: one per distinct 128-byte line a vector-memory instruction touches -- what a gather costs
-            # (tools/micro/ta_rate.hip: ~1 cycle each)
+            # L1 (TCP) tag lookups.  What one costs was measured (tools/micro/ta_rate.hip, profiles/ceilings.json): a hit
+            # 1 / 2.1 clock of the CU's gather pipe, a miss (L2 hit) 2.3 clocks
             rec["l1_line_lookups_per_launch"] = int(c["TCP_TOTAL_CACHE_ACCESSES_sum"])
             if c.get("TA_FLAT_READ_WAVEFRONTS_sum"):
                 rec["l1_line_lookups_per_vmem_read"] = round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / c["TA_FLAT_READ_WAVEFRONTS_sum"], 1)
+            if c.get("GRBM_GUI_ACTIVE"):
+                rec["l1_lookups_per_cu_clk"] = round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (c["GRBM_GUI_ACTIVE"] / 8.0) / 256.0, 4)
+            if c.get("TCP_TCC_READ_REQ_sum"):
+                rec["l1_miss_ratio"] = round(c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"], 4)
         if c.get("TCP_TCC_READ_REQ_sum"):
             rec["l2_read_requests_per_launch"] = int(c["TCP_TCC_READ_REQ_sum"])  # L1 -> L2 read requests, 128 B lines
         if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum") is not None and (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) > 0:

@@ -32,7 +32,7 @@ struct Stamp {
 constexpr int kIters = 64;  // x 64 repeats x per_rep instructions per wave
 
 #define I4(OPSTR) \
-  REP64(asm volatile(OPSTR : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c), "s"(sb));)
+  REP64(asm volatile(OPSTR : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c), "s"(sb) : "vcc", "s20", "s21");)
 #define D2(OPSTR) REP64(asm volatile(OPSTR : "+v"(d0), "+v"(d1) : "v"(d2), "v"(d3));)
 
 template <int OP>
@@ -109,6 +109,16 @@ __global__ void __launch_bounds__(64) k(uint32_t* out, Stamp* st, uint32_t seed)
     if (OP == 68) { REP64(asm volatile("v_mad_u64_u32 %0, s[20:21], %2, %3, %0\n v_mad_u64_u32 %1, s[20:21], %2, %3, %1" : "+v"(d0), "+v"(d1) : "v"(a0), "v"(a1));) }
     if (OP == 69) { I4("v_and_b32 %0, 3, %0\n v_and_b32 %1, 3, %1\n v_and_b32 %2, 3, %2\n v_and_b32 %3, 3, %3") }
     if (OP == 70) { I4("v_mul_f32 %0, %6, %0\n v_mul_f32 %1, %6, %1\n v_mul_f32 %2, %6, %2\n v_mul_f32 %3, %6, %3") }
+    if (OP == 71) { I4("v_cndmask_b32 %0, %0, %4, vcc\n v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_cndmask_b32 %1, %1, %4, vcc\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_cndmask_b32 %2, %2, %4, vcc\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n v_add_u32 %0, %0, %4\n v_cndmask_b32 %3, %3, %4, vcc\n v_add_u32 %3, %3, %4\n v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4") }
+    if (OP == 72) { I4("v_cndmask_b32_e64 %0, %0, %4, vcc\n v_cndmask_b32_e64 %1, %1, %4, vcc\n v_cndmask_b32_e64 %2, %2, %4, vcc\n v_cndmask_b32_e64 %3, %3, %4, vcc") }
+    if (OP == 73) { I4("v_cndmask_b32 %0, 0, %0, vcc\n v_cndmask_b32 %1, 0, %1, vcc\n v_cndmask_b32 %2, 0, %2, vcc\n v_cndmask_b32 %3, 0, %3, vcc") }
+    if (OP == 74) { I4("v_cndmask_b32 %0, %1, %4, vcc\n v_cndmask_b32 %1, %2, %4, vcc\n v_cndmask_b32 %2, %3, %4, vcc\n v_cndmask_b32 %3, %0, %4, vcc") }
+    if (OP == 75) { I4("v_addc_co_u32 %0, vcc, %0, %4, vcc\n v_addc_co_u32 %1, vcc, %1, %4, vcc\n v_addc_co_u32 %2, vcc, %2, %4, vcc\n v_addc_co_u32 %3, vcc, %3, %4, vcc") }
+    if (OP == 76) { I4("v_cmp_lt_u32 vcc, %0, %4\n v_cndmask_b32 %0, %0, %5, vcc\n v_cmp_lt_u32 vcc, %1, %4\n v_cndmask_b32 %1, %1, %5, vcc\n v_cmp_lt_u32 vcc, %2, %4\n v_cndmask_b32 %2, %2, %5, vcc\n v_cmp_lt_u32 vcc, %3, %4\n v_cndmask_b32 %3, %3, %5, vcc") }
+    if (OP == 77) { I4("v_cmp_lt_u32_e64 s[20:21], %0, %4\n v_cndmask_b32_e64 %0, %0, %5, s[20:21]\n v_cmp_lt_u32_e64 s[20:21], %1, %4\n v_cndmask_b32_e64 %1, %1, %5, s[20:21]\n v_cmp_lt_u32_e64 s[20:21], %2, %4\n v_cndmask_b32_e64 %2, %2, %5, s[20:21]\n v_cmp_lt_u32_e64 s[20:21], %3, %4\n v_cndmask_b32_e64 %3, %3, %5, s[20:21]") }
+    if (OP == 78) { I4("v_add_co_u32 %0, vcc, %0, %4\n v_add_co_u32 %1, vcc, %1, %4\n v_add_co_u32 %2, vcc, %2, %4\n v_add_co_u32 %3, vcc, %3, %4") }
+    if (OP == 79) { I4("v_min_u32 %0, %0, %4\n v_min_u32 %1, %1, %4\n v_min_u32 %2, %2, %4\n v_min_u32 %3, %3, %4") }
+    if (OP == 80) { I4("v_mul_u32_u24 %0, %0, %4\n v_mul_u32_u24 %1, %1, %4\n v_mul_u32_u24 %2, %2, %4\n v_mul_u32_u24 %3, %3, %4") }
     // ---- 64-bit ----
     if (OP == 30) { D2("v_add_f64 %0, %0, %3\n v_add_f64 %1, %1, %3") }
     if (OP == 31) { D2("v_mul_f64 %0, %0, %2\n v_mul_f64 %1, %1, %2") }
@@ -210,6 +220,7 @@ int main(int argc, char** argv) {
     run<34>("v_cvt_f32_f64", 2, w); run<35>("v_cvt_i32_f64", 2, w); run<38>("v_cvt_f64_i32", 2, w); run<36>("v_rcp_f64", 2, w);
     run<37>("v_lshl_add_u64", 2, w);
     run<40>("v_mov_b32(const)", 4, w); run<41>("v_mov_b32(sgpr)", 4, w); run<42>("v_and_b32(literal)", 4, w); run<43>("v_add_u32(const)", 4, w); run<44>("v_sub_u32", 4, w); run<45>("v_or_b32", 4, w); run<46>("v_xor_b32", 4, w); run<47>("v_lshrrev_b32(const)", 4, w); run<48>("v_lshrrev_b32(vgpr)", 4, w); run<49>("v_lshlrev_b32(vgpr)", 4, w); run<50>("v_ashrrev_i32(const)", 4, w); run<51>("v_cndmask_b32(vcc=-1)", 4, w); run<52>("v_cndmask_b32_e64", 4, w); run<53>("v_cmp_le_u32(vcc)", 4, w); run<54>("v_mul_hi_u32", 4, w); run<55>("v_lshl_or_b32", 4, w); run<56>("v_xad_u32", 4, w); run<57>("v_or3_b32", 4, w); run<58>("v_bfe_u32", 4, w); run<59>("v_max_i32", 4, w); run<60>("v_cvt_u32_f32", 4, w); run<61>("v_cvt_f32_u32", 4, w); run<62>("v_sub_f32", 4, w); run<63>("v_add_f32", 4, w); run<64>("v_fmac_f32", 4, w); run<65>("v_readlane_b32", 4, w); run<66>("v_writelane_b32", 4, w); run<67>("v_lshlrev_b32_sdwa", 4, w); run<68>("v_mad_u64_u32", 2, w); run<69>("v_and_b32(const)", 4, w); run<70>("v_mul_f32(sgpr)", 4, w);
+    run<71>("cndmask_e32+3add", 16, w); run<72>("v_cndmask_b32_e64(vcc)", 4, w); run<73>("v_cndmask_b32(const0)", 4, w); run<74>("v_cndmask_b32(dst!=src)", 4, w); run<75>("v_addc_co_u32", 4, w); run<76>("v_cmp+v_cndmask(vcc)", 8, w); run<77>("v_cmp_e64+cndmask_e64", 8, w); run<78>("v_add_co_u32(vcc)", 4, w); run<79>("v_min_u32", 4, w); run<80>("v_mul_u32_u24", 4, w);
   }
   if (json) {
     FILE* f = fopen(json, "w");

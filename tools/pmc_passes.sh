@@ -2,7 +2,7 @@
 #   PMC_CMD="python tools/bench_extra.py --only cfg2 --map-scans 256" PMC_OUT=pmc_cfg2 bash tools/pmc_passes.sh
 R=$GRAFT_REPO_ROOT
 OUT=${PMC_OUT:-pmc}
-CMD=${PMC_CMD:-python $R/bench.py --steps 2 --warmup 1 --no-cpu --no-diagnostics --sustained-s 0 --pipeline-depth 1 --plain-steps 2}
+CMD=${PMC_CMD:-python $R/bench.py --steps 2 --warmup 1 --no-cpu --no-diagnostics --sustained-s 0 --pipeline-depth 1 --pipelined-leg-depth 0 --plain-steps 2}
 mkdir -p $R/gpurun_out/$OUT && cd /tmp && export TMPDIR=/tmp
 run() { n=$1; shift; (cd $R && rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/$OUT/$n -o p -- $CMD > $R/gpurun_out/$OUT/$n.log 2>&1); }
 run sq SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU
