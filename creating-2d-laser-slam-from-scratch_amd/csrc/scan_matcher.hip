@@ -42,6 +42,10 @@ using namespace lslam;
 
 namespace {
 
+// diagnostic builds (-DLSLAM_PHASE_STAMPS, tools/phase_stamps.py): kernel ids of this translation unit's stamp table --
+// 0 k_find_valid (base-scan blocks), 1 k_smear_gather, 2 k_anchor_chain, 3 reduce_coarse_lds_block, 4 reduce_fine_block,
+// 5 resp_rows_wave (SOLO), 6 scan_prep_block
+LSLAM_STAMP_TABLE(g_sm_stamps)
 constexpr int kMaxLattice = 128;  // nX, nY per pass (loop-closure matcher: 101 x 101, Mapper.cpp:862-871)
 constexpr int kMaxAngles = 128;   // nA per pass
 constexpr int kMaxProbsSide = 255; // search-space probability grid side (loop closure: 201)
@@ -131,6 +135,7 @@ __device__ __forceinline__ void scan_prep_block(const RT* __restrict__ ranges, i
                                                 int setup_step, int bx, int nbx, int s) {
   const int nt = (int)blockDim.x;  // 256 (k_scan_prep) or 1024 (riding in k_find_valid's launch)
   int b = bx * nt + threadIdx.x;
+  LSLAM_PHASE_CLOCK(pck);
   // the scan's own transform (two rotation matrices, one normalised heading) is the same for all of
   // its beams: one thread of the block evaluates it
   __shared__ SensorXform s_t;
@@ -151,7 +156,9 @@ __device__ __forceinline__ void scan_prep_block(const RT* __restrict__ ranges, i
     r = (double)ranges[(size_t)s * stride + b];
     beam_world_point(sx, sy, sh, g.min_angle, g.ang_res, (uint32_t)b, r, px, py);
   }
+  LSLAM_PHASE_MARK(pck, 0);  // first world point (all) | the scan's transform (thread 0) | lattice + cos/sin (last wave)
   __syncthreads();
+  LSLAM_PHASE_MARK(pck, 1);  // waiting for the slowest of the three
   // nbx blocks share the beams of a scan: ONE for chip-filling batches (the single-thread transform above is
   // then paid once per scan, not once per 256 beams -- it was most of this kernel's time), ceil(n/256) otherwise
   for (bool first = true; b < g.n_beams; b += nbx * nt, first = false) {
@@ -171,6 +178,8 @@ __device__ __forceinline__ void scan_prep_block(const RT* __restrict__ ranges, i
       local[o] = make_double2(lx, ly);
     }
   }
+  LSLAM_PHASE_MARK(pck, 2);  // scan-frame points (+ further beams)
+  LSLAM_PHASE_FLUSH(pck, g_sm_stamps, 6, (unsigned)(blockIdx.x * (nt >> 6) + (threadIdx.x >> 6)), (threadIdx.x & 63) == 0);
 }
 
 template <typename RT>
@@ -492,6 +501,7 @@ __device__ __forceinline__ void resp_rows_wave(
   [[maybe_unused]] uint16_t* const ambq = lds.ambq;
   [[maybe_unused]] uint32_t (*const patch)[kPatchDw] = lds.patch;
   [[maybe_unused]] unsigned long long* const ambm = lds.ambm;
+  LSLAM_PHASE_CLOCK(pck);
   const Lattice& L = lat[s];
   if (!L.active || L.status != 0 || L.step_x != step || L.step_y != step) return;
 
@@ -513,6 +523,7 @@ __device__ __forceinline__ void resp_rows_wave(
   const uint32_t strip_bytes = (uint32_t)tile_rows * 32u;  // one 32-byte-wide strip, all class rows
   [[maybe_unused]] const int occ_wph = occ_wpc >> 1;  // words per (column, row parity)
 
+  LSLAM_PHASE_MARK(pck, 0);  // lattice record, cos/sin of the angle
   for (int j0 = 0; j0 < pc.ny; j0 += NYC) {
     // PEEL (the chip-filling variants): the accumulators are NOT zeroed -- phase A runs in two stages: until the first 64
     // beams are queued nothing is drained (the accumulators are not even live), the FIRST drain then WRITES them
@@ -932,6 +943,7 @@ __device__ __forceinline__ void resp_rows_wave(
     }
     if (qcount > 0) drain(qhead, qcount);
     wsync<SOLO>();
+    LSLAM_PHASE_MARK(pck, 1);  // phases A + B: every beam's cell, the queued beams' rows
     if constexpr (STATS) {
       const uint32_t t0 = wave_sum(st_rows), t1 = wave_sum(st_live), t2 = wave_sum(st_beams), t3 = wave_sum(st_queued);
       if (lane == 0 && stats) {
@@ -993,7 +1005,9 @@ __device__ __forceinline__ void resp_rows_wave(
       }
     }
     wsync<SOLO>();
+    LSLAM_PHASE_MARK(pck, 2);  // wave reduction + stores
   }
+  if constexpr (SOLO) LSLAM_PHASE_FLUSH(pck, g_sm_stamps, 5, (unsigned)blockIdx.x, (threadIdx.x & 63) == 0);
 }
 
 // The row kernel proper: one wave64 per block.
@@ -1564,6 +1578,7 @@ __device__ __forceinline__ void reduce_coarse_lds_block(
     if (tid == 0) { out[s].status = L.status; out[s].expand = 0; out[s].best = 0.0; }
     return;
   }
+  LSLAM_PHASE_CLOCK(pck);
   block_generic_fallback(grid, g, pc, L, local + (size_t)s * g.n_beams, r, fb_step, tid, NT);
   const int ncand = pc.nx * pc.ny;
   const int total = ncand * pc.na;
@@ -1605,6 +1620,7 @@ __device__ __forceinline__ void reduce_coarse_lds_block(
   for (int wd = tid; wd < words; wd += NT) mask[wd] = 0u;
   for (int c = tid; c < g.probs_side * g.probs_side; c += NT) probs[c] = 0.0;  // Clear (:329)
   __syncthreads();
+  LSLAM_PHASE_MARK(pck, 0);  // penalty tables, search-space cells, clears
 
   // penalised response of candidate (c, a): GetResponse normalisation (:852) and r *= (dp * ap) (:399-414)
   auto value_of = [&](int32_t sum, int c, int a) -> double {
@@ -1634,7 +1650,9 @@ __device__ __forceinline__ void reduce_coarse_lds_block(
     latmax[(size_t)part * ncand + c] = m;
     lm = lm > m ? lm : m;
   }
+  LSLAM_PHASE_MARK(pck, 1);  // numerators -> penalised responses (one division each), cell maxima
   const double best = block_max(lm, sh, tid, NT);  // contains the barriers that publish the latmax rows
+  LSLAM_PHASE_MARK(pck, 2);  // block maximum
 
   // best response per lattice cell over all angles, max-merged into the search-space probabilities
   // (Mapper.cpp:437-450); responses are >= +0, so the unsigned order of the bit patterns is the fp order
@@ -1662,6 +1680,7 @@ __device__ __forceinline__ void reduce_coarse_lds_block(
     if ((tid & 63) == 0 && wd < 256) s_nz[wd >> 6] = nz;
   }
   __syncthreads();
+  LSLAM_PHASE_MARK(pck, 3);  // probabilities merged, tie candidates re-evaluated, mask words
   if (tid == 0) {
     int st = s_bad ? LSLAM_ERR_PROBABILITY_SEARCH : 0;
     double avg[3] = {0, 0, 0};
@@ -1698,6 +1717,7 @@ __device__ __forceinline__ void reduce_coarse_lds_block(
     s_status = st;
   }
   __syncthreads();
+  LSLAM_PHASE_MARK(pck, 4);  // ordered tie average on thread 0 (cos, sin per tie, atan2)
   // No expansion passes follow: the block's LAST wave lays out the scan's fine lattice around the mean
   // just found (k_pass_setup, mode 2; one launch fewer) while the other waves go on to the covariance.
   // The lattice record of this pass is not read again below (centre and flags are in registers).
@@ -1737,6 +1757,7 @@ __device__ __forceinline__ void reduce_coarse_lds_block(
     }
     __syncthreads();
   }
+  LSLAM_PHASE_MARK(pck, 5);  // fine lattice (last wave) | covariance terms compacted in lattice order
   if (tid == 0) {
     CoarseOut o;
     o.status = s_status;
@@ -1782,6 +1803,8 @@ __device__ __forceinline__ void reduce_coarse_lds_block(
   // The fine pass follows at once and its beam-sliced form accumulates with atomics: clear its numerators here (every read
   // of this scan's coarse numerators is behind the barriers above) instead of a fill operation on the stream.
   for (int i = tid; i < zero_fine_words; i += NT) r[i] = 0;
+  LSLAM_PHASE_MARK(pck, 6);  // ordered covariance sums + record on thread 0, fine numerators cleared
+  LSLAM_PHASE_FLUSH(pck, g_sm_stamps, 3, (unsigned)(s * (NT >> 6) + (tid >> 6)), (tid & 63) == 0);
 }
 
 template <int NT>
@@ -2473,6 +2496,7 @@ __device__ __forceinline__ void reduce_fine_block(
     }
     return;
   }
+  LSLAM_PHASE_CLOCK(pck);
   block_generic_fallback(grid, g, pc, L, local + (size_t)s * g.n_beams, r, fb_step, tid, NT);
   const int ncand = pc.nx * pc.ny;
   const int total = ncand * pc.na;
@@ -2499,7 +2523,9 @@ __device__ __forceinline__ void reduce_fine_block(
   const int words = (total + 31) / 32;
   for (int wd = tid; wd < words; wd += NT) mask[wd] = 0u;
   for (int a = tid; a < kMaxAngles; a += NT) asum[a] = 0;
+  LSLAM_PHASE_MARK(pck, 0);  // penalised responses of the fine lattice
   const double best = block_max(lm, sh, tid, NT);
+  LSLAM_PHASE_MARK(pck, 1);  // block maximum
 #pragma unroll
   for (int i = 0; i < kKeep; i++) {
     const int k = tid + NT * i;
@@ -2525,6 +2551,7 @@ __device__ __forceinline__ void reduce_fine_block(
     s_pos = pos;
   }
   __syncthreads();
+  LSLAM_PHASE_MARK(pck, 2);  // tie mask + ordered tie average on thread 0
   if (s_status == 0) {
     // GetResponse(angleIndex, gridIndex) for every fine angle at the best cell (:663-666).
     // Usually that cell is one of the fine lattice cells whose numerators are already there.
@@ -2556,6 +2583,8 @@ __device__ __forceinline__ void reduce_fine_block(
     }
   }
   __syncthreads();
+  LSLAM_PHASE_MARK(pck, 3);  // angular-covariance numerators at the best cell
+  LSLAM_PHASE_FLUSH(pck, g_sm_stamps, 4, (unsigned)(s * (NT >> 6) + (tid >> 6)), (tid & 63) == 0 && tid != 0);
   if (tid != 0) return;
   lslam_match_result res;
   memset(&res, 0, sizeof res);
@@ -2586,6 +2615,8 @@ __device__ __forceinline__ void reduce_fine_block(
   }
   out[s] = res;
   signal_done();
+  LSLAM_PHASE_MARK(pck, 4);  // angular covariance + the record + ticket (thread 0)
+  LSLAM_PHASE_FLUSH(pck, g_sm_stamps, 4, (unsigned)(s * (NT >> 6)), true);
 }
 
 template <int NT>  // threads per block: 128 for chip-filling batches (residency), 256 otherwise; see k_reduce_coarse_lds
@@ -2804,6 +2835,7 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
     }
     return;
   }
+  LSLAM_PHASE_CLOCK(pck);
   const int slot = x.slot_list ? x.slot_list[b] : (ring_start + b) % cap;
   const double2* gp = world + (size_t)slot * n;
   uint8_t* gv = valid + (size_t)b * n;
@@ -2828,6 +2860,7 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
   }
   if (tid == 0) { s_first = n; s_len = 0; }
   __syncthreads();
+  LSLAM_PHASE_MARK(pck, 0);  // world points of the scan into LDS
   // the side test of anchor a against its successor f, and the run it keeps (:788-806)
   auto keep_run = [&](int a, int f, bool first) {
     const double fx = p[a].x, fy = p[a].y, cx = p[f].x, cy = p[f].y;
@@ -2871,6 +2904,7 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
     }
   }
   __syncthreads();
+  LSLAM_PHASE_MARK(pck, 1);  // anchors' side tests, runs marked valid
   if (use_lds)
     for (int i = tid; i < n; i += nt) gv[i] = v[i];
   // Fused AddScan stage (the streaming front-end rebuilds the grid once per scan, so a launch and the valid[] round trip
@@ -2894,6 +2928,8 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
       if (idx != 0xFFFFFFFFu && ((tid & 63) == 0 || left != idx)) grid[idx] = (uint8_t)mark_value;
     }
   }
+  LSLAM_PHASE_MARK(pck, 2);  // valid[] out, cells of the valid points tagged in the mark plane
+  LSLAM_PHASE_FLUSH(pck, g_sm_stamps, 0, (unsigned)(b * (nt >> 6) + (tid >> 6)), (tid & 63) == 0);
 }
 
 // The anchor chain of FindValidPoints for ONE scan (see k_find_valid), as row = [count, anchor indices in order]: launched
@@ -2910,6 +2946,7 @@ __device__ __forceinline__ void anchor_chain_block(int n, double2* __restrict__ 
   int* jb = ja + n;
   uint8_t* reach = (uint8_t*)(jb + n);
   const int tid = threadIdx.x, nt = blockDim.x;
+  LSLAM_PHASE_CLOCK(pck);
   for (int i = tid; i < n; i += nt) {
     double2 q;
     if (ranges) {
@@ -2923,6 +2960,7 @@ __device__ __forceinline__ void anchor_chain_block(int n, double2* __restrict__ 
   }
   if (tid == 0) s_first = n;
   __syncthreads();
+  LSLAM_PHASE_MARK(pck, 0);  // world points (fp64 sincos per beam)
   const double min_sq = ksq(0.1);
   for (int i = tid; i < n; i += nt) {
     if (!isnan(p[i].x) && !isnan(p[i].y)) atomicMin(&s_first, i);  // first anchor (Mapper.cpp:774-778)
@@ -2930,8 +2968,10 @@ __device__ __forceinline__ void anchor_chain_block(int n, double2* __restrict__ 
     ja[i] = next[i];
   }
   __syncthreads();
+  LSLAM_PHASE_MARK(pck, 1);  // successor of every point
   mark_reachable(n, s_first, ja, jb, reach, tid, nt);
   __syncthreads();
+  LSLAM_PHASE_MARK(pck, 2);  // pointer doubling
   int base = 0;
   for (int i0 = 0; i0 < n; i0 += nt) {  // ordered compaction of the anchors
     const int i = i0 + tid;
@@ -2946,6 +2986,8 @@ __device__ __forceinline__ void anchor_chain_block(int n, double2* __restrict__ 
     __syncthreads();
   }
   if (tid == 0) row[0] = base;
+  LSLAM_PHASE_MARK(pck, 3);  // ordered compaction of the anchors
+  LSLAM_PHASE_FLUSH(pck, g_sm_stamps, 2, (unsigned)(blockIdx.x * (nt >> 6) + (tid >> 6)), (tid & 63) == 0);
 }
 __global__ void __launch_bounds__(1024)
 k_anchor_chain(int n, double2* __restrict__ world, int* __restrict__ row, const double* __restrict__ ranges, PoseArg pose,
@@ -2994,8 +3036,10 @@ k_smear_gather(Geom g, const uint8_t* __restrict__ kernel, const uint8_t* __rest
                uint8_t* __restrict__ grid, uint8_t* __restrict__ f0, uint8_t* __restrict__ f1) {
   __shared__ uint8_t s_k[kMaxKernel * kMaxKernel];
   const int tid = threadIdx.x, ks = g.kernel_size, hk = ks / 2;
+  LSLAM_PHASE_CLOCK(pck);
   for (int i = tid; i < ks * ks; i += 256) s_k[i] = kernel[i];
   __syncthreads();
+  LSLAM_PHASE_MARK(pck, 0);  // smear kernel into LDS
   const long long f = ((long long)blockIdx.x * 256 + tid) * 16;
   if (f >= g.data_size) return;
   const uint32_t ep4 = epoch * 0x01010101u;
@@ -3052,6 +3096,7 @@ k_smear_gather(Geom g, const uint8_t* __restrict__ kernel, const uint8_t* __rest
       }
     }
   }
+  LSLAM_PHASE_MARK(pck, 1);  // own bytes + the neighbour rows' windows of the mark plane
   // every grid byte is written, so the grid needs no clear; the tail of the last chunk lies in the guard band and gets
   // its zeros back (no centre reaches past dataSize: the ROI keeps a border)
   *(uint4*)(grid + f) = make_uint4(out[0], out[1], out[2], out[3]);
@@ -3066,6 +3111,8 @@ k_smear_gather(Geom g, const uint8_t* __restrict__ kernel, const uint8_t* __rest
       ((uint32_t*)f1)[f / 8 + h] = o;
     }
   }
+  LSLAM_PHASE_MARK(pck, 2);  // grid bytes + parity planes stored
+  LSLAM_PHASE_FLUSH(pck, g_sm_stamps, 1, (unsigned)(blockIdx.x * 4 + (tid >> 6)), (tid & 63) == 0);
 }
 
 // AddScan (Mapper.cpp:716-748) for every valid point of every base scan in parallel: the thread
@@ -4417,6 +4464,29 @@ int lslam_matcher_flush(lslam_matcher* m) {
 
 int64_t lslam_matcher_pipelined_steps(const lslam_matcher* m) { return m ? (int64_t)m->pipe_steps : 0; }
 int64_t lslam_matcher_step_kernel_launches(const lslam_matcher* m) { return m ? (int64_t)m->step_launches : 0; }
+
+#if defined(LSLAM_PHASE_STAMPS)
+// diagnostic builds only: out[kernel][8 cycle sums | 8 visit counts] of this translation unit's stamp table (summed over the
+// wave slots); reset != 0 clears it
+int lslam_debug_matcher_stamps(lslam_context* ctx, unsigned long long* out, int reset) {
+  if (!ctx || !out) return LSLAM_ERR_INVALID_ARGUMENT;
+  LSLAM_HIP(ctx, hipDeviceSynchronize());
+  const size_t n = (size_t)lslam::kStampKernels * lslam::kStampSlots * 16;
+  std::vector<unsigned long long> h(n);
+  LSLAM_HIP(ctx, hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_sm_stamps_slots), n * sizeof(unsigned long long)));
+  for (int k = 0; k < lslam::kStampKernels; k++)
+    for (int i = 0; i < 16; i++) {
+      unsigned long long sum = 0;
+      for (int sl = 0; sl < lslam::kStampSlots; sl++) sum += h[((size_t)k * lslam::kStampSlots + sl) * 16 + i];
+      out[k * 16 + i] = sum;
+    }
+  if (reset) {
+    std::fill(h.begin(), h.end(), 0ull);
+    LSLAM_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_sm_stamps_slots), h.data(), n * sizeof(unsigned long long)));
+  }
+  return LSLAM_OK;
+}
+#endif
 
 int lslam_matcher_read_stats(lslam_matcher* m, uint64_t out[4]) {
   if (!m || !out) return LSLAM_ERR_INVALID_ARGUMENT;

@@ -22,7 +22,55 @@ from lslam_amd import api, synth  # noqa: E402
 
 MAP_KERNELS = {0: ("k_lo_batch_rays", ["scan header", "beam line (point load + transform)", "cell addresses (closed-form Bresenham)",
                                        "plane bytes back (loads)", "marks + flags issued"])}
-MATCHER_KERNELS = {}
+MATCHER_KERNELS = {
+    0: ("k_find_valid (base-scan blocks)", ["world points of the scan into LDS", "anchors' side tests, runs marked valid",
+                                            "valid[] out, cells tagged in the mark plane"]),
+    1: ("k_smear_gather", ["smear kernel into LDS", "own bytes + neighbour rows of the mark plane", "grid + parity planes stored"]),
+    2: ("k_anchor_chain", ["world points (fp64 sincos per beam)", "successor of every point", "pointer doubling",
+                           "ordered compaction of the anchors"]),
+    3: ("reduce_coarse_lds_block", ["penalty tables, cells, clears", "numerators -> responses (division), cell maxima", "block maximum",
+                                    "probabilities merged, tie candidates, mask words", "ordered tie average (thread 0)",
+                                    "fine lattice | covariance terms compacted", "ordered covariance sums + record (thread 0)"]),
+    4: ("reduce_fine_block", ["penalised responses", "block maximum", "tie mask + ordered tie average (thread 0)",
+                              "angular-covariance numerators", "angular covariance + record + ticket (thread 0)"]),
+    5: ("resp_rows_wave (one wave per block)", ["lattice record, cos/sin", "phases A + B", "wave reduction + stores"]),
+    6: ("scan_prep_block", ["first world point | transform (thread 0) | lattice (last wave)", "barrier: the slowest of the three",
+                            "scan-frame points"]),
+}
+
+
+def lone(ctx):
+    """The streamed single-scan chain: lslam_frontend_process, pose graph bookkeeping on, loop closing off, 600 scans."""
+    import bench
+
+    L = api.lib()
+    L.lslam_debug_matcher_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    n = 600
+    laser = synth.Laser()
+    path = synth.rings_trajectory(n)
+    world = synth.arena_around_path(path, size=100.0, n_axis=30, n_rot=10, seed=6)
+    odom = synth.drifting_odometry(path, scale=1.01, sigma_xy=0.004, sigma_th=0.0015, seed=6)
+    import os
+
+    scans32 = bench.cast_scans(world, laser, path, 0, 6, max(1, min(32, os.cpu_count() or 1)))
+    r64 = [synth.ranges_to_f64(r) for r in scans32]
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
+    fe = api.FrontEnd(gm)
+    for r, o in zip(r64[:80], odom[:80]):
+        fe.Process(r, o)
+    fe.reset()
+    ctx.synchronize()
+    read(ctx, L.lslam_debug_matcher_stamps)
+    import time
+
+    t0 = time.perf_counter()
+    for r, o in zip(r64, odom):
+        fe.Process(r, o)
+    ctx.synchronize()
+    wall = time.perf_counter() - t0
+    cyc, vis = read(ctx, L.lslam_debug_matcher_stamps)
+    return {"workload": "streaming front-end, 600 scans, 70-scan window, loop closing off (diagnostic build: the stamps cost time)",
+            "us_per_scan_instrumented": round(1e6 * wall / n, 1), "scans": n, "kernels": table(cyc, vis, MATCHER_KERNELS)}
 
 
 def read(ctx, fn, reset=True):
