@@ -1386,8 +1386,10 @@ __device__ int tie_average(const uint32_t* mask, int total, const PassCfg& pc, c
       double h = normalize_angle(cd.angle);  // stored heading (:417-418)
       ax += center[0] + cd.x;
       ay += center[1] + cd.y;
-      tx += cos(h);
-      ty += sin(h);
+      double sn, cs;  // one argument reduction for both (ocml's sincos returns sin's and cos's own values)
+      sincos(h, &sn, &cs);
+      tx += cs;
+      ty += sn;
       cnt++;
     }
   }
@@ -1700,8 +1702,10 @@ __device__ __forceinline__ void reduce_coarse_lds_block(
             const double h = normalize_angle(cd.angle);  // stored heading (:417-418)
             ax += center[0] + cd.x;
             ay += center[1] + cd.y;
-            tx += cos(h);
-            ty += sin(h);
+            double sn, cs;  // one argument reduction for both (ocml's sincos returns sin's and cos's own values)
+            sincos(h, &sn, &cs);
+            tx += cs;
+            ty += sn;
             cnt++;
           }
         }
@@ -2297,7 +2301,9 @@ k_reduce_coarse_big(Geom g, PassCfg pc, SearchCfg sc, const Lattice* __restrict_
       Cand cd = cand_of(k, pc, center);
       double h = normalize_angle(cd.angle);
       ax += center[0] + cd.x; ay += center[1] + cd.y;
-      tx += cos(h); ty += sin(h);
+      double sn, cs;
+      sincos(h, &sn, &cs);
+      tx += cs; ty += sn;
       cnt++;
     };
     if (listed) {
