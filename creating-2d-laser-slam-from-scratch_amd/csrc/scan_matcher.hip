@@ -40,6 +40,17 @@
 
 using namespace lslam;
 
+// A block's ordered sums run on ONE thread while its other waves wait at the next barrier: that wave's instructions are the
+// block's critical path, and on a SIMD it shares with seven other waves it gets an eighth of the issue slots.  Raising its
+// priority for the length of the section hands it the slots the waiting waves do not need (s_setprio: arbitration only).
+#if defined(LSLAM_EXP_SERIAL_PRIO)
+#define LSLAM_SERIAL_BEGIN() __builtin_amdgcn_s_setprio(3)
+#define LSLAM_SERIAL_END() __builtin_amdgcn_s_setprio(0)
+#else
+#define LSLAM_SERIAL_BEGIN()
+#define LSLAM_SERIAL_END()
+#endif
+
 namespace {
 
 // diagnostic builds (-DLSLAM_PHASE_STAMPS, tools/phase_stamps.py): kernel ids of this translation unit's stamp table --
@@ -141,9 +152,11 @@ __device__ __forceinline__ void scan_prep_block(const RT* __restrict__ ranges, i
   __shared__ SensorXform s_t;
   __shared__ double s_h;
   if (local && threadIdx.x == 0) {
+    LSLAM_SERIAL_BEGIN();
     s_t = sensor_xform(sx, sy, sh);
     // rSourcePose - m_Transform (Pose2 operator-, Karto.h:2138-2141), heading = normalize(0 - th)
     s_h = normalize_angle(0.0 - s_t.th);
+    LSLAM_SERIAL_END();
   }
   // Meanwhile the LAST wave of the scan's first block lays out the coarse search lattice (k_pass_setup, mode 0), and
   // every thread evaluates its first world point: neither needs the transform thread 0 is working on.
@@ -1637,7 +1650,10 @@ __device__ __forceinline__ void reduce_coarse_lds_block(
     const int part = idx / ncand, c = idx - part * ncand;
     const int a_lo = part * pc.na / parts, a_hi = (part + 1) * pc.na / parts;
     double m = -1.0;
-    constexpr int kBatch = 11;
+#if !defined(LSLAM_TUNE_REDUCE_BATCH)
+#define LSLAM_TUNE_REDUCE_BATCH 11
+#endif
+    constexpr int kBatch = LSLAM_TUNE_REDUCE_BATCH;
     for (int a0 = a_lo; a0 < a_hi; a0 += kBatch) {
       int32_t rv[kBatch];
 #pragma unroll
@@ -1684,6 +1700,7 @@ __device__ __forceinline__ void reduce_coarse_lds_block(
   __syncthreads();
   LSLAM_PHASE_MARK(pck, 3);  // probabilities merged, tie candidates re-evaluated, mask words
   if (tid == 0) {
+    LSLAM_SERIAL_BEGIN();
     int st = s_bad ? LSLAM_ERR_PROBABILITY_SEARCH : 0;
     double avg[3] = {0, 0, 0};
     if (st == 0) {  // tie average in lattice order (Mapper.cpp:456-483), only over the words that hold ties
@@ -1719,6 +1736,7 @@ __device__ __forceinline__ void reduce_coarse_lds_block(
     }
     s_avg[0] = avg[0]; s_avg[1] = avg[1]; s_avg[2] = avg[2];
     s_status = st;
+    LSLAM_SERIAL_END();
   }
   __syncthreads();
   LSLAM_PHASE_MARK(pck, 4);  // ordered tie average on thread 0 (cos, sin per tie, atan2)
@@ -2541,6 +2559,7 @@ __device__ __forceinline__ void reduce_fine_block(
     if (double_equal(value(k), best)) atomicOr(&mask[k >> 5], 1u << (k & 31));
   __syncthreads();
   if (tid == 0) {
+    LSLAM_SERIAL_BEGIN();
     double avg[3] = {0, 0, 0};
     int st = 0;
     if (tie_average(mask, total, pc, center, avg) == 0) st = LSLAM_ERR_NO_BEST_POSE;
@@ -2555,6 +2574,7 @@ __device__ __forceinline__ void reduce_fine_block(
     s_best = best;
     s_status = st;
     s_pos = pos;
+    LSLAM_SERIAL_END();
   }
   __syncthreads();
   LSLAM_PHASE_MARK(pck, 2);  // tie mask + ordered tie average on thread 0
@@ -2592,6 +2612,7 @@ __device__ __forceinline__ void reduce_fine_block(
   LSLAM_PHASE_MARK(pck, 3);  // angular-covariance numerators at the best cell
   LSLAM_PHASE_FLUSH(pck, g_sm_stamps, 4, (unsigned)(s * (NT >> 6) + (tid >> 6)), (tid & 63) == 0 && tid != 0);
   if (tid != 0) return;
+  LSLAM_SERIAL_BEGIN();
   lslam_match_result res;
   memset(&res, 0, sizeof res);
   res.flags = co.flags;

@@ -125,10 +125,46 @@ def rays(ctx):
             "kernels": table(cyc, vis, MAP_KERNELS)}
 
 
+def batch(ctx, n_scans=4096, steps=10):
+    """The headline step: `n_scans` distinct scans vs the shared grid (bench.py's workload), plain steps."""
+    import bench
+    import torch
+
+    L = api.lib()
+    L.lslam_debug_matcher_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    laser, world = synth.Laser(), synth.arena()
+    wl = synth.make_match_workload(n_base=70, n_query=1, seed=5, query_spread=3.0, world=world)
+    truth = bench.query_poses(world, wl.center_pose, n_scans, 3.0, seed=55)
+    odom = synth.perturb(truth, 0.3, np.deg2rad(10.0), 77)
+    ranges = bench.cast_scans(world, laser, truth, 0, 555, 8)
+    gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
+    gm.AddScans(wl.base_ranges, wl.base_poses, wl.center_pose)
+    dev = torch.device("cuda", 0)
+    r = torch.from_numpy(np.ascontiguousarray(ranges)).to(dev)
+    p = torch.from_numpy(np.ascontiguousarray(odom)).to(dev)
+    out = torch.empty((n_scans, 112), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        gm.match_batch_dev(n_scans, r.data_ptr(), r.shape[1], p.data_ptr(), out.data_ptr(), dtype="f32")
+    ctx.synchronize()
+    read(ctx, L.lslam_debug_matcher_stamps)
+    c0 = ctx.clock_sample()
+    for _ in range(steps):
+        gm.match_batch_dev(n_scans, r.data_ptr(), r.shape[1], p.data_ptr(), out.data_ptr(), dtype="f32")
+    ctx.synchronize()
+    c1 = ctx.clock_sample()
+    cyc, vis = read(ctx, L.lslam_debug_matcher_stamps)
+    return {"workload": "bench.py's step: %d distinct scans vs the shared 2005^2 grid, %d plain steps (diagnostic build)" % (n_scans, steps),
+            "shader_clock_ghz": ctx.clock_ghz(c0, c1), "kernels": table(cyc, vis, MATCHER_KERNELS)}
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "rays"
+    import torch  # (initialised before the library's own HIP context, like bench.py and the tests do)
+
+    torch.cuda.init()
     ctx = api.Context(0)
-    out = rays(ctx) if what == "rays" else lone(ctx)
+    out = rays(ctx) if what == "rays" else batch(ctx, int(sys.argv[2]) if len(sys.argv) > 2 else 4096) if what == "batch" else lone(ctx)
     print(json.dumps(out, indent=1))
 
 
