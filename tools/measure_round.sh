@@ -23,6 +23,10 @@ python tools/pmc_summary.py gpurun_out/pmc_cfg2_$TAG > $O/pmc_cfg2_per_launch.js
 python tools/pmc_summary.py gpurun_out/pmc_cfg2_4000_$TAG > $O/pmc_cfg2_4000_per_launch.json
 rm -rf gpurun_out/pmc_$TAG gpurun_out/pmc_cfg2_$TAG gpurun_out/pmc_cfg2_4000_$TAG gpurun_out/prof_stats
 python tools/make_traffic.py $O/pmc_per_launch.json 4096 $O/pmc_cfg2_per_launch.json > $O/traffic.json
+# the mix-weighted VALU floor of the two throughput kernels from the same PMC pass (needs hipcc: compiles the source with line tables)
+(timeout 600 python tools/make_valu_mix.py $O/pmc_per_launch.json 4096 > $O/valu_mix.json 2> $O/valu_mix.err)
+# round 6: the five-kernel step against the step kernel / multi-wave coarse blocks (measured options, default off)
+(timeout 400 python tools/step_ab.py --variants 0,3,4,104 --sizes 512,4096 > $O/step_ab.json 2> $O/step_ab.err)
 (timeout 600 python tools/bench_extra.py --stream-ref 0 2>/dev/null | grep "^{" > $O/extra_configs.jsonl)
 (timeout 200 python tools/bench_extra.py --only cfg2 --map-size 4000 --map-cell 0.025 2>/dev/null | grep "^{" > $O/extra_cfg2_4000.jsonl)
 (timeout 300 python tools/dropin_bench.py 2>/dev/null | grep "^{" > $O/dropin.jsonl)
