@@ -330,6 +330,8 @@ def lib() -> C.CDLL:
     L.lslam_matcher_pipelined_steps.restype = C.c_int64
     L.lslam_matcher_step_kernel_launches.argtypes = [vp]
     L.lslam_matcher_step_kernel_launches.restype = C.c_int64
+    L.lslam_matcher_lone_kernel_launches.argtypes = [vp]
+    L.lslam_matcher_lone_kernel_launches.restype = C.c_int64
     i64 = C.c_int64
     L.lslam_scan_cache_create.argtypes = [vp, C.POINTER(LaserParams), C.POINTER(vp)]
     L.lslam_scan_cache_destroy.argtypes = [vp]
@@ -524,13 +526,18 @@ class ScanMatcher:
 
     def set_option(self, name: str, value: int):
         opt = {"row_occupancy": 1, "collect_stats": 2, "lds_staged": 3, "pipeline_depth": 4, "step_kernel": 5,
-               "step_min_scans": 6, "rows_waves": 7, "check_output_reuse": 8}[name]
+               "step_min_scans": 6, "rows_waves": 7, "check_output_reuse": 8, "lone_kernel": 9}[name]
         self.ctx.check(self.L.lslam_matcher_set_option(self.h, opt, int(value)))
 
     @property
     def step_kernel_launches(self) -> int:
         """Batched matches that went out as ONE launch (set_option('step_kernel', 3 or 4)) so far."""
         return int(self.L.lslam_matcher_step_kernel_launches(self.h))
+
+    @property
+    def lone_kernel_launches(self) -> int:
+        """Single-scan matches that went out as ONE launch (set_option('lone_kernel', 4 / 8 / 16)) so far."""
+        return int(self.L.lslam_matcher_lone_kernel_launches(self.h))
 
     def flush(self):
         """Order the context stream behind every pipelined step in flight (set_option('pipeline_depth', D > 1))."""

@@ -507,7 +507,7 @@ __device__ __forceinline__ void resp_rows_wave(
   constexpr bool EST = TILED;  // phase A on the fp32 estimate, two blocks in flight: the chip-filling batches (see phase A)
   constexpr int kQueue = kRowsQueue;
   static_assert(NYC <= 16 && 2 * (NYC - 1) < 32, "row mask / occupancy window width");
-  static_assert(SOLO || (TILED && !STATS && !LDSB), "multi-wave blocks run the tiled production variant only");
+  static_assert(SOLO || (!STATS && !LDSB), "multi-wave blocks run the production variants only");
   static_assert(!(SOLO && OUT_LDS), "a lone wave writes its numerators to global memory");
   uint32_t (*const red)[8] = lds.red;
   int2* const queue = lds.queue;
@@ -2732,6 +2732,140 @@ k_match_step(const RT* __restrict__ ranges, int stride, const double* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_match_lone -- the four kernels of ONE scan's match (coarse responses, coarse reduce, fine responses, fine reduce) as
+// ONE launch with device-side hand-overs (round 6; profiles/r06/lone_chain_phases.md).
+// A lone MatchScan is a chain of small dependent launches, and a dependent launch costs 4-5 us on this stack against
+// 3-11 us of work in each kernel.  Moving the chain onto ONE CU loses (k_match_tail: the fine pass does not fit there), so
+// this kernel keeps the chain's SHAPE and replaces the launches by words in device memory:
+//   * the response passes want one wave per CU (a wave's gathers are bound by its CU's lookup rate: four waves on a CU
+//     take twice as long as four CUs), the reduces want a wide block (1024 threads: a cell's angles over 8 threads).  So a
+//     block is WAVES waves of which only the first TW draw (angle, beam slice) tasks -- the others go straight to the barrier
+//     and cost nothing there -- and the launch is as many blocks as there are tasks / TW;
+//   * every block bumps `c_done` when its tasks are done (release); the block that arrives LAST runs the coarse reduce with all
+//     its waves (nobody waits for it to start) and posts `fine_ready`; the other blocks wait on that one word (bounded; s_sleep
+//     between polls); fine tasks the same way, the last block to arrive runs the fine reduce and writes the record (+ the
+//     caller's ticket).
+// One wait per block, bounded by the coarse reduce.  A wait that does not end (it would take a grid that does not fit the
+// chip -- it is at most 168 blocks, one per CU -- and a dispatcher that starts nothing new) gives up after ~40 ms, the record
+// carries LSLAM_ERR_HIP, nothing hangs.  The words of a launch live in slot seq % kLoneRing of a ring; the last block clears
+// the slot half a ring ahead (launches of a matcher are ordered on its stream).  Same wave functions, same beam slices, same
+// atomically accumulated integers as the four-kernel chain: records are byte-identical.
+// (Tried and dropped: tasks drawn from a ticket counter -- two more dependent atomics per wave and pass, +6 us; all
+//  participants on ONE XCD so that a hand-over needs no L2 write-back / invalidate -- 168 tasks on 32 CUs, +12 us.)
+// ------------------------------------------------------------------------------------------
+struct LoneSync {
+  unsigned c_done, fine_ready, f_done, timeouts, pad[4];
+};
+constexpr int kLoneRing = 16;
+// the word as memory holds it: a compare-and-swap that changes nothing (never served from an L1, never folded into a load)
+__device__ __forceinline__ unsigned lone_peek(unsigned* w) {
+  unsigned expected = 0xFFFFFFFFu;
+  __hip_atomic_compare_exchange_strong(w, &expected, 0xFFFFFFFFu, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return expected;
+}
+__device__ __forceinline__ bool lone_wait(unsigned* w) {
+  for (int i = 0; i < (1 << 15); i++) {  // ~40 ms; the wait is for one block's coarse reduce (~10 us)
+    if (lone_peek(w) != 0u) return true;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return false;
+}
+// the hand-overs' fences, as weak as each side allows (a full agent-scope fence is an L2 write-back AND an invalidate: ~2.5 us)
+#if defined(LSLAM_EXP_LONE_FULL_FENCES)  // A/B switch: the first draft
+#define LONE_ARRIVE_FENCE() __threadfence()
+#define LONE_ACQUIRE() __threadfence()
+#define LONE_RELEASE() __threadfence()
+#else
+#define LONE_ARRIVE_FENCE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define LONE_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#define LONE_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#endif
+template <int NXD, int NYC, int WAVES, int TW>
+__global__ void __launch_bounds__(64 * WAVES)
+k_match_lone(const uint8_t* sub0, const uint8_t* sub1, const uint8_t* grid, Geom g, PassCfg pc, PassCfg pf, SearchCfg sc,
+             Lattice* lat, double2* cossin, double2* local, int32_t* resp, CoarseOut* coarse, lslam_match_result* out,
+             const uint2* occ, int occ_wpc, int c_slices, int f_slices, int parts, LoneSync* ring, unsigned seq,
+             int* done_flag, int done_ticket) {
+  constexpr int NT = 64 * WAVES;
+  constexpr int kArea = rows_wave_area<NXD>();
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  LoneSync* const sy = ring + (seq % kLoneRing);
+  const int nwaves = (int)gridDim.x * TW, w = (int)blockIdx.x * TW + wave;
+  LSLAM_PHASE_CLOCK(pck);
+
+  // 1: coarse response numerators (Mapper.cpp:373-424, 819-856), one (angle, beam slice) per task wave
+  if (wave < TW) {
+    unsigned char* wa = smem + wave * kArea;
+    const RowsLds lds{(uint32_t (*)[8])wa, (int2*)wa, nullptr, nullptr, nullptr};
+    for (int t = w; t < pc.na * c_slices; t += nwaves)
+      resp_rows_wave<NXD, NYC, false, false, false, false, false>(0, t / c_slices, t % c_slices, sub0, sub1, 2, g.data_size / 2, g, pc,
+                                                                  lat, cossin, local, resp, 0, c_slices, occ, occ_wpc, 0, 0u,
+                                                                  (unsigned long long*)nullptr, lds, (int32_t*)nullptr);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's atomics are performed
+  LSLAM_PHASE_MARK(pck, 0);  // coarse tasks
+  __syncthreads();
+  if (tid == 0) {
+    LONE_ARRIVE_FENCE();  // this block published nothing but atomics: they are performed (every wave waited before the barrier)
+    s_last = __hip_atomic_fetch_add(&sy->c_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+  }
+  __syncthreads();
+  LSLAM_PHASE_MARK(pck, 1);  // the block's slowest wave, release fence, arrival
+  if (s_last) {
+    // 2: Mapper.cpp:431-501, 535-630 (+ the fine lattice around the mean, the fine numerators cleared)
+    LONE_ACQUIRE();  // every block's numerators
+    reduce_coarse_lds_block<NT>(0, tid, g, pc, sc, lat, resp, coarse, 0, 0, grid, local, 2, pf, cossin, 1, pf.nx * pf.ny * pf.na,
+                                parts, smem);
+    LONE_RELEASE();  // the fine lattice, cos/sin, the cleared numerators, the coarse record
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(&sy->fine_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (tid == 0 && !lone_wait(&sy->fine_ready)) __hip_atomic_fetch_add(&sy->timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    LONE_ACQUIRE();  // the fine lattice, cos/sin, the cleared numerators
+  }
+  LSLAM_PHASE_MARK(pck, 2);  // the coarse reduce (last block) | the wait for it + acquire fence (the others)
+  // 3: fine response numerators, one-cell steps on the grid itself
+  if (wave < TW) {
+    unsigned char* wa = smem + wave * kArea;
+    const RowsLds lds{(uint32_t (*)[8])wa, (int2*)wa, nullptr, nullptr, nullptr};
+    for (int t = w; t < pf.na * f_slices; t += nwaves)
+      resp_rows_wave<1, 4, false, false, false, false, false>(0, t / f_slices, t % f_slices, grid, grid, 1, g.data_size, g, pf, lat,
+                                                              cossin, local, resp, 0, f_slices, (const uint2*)nullptr, occ_wpc, 0, 0u,
+                                                              (unsigned long long*)nullptr, lds, (int32_t*)nullptr);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  LSLAM_PHASE_MARK(pck, 3);  // fine tasks
+  __syncthreads();
+  if (tid == 0) {
+    LONE_ARRIVE_FENCE();
+    s_last = __hip_atomic_fetch_add(&sy->f_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+  }
+  __syncthreads();
+  LSLAM_PHASE_MARK(pck, 4);  // slowest wave, release fence, arrival
+  LSLAM_PHASE_FLUSH(pck, g_sm_stamps, 7, (unsigned)blockIdx.x, tid == 0);
+  if (!s_last) return;
+  // 4: Mapper.cpp:431-506, 641-692, the record
+  LONE_ACQUIRE();
+  const bool timed_out = lone_peek(&sy->timeouts) != 0u;
+  reduce_fine_block<NT>(0, tid, grid, g, pf, sc, lat, resp, local, coarse, out, 1, 1, timed_out ? (int*)nullptr : done_flag,
+                        done_ticket, smem);
+  if (tid < (int)(sizeof(LoneSync) / 4)) ((unsigned*)(ring + ((seq + kLoneRing / 2) % kLoneRing)))[tid] = 0u;
+  if (timed_out) {  // a hand-over that did not arrive: the record must not pass for a result
+    __syncthreads();
+    if (tid == 0) {
+      out[0].status = LSLAM_ERR_HIP;
+      if (done_flag) {
+        __threadfence_system();
+        *(volatile int*)done_flag = done_ticket;
+      }
+    }
+  }
+}
+
 // result for a laser with zero beams (Mapper.cpp:199-209)
 __global__ void k_result_no_readings(int S, const double* poses, double coarse_ang_res,
                                      lslam_match_result* out) {
@@ -3290,6 +3424,11 @@ struct lslam_matcher {
   bool collect_stats = false;       // lslam_matcher_set_option(LSLAM_OPT_COLLECT_STATS): instrumented coarse kernel
   bool lds_staged = false;          // lslam_matcher_set_option(LSLAM_OPT_LDS_STAGED): the measured-and-dropped LDS-staged phase B
   int rows_waves = 1;               // lslam_matcher_set_option(LSLAM_OPT_ROWS_WAVES): waves per block of the tiled coarse kernel (1 = k_resp_rows, 2 / 4 / 8 = k_resp_rows_mw)
+  int lone_waves = 0;               // LSLAM_OPT_LONE_KERNEL: 0 = four launches for the match of ONE scan, 4 / 8 / 16 = k_match_lone with that many waves per block
+  LoneSync* d_lone_sync = nullptr;  // its hand-over words: a ring of kLoneRing slots
+  unsigned lone_seq = 0;            // launches so far: slot seq % kLoneRing of the ring
+  bool lone_task_waves_all = false; // option value + 100: every wave of a block takes response tasks (the A/B reference)
+  long long lone_launches = 0;
   int step_waves = 0;               // lslam_matcher_set_option(LSLAM_OPT_STEP_KERNEL): 0 = five launches per step, 3 / 4 = k_match_step with that many waves per scan
   int step_min_scans = 64;          // batches below this keep the five-kernel path (its beam-sliced kernels fill the chip)
   uint64_t step_launches = 0;       // k_match_step launches so far (diagnostics / tests)
@@ -3895,6 +4034,63 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     launch(ctx, "scan_prep", k_scan_prep<RT>, dim3(S >= kReduceNarrowMinScans ? 1 : (g.n_beams + 255) / 256, S), dim3(256), 0, d_ranges,
            stride, d_poses, g, m->d_local.p, (double2*)nullptr, pc, m->d_lat.p, m->d_cossin.p, 2, PoseArg{});
 
+  // ONE launch for the match of ONE scan (k_match_lone): the chain's four kernels behind device-side hand-overs.  The same
+  // conditions as the kernels it replaces (<3,11> / <4,8> coarse, <1,4> fine, the LDS form of the coarse reduce, eight beam
+  // slices at most), nothing that reads the numerators between the passes.
+  if (m->lone_waves > 0 && S == 1 && !m->pipe_in_step) {
+    const int cvar = (pc.nx <= 4 && pc.ny <= 4) ? 1 : (pc.nx <= 12) ? 2 : (pc.nx <= 16) ? 3 : 0;
+    const size_t ctotal = (size_t)pc.nx * pc.ny * pc.na, ftotal = (size_t)pf.nx * pf.ny * pf.na;
+    auto slices_for = [&](int na) {
+      int sl = 1;
+      while (sl < 8 && 8LL * na * sl < 2048) sl *= 2;
+      while ((g.n_beams + 64 * sl - 1) / (64 * sl) > kMaxBeamsPerLane) sl *= 2;
+      return sl;
+    };
+    const int W = m->lone_waves, NT = 64 * W, parts = reduce_parts(pc, NT);
+    const int TW = m->lone_task_waves_all ? W : 1;  // waves of a block that take response tasks
+    const int c_slices = slices_for(pc.na), f_slices = slices_for(pf.na);
+    const int area = cvar == 2 ? rows_wave_area<3>() : rows_wave_area<4>();
+    const size_t lds = std::max<size_t>({(size_t)TW * area, reduce_lds_nocache(pc, parts), ((ftotal + 31) / 32) * 4 + 16});
+    const int tasks = std::max(pc.na * c_slices, pf.na * f_slices);
+    const bool ok = !force_generic && n_exp == 0 && do_refine && !m->collect_stats && !m->lds_staged && !dbg_coarse_sums &&
+                    !m->dbg_fine && (cvar == 2 || cvar == 3) && pc.ny <= 32 && pf.nx <= 4 && pf.ny <= 4 && g.probs_side <= 63 &&
+                    (ctotal + 31) / 32 <= 256 && (ftotal + 31) / 32 <= 256 && lds <= 60 * 1024 && c_slices > 1 && f_slices > 1 &&
+                    (tasks + TW - 1) / TW <= 256;  // every block resident at once: one per CU
+    if (ok) {
+      if (!m->d_lone_sync) {
+        LSLAM_HIP(ctx, hipMalloc((void**)&m->d_lone_sync, kLoneRing * sizeof(LoneSync)));
+        LSLAM_HIP(ctx, hipMemsetAsync(m->d_lone_sync, 0, kLoneRing * sizeof(LoneSync), ctx->stream));
+        m->lone_seq = 0;
+      }
+      if (prezeroed >= resp_stride) prezeroed = 0;  // k_rebuild_begin cleared the numerators; one use
+      else LSLAM_HIP(ctx, hipMemsetAsync(m->d_resp.p, 0, resp_stride * sizeof(int32_t), ctx->stream));
+      const unsigned nb = (unsigned)((tasks + TW - 1) / TW);
+      const uint2* occ = (want_occ && 2 * (pc.nx - 1) + 1 <= m->occ_win) ? m->d_occ_x : (const uint2*)nullptr;
+      const unsigned seq = m->lone_seq++;
+#define LSLAM_LONE(NXD_, NYC_, W_, TW_)                                                                                     \
+  launch(ctx, "match_lone", k_match_lone<NXD_, NYC_, W_, TW_>, dim3(nb), dim3(64 * W_), lds, (const uint8_t*)m->d_sub[0],     \
+         (const uint8_t*)m->d_sub[1], (const uint8_t*)m->d_grid, g, pc, pf, sc, m->d_lat.p, m->d_cossin.p, m->d_local.p,      \
+         m->d_resp.p, m->d_coarse.p, d_out, occ, m->occ_wpc, c_slices, f_slices, parts, m->d_lone_sync, seq, done_flag,       \
+         done_ticket)
+#define LSLAM_LONE_W(NXD_, NYC_)                                                                                            \
+  do {                                                                                                                       \
+    if (W == 4 && TW == 1) LSLAM_LONE(NXD_, NYC_, 4, 1);                                                                     \
+    else if (W == 8 && TW == 1) LSLAM_LONE(NXD_, NYC_, 8, 1);                                                                \
+    else if (TW == 1) LSLAM_LONE(NXD_, NYC_, 16, 1);                                                                         \
+    else if (W == 4) LSLAM_LONE(NXD_, NYC_, 4, 4);                                                                           \
+    else if (W == 8) LSLAM_LONE(NXD_, NYC_, 8, 8);                                                                           \
+    else LSLAM_LONE(NXD_, NYC_, 16, 16);                                                                                     \
+  } while (0)
+      if (cvar == 2) LSLAM_LONE_W(3, 11);
+      else LSLAM_LONE_W(4, 8);
+#undef LSLAM_LONE_W
+#undef LSLAM_LONE
+      m->lone_launches++;
+      LSLAM_HIP(ctx, hipGetLastError());
+      return LSLAM_OK;
+    }
+  }
+
   int rc = run_coarse(pc, 0);
   if (rc) return rc;
   for (int e = 0; e < n_exp; e++) {
@@ -4340,6 +4536,7 @@ void lslam_matcher_destroy(lslam_matcher* m) {
   m->d_tbl.release(); m->d_part.release(); m->d_big.release(); m->d_results.release(); m->d_dbg.release();
   m->d_query.release(); m->d_qpose.release();
   if (m->h_done) (void)hipHostFree(m->h_done);
+  if (m->d_lone_sync) (void)hipFree(m->d_lone_sync);
   if (m->h_query) (void)hipHostFree(m->h_query);
   if (m->h_result) (void)hipHostFree(m->h_result);
   delete m;
@@ -4440,6 +4637,17 @@ int lslam_matcher_set_option(lslam_matcher* m, int option, int value) {
     case LSLAM_OPT_CHECK_OUTPUT_REUSE:
       m->check_out_reuse = value != 0;
       return LSLAM_OK;
+    case LSLAM_OPT_LONE_KERNEL: {
+      const int wv = value >= 100 ? value - 100 : value;  // + 100: every wave of a block takes response tasks (the A/B reference)
+      if (wv != 0 && wv != 4 && wv != 8 && wv != 16)
+        return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "lone kernel: 0 (four launches per match), 4, 8 or 16 (waves per block), not %d", value);
+      LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+      int rc = pipe_join(m);
+      if (rc) return rc;
+      m->lone_waves = wv;
+      m->lone_task_waves_all = value >= 100;
+      return LSLAM_OK;
+    }
     case LSLAM_OPT_ROWS_WAVES: {
       if (value != 1 && value != 2 && value != 4 && value != 8)
         return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "coarse kernel: 1, 2, 4 or 8 waves per block, not %d", value);
@@ -4479,6 +4687,7 @@ int lslam_matcher_get_option(const lslam_matcher* m, int option) {
     case LSLAM_OPT_STEP_MIN_SCANS: return m->step_min_scans;
     case LSLAM_OPT_ROWS_WAVES: return m->rows_waves;
     case LSLAM_OPT_CHECK_OUTPUT_REUSE: return m->check_out_reuse ? 1 : 0;
+    case LSLAM_OPT_LONE_KERNEL: return m->lone_waves + (m->lone_waves && m->lone_task_waves_all ? 100 : 0);
     default: return LSLAM_ERR_INVALID_ARGUMENT;
   }
 }
@@ -4491,6 +4700,16 @@ int lslam_matcher_flush(lslam_matcher* m) {
 
 int64_t lslam_matcher_pipelined_steps(const lslam_matcher* m) { return m ? (int64_t)m->pipe_steps : 0; }
 int64_t lslam_matcher_step_kernel_launches(const lslam_matcher* m) { return m ? (int64_t)m->step_launches : 0; }
+int64_t lslam_matcher_lone_kernel_launches(const lslam_matcher* m) { return m ? (int64_t)m->lone_launches : 0; }
+// diagnostics: the hand-over words of k_match_lone (kLoneRing slots of 8 words) after a stream sync
+int lslam_debug_lone_sync(lslam_matcher* m, unsigned* out128) {
+  if (!m || !out128) return LSLAM_ERR_INVALID_ARGUMENT;
+  if (!m->d_lone_sync) return LSLAM_ERR_NO_DATA;
+  LSLAM_HIP(m->ctx, hipSetDevice(m->ctx->device));
+  LSLAM_HIP(m->ctx, hipStreamSynchronize(m->ctx->stream));
+  LSLAM_HIP(m->ctx, hipMemcpy(out128, m->d_lone_sync, kLoneRing * sizeof(LoneSync), hipMemcpyDeviceToHost));
+  return LSLAM_OK;
+}
 
 #if defined(LSLAM_PHASE_STAMPS)
 // diagnostic builds only: out[kernel][8 cycle sums | 8 visit counts] of this translation unit's stamp table (summed over the

@@ -189,8 +189,15 @@ void* lslam_matcher_grid_dev_ptr(lslam_matcher* m);
  *    kernels: no response expansion, refinement on, coarse lattice rows of 5..16 positions, the 3 x 3 fine lattice;
  *    everything else keeps the five-kernel path (value 0 = always).  lslam_matcher_step_kernel_launches counts the
  *    launches that did go out as one kernel.  The reference has no counterpart (Mapper.cpp:184-291 is one scan at a time). */
+/*  LSLAM_OPT_LONE_KERNEL (0, 4, 8 or 16): the match of ONE scan (lslam_matcher_match_scan, the streaming front-end, a
+ *    batch of one) as ONE launch instead of four: k_match_lone keeps the width of the chain -- one (angle, beam slice) task
+ *    per wave, blocks of that many wave64s -- and replaces the launches between coarse responses, coarse reduce, fine
+ *    responses and fine reduce by counters in device memory (the last block to arrive runs the reduce; the others wait, bounded,
+ *    on one word).  Same device functions, same atomically accumulated integers: byte-identical records.  A hand-over that does
+ *    not arrive within ~40 ms makes the record's status LSLAM_ERR_HIP; nothing hangs.  lslam_matcher_lone_kernel_launches counts
+ *    the matches that did go out as one kernel.  The reference has no counterpart. */
 enum { LSLAM_OPT_ROW_OCCUPANCY = 1, LSLAM_OPT_COLLECT_STATS = 2, LSLAM_OPT_LDS_STAGED = 3, LSLAM_OPT_PIPELINE_DEPTH = 4,
-       LSLAM_OPT_STEP_KERNEL = 5, LSLAM_OPT_STEP_MIN_SCANS = 6, LSLAM_OPT_ROWS_WAVES = 7, LSLAM_OPT_CHECK_OUTPUT_REUSE = 8 };
+       LSLAM_OPT_STEP_KERNEL = 5, LSLAM_OPT_STEP_MIN_SCANS = 6, LSLAM_OPT_ROWS_WAVES = 7, LSLAM_OPT_CHECK_OUTPUT_REUSE = 8, LSLAM_OPT_LONE_KERNEL = 9 };
 /* current value of an option (negative: error code) */
 int lslam_matcher_get_option(const lslam_matcher* m, int option);
 /* Order the context stream behind every pipelined step in flight (no host wait).  No-op at depth 1. */
@@ -199,6 +206,11 @@ int lslam_matcher_flush(lslam_matcher* m);
 int64_t lslam_matcher_pipelined_steps(const lslam_matcher* m);
 /* diagnostics: batched matches that went out as ONE launch (LSLAM_OPT_STEP_KERNEL) so far */
 int64_t lslam_matcher_step_kernel_launches(const lslam_matcher* m);
+/* diagnostics: single-scan matches that went out as ONE launch (LSLAM_OPT_LONE_KERNEL) so far */
+int64_t lslam_matcher_lone_kernel_launches(const lslam_matcher* m);
+/* diagnostics: k_match_lone's hand-over words, 16 slots x 8 words {coarse tickets, coarse done, fine ready, fine tickets,
+ * fine done, timeouts, 0, 0}; LSLAM_ERR_NO_DATA before the first such launch */
+int lslam_debug_lone_sync(lslam_matcher* m, unsigned* out128);
 int lslam_matcher_set_option(lslam_matcher* m, int option, int value);
 int lslam_matcher_read_stats(lslam_matcher* m, uint64_t out[4]);
 /* after an instrumented pass: out[0] = readable (scan, beam) pairs of that batch, out[1] = those with a live lattice row in

@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scans", type=int, default=600)
     ap.add_argument("--loop", action="store_true", help="pose graph with loop closing on (cfg 5's settings)")
+    ap.add_argument("--lone-kernel", type=int, default=-1, help="LSLAM_OPT_LONE_KERNEL (0, 4, 8, 16); -1 = the library's default")
     args = ap.parse_args()
     import bench
     laser = synth.Laser()
@@ -31,6 +32,8 @@ def main():
     r64 = [synth.ranges_to_f64(r) for r in scans32]
     ctx = api.Context(0)
     gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
+    if args.lone_kernel >= 0:
+        gm.set_option("lone_kernel", args.lone_kernel)
     if args.loop:
         fe = api.FrontEnd(gm, config=api.frontend_config(scan_buffer_size=70, scan_buffer_maximum_scan_distance=20.0, do_loop_closing=1,
                                                          link_scan_maximum_distance=1.5, loop_search_maximum_distance=3.0,
@@ -60,6 +63,10 @@ def main():
     out["kernel_us_total"] = round(sum(out["kernel_us_per_scan"].values()), 1)
     out["launches"] = {k: v[0] for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
     out["graph"] = fe.stats()
+    out["lone_kernel"] = args.lone_kernel
+    out["lone_kernel_launches"] = gm.lone_kernel_launches
+    import hashlib
+    out["poses_sha256"] = hashlib.sha256(np.stack([fe.scan_pose(i) for i in range(fe.num_scans())]).tobytes()).hexdigest()[:16]
     print(json.dumps(out))
 
 

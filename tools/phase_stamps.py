@@ -36,6 +36,8 @@ MATCHER_KERNELS = {
     5: ("resp_rows_wave (one wave per block)", ["lattice record, cos/sin", "phases A + B", "wave reduction + stores"]),
     6: ("scan_prep_block", ["first world point | transform (thread 0) | lattice (last wave)", "barrier: the slowest of the three",
                             "scan-frame points"]),
+    7: ("k_match_lone (thread 0 of every block)", ["coarse tasks", "block barrier, release fence, arrival", "coarse reduce (last block) | wait + acquire",
+                                                    "fine tasks", "block barrier, release fence, arrival"]),
 }
 
 
@@ -55,6 +57,8 @@ def lone(ctx):
     scans32 = bench.cast_scans(world, laser, path, 0, 6, max(1, min(32, os.cpu_count() or 1)))
     r64 = [synth.ranges_to_f64(r) for r in scans32]
     gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
+    if os.environ.get("LSLAM_LONE_KERNEL"):
+        gm.set_option("lone_kernel", int(os.environ["LSLAM_LONE_KERNEL"]))
     fe = api.FrontEnd(gm)
     for r, o in zip(r64[:80], odom[:80]):
         fe.Process(r, o)
