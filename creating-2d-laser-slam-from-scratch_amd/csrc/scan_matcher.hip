@@ -3427,7 +3427,7 @@ struct lslam_matcher {
   int lone_waves = 0;               // LSLAM_OPT_LONE_KERNEL: 0 = four launches for the match of ONE scan, 4 / 8 / 16 = k_match_lone with that many waves per block
   LoneSync* d_lone_sync = nullptr;  // its hand-over words: a ring of kLoneRing slots
   unsigned lone_seq = 0;            // launches so far: slot seq % kLoneRing of the ring
-  bool lone_task_waves_all = false; // option value + 100: every wave of a block takes response tasks (the A/B reference)
+  bool lone_one_task_wave = false;  // option value + 100: ONE wave of a block takes response tasks (168 blocks; the A/B reference)
   long long lone_launches = 0;
   int step_waves = 0;               // lslam_matcher_set_option(LSLAM_OPT_STEP_KERNEL): 0 = five launches per step, 3 / 4 = k_match_step with that many waves per scan
   int step_min_scans = 64;          // batches below this keep the five-kernel path (its beam-sliced kernels fill the chip)
@@ -4047,7 +4047,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       return sl;
     };
     const int W = m->lone_waves, NT = 64 * W, parts = reduce_parts(pc, NT);
-    const int TW = m->lone_task_waves_all ? W : 1;  // waves of a block that take response tasks
+    const int TW = m->lone_one_task_wave ? 1 : W;  // waves of a block that take response tasks
     const int c_slices = slices_for(pc.na), f_slices = slices_for(pf.na);
     const int area = cvar == 2 ? rows_wave_area<3>() : rows_wave_area<4>();
     const size_t lds = std::max<size_t>({(size_t)TW * area, reduce_lds_nocache(pc, parts), ((ftotal + 31) / 32) * 4 + 16});
@@ -4638,14 +4638,14 @@ int lslam_matcher_set_option(lslam_matcher* m, int option, int value) {
       m->check_out_reuse = value != 0;
       return LSLAM_OK;
     case LSLAM_OPT_LONE_KERNEL: {
-      const int wv = value >= 100 ? value - 100 : value;  // + 100: every wave of a block takes response tasks (the A/B reference)
+      const int wv = value >= 100 ? value - 100 : value;  // + 100: one task wave per block (the A/B reference)
       if (wv != 0 && wv != 4 && wv != 8 && wv != 16)
         return ctx->fail(LSLAM_ERR_INVALID_ARGUMENT, "lone kernel: 0 (four launches per match), 4, 8 or 16 (waves per block), not %d", value);
       LSLAM_HIP(ctx, hipSetDevice(ctx->device));
       int rc = pipe_join(m);
       if (rc) return rc;
       m->lone_waves = wv;
-      m->lone_task_waves_all = value >= 100;
+      m->lone_one_task_wave = value >= 100;
       return LSLAM_OK;
     }
     case LSLAM_OPT_ROWS_WAVES: {
@@ -4687,7 +4687,7 @@ int lslam_matcher_get_option(const lslam_matcher* m, int option) {
     case LSLAM_OPT_STEP_MIN_SCANS: return m->step_min_scans;
     case LSLAM_OPT_ROWS_WAVES: return m->rows_waves;
     case LSLAM_OPT_CHECK_OUTPUT_REUSE: return m->check_out_reuse ? 1 : 0;
-    case LSLAM_OPT_LONE_KERNEL: return m->lone_waves + (m->lone_waves && m->lone_task_waves_all ? 100 : 0);
+    case LSLAM_OPT_LONE_KERNEL: return m->lone_waves + (m->lone_waves && m->lone_one_task_wave ? 100 : 0);
     default: return LSLAM_ERR_INVALID_ARGUMENT;
   }
 }

@@ -189,13 +189,15 @@ void* lslam_matcher_grid_dev_ptr(lslam_matcher* m);
  *    kernels: no response expansion, refinement on, coarse lattice rows of 5..16 positions, the 3 x 3 fine lattice;
  *    everything else keeps the five-kernel path (value 0 = always).  lslam_matcher_step_kernel_launches counts the
  *    launches that did go out as one kernel.  The reference has no counterpart (Mapper.cpp:184-291 is one scan at a time). */
-/*  LSLAM_OPT_LONE_KERNEL (0, 4, 8 or 16): the match of ONE scan (lslam_matcher_match_scan, the streaming front-end, a
- *    batch of one) as ONE launch instead of four: k_match_lone keeps the width of the chain -- one (angle, beam slice) task
- *    per wave, blocks of that many wave64s -- and replaces the launches between coarse responses, coarse reduce, fine
- *    responses and fine reduce by counters in device memory (the last block to arrive runs the reduce; the others wait, bounded,
- *    on one word).  Same device functions, same atomically accumulated integers: byte-identical records.  A hand-over that does
- *    not arrive within ~40 ms makes the record's status LSLAM_ERR_HIP; nothing hangs.  lslam_matcher_lone_kernel_launches counts
- *    the matches that did go out as one kernel.  The reference has no counterpart. */
+/*  LSLAM_OPT_LONE_KERNEL (0, 4, 8 or 16; default 0): the match of ONE scan (lslam_matcher_match_scan, the streaming
+ *    front-end, a batch of one) as ONE launch instead of four: k_match_lone keeps the width of the chain -- one (angle, beam
+ *    slice) task per wave, blocks of that many wave64s -- and replaces the launches between coarse responses, coarse reduce,
+ *    fine responses and fine reduce by counters in device memory (the last block to arrive runs the reduce; the others wait,
+ *    bounded, on one word).  Same device functions, same atomically accumulated integers: byte-identical records.  A hand-over
+ *    that does not arrive within ~40 ms makes the record's status LSLAM_ERR_HIP; nothing hangs.  Measured: 3 us per scan SLOWER
+ *    than the four launches (profiles/r06/experiments/README.md section 6), hence off by default; value + 100 = one task wave
+ *    per block (the A/B form).  lslam_matcher_lone_kernel_launches counts the matches that did go out as one kernel.  The
+ *    reference has no counterpart. */
 enum { LSLAM_OPT_ROW_OCCUPANCY = 1, LSLAM_OPT_COLLECT_STATS = 2, LSLAM_OPT_LDS_STAGED = 3, LSLAM_OPT_PIPELINE_DEPTH = 4,
        LSLAM_OPT_STEP_KERNEL = 5, LSLAM_OPT_STEP_MIN_SCANS = 6, LSLAM_OPT_ROWS_WAVES = 7, LSLAM_OPT_CHECK_OUTPUT_REUSE = 8, LSLAM_OPT_LONE_KERNEL = 9 };
 /* current value of an option (negative: error code) */

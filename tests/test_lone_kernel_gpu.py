@@ -18,7 +18,7 @@ def _matcher(ctx, wl, **cfg):
     return gm
 
 
-@pytest.mark.parametrize("waves", [4, 8, 16, 104])  # 104: blocks on every XCD, agent-scope fences
+@pytest.mark.parametrize("waves", [4, 8, 16, 104])  # 104: one task wave per block of four
 def test_batches_of_one_equal_the_four_kernel_chain(ctx, waves):
     wl = synth.make_match_workload(n_base=30, n_query=40, seed=61, query_spread=2.0)
     wl.query_ranges[np.random.default_rng(2).random(wl.query_ranges.shape) < 0.02] = np.nan
