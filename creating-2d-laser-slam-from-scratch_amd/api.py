@@ -269,6 +269,8 @@ def lib() -> C.CDLL:
     L.lslam_frontend_stats.argtypes = [vp, vp]
     L.lslam_frontend_process_many.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
     L.lslam_frontend_lookahead_stats.argtypes = [vp, vp]
+    L.lslam_frontend_spec_chain_stats.argtypes = [vp, vp]
+    L.lslam_debug_frontend_anchor_row.argtypes = [vp, C.c_int, vp]
     L.lslam_occgrid_create_from_scans.argtypes = [vp, C.POINTER(LaserParams), i32, vp, i32, vp, dbl, C.POINTER(vp)]
     L.lslam_occgrid_destroy.argtypes = [vp]
     L.lslam_occgrid_destroy.restype = None
@@ -863,6 +865,18 @@ class FrontEnd:
                                                           None if t is None else t.ctypes.data, ok.ctypes.data, pose.ctypes.data,
                                                           cov.ctypes.data, resp.ctypes.data))
         return ok.astype(bool), pose, cov.reshape(n, 3, 3), resp
+
+    def anchor_row(self, scan_id: int) -> np.ndarray:
+        """FindValidPoints' anchors of a resident scan at its current pose (beam indices in order)."""
+        out = np.zeros(self.m.num_beams + 1, dtype=np.int32)
+        self.ctx.check(self.L.lslam_debug_frontend_anchor_row(self.h, int(scan_id), out.ctypes.data))
+        return out[1:1 + out[0]].copy()
+
+    def spec_chain_stats(self) -> dict:
+        """Speculative anchor chains: world-point refreshes handed one / of those, the ones that recomputed the chain."""
+        out = np.zeros(2, dtype=np.int64)
+        self.ctx.check(self.L.lslam_frontend_spec_chain_stats(self.h, out.ctypes.data))
+        return {"handed": int(out[0]), "recomputed": int(out[1])}
 
     def lookahead_stats(self) -> dict:
         out = np.zeros(3, dtype=np.int64)

@@ -60,6 +60,12 @@ struct lslam_frontend {
   double2* d_world = nullptr;              // [cap][n] world points at the scans' current poses
   double* d_ranges = nullptr;              // [cap][n] readings (kept to re-pose a scan after a closed loop)
   int* d_next = nullptr;                   // [cap][n + 1] k_anchor_chain rows: FindValidPoints' anchors of the world points
+  // the newest scan's anchor chain worked out beside its own match (anchor_spec_block): [ok, count, anchors (n), classes
+  // (n bytes, padded), fall-backs]; spec_chain_id = the scan it belongs to (-1: none)
+  int* d_spec_chain = nullptr;
+  int spec_chain_id = -1;
+  bool cfg_spec_chain = true;              // LSLAM_FE_SPEC_CHAIN=0 in the environment: off (A/B)
+  int64_t n_spec_chain_used = 0;           // k_anchor_chain launches that were handed a speculative chain
   DevBuf<double> d_q;                      // query pose (3)
   DevBuf<lslam_match_result> d_res;
   lslam_match_result* h_res = nullptr;     // pinned host memory the match's last kernel writes its record to
@@ -82,6 +88,7 @@ struct lslam_frontend {
   const LookAhead* la = nullptr;  // the scan after the one being processed (process_many only)
   struct Spec {
     bool started = false, finished = false, invalid = false;
+    bool chain_launched = false;       // its launch carried the scan's speculative anchor chain
     const double* ranges = nullptr;
     double odom[3] = {0, 0, 0}, time = 0;
     int id = -1;
@@ -98,6 +105,7 @@ struct lslam_frontend {
 namespace {
 
 inline double sq_dist2(const double* a, const double* b) { return ksq(a[0] - b[0]) + ksq(a[1] - b[1]); }
+inline size_t spec_chain_bytes(int n) { return (size_t)(2 + std::max(n, 1)) * 4 + (((size_t)std::max(n, 1) + 3) & ~(size_t)3) + 4; }
 inline size_t fe_anchor_lds(int n) { return (size_t)n * (sizeof(double2) + 13) + 16; }  // points, three tables, reach
 
 int fe_grow(lslam_frontend* f, int need) {
@@ -166,9 +174,14 @@ int fe_update_world(lslam_frontend* f, int id) {
   if (fe_anchor_lds(n) <= 60 * 1024) {
     // world points AND FindValidPoints' anchor chain of the scan at this pose in one launch: the chain once here, not once
     // per rebuild of every window the scan will be part of
+    // the chain worked out beside the scan's own match, if it was (the kernel takes it over only when it is provably the
+    // chain of the final points: see k_anchor_chain)
+    const int* spec = (f->spec_chain_id == id && f->d_spec_chain) ? f->d_spec_chain : (const int*)nullptr;
+    f->spec_chain_id = -1;
+    if (spec) f->n_spec_chain_used++;
     launch(ctx, "scan_prep_base", k_anchor_chain, dim3(1), dim3(n > 512 ? 1024 : 256), fe_anchor_lds(n), n,
            f->d_world + (size_t)id * n, f->d_next + (size_t)id * (n + 1), (const double*)(f->d_ranges + (size_t)id * n), pv,
-           m->g);
+           m->g, spec);
   } else {
     launch(ctx, "scan_prep_base", k_scan_prep<double>, dim3((n + 255) / 256, 1), dim3(256), 0,
            (const double*)(f->d_ranges + (size_t)id * n), n, (const double*)nullptr, m->g, (double2*)nullptr,
@@ -394,7 +407,14 @@ void fe_spec_try_start(lslam_frontend* f) {
   lslam_sensor_pose_from_robot(&m->laser, corrected, sp.sp);
   memcpy(f->h_ranges, f->la->ranges, (size_t)n * sizeof(double));  // staged: the match's first kernel moves them into HBM
   f->pending_ranges = f->h_ranges;
+  if (f->d_spec_chain && f->cfg_spec_chain) {  // ... and its speculative anchor chain (see k_anchor_chain)
+    m->spec_req.ranges = f->d_ranges + (size_t)id * n;
+    for (int i = 0; i < 3; i++) m->spec_req.pose[i] = sp.sp[i];
+    m->spec_req.out = f->d_spec_chain;
+    m->spec_armed = true;
+  }
   const int rc = fe_match_enqueue(f, m, f->d_q_spec.p, f->h_res_spec, id, sp.sp, f->run_start, f->run_count, 1, 1);
+  sp.chain_launched = rc == 0 && m->spec_launched;
   f->pending_ranges = nullptr;
   if (rc) {  // could not even be enqueued: Process(t + 1) does it the plain way (and reports whatever is wrong)
     (void)hipStreamSynchronize(m->ctx->stream);
@@ -590,7 +610,9 @@ int lslam_frontend_create_ex(lslam_matcher* m, const lslam_frontend_config* cfg,
   if (f->d_q.reserve(4 + 4 * 8) != hipSuccess || f->d_res.reserve(1) != hipSuccess || f->d_q_spec.reserve(4 + 4 * 8) != hipSuccess ||
       hipHostMalloc((void**)&f->h_res, sizeof(lslam_match_result), hipHostMallocDefault) != hipSuccess ||
       hipHostMalloc((void**)&f->h_res_spec, sizeof(lslam_match_result), hipHostMallocDefault) != hipSuccess ||
-      hipHostMalloc((void**)&f->h_ranges, sizeof(double) * (size_t)std::max(m->g.n_beams, 1), hipHostMallocDefault) != hipSuccess) {
+      hipHostMalloc((void**)&f->h_ranges, sizeof(double) * (size_t)std::max(m->g.n_beams, 1), hipHostMallocDefault) != hipSuccess ||
+      hipMalloc((void**)&f->d_spec_chain, spec_chain_bytes(m->g.n_beams)) != hipSuccess ||
+      hipMemset(f->d_spec_chain, 0, spec_chain_bytes(m->g.n_beams)) != hipSuccess) {
     (void)hipGetLastError();
     lslam_frontend_destroy(f);
     return ctx->fail(LSLAM_ERR_HIP, "cannot allocate the front-end scratch in HBM");
@@ -600,6 +622,7 @@ int lslam_frontend_create_ex(lslam_matcher* m, const lslam_frontend_config* cfg,
     lslam_frontend_destroy(f);
     return rc;
   }
+  if (const char* e = getenv("LSLAM_FE_SPEC_CHAIN")) f->cfg_spec_chain = atoi(e) != 0;
   const int n = m->g.n_beams;
   f->cos_a.resize(n);
   f->sin_a.resize(n);
@@ -641,6 +664,7 @@ void lslam_frontend_destroy(lslam_frontend* f) {
   if (f->d_world) (void)hipFree(f->d_world);
   if (f->d_ranges) (void)hipFree(f->d_ranges);
   if (f->d_next) (void)hipFree(f->d_next);
+  if (f->d_spec_chain) (void)hipFree(f->d_spec_chain);
   f->d_q.release();
   f->d_res.release();
   f->d_q_spec.release();
@@ -658,6 +682,7 @@ int lslam_frontend_reset(lslam_frontend* f) {
   f->n_chain_matches = f->n_loop_coarse = f->n_loop_fine = f->n_loops_closed = f->n_edges = f->n_loop_discarded = 0;
   if (f->spec.started) fe_spec_finish(f);
   f->spec = lslam_frontend::Spec{};
+  f->spec_chain_id = -1;
   f->n_spec_started = f->n_spec_used = f->n_spec_discarded = 0;
   return LSLAM_OK;
 }
@@ -724,7 +749,9 @@ int lslam_frontend_process_stamped(lslam_frontend* f, const double* ranges, int 
     if (have_spec) {
       spec_r = q.r;
       f->n_spec_used++;
+      f->spec_chain_id = q.chain_launched ? id : -1;
     } else {
+      f->spec_chain_id = -1;
       f->n_spec_discarded++;
     }
     f->spec.started = false;
@@ -755,8 +782,16 @@ int lslam_frontend_process_stamped(lslam_frontend* f, const double* ranges, int 
     if (have_spec) {
       r = spec_r;
     } else {
+      // ask the match for the scan's speculative anchor chain (an extra block of its lone coarse reduce)
+      if (f->d_spec_chain && f->cfg_spec_chain) {
+        m->spec_req.ranges = f->d_ranges + (size_t)id * n;
+        for (int i = 0; i < 3; i++) m->spec_req.pose[i] = sp[i];
+        m->spec_req.out = f->d_spec_chain;
+        m->spec_armed = true;
+      }
       rc = fe_match(f, m, id, sp, f->run_start, f->run_count, 1, 1, &r);
       if (rc) return rc;
+      f->spec_chain_id = m->spec_launched ? id : -1;
     }
     resp = r.response;
     for (int i = 0; i < 9; i++) cov[i] = r.covariance[i];
@@ -854,6 +889,35 @@ int lslam_frontend_process_many(lslam_frontend* f, int n_scans, const double* ra
 
 // out[0] = look-ahead matches started, [1] = accepted, [2] = discarded (a loop closed in between, or the scan was not the one
 // announced)
+// diagnostics: FindValidPoints' anchors of a resident scan at its current pose, row = [count, indices...] (n + 1 ints)
+int lslam_debug_frontend_anchor_row(lslam_frontend* f, int scan_id, int32_t* out) {
+  if (!f || !out || scan_id < 0 || scan_id >= (int)f->scans.size()) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = f->m->ctx;
+  const int n = f->m->g.n_beams;
+  LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+  LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  LSLAM_HIP(ctx, hipMemcpy(out, f->d_next + (size_t)scan_id * (n + 1), (size_t)(n + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  return LSLAM_OK;
+}
+
+// diagnostics: k_anchor_chain launches that were handed a speculative chain / of those, the ones that could not take it
+// over (a comparison inside the band, a point whose class changed) and worked the chain out themselves
+int lslam_frontend_spec_chain_stats(lslam_frontend* f, int64_t out[2]) {
+  if (!f || !out) return LSLAM_ERR_INVALID_ARGUMENT;
+  lslam_context* ctx = f->m->ctx;
+  out[0] = f->n_spec_chain_used;
+  out[1] = 0;
+  if (f->d_spec_chain) {
+    const int n = std::max(f->m->g.n_beams, 1);
+    int fb = 0;
+    LSLAM_HIP(ctx, hipSetDevice(ctx->device));
+    LSLAM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LSLAM_HIP(ctx, hipMemcpy(&fb, f->d_spec_chain + 2 + n + ((n + 3) >> 2), sizeof fb, hipMemcpyDeviceToHost));
+    out[1] = fb;
+  }
+  return LSLAM_OK;
+}
+
 int lslam_frontend_lookahead_stats(const lslam_frontend* f, int64_t out[3]) {
   if (!f || !out) return LSLAM_ERR_INVALID_ARGUMENT;
   out[0] = f->n_spec_started;

@@ -1829,14 +1829,28 @@ __device__ __forceinline__ void reduce_coarse_lds_block(
   LSLAM_PHASE_FLUSH(pck, g_sm_stamps, 3, (unsigned)(s * (NT >> 6) + (tid >> 6)), (tid & 63) == 0);
 }
 
+// (anchor_spec_block: the speculative anchor chain of the scan being matched, see k_anchor_chain -- an extra block of the
+//  lone launch, blockIdx.x == the number of scans)
+struct SpecArgs {
+  const double* ranges;  // the scan's readings (resident)
+  double pose[3];        // sensor pose the match starts from
+  int* out;              // nullptr: no speculative block in this launch
+};
+__device__ __forceinline__ void anchor_spec_block(int n, const SpecArgs& sa, const Geom& g, unsigned char* smem);
 template <int NT>
 __global__ void __launch_bounds__(NT)
 k_reduce_coarse_lds(Geom g, PassCfg pc, SearchCfg sc, Lattice* lat,
                     int32_t* resp, size_t resp_stride, CoarseOut* __restrict__ out,
                     int use_expansion, int pass_index, const uint8_t* __restrict__ grid,
                 const double2* __restrict__ local, int fb_step, PassCfg fine_pc,
-                    double2* fine_cossin, int fine_step, int zero_fine_words, int parts) {
+                    double2* fine_cossin, int fine_step, int zero_fine_words, int parts, SpecArgs spec) {
   extern __shared__ __align__(16) unsigned char smem[];
+  if constexpr (NT == 1024) {
+    if (spec.out && blockIdx.x + 1 == gridDim.x) {
+      anchor_spec_block(g.n_beams, spec, g, smem);
+      return;
+    }
+  }
   reduce_coarse_lds_block<NT>((int)blockIdx.x, (int)threadIdx.x, g, pc, sc, lat, resp + (size_t)blockIdx.x * resp_stride, out,
                               use_expansion, pass_index, grid, local, fb_step, fine_pc, fine_cossin, fine_step, zero_fine_words,
                               parts, smem);
@@ -3097,44 +3111,25 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
 // by the streaming front-end when a scan's world points are (re)computed, off the per-scan critical path.
 // With `ranges` it first evaluates the world points themselves (k_scan_prep's world branch: LocalizedRangeScan::Update,
 // Karto.h:5384-5388, at the pose passed as a kernel argument) and stores them: one launch for both.
-__device__ __forceinline__ void anchor_chain_block(int n, double2* __restrict__ world, int* __restrict__ row,
-                                                   const double* __restrict__ ranges, const PoseArg& pose, const Geom& g) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ int s_first, s_wc[16];
-  double2* p = (double2*)smem;
-  int* next = (int*)(p + n);
-  int* ja = next + n;
-  int* jb = ja + n;
-  uint8_t* reach = (uint8_t*)(jb + n);
-  const int tid = threadIdx.x, nt = blockDim.x;
-  LSLAM_PHASE_CLOCK(pck);
-  for (int i = tid; i < n; i += nt) {
-    double2 q;
-    if (ranges) {
-      beam_world_point(pose.v[0], pose.v[1], pose.v[2], g.min_angle, g.ang_res, (uint32_t)i, ranges[i], q.x, q.y);
-      world[i] = q;
-    } else {
-      q = world[i];
-    }
-    p[i] = q;
-    reach[i] = 0;
-  }
-  if (tid == 0) s_first = n;
-  __syncthreads();
-  LSLAM_PHASE_MARK(pck, 0);  // world points (fp64 sincos per beam)
-  const double min_sq = ksq(0.1);
-  for (int i = tid; i < n; i += nt) {
-    if (!isnan(p[i].x) && !isnan(p[i].y)) atomicMin(&s_first, i);  // first anchor (Mapper.cpp:774-778)
-    next[i] = successor_of(p, n, i, min_sq);
-    ja[i] = next[i];
-  }
-  __syncthreads();
-  LSLAM_PHASE_MARK(pck, 1);  // successor of every point
-  mark_reachable(n, s_first, ja, jb, reach, tid, nt);
-  __syncthreads();
-  LSLAM_PHASE_MARK(pck, 2);  // pointer doubling
+//
+// SPECULATIVE ANCHORS (round 6).  The chain is 11 of this kernel's 13 us and sits between a match and the next rebuild.  But
+// which point follows which depends on the scan's SHAPE only -- distances between its points -- and a rigid motion changes a
+// squared distance by no more than the roundings of the coordinates (~1e-13 m^2 at 100 m).  So the chain is worked out EARLY,
+// on the points at the pose the match STARTS from (anchor_spec_block: an extra block of the lone coarse reduce's launch, where
+// it costs nothing), with every comparison that comes closer to the 0.1 m threshold than kSpecBand flagged, and this kernel
+// -- which still evaluates the world points at the FINAL pose -- takes the speculative row over when (a) nothing was flagged
+// and (b) every point has the same class (finite / +inf / -inf / NaN per coordinate) at both poses: a comparison that
+// involves a non-finite point is decided by the classes alone (inf - inf, inf - finite, NaN).  Otherwise it computes the
+// chain as before.  Either way the row is the one the reference's walk produces on the final points.
+constexpr double kSpecBand = 1e-13;  // x (1 + largest coordinate): >= 40 x the bound on |d^2(pose A) - d^2(pose B)|
+__device__ __forceinline__ uint32_t point_class(double2 q) {
+  auto c = [](double v) -> uint32_t { return isnan(v) ? 3u : isinf(v) ? (v > 0.0 ? 1u : 2u) : 0u; };
+  return c(q.x) | (c(q.y) << 2);
+}
+// ordered compaction of the points marked in reach[] into row = [count, indices...]; ends with the row complete
+__device__ __forceinline__ void anchors_to_row(int n, const uint8_t* reach, int* __restrict__ row, int* s_wc, int tid, int nt) {
   int base = 0;
-  for (int i0 = 0; i0 < n; i0 += nt) {  // ordered compaction of the anchors
+  for (int i0 = 0; i0 < n; i0 += nt) {
     const int i = i0 + tid;
     const bool is_anchor = i < n && reach[i];
     const unsigned long long bal = __ballot(is_anchor);
@@ -3147,13 +3142,123 @@ __device__ __forceinline__ void anchor_chain_block(int n, double2* __restrict__ 
     __syncthreads();
   }
   if (tid == 0) row[0] = base;
+}
+// spec = [ok, count, anchors (n), classes (n bytes)] (anchor_spec_block) or nullptr
+__device__ __forceinline__ void anchor_chain_block(int n, double2* __restrict__ world, int* __restrict__ row,
+                                                   const double* __restrict__ ranges, const PoseArg& pose, const Geom& g,
+                                                   const int* __restrict__ spec) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ int s_first, s_wc[16], s_spec_ok;
+  double2* p = (double2*)smem;
+  int* next = (int*)(p + n);
+  int* ja = next + n;
+  int* jb = ja + n;
+  uint8_t* reach = (uint8_t*)(jb + n);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  LSLAM_PHASE_CLOCK(pck);
+  if (tid == 0) { s_first = n; s_spec_ok = (spec && spec[0] == 1) ? 1 : 0; }
+  __syncthreads();
+  const uint8_t* spec_cls = spec ? (const uint8_t*)(spec + 2 + n) : nullptr;
+  bool same = true;
+  for (int i = tid; i < n; i += nt) {
+    double2 q;
+    if (ranges) {
+      beam_world_point(pose.v[0], pose.v[1], pose.v[2], g.min_angle, g.ang_res, (uint32_t)i, ranges[i], q.x, q.y);
+      world[i] = q;
+    } else {
+      q = world[i];
+    }
+    p[i] = q;
+    reach[i] = 0;
+    if (spec_cls) same = same && point_class(q) == (uint32_t)spec_cls[i];
+  }
+  if (spec_cls && !same) s_spec_ok = 0;
+  __syncthreads();
+  LSLAM_PHASE_MARK(pck, 0);  // world points (fp64 sincos per beam)
+  if (spec && tid == 0 && !s_spec_ok) atomicAdd((int*)spec + 2 + n + ((n + 3) >> 2), 1);  // diagnostics: fall-backs
+  if (s_spec_ok) {  // the speculative row is the row (block-uniform)
+    const int cnt = spec[1];
+    for (int k = tid; k <= cnt; k += nt) row[k] = spec[1 + k];
+    LSLAM_PHASE_MARK(pck, 3);
+    LSLAM_PHASE_FLUSH(pck, g_sm_stamps, 2, (unsigned)(blockIdx.x * (nt >> 6) + (tid >> 6)), (tid & 63) == 0);
+    return;
+  }
+  const double min_sq = ksq(0.1);
+  for (int i = tid; i < n; i += nt) {
+    if (!isnan(p[i].x) && !isnan(p[i].y)) atomicMin(&s_first, i);  // first anchor (Mapper.cpp:774-778)
+    next[i] = successor_of(p, n, i, min_sq);
+    ja[i] = next[i];
+  }
+  __syncthreads();
+  LSLAM_PHASE_MARK(pck, 1);  // successor of every point
+  mark_reachable(n, s_first, ja, jb, reach, tid, nt);
+  __syncthreads();
+  LSLAM_PHASE_MARK(pck, 2);  // pointer doubling
+  anchors_to_row(n, reach, row, s_wc, tid, nt);
   LSLAM_PHASE_MARK(pck, 3);  // ordered compaction of the anchors
   LSLAM_PHASE_FLUSH(pck, g_sm_stamps, 2, (unsigned)(blockIdx.x * (nt >> 6) + (tid >> 6)), (tid & 63) == 0);
 }
+// The speculative chain of ONE scan at the pose its match starts from: out = [ok, count, anchors (n), classes (n bytes)].
+// Same walk as above; a comparison between two FINITE points within kSpecBand (1 + coordinates) of the threshold clears `ok`.
+__device__ __forceinline__ int successor_spec(const double2* p, int n, int i, double min_sq, bool& clear) {
+  const double fx = p[i].x, fy = p[i].y;
+  const double fm = fabs(fx) + fabs(fy);
+  int j = i + 1;
+  for (bool found = false; !found && j < n;) {
+    double2 q[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) q[u] = p[min(j + u, n - 1)];
+    int hit = 4;
+#pragma unroll
+    for (int u = 3; u >= 0; u--) {
+      const double dx = fx - q[u].x, dy = fy - q[u].y;
+      const double d2 = ksq(dx) + ksq(dy);
+      if (d2 > min_sq) hit = u;
+      const double mag = fm + fabs(q[u].x) + fabs(q[u].y);  // (a non-finite point: mag is inf or NaN, the test is skipped)
+      if (mag < 1e300 && fabs(d2 - min_sq) <= kSpecBand * (1.0 + mag)) clear = false;
+    }
+    if (hit < 4 && j + hit < n) { j += hit; found = true; }
+    else j = min(j + 4, n);
+  }
+  return j;
+}
+__device__ __forceinline__ void anchor_spec_block(int n, const SpecArgs& sa, const Geom& g, unsigned char* smem) {
+  __shared__ int s_first, s_wc[16], s_clear;
+  double2* p = (double2*)smem;
+  int* next = (int*)(p + n);
+  int* ja = next + n;
+  int* jb = ja + n;
+  uint8_t* reach = (uint8_t*)(jb + n);
+  uint8_t* cls = (uint8_t*)(sa.out + 2 + n);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  if (tid == 0) { s_first = n; s_clear = 1; sa.out[0] = 0; }
+  for (int i = tid; i < n; i += nt) {
+    double2 q;
+    beam_world_point(sa.pose[0], sa.pose[1], sa.pose[2], g.min_angle, g.ang_res, (uint32_t)i, sa.ranges[i], q.x, q.y);
+    p[i] = q;
+    reach[i] = 0;
+    cls[i] = (uint8_t)point_class(q);
+  }
+  __syncthreads();
+  const double min_sq = ksq(0.1);
+  bool clear = true;
+  for (int i = tid; i < n; i += nt) {
+    if (!isnan(p[i].x) && !isnan(p[i].y)) atomicMin(&s_first, i);
+    next[i] = successor_spec(p, n, i, min_sq, clear);
+    ja[i] = next[i];
+  }
+  if (!clear) s_clear = 0;
+  __syncthreads();
+  mark_reachable(n, s_first, ja, jb, reach, tid, nt);
+  __syncthreads();
+  anchors_to_row(n, reach, sa.out + 1, s_wc, tid, nt);
+  __syncthreads();
+  if (tid == 0) sa.out[0] = s_clear;
+}
 __global__ void __launch_bounds__(1024)
 k_anchor_chain(int n, double2* __restrict__ world, int* __restrict__ row, const double* __restrict__ ranges, PoseArg pose,
-               Geom g) {
-  anchor_chain_block(n, world, row, ranges, pose, g);
+               Geom g, const int* __restrict__ spec) {
+  anchor_chain_block(n, world, row, ranges, pose, g, spec);
 }
 // The same for a LIST of resident scans of a scan cache (block e = entry e): slot and pose come from a small table the
 // host wrote into pinned memory (read over the bus: 32 bytes per block), or -- `from_result` -- the pose is the mean a
@@ -3178,7 +3283,7 @@ k_anchor_chain_list(int n, double2* __restrict__ world, int* __restrict__ rows, 
     slot = e.slot;
     for (int i = 0; i < 3; i++) pose.v[i] = e.pose[i];
   }
-  anchor_chain_block(n, world + (size_t)slot * n, rows + (size_t)slot * (n + 1), ranges + (size_t)slot * n, pose, g);
+  anchor_chain_block(n, world + (size_t)slot * n, rows + (size_t)slot * (n + 1), ranges + (size_t)slot * n, pose, g, nullptr);
 }
 
 // SmearPoint (Mapper.h:971-1005) of every centre k_find_valid marked, as a GATHER over the cleared-and-marked grid: one
@@ -3424,6 +3529,9 @@ struct lslam_matcher {
   bool collect_stats = false;       // lslam_matcher_set_option(LSLAM_OPT_COLLECT_STATS): instrumented coarse kernel
   bool lds_staged = false;          // lslam_matcher_set_option(LSLAM_OPT_LDS_STAGED): the measured-and-dropped LDS-staged phase B
   int rows_waves = 1;               // lslam_matcher_set_option(LSLAM_OPT_ROWS_WAVES): waves per block of the tiled coarse kernel (1 = k_resp_rows, 2 / 4 / 8 = k_resp_rows_mw)
+  // the streaming front-end's speculative anchor chain (anchor_spec_block): asked for before a match, reported after it
+  SpecArgs spec_req{};
+  bool spec_armed = false, spec_launched = false;
   int lone_waves = 0;               // LSLAM_OPT_LONE_KERNEL: 0 = four launches for the match of ONE scan, 4 / 8 / 16 = k_match_lone with that many waves per block
   LoneSync* d_lone_sync = nullptr;  // its hand-over words: a ring of kLoneRing slots
   unsigned lone_seq = 0;            // launches so far: slot seq % kLoneRing of the ring
@@ -3630,6 +3738,9 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
     m->done_armed = true;
   }
   m->arm_next = false;
+  const SpecArgs spec_req = m->spec_armed ? m->spec_req : SpecArgs{};  // consumed here whatever path the match takes
+  m->spec_armed = false;
+  m->spec_launched = false;
   if (S <= 0) return LSLAM_OK;
   LSLAM_HIP(ctx, hipSetDevice(ctx->device));
   if (g.n_beams == 0) {
@@ -3958,11 +4069,20 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       const bool fuse_fine = n_exp == 0 && do_refine;  // nothing between this pass and the fine pass
       // (the block also clears the fine numerators -- unless a debug caller is about to copy the COARSE ones out of the same words)
       const bool fuse_zero = fuse_fine && !(dbg_coarse_sums && pass_index == 0);
+      // the front-end's speculative anchor chain of this scan rides in the lone launch (pass 0 only; see k_anchor_chain)
+      SpecArgs spec{};
+      const size_t spec_lds = (size_t)g.n_beams * (sizeof(double2) + 13) + 16;
+      if (spec_req.out && pass_index == 0 && S == 1 && spec_lds <= 60 * 1024) {
+        spec = spec_req;
+        m->spec_launched = true;
+      }
 #define LSLAM_RC_LDS(NT)                                                                                                 \
-  launch(ctx, "reduce_coarse", k_reduce_coarse_lds<NT>, dim3(S), dim3(NT), reduce_lds_nocache(p, reduce_parts(p, NT)), g, p,  \
+  launch(ctx, "reduce_coarse", k_reduce_coarse_lds<NT>, dim3(S + (NT == 1024 && spec.out ? 1 : 0)), dim3(NT),                \
+         std::max(reduce_lds_nocache(p, reduce_parts(p, NT)), NT == 1024 && spec.out ? spec_lds : (size_t)0), g, p,           \
          sc, m->d_lat.p, m->d_resp.p, resp_stride, m->d_coarse.p, (int)m->cfg.use_response_expansion, pass_index,            \
          (const uint8_t*)m->d_grid, (const double2*)m->d_local.p, fb_step, pf,                                               \
-         fuse_fine ? m->d_cossin.p : (double2*)nullptr, 1, fuse_zero ? pf.nx * pf.ny * pf.na : 0, reduce_parts(p, NT))
+         fuse_fine ? m->d_cossin.p : (double2*)nullptr, 1, fuse_zero ? pf.nx * pf.ny * pf.na : 0, reduce_parts(p, NT),        \
+         NT == 1024 ? spec : SpecArgs{})
       // 128 threads: residency for chip-filling batches; 1024: a lone block (streaming front-end, MatchScan) splits a cell's
       // angles over 8 threads -- its fill phase was 11 fp64 divisions in a row per thread
       if (S >= kReduceNarrowMinScans) LSLAM_RC_LDS(128);

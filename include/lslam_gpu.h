@@ -418,6 +418,13 @@ int lslam_frontend_process_stamped(lslam_frontend* f, const double* ranges, int 
 int lslam_frontend_process_many(lslam_frontend* f, int n_scans, const double* ranges, int ranges_stride,
                                 const double* odom_poses, const double* times_s, int32_t* processed,
                                 double* corrected_poses, double* covariances, double* responses);
+/* diagnostics of the speculative anchor chains (the newest scan's FindValidPoints anchors are worked out beside its own
+ * match, on the points at the pose the match starts from, and taken over at the final pose when that is provably the same
+ * chain): out[0] = world-point refreshes that were handed one, out[1] = of those, the ones that worked the chain out again. */
+int lslam_frontend_spec_chain_stats(lslam_frontend* f, int64_t out[2]);
+/* diagnostics: FindValidPoints' anchors (Mapper.cpp:774-787) of resident scan scan_id at its current pose: out[0] = count,
+ * out[1..count] = beam indices in order; out holds num_beams + 1 ints */
+int lslam_debug_frontend_anchor_row(lslam_frontend* f, int scan_id, int32_t* out);
 /* out[3] = look-ahead matches started, accepted, discarded */
 int lslam_frontend_lookahead_stats(const lslam_frontend* f, int64_t out[3]);
 /* GetAllProcessedScans().size(); corrected ROBOT pose of processed scan `scan_id` as it stands now (a closed loop
