@@ -17,7 +17,9 @@
   dense     the same for the loop-closure matcher's lattices (Mapper.cpp:862-871, 976-1051: search space 4-10 m -> 41^2..101^2
             positions x 21 angles, k_resp_dense in its lone and batched forms), 2 scans per case against the restatement.
 
-usage: fuzz_round5.py [windows|lookahead|sums|dense|all] [N_CASES] [FIRST_SEED]   (prints one line per case, exit code 1 on a mismatch)
+  specchain the streaming front-end with speculative anchor chains (round 6) against the plain path: every scan's anchors and pose.
+
+usage: fuzz_round5.py [windows|lookahead|sums|dense|specchain|all] [N_CASES] [FIRST_SEED]   (prints one line per case, exit code 1 on a mismatch)
 """
 import os
 import sys
@@ -148,6 +150,49 @@ def fuzz_lookahead(ctx, seed):
     return same
 
 
+def fuzz_specchain(ctx, seed):
+    """Speculative anchor chains (round 6, k_anchor_chain / anchor_spec_block) against the plain path (LSLAM_FE_SPEC_CHAIN=0):
+    every scan's anchor row and every pose bit for bit.  Random trajectories, worlds, shares of +inf / NaN readings, windows."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(150, 500))
+    laser = synth.Laser()
+    outer = rng.uniform(8.0, 30.0)
+    halves = tuple(outer - 2.5 * k for k in range(int(rng.integers(1, 4))))
+    path = synth.rings_trajectory(n, half_sizes=halves, laps=int(rng.integers(1, 3)), radius=2.0, change_len=6.0)
+    world = synth.arena_around_path(path, size=2.0 * (outer + rng.uniform(4.0, 40.0)), n_axis=int(rng.integers(4, 30)),
+                                    n_rot=int(rng.integers(0, 10)), seed=seed)
+    odom = synth.drifting_odometry(path, scale=rng.uniform(0.99, 1.03), sigma_xy=rng.uniform(0.001, 0.01),
+                                   sigma_th=rng.uniform(0.0005, 0.004), seed=seed)
+    dropout = float(rng.choice([0.0, 0.01, 0.1, 0.5]))
+    nan_share = float(rng.choice([0.0, 0.0, 0.02]))
+    r64 = []
+    for q in path:
+        r = synth.ranges_to_f64(synth.cast_scan(world, q, laser, float(rng.choice([0.0, 0.01])), dropout, rng))
+        if nan_share:
+            r[rng.random(r.shape) < nan_share] = np.nan
+        r64.append(r)
+    loop = rng.random() < 0.4
+    cfg = api.frontend_config(scan_buffer_size=int(rng.choice([10, 70])), scan_buffer_maximum_scan_distance=float(rng.choice([10.0, 20.0])),
+                              do_loop_closing=int(loop), link_scan_maximum_distance=1.5, loop_search_maximum_distance=3.0,
+                              loop_match_minimum_chain_size=10)
+    out = {}
+    for on in (0, 1):
+        os.environ["LSLAM_FE_SPEC_CHAIN"] = str(on)
+        gm = api.ScanMatcher(ctx, api.baseline_config(), api.laser_params(laser))
+        fe = api.FrontEnd(gm, config=cfg)
+        del os.environ["LSLAM_FE_SPEC_CHAIN"]
+        for r, o in zip(r64, odom):
+            fe.Process(r, o)
+        k = fe.num_scans()
+        out[on] = ([fe.anchor_row(i) for i in range(k)], np.stack([fe.scan_pose(i) for i in range(k)]), fe.spec_chain_stats())
+        fe.close(); gm.close()
+    same = (len(out[0][0]) == len(out[1][0]) and all(np.array_equal(a, b) for a, b in zip(out[0][0], out[1][0])) and
+            out[0][1].tobytes() == out[1][1].tobytes())
+    print("specchain seed %d: %4d scans, +inf share %.2f, NaN share %.2f, loop closing %d, chains %s -> %s" %
+          (seed, n, dropout, nan_share, int(loop), out[1][2], "equal" if same else "MISMATCH"), flush=True)
+    return same
+
+
 def fuzz_sums(ctx, seed):
     import math
 
@@ -242,5 +287,7 @@ for k in range(n_cases):
         bad += not fuzz_sums(ctx, seed0 + k)
     if what in ("dense", "all"):
         bad += not fuzz_dense(ctx, seed0 + k)
+    if what in ("specchain", "all"):
+        bad += not fuzz_specchain(ctx, seed0 + k)
 print("%d case(s) differ; %.0f s" % (bad, time.time() - t0))
 sys.exit(1 if bad else 0)
