@@ -342,6 +342,12 @@ struct BatchGeom {
 constexpr uint32_t kCodeCrossed = 1u, kCodeHit = 2u, kCodeHitUndo = 3u;
 constexpr uint32_t kHashEmpty = 0xFFFFFFFFu;
 constexpr int kBatchSlots = 64;  // scans per batch = flag bytes per tile
+#if !defined(LSLAM_TUNE_APPLY_CHUNK)
+#define LSLAM_TUNE_APPLY_CHUNK 8
+#endif
+constexpr int kApplyChunk = LSLAM_TUNE_APPLY_CHUNK;  // planes whose bytes k_lo_batch_apply has in flight at a time (A/B, round 6:
+                                                     // 8 / 16 / 32 / 64 -> 0.271 / 0.261 / 0.292 / 0.327 ms per 1000 scans: the tiles every
+                                                     // scan touches are NOT what the launch waits for; the unrolled slot bookkeeping is)
 
 __device__ __forceinline__ Line batch_line(const BatchGeom& g, const ScanHdr& h, const float* __restrict__ pts, int i) {
   LevelGeom lg;
@@ -548,16 +554,17 @@ k_lo_batch_apply(BatchGeom g, const ScanHdr* __restrict__ hdr, const uint8_t* __
     const int4 w = *(const int4*)((const char*)(hdr + lane) + 32);  // tx0, ty0, tw, base
     my_off = (((uint32_t)w.w + (uint32_t)(tty - w.y) * (uint32_t)w.z + (uint32_t)(ttx - w.x)) << 6);
   }
-  while (touched) {  // ascending slot = scan order; eight planes' bytes in flight at a time (the mask is wave-uniform)
-    int sl[8];
+  // ascending slot = scan order; kApplyChunk planes' bytes in flight at a time (the mask is wave-uniform)
+  while (touched) {
+    int sl[kApplyChunk];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < kApplyChunk; u++) {
       sl[u] = touched ? __ffsll((long long)touched) - 1 : -1;
       touched &= touched - 1;  // 0 stays 0
     }
-    uint32_t bv[8];
+    uint32_t bv[kApplyChunk];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < kApplyChunk; u++) {
       bv[u] = 0u;
       if (sl[u] >= 0) {  // wave-uniform; a flagged tile lies inside the window of the scan that flagged it
         const uint32_t tile_off = (uint32_t)__builtin_amdgcn_readlane((int)my_off, sl[u]);
@@ -565,7 +572,7 @@ k_lo_batch_apply(BatchGeom g, const ScanHdr* __restrict__ hdr, const uint8_t* __
       }
     }
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < kApplyChunk; u++) {
       const uint32_t b = bv[u];
       if ((b & 0xFCu) != g.tag) continue;  // also the empty slots (tags start at 1 << 2)
       const uint32_t code = b & 3u;
