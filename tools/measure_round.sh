@@ -13,11 +13,11 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 (timeout 300 bash tools/prof_stats.sh > $O/prof_stats.log 2>&1); cp gpurun_out/prof_stats/kernel_stats.csv $O/kernel_stats_bench_default.csv
-(PMC_OUT=pmc_$TAG timeout 600 bash tools/pmc_passes.sh > $O/pmc_passes.log 2>&1)
+(PMC_OUT=pmc_$TAG timeout 1900 bash tools/pmc_passes.sh > $O/pmc_passes.log 2>&1)
 python tools/pmc_summary.py gpurun_out/pmc_$TAG > $O/pmc_per_launch.json
-(PMC_CMD="python tools/bench_extra.py --only cfg2 --map-scans 256" PMC_OUT=pmc_cfg2_$TAG timeout 600 bash tools/pmc_passes.sh > $O/pmc_cfg2_passes.log 2>&1)
+(PMC_CMD="python tools/bench_extra.py --only cfg2 --map-scans 256" PMC_OUT=pmc_cfg2_$TAG timeout 1900 bash tools/pmc_passes.sh > $O/pmc_cfg2_passes.log 2>&1)
 python tools/pmc_summary.py gpurun_out/pmc_cfg2_$TAG > $O/pmc_cfg2_per_launch.json
-(PMC_CMD="python tools/bench_extra.py --only cfg2 --map-scans 256 --map-size 4000 --map-cell 0.025" PMC_OUT=pmc_cfg2_4000_$TAG timeout 600 bash tools/pmc_passes.sh > $O/pmc_cfg2_4000_passes.log 2>&1)
+(PMC_CMD="python tools/bench_extra.py --only cfg2 --map-scans 256 --map-size 4000 --map-cell 0.025" PMC_OUT=pmc_cfg2_4000_$TAG timeout 1900 bash tools/pmc_passes.sh > $O/pmc_cfg2_4000_passes.log 2>&1)
 python tools/pmc_summary.py gpurun_out/pmc_cfg2_4000_$TAG > $O/pmc_cfg2_4000_per_launch.json
 rm -rf gpurun_out/pmc_$TAG gpurun_out/pmc_cfg2_$TAG gpurun_out/pmc_cfg2_4000_$TAG gpurun_out/prof_stats
 python tools/make_traffic.py $O/pmc_per_launch.json 4096 $O/pmc_cfg2_per_launch.json > $O/traffic.json

@@ -4,7 +4,15 @@ R=$GRAFT_REPO_ROOT
 OUT=${PMC_OUT:-pmc}
 CMD=${PMC_CMD:-python $R/bench.py --steps 2 --warmup 1 --no-cpu --no-diagnostics --sustained-s 0 --pipeline-depth 1 --pipelined-leg-depth 0 --plain-steps 2}
 mkdir -p $R/gpurun_out/$OUT && cd /tmp && export TMPDIR=/tmp
-run() { n=$1; shift; (cd $R && rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/$OUT/$n -o p -- $CMD > $R/gpurun_out/$OUT/$n.log 2>&1); }
+# (each pass under its own timeout, with one retry: a pass that hangs must not take the passes behind it with it)
+run() {
+  n=$1; shift
+  for attempt in 1 2; do
+    rm -rf $R/gpurun_out/$OUT/$n
+    (cd $R && timeout ${PMC_PASS_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/$OUT/$n -o p -- $CMD > $R/gpurun_out/$OUT/$n.log 2>&1) && break
+    echo "pass $n: attempt $attempt failed (rc $?)"
+  done
+}
 run sq SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU
 run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_FLAT_READ_WAVEFRONTS_sum TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE
 run fetch FETCH_SIZE TCC_HIT_sum
