@@ -469,6 +469,13 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
              min((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }
+// the first anchor of FindValidPoints (Mapper.cpp:774-778): the lowest index whose point has no NaN.  One LDS atomic per
+// WAVE that has such a point (its lowest lane: lanes hold ascending indices) -- an atomic per point on one address is
+// served lane by lane
+__device__ __forceinline__ void first_valid_min(int* s_first, bool valid, int i) {
+  const unsigned long long m = __ballot(valid);
+  if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicMin(s_first, i);
+}
 
 constexpr int kRowsQueue = 256;  // >= 63 waiting + two blocks of 64 coming in
 // LDS of ONE wave of the row kernel.  SOLO (k_resp_rows, a block = a wave): four arrays of their own.  In the scan-resident
@@ -1835,6 +1842,7 @@ struct SpecArgs {
   const double* ranges;  // the scan's readings (resident)
   double pose[3];        // sensor pose the match starts from
   int* out;              // nullptr: no speculative block in this launch
+  const double2* local;  // nullptr, or the scan's scan-frame points (k_scan_prep) -- see anchor_spec_block
 };
 __device__ __forceinline__ void anchor_spec_block(int n, const SpecArgs& sa, const Geom& g, unsigned char* smem);
 template <int NT>
@@ -3057,7 +3065,7 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
     const double min_sq = ksq(0.1);
     for (int i = tid; i < n; i += nt) {
       const double fx = p[i].x, fy = p[i].y;
-      if (!isnan(fx) && !isnan(fy)) atomicMin(&s_first, i);  // first anchor (Mapper.cpp:774-778)
+      first_valid_min(&s_first, !isnan(fx) && !isnan(fy), i);
       next[i] = successor_of(p, n, i, min_sq);
       if (use_lds) chain[i] = next[i];
     }
@@ -3114,14 +3122,19 @@ k_find_valid(int n, const double2* __restrict__ world, int ring_start, int cap, 
 //
 // SPECULATIVE ANCHORS (round 6).  The chain is 11 of this kernel's 13 us and sits between a match and the next rebuild.  But
 // which point follows which depends on the scan's SHAPE only -- distances between its points -- and a rigid motion changes a
-// squared distance by no more than the roundings of the coordinates (~1e-13 m^2 at 100 m).  So the chain is worked out EARLY,
+// squared distance by no more than the roundings of the coordinates (~3e-14 m^2 at 100 m).  So the chain is worked out EARLY,
 // on the points at the pose the match STARTS from (anchor_spec_block: an extra block of the lone coarse reduce's launch, where
 // it costs nothing), with every comparison that comes closer to the 0.1 m threshold than kSpecBand flagged, and this kernel
 // -- which still evaluates the world points at the FINAL pose -- takes the speculative row over when (a) nothing was flagged
-// and (b) every point has the same class (finite / +inf / -inf / NaN per coordinate) at both poses: a comparison that
-// involves a non-finite point is decided by the classes alone (inf - inf, inf - finite, NaN).  Otherwise it computes the
-// chain as before.  Either way the row is the one the reference's walk produces on the final points.
-constexpr double kSpecBand = 1e-13;  // x (1 + largest coordinate): >= 40 x the bound on |d^2(pose A) - d^2(pose B)|
+// and (b) the non-finite points cannot change the walk.  A comparison that involves a non-finite point is decided by the
+// points' classes (finite / +inf / -inf / NaN per coordinate) alone: finite against infinite is always "farther" (inf^2), NaN
+// never is, and two infinite points are farther only when BOTH coordinates differ in sign -- opposite quadrants, i.e. beams a
+// quarter turn apart with nothing finite between them.  A scan whose non-finite readings together span less than a quadrant
+// (1.5 rad of beams) therefore has the same chain at every heading, and only the KIND of each point (finite / infinite / NaN:
+// a function of the reading alone) is checked; a scan with more of them is taken over only if every point's class, signs
+// included, is the predicted one.  Otherwise the kernel computes the chain as before.  Either way the row is the one the
+// reference's walk produces on the final points.
+constexpr double kSpecBand = 1e-13;  // x (1 + 2 x the scan's largest |x| + |y|): >= 40 x the bound on |d^2(pose A) - d^2(pose B)|
 __device__ __forceinline__ uint32_t point_class(double2 q) {
   auto c = [](double v) -> uint32_t { return isnan(v) ? 3u : isinf(v) ? (v > 0.0 ? 1u : 2u) : 0u; };
   return c(q.x) | (c(q.y) << 2);
@@ -3156,9 +3169,12 @@ __device__ __forceinline__ void anchor_chain_block(int n, double2* __restrict__ 
   uint8_t* reach = (uint8_t*)(jb + n);
   const int tid = threadIdx.x, nt = blockDim.x;
   LSLAM_PHASE_CLOCK(pck);
-  if (tid == 0) { s_first = n; s_spec_ok = (spec && spec[0] == 1) ? 1 : 0; }
+  if (tid == 0) { s_first = n; s_spec_ok = (spec && spec[0] >= 1) ? spec[0] : 0; }
   __syncthreads();
   const uint8_t* spec_cls = spec ? (const uint8_t*)(spec + 2 + n) : nullptr;
+  // (1: the KIND of every point -- finite / infinite / NaN -- must be the predicted one; 2: its class, signs included)
+  const bool kinds_only = s_spec_ok == 1;
+  auto kind_of = [](uint32_t c) -> uint32_t { return ((c & 3u) == 3u || (c >> 2) == 3u) ? 2u : c ? 1u : 0u; };
   bool same = true;
   for (int i = tid; i < n; i += nt) {
     double2 q;
@@ -3170,7 +3186,10 @@ __device__ __forceinline__ void anchor_chain_block(int n, double2* __restrict__ 
     }
     p[i] = q;
     reach[i] = 0;
-    if (spec_cls) same = same && point_class(q) == (uint32_t)spec_cls[i];
+    if (spec_cls) {
+      const uint32_t c = point_class(q), c0 = (uint32_t)spec_cls[i];
+      same = same && (kinds_only ? kind_of(c) == kind_of(c0) : c == c0);
+    }
   }
   if (spec_cls && !same) s_spec_ok = 0;
   __syncthreads();
@@ -3185,7 +3204,7 @@ __device__ __forceinline__ void anchor_chain_block(int n, double2* __restrict__ 
   }
   const double min_sq = ksq(0.1);
   for (int i = tid; i < n; i += nt) {
-    if (!isnan(p[i].x) && !isnan(p[i].y)) atomicMin(&s_first, i);  // first anchor (Mapper.cpp:774-778)
+    first_valid_min(&s_first, !isnan(p[i].x) && !isnan(p[i].y), i);
     next[i] = successor_of(p, n, i, min_sq);
     ja[i] = next[i];
   }
@@ -3200,9 +3219,11 @@ __device__ __forceinline__ void anchor_chain_block(int n, double2* __restrict__ 
 }
 // The speculative chain of ONE scan at the pose its match starts from: out = [ok, count, anchors (n), classes (n bytes)].
 // Same walk as above; a comparison between two FINITE points within kSpecBand (1 + coordinates) of the threshold clears `ok`.
-__device__ __forceinline__ int successor_spec(const double2* p, int n, int i, double min_sq, bool& clear) {
+// The walk of successor_of with the band test: lo / hi = the threshold -+ kSpecBand (1 + the scan's largest coordinates), a
+// block-wide constant (the search is fp64 VALU work on ONE CU -- 12.8 k cycles of the plain kernel's phase -- so the test is
+// two more compares per candidate, not a band evaluated per pair).  inf and NaN distances are never "near".
+__device__ __forceinline__ int successor_spec(const double2* p, int n, int i, double min_sq, double lo, double hi, bool& clear) {
   const double fx = p[i].x, fy = p[i].y;
-  const double fm = fabs(fx) + fabs(fy);
   int j = i + 1;
   for (bool found = false; !found && j < n;) {
     double2 q[4];
@@ -3214,16 +3235,19 @@ __device__ __forceinline__ int successor_spec(const double2* p, int n, int i, do
       const double dx = fx - q[u].x, dy = fy - q[u].y;
       const double d2 = ksq(dx) + ksq(dy);
       if (d2 > min_sq) hit = u;
-      const double mag = fm + fabs(q[u].x) + fabs(q[u].y);  // (a non-finite point: mag is inf or NaN, the test is skipped)
-      if (mag < 1e300 && fabs(d2 - min_sq) <= kSpecBand * (1.0 + mag)) clear = false;
+      if ((d2 > lo) != (d2 > hi)) clear = false;
     }
     if (hit < 4 && j + hit < n) { j += hit; found = true; }
     else j = min(j + 4, n);
   }
   return j;
 }
+// sa.local (the scan-frame points k_scan_prep wrote for the match: a rigid image of the world points) spares this block the
+// fp64 sincos of every beam: finite readings take their scan-frame point; a non-finite reading takes a point of the CLASS its
+// world point will have -- r * cos(angle) is +-inf by the signs of r and of the cosine, i.e. by the angle's quadrant (a
+// misjudged quadrant is caught like everything else: k_anchor_chain compares the classes with the final points').
 __device__ __forceinline__ void anchor_spec_block(int n, const SpecArgs& sa, const Geom& g, unsigned char* smem) {
-  __shared__ int s_first, s_wc[16], s_clear;
+  __shared__ int s_first, s_wc[16], s_clear, s_nonfinite, s_mag_hi;
   double2* p = (double2*)smem;
   int* next = (int*)(p + n);
   int* ja = next + n;
@@ -3231,20 +3255,51 @@ __device__ __forceinline__ void anchor_spec_block(int n, const SpecArgs& sa, con
   uint8_t* reach = (uint8_t*)(jb + n);
   uint8_t* cls = (uint8_t*)(sa.out + 2 + n);
   const int tid = threadIdx.x, nt = blockDim.x;
-  if (tid == 0) { s_first = n; s_clear = 1; sa.out[0] = 0; }
-  for (int i = tid; i < n; i += nt) {
-    double2 q;
-    beam_world_point(sa.pose[0], sa.pose[1], sa.pose[2], g.min_angle, g.ang_res, (uint32_t)i, sa.ranges[i], q.x, q.y);
-    p[i] = q;
-    reach[i] = 0;
-    cls[i] = (uint8_t)point_class(q);
+  if (tid == 0) { s_first = n; s_clear = 1; s_nonfinite = 0; s_mag_hi = 0; sa.out[0] = 0; }
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += nt) {  // whole waves iterate together: the wave-level reductions below need every lane
+    const int i = i0 + tid;
+    const bool in = i < n;
+    double2 q = make_double2(0.0, 0.0);
+    const double r = in ? sa.ranges[i] : 0.0;
+    {
+      const unsigned long long nf = __ballot(in && (isnan(r) || isinf(r)));
+      if (nf && (tid & 63) == 0) atomicAdd(&s_nonfinite, __popcll(nf));
+    }
+    if (sa.local && !isnan(r) && !isinf(r)) {
+      if (in) q = sa.local[i];
+    } else if (sa.local) {
+      const double inf = __builtin_inf(), nan = __builtin_nan("");
+      if (isnan(r)) {
+        q = make_double2(nan, nan);
+      } else {
+        const double angle = sa.pose[2] + g.min_angle + (uint32_t)i * g.ang_res;
+        const long long quad = (long long)floor(angle * 0.63661977236758134308);  // angle / (pi / 2)
+        const int k4 = (int)(((quad % 4) + 4) % 4);
+        const bool cpos = (k4 == 0 || k4 == 3), spos = (k4 == 0 || k4 == 1);
+        q = make_double2((r > 0.0) == cpos ? inf : -inf, (r > 0.0) == spos ? inf : -inf);
+      }
+    } else if (in) {
+      beam_world_point(sa.pose[0], sa.pose[1], sa.pose[2], g.min_angle, g.ang_res, (uint32_t)i, r, q.x, q.y);
+    }
+    const uint32_t c = point_class(q);
+    if (in) {
+      p[i] = q;
+      reach[i] = 0;
+      cls[i] = (uint8_t)c;
+    }
+    const uint32_t mh = wave_max_u32(in && c == 0u ? (uint32_t)__double2hiint(fabs(q.x) + fabs(q.y)) : 0u);
+    if ((tid & 63) == 0 && mh) atomicMax(&s_mag_hi, (int)mh);
   }
   __syncthreads();
   const double min_sq = ksq(0.1);
-  bool clear = true;
+  // >= |x| + |y| of every finite point (the high word of a positive double orders like the double)
+  const double mag = __hiloint2double(s_mag_hi + 1, 0);
+  const double band = kSpecBand * (1.0 + 2.0 * mag), lo = min_sq - band, hi = min_sq + band;
+  bool clear = band < 0.5 * min_sq;  // (coordinates beyond ~1e10 m: no speculation)
   for (int i = tid; i < n; i += nt) {
-    if (!isnan(p[i].x) && !isnan(p[i].y)) atomicMin(&s_first, i);
-    next[i] = successor_spec(p, n, i, min_sq, clear);
+    first_valid_min(&s_first, !isnan(p[i].x) && !isnan(p[i].y), i);
+    next[i] = successor_spec(p, n, i, min_sq, lo, hi, clear);
     ja[i] = next[i];
   }
   if (!clear) s_clear = 0;
@@ -3253,7 +3308,9 @@ __device__ __forceinline__ void anchor_spec_block(int n, const SpecArgs& sa, con
   __syncthreads();
   anchors_to_row(n, reach, sa.out + 1, s_wc, tid, nt);
   __syncthreads();
-  if (tid == 0) sa.out[0] = s_clear;
+  // 1: the chain holds whatever the signs of the +-inf points (see k_anchor_chain); 2: only if they stay as predicted -- the
+  // scan has enough non-finite readings for a run of them to span a quadrant
+  if (tid == 0) sa.out[0] = !s_clear ? 0 : ((double)s_nonfinite * fabs(g.ang_res) < 1.5 ? 1 : 2);
 }
 __global__ void __launch_bounds__(1024)
 k_anchor_chain(int n, double2* __restrict__ world, int* __restrict__ row, const double* __restrict__ ranges, PoseArg pose,
@@ -4074,6 +4131,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       const size_t spec_lds = (size_t)g.n_beams * (sizeof(double2) + 13) + 16;
       if (spec_req.out && pass_index == 0 && S == 1 && spec_lds <= 60 * 1024) {
         spec = spec_req;
+        spec.local = (const double2*)m->d_local.p;  // of scan 0 of this match: the scan the request is for
         m->spec_launched = true;
       }
 #define LSLAM_RC_LDS(NT)                                                                                                 \

@@ -89,3 +89,35 @@ def test_a_scan_whose_points_change_class_is_recomputed(ctx):
         assert np.array_equal(g, w), i
     assert got_poses.tobytes() == want_poses.tobytes()
     assert on["handed"] > 100
+
+
+def test_the_shipped_indoor_configuration_with_response_expansion(ctx):
+    # lesson6/config/mapper_params.yaml: 0.01 m cells, 16 x 16 x 21 lattice, expansion passes on, 12 m range threshold (the
+    # readings beyond it are points all the same: LocalizedRangeScan::Update's unfiltered list, Karto.h:5379-5404)
+    import math
+    laser = synth.Laser(range_max=30.0)
+    world = synth.arena(size=24.0, n_axis=8, n_rot=3, seed=12)
+    path = synth.trajectory(world, 150, step=0.05, max_turn=math.radians(2.0), seed=12)
+    odom = synth.drifting_odometry(path, scale=1.005, sigma_xy=0.001, sigma_th=0.0005, seed=12)
+    rng = np.random.default_rng(12)
+    scans = [synth.ranges_to_f64(synth.cast_scan(world, p, laser, 0.005, 0.01, rng)) for p in path]
+    out = {}
+    for on in (0, 1):
+        os.environ["LSLAM_FE_SPEC_CHAIN"] = str(on)
+        try:
+            gm = api.ScanMatcher(ctx, api.baseline_config(search_size=0.3, resolution=0.01, smear_deviation=0.03, use_response_expansion=1,
+                                                          distance_variance_penalty=0.25, angle_variance_penalty=0.01,
+                                                          range_threshold=12.0), api.laser_params(laser, 12.0))
+            fe = api.FrontEnd(gm, scan_buffer_size=30, min_travel_distance=0.02, min_travel_heading=math.radians(1.0))
+        finally:
+            del os.environ["LSLAM_FE_SPEC_CHAIN"]
+        for r, o in zip(scans, odom):
+            fe.Process(r, o)
+        n = fe.num_scans()
+        out[on] = ([fe.anchor_row(i) for i in range(n)], np.stack([fe.scan_pose(i) for i in range(n)]), fe.spec_chain_stats())
+        fe.close()
+        gm.close()
+    assert len(out[1][0]) > 100 and out[1][2]["handed"] > 100
+    for i, (g, w) in enumerate(zip(out[1][0], out[0][0])):
+        assert np.array_equal(g, w), i
+    assert out[1][1].tobytes() == out[0][1].tobytes()
