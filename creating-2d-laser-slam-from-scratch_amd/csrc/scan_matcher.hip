@@ -1273,10 +1273,6 @@ constexpr int kPosChunk = 16;
 #if !defined(LSLAM_TUNE_REDUCE_NARROW_MIN)
 #define LSLAM_TUNE_REDUCE_NARROW_MIN 2048
 #endif
-#if !defined(LSLAM_TUNE_REDUCE_NARROW_THREADS)
-#define LSLAM_TUNE_REDUCE_NARROW_THREADS 128
-#endif
-constexpr int kReduceNarrowThreads = LSLAM_TUNE_REDUCE_NARROW_THREADS;  // threads per block of k_reduce_coarse_lds for such batches (A/B: 64 / 128 / 256)
 constexpr int kReduceNarrowMinScans = LSLAM_TUNE_REDUCE_NARROW_MIN;  // batches from here on run k_reduce_coarse_lds with 128-thread blocks
 // one work item = (angle a, chunk c of 16 lattice positions) of one scan, done by one wave
 __device__ __forceinline__ void generic_item(const uint8_t* __restrict__ grid, const Geom& g, const PassCfg& pc,
@@ -4125,7 +4121,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
       fb_step
     // the LDS form keeps no per-candidate cache, so it also covers lattices whose cached form would not fit (the reference's
     // shipped 16 x 16 x 21: 62 KB cached, 21 KB here -- k_reduce_coarse<false> was 0.36 ms of that configuration's 1.98 ms step)
-    const int nt_sel = S >= kReduceNarrowMinScans ? kReduceNarrowThreads : (S <= 8 ? 1024 : 256);
+    const int nt_sel = S >= kReduceNarrowMinScans ? 128 : (S <= 8 ? 1024 : 256);
     if (((size_t)p.nx * p.ny * p.na + 31) / 32 <= 256 && reduce_lds_nocache(p, reduce_parts(p, nt_sel)) <= 60 * 1024) {
       const bool fuse_fine = n_exp == 0 && do_refine;  // nothing between this pass and the fine pass
       // (the block also clears the fine numerators -- unless a debug caller is about to copy the COARSE ones out of the same words)
@@ -4147,7 +4143,7 @@ int match_batch_impl(lslam_matcher* m, int S, const RT* d_ranges, int stride, co
          NT == 1024 ? spec : SpecArgs{})
       // 128 threads: residency for chip-filling batches; 1024: a lone block (streaming front-end, MatchScan) splits a cell's
       // angles over 8 threads -- its fill phase was 11 fp64 divisions in a row per thread
-      if (S >= kReduceNarrowMinScans) LSLAM_RC_LDS(kReduceNarrowThreads);
+      if (S >= kReduceNarrowMinScans) LSLAM_RC_LDS(128);
       else if (S <= 8) LSLAM_RC_LDS(1024);
       else LSLAM_RC_LDS(256);
 #undef LSLAM_RC_LDS
