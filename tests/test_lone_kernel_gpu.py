@@ -103,3 +103,18 @@ def test_streaming_front_end_and_thousands_of_launches(ctx):
         fe.close()
         gm.close()
     assert poses[4].tobytes() == poses[0].tobytes()
+
+
+def test_option_values(ctx):
+    wl = synth.make_match_workload(n_base=10, n_query=1, seed=64)
+    gm = _matcher(ctx, wl)
+    opt = 9  # LSLAM_OPT_LONE_KERNEL
+    assert gm.L.lslam_matcher_get_option(gm.h, opt) == 0  # off by default: the four-launch chain is the faster one
+    for v in (4, 8, 16, 104, 108, 116, 0):
+        gm.set_option("lone_kernel", v)
+        assert gm.L.lslam_matcher_get_option(gm.h, opt) == v
+    for bad in (1, 5, 32, 101, 132, -4):
+        with pytest.raises(api.LslamError):
+            gm.set_option("lone_kernel", bad)
+    assert gm.L.lslam_matcher_get_option(gm.h, opt) == 0
+    gm.close()
