@@ -104,9 +104,11 @@ struct ResidentScan {
   int64_t id;
   kt_int32s unique_id;        // -1: provisional (cached as the query of Mapper::Process before AddScan numbered it)
   const kt_double* readings;  // LocalizedRangeScan::GetRangeReadings() at upload time
-  uint64_t checksum;          // of the uploaded readings; re-checked once, when a provisional entry is adopted
+  uint64_t checksum;          // of the uploaded readings; re-checked when a provisional entry is adopted and on every
+                              // kFullCheckEvery-th hit
   uint64_t fingerprint;       // of kFingerprintSamples readings spread over the scan; re-checked on EVERY hit
   uint64_t last_use;          // Residents::clock at the last hit (capacity bound: least recently used goes first)
+  uint32_t hits = 0;          // hits so far (every kFullCheckEvery-th one re-reads the whole scan)
 };
 struct Residents {
   lslam_laser laser;
@@ -150,6 +152,7 @@ static uint64_t checksum(const kt_double* r, int n) {
 // (ADVICE r04): a hit is therefore also held against a fingerprint of the CONTENTS -- 16 readings spread over the scan,
 // a few loads per base scan per call where the full checksum would cost more than the device call it guards.
 constexpr int kFingerprintSamples = 16;
+constexpr uint32_t kFullCheckEvery = 64;
 static uint64_t fingerprint(const kt_double* r, int n) {
   uint64_t h = 1469598103934665603ull ^ (uint64_t)n;
   if (n <= 0) return h;
@@ -183,6 +186,9 @@ static ResidentScan* find_resident(Residents& R, karto::LocalizedRangeScan* s, i
   auto it = R.scans.find(s);
   if (uid < 0 || it == R.scans.end() || it->second.readings != rd) return nullptr;
   if (it->second.fingerprint != fingerprint(rd, nb)) return nullptr;  // same address, other contents: a recycled scan
+  // ... and every kFullCheckEvery-th hit re-reads ALL readings (a recycled scan that happens to agree in the 16
+  // samples would otherwise be served stale for ever): 8.6 KB hashed once per 64 device calls
+  if ((++it->second.hits % kFullCheckEvery) == 0 && it->second.checksum != checksum(rd, nb)) return nullptr;
   if (it->second.unique_id == uid) {
     it->second.last_use = ++R.clock;
     return &it->second;
